@@ -1,0 +1,222 @@
+"""ctypes binding of include/celeste_mi355x.h (the C-ABI drop-in boundary).
+
+`load_library()` fails loudly when the HIP shared library has not been built:
+there is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+P = 44
+STAMP = 51
+COEF = 53
+
+OK, ERR_INVALID_ARG, ERR_NONFINITE_INPUT, ERR_NONFINITE_RESULT, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = range(7)
+FLAG_GRAD, FLAG_HESS, FLAG_KL = 1, 2, 4
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libceleste_mi355x.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class ImageT(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("band", C.c_int32), ("reserved", C.c_int32),
+                ("pixels", c_float_p), ("sky", c_float_p), ("nelec_per_nmgy", c_float_p)]
+
+
+class PatchT(C.Structure):
+    _fields_ = [("off_h", C.c_int32), ("off_w", C.c_int32), ("H2", C.c_int32), ("W2", C.c_int32),
+                ("bitmap", c_uint8_p), ("wcs_jacobian", C.c_double * 4), ("world_center", C.c_double * 2),
+                ("pixel_center", C.c_double * 2), ("psf", c_double_p), ("stamp", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class PriorT(C.Structure):
+    _fields_ = [("is_star", C.c_double * 2), ("flux_mean", C.c_double * 2), ("flux_var", C.c_double * 2),
+                ("k", (C.c_double * 8) * 2), ("color_mean", ((C.c_double * 4) * 8) * 2),
+                ("color_cov", ((C.c_double * 16) * 8) * 2), ("gal_radius_px_mean", C.c_double),
+                ("gal_radius_px_var", C.c_double)]
+
+
+class ProblemT(C.Structure):
+    _fields_ = [("n_images", C.c_int32), ("n_sources", C.c_int32), ("psf_K", C.c_int32), ("n_stamps", C.c_int32),
+                ("images", C.POINTER(ImageT)), ("patches", C.POINTER(PatchT)), ("stamps", c_double_p),
+                ("nbr_offsets", c_int64_p), ("nbr_index", c_int32_p), ("prior", C.POINTER(PriorT))]
+
+
+class WorkStatsT(C.Structure):
+    _fields_ = [("n_targets", C.c_int64), ("active_pixel_visits", C.c_int64), ("patch_rows", C.c_int64),
+                ("neighbor_links", C.c_int64), ("algorithmic_bytes", C.c_int64)]
+
+
+class CelesteError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__("celeste_mi355x status %d: %s" % (status, msg))
+        self.status = status
+
+
+# every symbol include/celeste_mi355x.h declares
+EXPORTED_SYMBOLS = [
+    "celeste_version", "celeste_strerror", "celeste_ctx_create", "celeste_ctx_destroy", "celeste_elbo_eval",
+    "celeste_elbo_eval_batch", "celeste_elbo_eval_batch_device", "celeste_ctx_enable_timing",
+    "celeste_ctx_last_kernel_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter", "celeste_psf_raster",
+]
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(
+            "HIP extension %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.celeste_version.restype = C.c_int
+    lib.celeste_strerror.restype = C.c_char_p
+    lib.celeste_strerror.argtypes = [C.c_int]
+    lib.celeste_ctx_create.argtypes = [C.POINTER(ProblemT), C.c_int, C.POINTER(vp)]
+    lib.celeste_ctx_destroy.argtypes = [vp]
+    lib.celeste_ctx_destroy.restype = None
+    lib.celeste_elbo_eval.argtypes = [vp, c_double_p, C.c_int32, C.c_uint32, c_double_p, c_double_p, c_double_p,
+                                      c_int64_p, c_int64_p]
+    lib.celeste_elbo_eval_batch.argtypes = [vp, c_double_p, C.c_int32, c_int32_p, C.c_uint32, c_double_p,
+                                            c_double_p, c_double_p, c_int64_p, c_int32_p]
+    lib.celeste_elbo_eval_batch_device.argtypes = [vp, vp, C.c_int32, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    lib.celeste_ctx_enable_timing.argtypes = [vp, C.c_int]
+    lib.celeste_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.celeste_ctx_work_stats.argtypes = [vp, C.c_int32, c_int32_p, C.POINTER(WorkStatsT)]
+    lib.celeste_spline_prefilter.argtypes = [c_double_p, c_double_p]
+    lib.celeste_psf_raster.argtypes = [C.c_int, c_double_p, C.c_int32, c_double_p, C.c_int32, c_double_p,
+                                       C.c_int32, c_double_p]
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def check(status: int, lib=None):
+    if status != OK:
+        lib = lib or load_library()
+        raise CelesteError(status, lib.celeste_strerror(status).decode())
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(c_double_p)
+
+
+def prior_struct(prior: dict) -> PriorT:
+    """dict with the layout of tests/golden/priors.json -> celeste_prior_t"""
+    p = PriorT()
+    for i in range(2):
+        p.is_star[i] = prior["is_star"][i]
+        p.flux_mean[i] = prior["flux_mean"][i]
+        p.flux_var[i] = prior["flux_var"][i]
+        for d in range(8):
+            p.k[i][d] = prior["k"][i][d]
+            for c in range(4):
+                p.color_mean[i][d][c] = prior["color_mean"][i][d][c]
+            for c in range(16):
+                p.color_cov[i][d][c] = prior["color_cov"][i][d][c]
+    p.gal_radius_px_mean = prior["gal_radius_px_mean"]
+    p.gal_radius_px_var = prior["gal_radius_px_var"]
+    return p
+
+
+class Problem:
+    """Marshals images / patches / neighbour lists into a celeste_problem_t.
+
+    Keeps every numpy buffer alive for as long as the struct is in use.  Images are
+    stored column-major (h fastest) as the reference stores them.
+    """
+
+    def __init__(self, images, patches, neighbors: Optional[Sequence[Sequence[int]]] = None, psf_K: int = 2,
+                 prior: Optional[dict] = None):
+        from .model import Image, ImagePatch  # noqa: F401
+        self.images = images
+        self.patches = patches
+        N, S = len(images), len(patches)
+        self._keep: List[object] = []
+        self.c_images = (ImageT * N)()
+        for n, im in enumerate(images):
+            pix = np.asfortranarray(im.pixels, dtype=np.float32)
+            sky = np.asfortranarray(im.sky, dtype=np.float32)
+            iota = np.ascontiguousarray(im.nelec_per_nmgy, dtype=np.float32)
+            assert sky.shape == pix.shape and iota.shape == (pix.shape[0],)
+            self._keep += [pix, sky, iota]
+            ci = self.c_images[n]
+            ci.H, ci.W, ci.band = pix.shape[0], pix.shape[1], int(im.b)
+            ci.pixels = pix.ctypes.data_as(c_float_p)
+            ci.sky = sky.ctypes.data_as(c_float_p)
+            ci.nelec_per_nmgy = iota.ctypes.data_as(c_float_p)
+        # shared stamp table: deduplicate by object identity / content of the raw stamp
+        stamps: List[np.ndarray] = []
+        stamp_key = {}
+        self.c_patches = (PatchT * (S * N))()
+        for s in range(S):
+            assert len(patches[s]) == N
+            for n in range(N):
+                p = patches[s][n]
+                st = np.ascontiguousarray(np.asfortranarray(p.stamp, dtype=np.float64).T)  # column-major bytes
+                key = st.tobytes()
+                if key not in stamp_key:
+                    stamp_key[key] = len(stamps)
+                    stamps.append(st.reshape(-1))
+                cp = self.c_patches[s * N + n]
+                cp.off_h, cp.off_w = int(p.bitmap_offset[0]), int(p.bitmap_offset[1])
+                bm = np.asfortranarray(p.active_pixel_bitmap, dtype=np.uint8)
+                cp.H2, cp.W2 = bm.shape[0], bm.shape[1]
+                sub = images[n].pixels[cp.off_h:cp.off_h + cp.H2, cp.off_w:cp.off_w + cp.W2]
+                if bm.size and not np.array_equal(bm.astype(bool), ~np.isnan(sub)):
+                    self._keep.append(bm)
+                    cp.bitmap = bm.ctypes.data_as(c_uint8_p)  # explicit bitmap only when it differs from !isnan
+                J = np.asarray(p.wcs_jacobian, dtype=np.float64)
+                cp.wcs_jacobian[0], cp.wcs_jacobian[1], cp.wcs_jacobian[2], cp.wcs_jacobian[3] = \
+                    J[0, 0], J[1, 0], J[0, 1], J[1, 1]
+                cp.world_center[0], cp.world_center[1] = float(p.world_center[0]), float(p.world_center[1])
+                cp.pixel_center[0], cp.pixel_center[1] = float(p.pixel_center[0]), float(p.pixel_center[1])
+                psf = np.ascontiguousarray(p.psf, dtype=np.float64)
+                assert psf.shape == (psf_K, 6)
+                self._keep.append(psf)
+                cp.psf = _dp(psf)
+                cp.stamp = stamp_key[key]
+        self.stamps = np.ascontiguousarray(np.stack(stamps))
+        if neighbors is None:
+            neighbors = [[] for _ in range(S)]
+        off = np.zeros(S + 1, dtype=np.int64)
+        for s in range(S):
+            off[s + 1] = off[s] + len(neighbors[s])
+        idx = np.array([j for row in neighbors for j in row], dtype=np.int32)
+        if idx.size == 0:
+            idx = np.zeros(1, dtype=np.int32)
+        self.nbr_off, self.nbr_idx = off, idx
+        self.neighbors = [list(r) for r in neighbors]
+        self.c_prior = prior_struct(prior) if prior is not None else None
+        self.c = ProblemT()
+        self.c.n_images, self.c.n_sources, self.c.psf_K, self.c.n_stamps = N, S, psf_K, len(stamps)
+        self.c.images = self.c_images
+        self.c.patches = self.c_patches
+        self.c.stamps = _dp(self.stamps)
+        self.c.nbr_offsets = off.ctypes.data_as(c_int64_p)
+        self.c.nbr_index = idx.ctypes.data_as(c_int32_p)
+        self.c.prior = C.pointer(self.c_prior) if self.c_prior is not None else None
+        self.n_images, self.n_sources = N, S
+
+
+def spline_prefilter(stamp: np.ndarray) -> np.ndarray:
+    """ImagePatch ctor arithmetic (imaged_sources.jl:97-107) -> 53 x 53 B-spline coefficients."""
+    lib = load_library()
+    st = np.ascontiguousarray(np.asarray(stamp, dtype=np.float64).T).reshape(-1)  # column-major
+    out = np.empty(COEF * COEF)
+    check(lib.celeste_spline_prefilter(_dp(st), _dp(out)), lib)
+    return out.reshape(COEF, COEF).T.copy()  # [h, w]

@@ -1,0 +1,448 @@
+// celeste_abi.hip -- host side of the C ABI declared in include/celeste_mi355x.h.
+//
+// Owns the device copies of the problem (images, patches, spline coefficients, neighbour
+// graph) and launches prep_kernel -> pixel_kernel -> lift_kernel on one HIP stream.
+// There is deliberately no CPU evaluation path: without a HIP device every entry point
+// that computes returns CELESTE_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "elbo_kernels.h"
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            fprintf(stderr, "celeste_mi355x: %s failed: %s (%s:%d)\n", #expr,            \
+                    hipGetErrorString(e__), __FILE__, __LINE__);                         \
+            return CELESTE_ERR_HIP;                                                      \
+        }                                                                                \
+    } while (0)
+
+static const celeste_prior_t DEFAULT_PRIOR =
+#include "prior_tables.inc"
+    ;
+
+struct celeste_ctx {
+    int device = 0;
+    int N = 0, S = 0, K = 0, NC = 0, n_stamps = 0;
+    int chunk_px = 1024, CH = 1;
+    int max_npx = 0;
+    // host mirrors (for work stats / validation)
+    std::vector<DevPatch> h_patches;
+    std::vector<int64_t> h_nbr_off;
+    std::vector<int32_t> h_nbr_idx;
+    std::vector<DevImage> h_images;
+    // device
+    std::vector<void *> plane_allocs;
+    DevImage *d_images = nullptr;
+    DevPatch *d_patches = nullptr;
+    double *d_coefs = nullptr;
+    uint8_t *d_bitmaps = nullptr;
+    int64_t *d_nbr_off = nullptr;
+    int32_t *d_nbr_idx = nullptr;
+    PriorDev *d_prior = nullptr;
+    SrcImg *d_srcimg = nullptr;
+    Comp *d_comps = nullptr;
+    SrcGeo *d_geo = nullptr;
+    // per-batch scratch (grown on demand)
+    double *d_acc = nullptr;
+    size_t acc_cap = 0;
+    // staging for the host-pointer API
+    double *d_vp = nullptr;
+    int32_t *d_targets = nullptr;
+    double *d_v = nullptr, *d_d = nullptr, *d_h = nullptr;
+    int64_t *d_cnt = nullptr;
+    int32_t *d_status = nullptr;
+    size_t stage_cap = 0;
+    // timing
+    int timing = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int ev_valid = 0;
+};
+
+extern "C" int celeste_version(void) { return 100; }
+
+extern "C" const char *celeste_strerror(int status) {
+    switch (status) {
+        case CELESTE_OK: return "ok";
+        case CELESTE_ERR_INVALID_ARG: return "invalid argument";
+        case CELESTE_ERR_NONFINITE_INPUT: return "vp contains NaNs or Infs";
+        case CELESTE_ERR_NONFINITE_RESULT: return "ELBO value, gradient or Hessian contains Inf/NaNs";
+        case CELESTE_ERR_HIP: return "HIP runtime error";
+        case CELESTE_ERR_NO_DEVICE: return "no HIP device (the engine has no CPU fallback)";
+        case CELESTE_ERR_ALLOC: return "allocation failed";
+        default: return "unknown status";
+    }
+}
+
+// ---- galaxy prototypes (light_source_model.jl:45-75) ----------------------------------------
+static void galaxy_prototypes(double eta[16], double nu[16]) {
+    const double dev_amp[8] = {4.26347652e-2, 2.40127183e-1, 6.85907632e-1, 1.51937350,
+                               2.83627243, 4.46467501, 5.72440830, 5.60989349};
+    const double dev_var[8] = {2.23759216e-4, 1.00220099e-3, 4.18731126e-3, 1.69432589e-2,
+                               6.84850479e-2, 2.87207080e-1, 1.33320254, 8.40215071};
+    const double exp_amp[6] = {2.34853813e-3, 3.07995260e-2, 2.23364214e-1, 1.17949102, 4.33873750, 5.99820770};
+    const double exp_var[6] = {1.20078965e-3, 8.84526493e-3, 3.91463084e-2, 1.39976817e-1, 4.60962500e-1, 1.50159566};
+    const double er0 = 1.078031, er1 = 0.928896;
+    double sd = 0, se = 0;
+    for (double a : dev_amp) sd += a;
+    for (double a : exp_amp) se += a;
+    for (int j = 0; j < 16; ++j) { eta[j] = 0; nu[j] = 0; }
+    for (int j = 0; j < 8; ++j) { eta[j] = dev_amp[j] / sd; nu[j] = dev_var[j] / (er0 * er0); }
+    for (int j = 0; j < 6; ++j) { eta[8 + j] = exp_amp[j] / se; nu[8 + j] = exp_var[j] / (er1 * er1); }
+}
+
+// ---- spline prefilter (imaged_sources.jl:97-107; Interpolations BSpline(Cubic(Line())), OnGrid) ----
+// 1-D: n samples -> n + 2 coefficients.  The two boundary rows c[0] - 2 c[1] + c[2] = 0 reduce the
+// first/last interior equations to c[1] = d[0], c[n] = d[n-1]; the rest is a tridiagonal
+// (1, 4, 1) / 6 system solved with the Thomas algorithm.
+static void prefilter_line(int n, const double *d, int dstride, double *c, int cstride) {
+    std::vector<double> cp(n), dp(n), x(n + 2);
+    x[1] = d[0];
+    x[n] = d[(size_t)(n - 1) * dstride];
+    const int m = n - 2;  // unknowns x[2..n-1]
+    if (m > 0) {
+        // (x[q-1] + 4 x[q] + x[q+1]) = 6 d[q-1], q = 2..n-1
+        for (int q = 0; q < m; ++q) {
+            double rhs = 6.0 * d[(size_t)(q + 1) * dstride];
+            if (q == 0) rhs -= x[1];
+            if (q == m - 1) rhs -= x[n];
+            const double lower = (q == 0) ? 0.0 : 1.0;
+            const double denom = 4.0 - lower * (q ? cp[q - 1] : 0.0);
+            cp[q] = 1.0 / denom;
+            dp[q] = (rhs - lower * (q ? dp[q - 1] : 0.0)) / denom;
+        }
+        x[2 + m - 1] = dp[m - 1];
+        for (int q = m - 2; q >= 0; --q) x[2 + q] = dp[q] - cp[q] * x[2 + q + 1];
+    }
+    x[0] = 2.0 * x[1] - x[2];
+    x[n + 1] = 2.0 * x[n] - x[n - 1];
+    for (int q = 0; q < n + 2; ++q) c[(size_t)q * cstride] = x[q];
+}
+
+extern "C" int celeste_spline_prefilter(const double *stamp51, double *coef53) {
+    if (!stamp51 || !coef53) return CELESTE_ERR_INVALID_ARG;
+    const int n = CEL_STAMP, m = CEL_COEF;
+    std::vector<double> g((size_t)n * n), tmp((size_t)m * n);
+    double sum = 0;
+    for (int k = 0; k < n * n; ++k) { g[k] = std::fmax(stamp51[k], 0.0) + 1e-6; sum += g[k]; }
+    for (int k = 0; k < n * n; ++k) {
+        const double x = g[k] / sum;
+        g[k] = (1000 * x > 1) ? 1000 * x - 1 : std::log(1000 * x);  // softpluslike (fsm_util.jl:221)
+    }
+    for (int w = 0; w < n; ++w) prefilter_line(n, g.data() + (size_t)n * w, 1, tmp.data() + (size_t)m * w, 1);
+    for (int h = 0; h < m; ++h) prefilter_line(n, tmp.data() + h, m, coef53 + h, m);
+    return CELESTE_OK;
+}
+
+static void inv4_logdet(const double *S, double *Inv, double *logdet) {
+    double a[4][8];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = S[r + 4 * c]; a[r][4 + c] = (r == c); }
+    double det = 1;
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (piv != c) { for (int k = 0; k < 8; ++k) std::swap(a[c][k], a[piv][k]); det = -det; }
+        det *= a[c][c];
+        const double inv = 1 / a[c][c];
+        for (int k = 0; k < 8; ++k) a[c][k] *= inv;
+        for (int r = 0; r < 4; ++r) if (r != c) { const double f = a[r][c]; for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k]; }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Inv[r + 4 * c] = a[r][4 + c];
+    *logdet = std::log(det);
+}
+
+template <class T>
+static int dev_upload(T **dst, const T *src, size_t n) {
+    *dst = nullptr;
+    if (n == 0) n = 1;
+    HIP_TRY(hipMalloc((void **)dst, n * sizeof(T)));
+    if (src) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return CELESTE_OK;
+}
+
+static int select_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return CELESTE_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return CELESTE_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(device));
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celeste_ctx_t **out) {
+    if (!pr || !out) return CELESTE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (pr->n_images <= 0 || pr->n_sources <= 0 || pr->psf_K <= 0 || pr->psf_K > CEL_MAXK ||
+        !pr->images || !pr->patches || pr->n_stamps <= 0 || !pr->stamps || 14 * pr->psf_K > 62)
+        return CELESTE_ERR_INVALID_ARG;
+    int st = select_device(device);
+    if (st != CELESTE_OK) return st;
+
+    celeste_ctx *c = new (std::nothrow) celeste_ctx();
+    if (!c) return CELESTE_ERR_ALLOC;
+    c->device = device;
+    c->N = pr->n_images; c->S = pr->n_sources; c->K = pr->psf_K; c->NC = 14 * pr->psf_K;
+    c->n_stamps = pr->n_stamps;
+#define CTX_TRY(expr) do { int s__ = (expr); if (s__ != CELESTE_OK) { celeste_ctx_destroy(c); return s__; } } while (0)
+
+    // images
+    c->h_images.resize(c->N);
+    for (int n = 0; n < c->N; ++n) {
+        const celeste_image_t &im = pr->images[n];
+        if (im.H <= 0 || im.W <= 0 || im.band < 1 || im.band > 5 || !im.pixels || !im.sky || !im.nelec_per_nmgy) {
+            celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG;
+        }
+        DevImage d; d.H = im.H; d.W = im.W; d.band = im.band; d.pad = 0;
+        float *dp = nullptr, *ds = nullptr, *di = nullptr;
+        CTX_TRY(dev_upload(&dp, im.pixels, (size_t)im.H * im.W)); c->plane_allocs.push_back(dp);
+        CTX_TRY(dev_upload(&ds, im.sky, (size_t)im.H * im.W)); c->plane_allocs.push_back(ds);
+        CTX_TRY(dev_upload(&di, im.nelec_per_nmgy, (size_t)im.H)); c->plane_allocs.push_back(di);
+        d.pixels = dp; d.sky = ds; d.iota = di;
+        c->h_images[n] = d;
+    }
+    CTX_TRY(dev_upload(&c->d_images, c->h_images.data(), c->h_images.size()));
+
+    // patches + explicit bitmaps
+    c->h_patches.resize((size_t)c->S * c->N);
+    std::vector<uint8_t> pool;
+    for (size_t q = 0; q < c->h_patches.size(); ++q) {
+        const celeste_patch_t &p = pr->patches[q];
+        const celeste_image_t &im = pr->images[q % c->N];
+        DevPatch d; memset(&d, 0, sizeof d);
+        d.off_h = p.off_h; d.off_w = p.off_w; d.H2 = p.H2 < 0 ? 0 : p.H2; d.W2 = p.W2 < 0 ? 0 : p.W2;
+        if (d.H2 > 0 && d.W2 > 0 &&
+            (p.off_h < 0 || p.off_w < 0 || p.off_h + d.H2 > im.H || p.off_w + d.W2 > im.W)) {
+            celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG;
+        }
+        if (p.stamp < 0 || p.stamp >= pr->n_stamps || !p.psf) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }
+        d.stamp = p.stamp;
+        d.bitmap_off = -1;
+        if (p.bitmap && d.H2 * d.W2 > 0) {
+            d.bitmap_off = (int64_t)pool.size();
+            pool.insert(pool.end(), p.bitmap, p.bitmap + (size_t)d.H2 * d.W2);
+        }
+        memcpy(d.J, p.wcs_jacobian, sizeof d.J);
+        memcpy(d.wc, p.world_center, sizeof d.wc);
+        memcpy(d.pc, p.pixel_center, sizeof d.pc);
+        memcpy(d.psf, p.psf, sizeof(double) * 6 * c->K);
+        c->h_patches[q] = d;
+        if (d.H2 * d.W2 > c->max_npx) c->max_npx = d.H2 * d.W2;
+    }
+    CTX_TRY(dev_upload(&c->d_patches, c->h_patches.data(), c->h_patches.size()));
+    CTX_TRY(dev_upload(&c->d_bitmaps, pool.data(), pool.size()));
+
+    // conditioned + prefiltered star splines
+    {
+        std::vector<double> coefs((size_t)c->n_stamps * CEL_COEF * CEL_COEF);
+        for (int k = 0; k < c->n_stamps; ++k)
+            celeste_spline_prefilter(pr->stamps + (size_t)k * CEL_STAMP * CEL_STAMP, coefs.data() + (size_t)k * CEL_COEF * CEL_COEF);
+        CTX_TRY(dev_upload(&c->d_coefs, coefs.data(), coefs.size()));
+    }
+
+    // neighbour CSR
+    c->h_nbr_off.assign((size_t)c->S + 1, 0);
+    if (pr->nbr_offsets) {
+        for (int s = 0; s <= c->S; ++s) c->h_nbr_off[s] = pr->nbr_offsets[s];
+        const int64_t tot = c->h_nbr_off[c->S];
+        if (tot < 0 || (tot > 0 && !pr->nbr_index)) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }
+        c->h_nbr_idx.assign(pr->nbr_index, pr->nbr_index + tot);
+        for (int32_t v : c->h_nbr_idx) if (v < 0 || v >= c->S) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }
+    }
+    CTX_TRY(dev_upload(&c->d_nbr_off, c->h_nbr_off.data(), c->h_nbr_off.size()));
+    CTX_TRY(dev_upload(&c->d_nbr_idx, c->h_nbr_idx.data(), c->h_nbr_idx.size()));
+
+    // prior (+ inverse covariances, parameter independent)
+    {
+        PriorDev pd;
+        pd.p = pr->prior ? *pr->prior : DEFAULT_PRIOR;
+        for (int i = 0; i < 2; ++i) for (int d = 0; d < 8; ++d) inv4_logdet(pd.p.color_cov[i][d], pd.inv_cov[i][d], &pd.logdet[i][d]);
+        CTX_TRY(dev_upload(&c->d_prior, &pd, 1));
+    }
+    {
+        double eta[16], nu[16];
+        galaxy_prototypes(eta, nu);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(c_eta), eta, sizeof eta) != hipSuccess ||
+            hipMemcpyToSymbol(HIP_SYMBOL(c_nu), nu, sizeof nu) != hipSuccess) {
+            celeste_ctx_destroy(c); return CELESTE_ERR_HIP;
+        }
+    }
+    CTX_TRY(dev_upload<SrcImg>(&c->d_srcimg, nullptr, (size_t)c->S * c->N));
+    CTX_TRY(dev_upload<Comp>(&c->d_comps, nullptr, (size_t)c->S * c->N * c->NC));
+    CTX_TRY(dev_upload<SrcGeo>(&c->d_geo, nullptr, (size_t)c->S));
+
+    const char *env_chunk = getenv("CELESTE_CHUNK_PX");
+    if (env_chunk && atoi(env_chunk) >= 64) c->chunk_px = (atoi(env_chunk) + 63) / 64 * 64;
+    c->CH = c->max_npx > 0 ? (c->max_npx + c->chunk_px - 1) / c->chunk_px : 1;
+    for (int i = 0; i < 4; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
+#undef CTX_TRY
+    *out = c;
+    return CELESTE_OK;
+}
+
+extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (void *p : c->plane_allocs) (void)hipFree(p);
+    void *ptrs[] = {c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_cnt, c->d_status};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+
+extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_vp, int32_t n_targets,
+                                              const int32_t *d_targets, uint32_t flags, double *d_v, double *d_d,
+                                              double *d_h, int64_t *d_counters, int32_t *d_status, void *stream_) {
+    if (!c || !d_vp || !d_targets || !d_v || !d_status || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
+    if ((flags & CELESTE_FLAG_HESS) && !d_h) return CELESTE_ERR_INVALID_ARG;
+    if ((flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) && !d_d) return CELESTE_ERR_INVALID_ARG;
+    if (n_targets == 0) return CELESTE_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t need = (size_t)n_targets * c->N * c->CH * ACC_N;
+    if (need > c->acc_cap) {
+        if (c->d_acc) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_acc)); c->d_acc = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_acc, need * sizeof(double)));
+        c->acc_cap = need;
+    }
+    const bool derivs = (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) != 0;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
+    hipLaunchKernelGGL(prep_kernel, dim3(c->S * c->N), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches, c->S,
+                       c->N, c->K, c->d_srcimg, c->d_comps, c->d_geo);
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
+    const dim3 grid((unsigned)((size_t)n_targets * c->N * c->CH));
+    if (derivs)
+        hipLaunchKernelGGL(pixel_kernel<2>, grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,
+                           c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, d_targets, c->N, c->NC,
+                           c->CH, c->chunk_px, c->d_acc);
+    else
+        hipLaunchKernelGGL(pixel_kernel<0>, grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,
+                           c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, d_targets, c->N, c->NC,
+                           c->CH, c->chunk_px, c->d_acc);
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
+    hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
+                       c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->N, c->CH, c->chunk_px, flags,
+                       d_v, d_d, d_h, d_counters, d_status);
+    if (c->timing) { HIP_TRY(hipEventRecord(c->ev[3], stream)); c->ev_valid = 1; }
+    HIP_TRY(hipGetLastError());
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32_t n_targets, const int32_t *targets,
+                                       uint32_t flags, double *v, double *d, double *h, int64_t *counters,
+                                       int32_t *status) {
+    if (!c || !vp || !targets || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
+    if (n_targets == 0) return CELESTE_OK;
+    for (int t = 0; t < n_targets; ++t) if (targets[t] < 0 || targets[t] >= c->S) return CELESTE_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_vp) HIP_TRY(hipMalloc((void **)&c->d_vp, (size_t)c->S * CEL_P * sizeof(double)));
+    if ((size_t)n_targets > c->stage_cap) {
+        void **ps[] = {(void **)&c->d_targets, (void **)&c->d_v, (void **)&c->d_d, (void **)&c->d_h, (void **)&c->d_cnt, (void **)&c->d_status};
+        for (void **p : ps) if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; }
+        const size_t n = (size_t)n_targets;
+        HIP_TRY(hipMalloc((void **)&c->d_targets, n * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&c->d_v, n * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&c->d_d, n * CEL_P * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&c->d_h, n * CEL_P * CEL_P * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&c->d_cnt, n * 2 * sizeof(int64_t)));
+        HIP_TRY(hipMalloc((void **)&c->d_status, n * sizeof(int32_t)));
+        c->stage_cap = n;
+    }
+    HIP_TRY(hipMemcpy(c->d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_targets, targets, (size_t)n_targets * sizeof(int32_t), hipMemcpyHostToDevice));
+    int st = celeste_elbo_eval_batch_device(c, c->d_vp, n_targets, c->d_targets, flags, c->d_v, c->d_d, c->d_h,
+                                            c->d_cnt, c->d_status, nullptr);
+    if (st != CELESTE_OK) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<int32_t> hst(n_targets);
+    HIP_TRY(hipMemcpy(hst.data(), c->d_status, (size_t)n_targets * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (v) HIP_TRY(hipMemcpy(v, c->d_v, (size_t)n_targets * sizeof(double), hipMemcpyDeviceToHost));
+    if (d && (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)))
+        HIP_TRY(hipMemcpy(d, c->d_d, (size_t)n_targets * CEL_P * sizeof(double), hipMemcpyDeviceToHost));
+    if (h && (flags & CELESTE_FLAG_HESS))
+        HIP_TRY(hipMemcpy(h, c->d_h, (size_t)n_targets * CEL_P * CEL_P * sizeof(double), hipMemcpyDeviceToHost));
+    if (counters) HIP_TRY(hipMemcpy(counters, c->d_cnt, (size_t)n_targets * 2 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    int worst = CELESTE_OK;
+    for (int t = 0; t < n_targets; ++t) {
+        if (status) status[t] = hst[t];
+        if (hst[t] != CELESTE_OK && worst == CELESTE_OK) worst = hst[t];
+    }
+    return worst;
+}
+
+extern "C" int celeste_elbo_eval(celeste_ctx_t *c, const double *vp, int32_t target, uint32_t flags, double *v,
+                                 double *d, double *h, int64_t *n_active_px, int64_t *n_inactive_px) {
+    int64_t cnt[2] = {0, 0};
+    int32_t st1 = 0;
+    double vv = 0;
+    int st = celeste_elbo_eval_batch(c, vp, 1, &target, flags, &vv, d, h, cnt, &st1);
+    if (v) *v = vv;
+    if (n_active_px) *n_active_px = cnt[0];
+    if (n_inactive_px) *n_inactive_px = cnt[1];
+    return st;
+}
+
+extern "C" int celeste_ctx_enable_timing(celeste_ctx_t *c, int enable) {
+    if (!c) return CELESTE_ERR_INVALID_ARG;
+    c->timing = enable ? 1 : 0;
+    c->ev_valid = 0;
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_ctx_last_kernel_ms(celeste_ctx_t *c, float ms[3]) {
+    if (!c || !ms || !c->ev_valid) return CELESTE_ERR_INVALID_ARG;
+    HIP_TRY(hipEventSynchronize(c->ev[3]));
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_ctx_work_stats(celeste_ctx_t *c, int32_t n_targets, const int32_t *targets,
+                                      celeste_work_stats_t *out) {
+    if (!c || !out || (n_targets > 0 && !targets)) return CELESTE_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    out->n_targets = n_targets;
+    for (int q = 0; q < n_targets; ++q) {
+        const int t = targets[q];
+        if (t < 0 || t >= c->S) return CELESTE_ERR_INVALID_ARG;
+        int64_t A = 0, R = 0;
+        for (int n = 0; n < c->N; ++n) {
+            const DevPatch &p = c->h_patches[(size_t)t * c->N + n];
+            A += (int64_t)p.H2 * p.W2;  // upper bound of visited pixels (NaN / masked pixels are skipped)
+            R += p.H2;
+        }
+        const int64_t Kn = c->h_nbr_off[t + 1] - c->h_nbr_off[t];
+        out->active_pixel_visits += A;
+        out->patch_rows += R;
+        out->neighbor_links += Kn;
+        out->algorithmic_bytes += 9 * A + 4 * R + 352 * (1 + Kn) + 200 * (int64_t)c->N * (1 + Kn) + 8288;
+    }
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, const double *rows, int32_t n_rows,
+                                  const double *cols, int32_t n_cols, double *out) {
+    if (!psf || K <= 0 || !rows || !cols || n_rows <= 0 || n_cols <= 0 || !out) return CELESTE_ERR_INVALID_ARG;
+    int st = select_device(device);
+    if (st != CELESTE_OK) return st;
+    double *d_psf = nullptr, *d_rows = nullptr, *d_cols = nullptr, *d_out = nullptr;
+    st = dev_upload(&d_psf, psf, (size_t)K * 6);
+    if (st == CELESTE_OK) st = dev_upload(&d_rows, rows, (size_t)n_rows);
+    if (st == CELESTE_OK) st = dev_upload(&d_cols, cols, (size_t)n_cols);
+    if (st == CELESTE_OK) st = dev_upload<double>(&d_out, nullptr, (size_t)n_rows * n_cols);
+    if (st == CELESTE_OK) {
+        const int n = n_rows * n_cols;
+        hipLaunchKernelGGL(psf_raster_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, d_psf, K, d_rows, n_rows,
+                           d_cols, n_cols, d_out);
+        if (hipMemcpy(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) st = CELESTE_ERR_HIP;
+    }
+    (void)hipFree(d_psf); (void)hipFree(d_rows); (void)hipFree(d_cols); (void)hipFree(d_out);
+    return st;
+}

@@ -1,0 +1,162 @@
+"""Host-side mirror of the reference's ELBO interface, backed by the HIP engine.
+
+  reference (src/deterministic_vi/)                      here
+  ------------------------------------------------------  --------------------------------
+  ElboArgs(images, patches, active_sources; psf_K,        ElboArgs(...)            elbo_args.jl:165-211
+           include_kl)
+  SensitiveFloat (v, d[P x S], h[PS x PS])                SensitiveFloat           SensitiveFloats.jl:23-47
+  elbo(ea, vp) / elbo_likelihood(ea, vp)                  elbo / elbo_likelihood   elbo_objective.jl:400-492
+  (per-box sweep of process_source)                       FieldContext.eval_batch  ParallelRun.jl:468-498
+
+Same names, argument meaning and error behaviour: non-finite parameters or results raise
+AssertionError like the reference's @assert (elbo_objective.jl:487, elbo_args.jl:145-149).
+Only Sa = 1 (the production configuration) is implemented in the device path.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import cabi
+from .cabi import FLAG_GRAD, FLAG_HESS, FLAG_KL, P
+
+
+@dataclass
+class SensitiveFloat:
+    """Value, gradient (P x 1) and Hessian (P x P) of the ELBO for one active source."""
+    v: float
+    d: Optional[np.ndarray]
+    h: Optional[np.ndarray]
+    active_pixel_counter: int = 0
+    inactive_pixel_counter: int = 0
+
+    @property
+    def has_gradient(self):
+        return self.d is not None
+
+    @property
+    def has_hessian(self):
+        return self.h is not None
+
+
+class FieldContext:
+    """Device-resident problem: images, all patches, neighbour graph (celeste_ctx_t)."""
+
+    def __init__(self, images, patches, neighbors=None, psf_K: int = 2, prior: Optional[dict] = None,
+                 device: int = 0):
+        self.lib = cabi.load_library()
+        self.problem = cabi.Problem(images, patches, neighbors, psf_K=psf_K, prior=prior)
+        self.S, self.N = self.problem.n_sources, self.problem.n_images
+        self.device = device
+        h = C.c_void_p()
+        cabi.check(self.lib.celeste_ctx_create(C.byref(self.problem.c), device, C.byref(h)), self.lib)
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.celeste_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-pointer API ---------------------------------------------------------------
+    def eval_batch(self, vp, targets: Sequence[int], flags: int = FLAG_GRAD | FLAG_HESS | FLAG_KL,
+                   raise_on_error: bool = True):
+        """vp: S x 44 array (row s = source s).  Returns (v[n], d[n,44], h[n,44,44], counters[n,2], status[n])."""
+        vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(self.S, P))
+        tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32))
+        n = tg.size
+        v = np.zeros(n)
+        d = np.zeros((n, P)) if flags & (FLAG_GRAD | FLAG_HESS) else None
+        h = np.zeros((n, P, P)) if flags & FLAG_HESS else None
+        cnt = np.zeros((n, 2), dtype=np.int64)
+        status = np.zeros(n, dtype=np.int32)
+        dp = cabi.c_double_p
+        st = self.lib.celeste_elbo_eval_batch(
+            self.handle, vp.ctypes.data_as(dp), n, tg.ctypes.data_as(cabi.c_int32_p), flags,
+            v.ctypes.data_as(dp), d.ctypes.data_as(dp) if d is not None else None,
+            h.ctypes.data_as(dp) if h is not None else None, cnt.ctypes.data_as(cabi.c_int64_p),
+            status.ctypes.data_as(cabi.c_int32_p))
+        if st in (cabi.ERR_NONFINITE_INPUT, cabi.ERR_NONFINITE_RESULT):
+            if raise_on_error:
+                raise AssertionError(self.lib.celeste_strerror(st).decode())
+        else:
+            cabi.check(st, self.lib)
+        # h is symmetric, so column-major == row-major
+        return v, d, h, cnt, status
+
+    # -- device-pointer API (torch tensors or raw pointers) -----------------------------------
+    def eval_batch_device(self, d_vp: int, n_targets: int, d_targets: int, flags: int, d_v: int, d_d: int,
+                          d_h: int, d_counters: int, d_status: int, stream: int = 0):
+        cabi.check(self.lib.celeste_elbo_eval_batch_device(self.handle, d_vp, n_targets, d_targets, flags, d_v, d_d,
+                                                           d_h, d_counters, d_status, stream), self.lib)
+
+    def enable_timing(self, on: bool = True):
+        cabi.check(self.lib.celeste_ctx_enable_timing(self.handle, 1 if on else 0), self.lib)
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 3)()
+        cabi.check(self.lib.celeste_ctx_last_kernel_ms(self.handle, ms), self.lib)
+        return [float(x) for x in ms]
+
+    def work_stats(self, targets: Sequence[int]) -> dict:
+        tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32))
+        ws = cabi.WorkStatsT()
+        cabi.check(self.lib.celeste_ctx_work_stats(self.handle, tg.size, tg.ctypes.data_as(cabi.c_int32_p),
+                                                   C.byref(ws)), self.lib)
+        return {k: int(getattr(ws, k)) for k, _ in cabi.WorkStatsT._fields_}
+
+
+class ElboArgs:
+    """elbo_args.jl:165-211.  `patches` is S x N (list of rows); `active_sources` 0-based.
+
+    The local source list is exactly the reference's: source 0..S-1 all contribute to any
+    pixel they cover; only the active source carries derivatives.
+    """
+
+    def __init__(self, images, patches, active_sources: Sequence[int], psf_K: int = 2, include_kl: bool = True,
+                 prior: Optional[dict] = None, device: int = 0):
+        self.S = len(patches)
+        self.Sa = len(active_sources)
+        self.N = len(images)
+        assert all(len(row) == self.N for row in patches)
+        assert psf_K > 0
+        if self.Sa != 1:
+            raise NotImplementedError("the MI355X engine evaluates Sa = 1 (production configuration, "
+                                      "ParallelRun.jl:482); got %d active sources" % self.Sa)
+        self.psf_K = psf_K
+        self.images = images
+        self.patches = patches
+        self.active_sources = list(active_sources)
+        self.include_kl = include_kl
+        a = self.active_sources[0]
+        nbrs = [[] for _ in range(self.S)]
+        nbrs[a] = [s for s in range(self.S) if s != a]  # every other local source is a neighbour
+        self._ctx = FieldContext(images, patches, nbrs, psf_K=psf_K, prior=prior, device=device)
+
+
+def _eval(ea: ElboArgs, vp, flags: int) -> SensitiveFloat:
+    vp = np.asarray(vp, dtype=np.float64).reshape(ea.S, P)
+    assert np.all(np.isfinite(vp)), "vp contains NaNs or Infs"
+    v, d, h, cnt, _ = ea._ctx.eval_batch(vp, ea.active_sources, flags)
+    return SensitiveFloat(float(v[0]), None if d is None else d[0].copy(), None if h is None else h[0].copy(),
+                          int(cnt[0, 0]), int(cnt[0, 1]))
+
+
+def elbo_likelihood(ea: ElboArgs, vp, calculate_gradient: bool = True, calculate_hessian: bool = True):
+    """elbo_objective.jl:400-474"""
+    flags = (FLAG_GRAD if calculate_gradient else 0) | (FLAG_HESS if calculate_gradient and calculate_hessian else 0)
+    return _eval(ea, vp, flags)
+
+
+def elbo(ea: ElboArgs, vp, calculate_gradient: bool = True, calculate_hessian: bool = True):
+    """elbo_objective.jl:482-492"""
+    flags = (FLAG_GRAD if calculate_gradient else 0) | (FLAG_HESS if calculate_gradient and calculate_hessian else 0)
+    if ea.include_kl:
+        flags |= FLAG_KL
+    return _eval(ea, vp, flags)

@@ -1,0 +1,229 @@
+"""Host-side data model: images, PSF components, image patches, neighbours.
+
+This is input preparation for the ELBO hot path (it runs once per inference,
+never per elbo() call) and mirrors, name for name, the reference's
+  src/model/image_model.jl:6-38        Image
+  src/model/psf_model.jl:17-75         PsfComponent, get_psf_width, render_psf, ConstantPSFMap
+  src/model/imaged_sources.jl:10-244   boxes, ImagePatch, box_from_catalog, get_sky_patches,
+                                       choose_patch_radius, find_neighbors
+  src/model/wcs_utils.jl:14-18         linear_world_to_pix
+Only linear (affine) WCS is supported: the synthetic configurations use the
+identity WCS of test/SampleData.jl:30-34.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+import math
+import numpy as np
+
+from .params import CatalogEntry
+
+STAMP = 51
+
+
+def julia_round(x: float) -> int:
+    """round(Int, x) with ties to even (RoundNearest), imaged_sources.jl:126-129."""
+    return int(np.rint(x))
+
+
+def make_psf(alpha: Sequence[float], xi: Sequence[Sequence[float]], tau: Sequence[np.ndarray]) -> np.ndarray:
+    """K x 6 array {alphaBar, xiBar1, xiBar2, tauBar11, tauBar12, tauBar22} (psf_model.jl:17-29)."""
+    out = np.zeros((len(alpha), 6))
+    for k in range(len(alpha)):
+        t = np.asarray(tau[k], dtype=float)
+        out[k] = [alpha[k], xi[k][0], xi[k][1], t[0, 0], t[0, 1], t[1, 1]]
+    return out
+
+
+def get_psf_width(psf: np.ndarray, width_scale: float = 1.0) -> float:
+    """psf_model.jl:32-52"""
+    alpha_norm = psf[:, 0].sum()
+    cov = np.zeros((2, 2))
+    for a, x1, x2, t11, t12, t22 in psf:
+        xi = np.array([x1, x2])
+        cov += a * (np.outer(xi, xi) + np.array([[t11, t12], [t12, t22]])) / alpha_norm
+    return width_scale * math.sqrt(np.linalg.eigvalsh(cov)[-1]) * alpha_norm
+
+
+def render_psf(psf: np.ndarray, dims: Tuple[int, int] = (STAMP, STAMP)) -> np.ndarray:
+    """psf_model.jl:61-75: stamp[i, j] = sum_k alphaBar_k N((i, j) - center; xiBar_k, tauBar_k)."""
+    c0, c1 = (dims[0] + 1) / 2, (dims[1] + 1) / 2
+    ii = np.arange(1, dims[0] + 1)[:, None] - c0
+    jj = np.arange(1, dims[1] + 1)[None, :] - c1
+    stamp = np.zeros(dims)
+    for a, x1, x2, t11, t12, t22 in psf:
+        det = t11 * t22 - t12 * t12
+        d0, d1 = ii - x1, jj - x2
+        q = (t22 * d0 * d0 - 2 * t12 * d0 * d1 + t11 * d1 * d1) / det
+        stamp += a * np.exp(-0.5 * q) / (2 * math.pi * math.sqrt(det))
+    return stamp
+
+
+@dataclass
+class ConstantPSFMap:
+    """psf_model.jl:89-92"""
+    stamp: np.ndarray
+
+    def __call__(self, x, y):
+        return self.stamp.copy()
+
+
+@dataclass
+class Image:
+    """image_model.jl:6-38.  pixels/sky are H x W (first index = row h), float32."""
+    pixels: np.ndarray
+    b: int                       # band 1..5
+    psf: np.ndarray              # K x 6
+    sky: np.ndarray              # H x W float32, nmgy
+    nelec_per_nmgy: np.ndarray   # H float32
+    psfmap: ConstantPSFMap
+    wcs_jacobian: np.ndarray = field(default_factory=lambda: np.eye(2))  # affine WCS: pix = J (world - w0) + p0
+    wcs_world0: np.ndarray = field(default_factory=lambda: np.zeros(2))
+    wcs_pix0: np.ndarray = field(default_factory=lambda: np.zeros(2))
+
+    @property
+    def H(self):
+        return self.pixels.shape[0]
+
+    @property
+    def W(self):
+        return self.pixels.shape[1]
+
+    def world_to_pix(self, world):
+        return self.wcs_jacobian @ (np.asarray(world, float) - self.wcs_world0) + self.wcs_pix0
+
+    def pix_to_world(self, pix):
+        return np.linalg.solve(self.wcs_jacobian, np.asarray(pix, float) - self.wcs_pix0) + self.wcs_world0
+
+
+Box = Tuple[Tuple[int, int], Tuple[int, int]]  # ((first, last), (first, last)), inclusive, 1-based
+
+
+def clamp_box(box: Box, dims: Tuple[int, int]) -> Box:
+    """imaged_sources.jl:10-14 (empty ranges allowed)."""
+    def cl(v, lo, hi):
+        return min(max(v, lo), hi)
+    return ((cl(box[0][0], 1, dims[0] + 1), cl(box[0][1], 0, dims[0])),
+            (cl(box[1][0], 1, dims[1] + 1), cl(box[1][1], 0, dims[1])))
+
+
+def _ranges_overlap(r1, r2) -> bool:
+    return r1[0] <= r2[1] and r2[0] <= r1[1]
+
+
+def boxes_overlap(b1: Box, b2: Box) -> bool:
+    """imaged_sources.jl:36-40"""
+    return _ranges_overlap(b1[0], b2[0]) and _ranges_overlap(b1[1], b2[1])
+
+
+@dataclass
+class ImagePatch:
+    """imaged_sources.jl:60-117"""
+    box: Box
+    world_center: np.ndarray
+    psf: np.ndarray
+    stamp: np.ndarray              # raw psfmap(pixel_center) output; conditioned + prefiltered downstream
+    wcs_jacobian: np.ndarray
+    pixel_center: np.ndarray
+    bitmap_offset: Tuple[int, int]
+    active_pixel_bitmap: np.ndarray  # H2 x W2 bool
+    stamp_id: int = -1               # index into a shared stamp table (set by the context builder)
+
+    @classmethod
+    def from_box(cls, img: Image, box: Box, stamp_id: int = -1) -> "ImagePatch":
+        box = clamp_box(box, (img.H, img.W))
+        pixel_center = np.array([(box[0][0] + box[0][1]) / 2, (box[1][0] + box[1][1]) / 2])
+        world_center = img.pix_to_world(pixel_center)
+        off = (box[0][0] - 1, box[1][0] - 1)
+        h2 = max(box[0][1] - box[0][0] + 1, 0)
+        w2 = max(box[1][1] - box[1][0] + 1, 0)
+        sub = img.pixels[off[0]:off[0] + h2, off[1]:off[1] + w2]
+        bitmap = ~np.isnan(sub)
+        return cls(box, world_center, img.psf, img.psfmap(pixel_center[0], pixel_center[1]),
+                   img.wcs_jacobian.copy(), pixel_center, off, bitmap, stamp_id)
+
+
+def box_around_point(img: Image, world_center, pixel_radius: float) -> Box:
+    """imaged_sources.jl:120-136"""
+    pc = img.world_to_pix(world_center)
+    return ((julia_round(pc[0] - pixel_radius), julia_round(pc[0] + pixel_radius)),
+            (julia_round(pc[1] - pixel_radius), julia_round(pc[1] + pixel_radius)))
+
+
+def choose_patch_radius(ce: CatalogEntry, img: Image, width_scale=1.0, max_radius=25) -> float:
+    """imaged_sources.jl:197-223"""
+    psf_width = get_psf_width(img.psf, width_scale=width_scale)
+    obj_width = 0.0 if ce.is_star else width_scale * ce.gal_radius_px / 0.67
+    obj_width += psf_width
+    flux = ce.star_fluxes[img.b - 1] if ce.is_star else ce.gal_fluxes[img.b - 1]
+    if not flux > 0.:
+        raise AssertionError("flux > 0")
+    epsilon = float(img.sky[img.H // 2 - 1, img.W // 2 - 1])
+    pdf_90 = math.exp(-0.5 * 1.64 ** 2) / (math.sqrt(2 * math.pi) * obj_width)
+    pdf_target = min(pdf_90, epsilon / (20 * flux))
+    rhs = math.log(pdf_target) + 0.5 * math.log(2 * math.pi) + math.log(obj_width)
+    radius_req = math.sqrt(-2 * obj_width ** 2 * rhs)
+    return min(radius_req, max_radius)
+
+
+def box_from_catalog(img: Image, ce: CatalogEntry, width_scale=1.0, max_radius=25) -> Box:
+    """imaged_sources.jl:147-160"""
+    r = choose_patch_radius(ce, img, width_scale=width_scale, max_radius=max_radius)
+    return box_around_point(img, ce.pos, r)
+
+
+def get_sky_patches(images: Sequence[Image], catalog: Sequence[CatalogEntry],
+                    radius_override_pix: float = math.nan) -> List[List[ImagePatch]]:
+    """imaged_sources.jl:165-182.  Returns patches[s][n]."""
+    out = []
+    for ce in catalog:
+        row = []
+        for img in images:
+            if math.isnan(radius_override_pix):
+                box = box_from_catalog(img, ce, width_scale=1.2)
+            else:
+                box = box_around_point(img, ce.pos, radius_override_pix)
+            row.append(ImagePatch.from_box(img, box))
+        out.append(row)
+    return out
+
+
+def find_neighbors(patches: List[List[ImagePatch]], target: int) -> List[int]:
+    """imaged_sources.jl:232-244"""
+    out = []
+    for i in range(len(patches)):
+        if i == target:
+            continue
+        for j in range(len(patches[i])):
+            if boxes_overlap(patches[target][j].box, patches[i][j].box):
+                out.append(i)
+                break
+    return out
+
+
+def neighbor_map(patches: List[List[ImagePatch]]) -> List[List[int]]:
+    """find_neighbors for every source, via a sort-based sweep instead of the O(S^2 N) scan
+    (same result, ascending order like the reference's loop)."""
+    S = len(patches)
+    if S == 0:
+        return []
+    N = len(patches[0])
+    nbrs = [set() for _ in range(S)]
+    for n in range(N):
+        lo_h = np.array([patches[s][n].box[0][0] for s in range(S)])
+        hi_h = np.array([patches[s][n].box[0][1] for s in range(S)])
+        lo_w = np.array([patches[s][n].box[1][0] for s in range(S)])
+        hi_w = np.array([patches[s][n].box[1][1] for s in range(S)])
+        order = np.argsort(lo_h, kind="stable")
+        for a_i, a in enumerate(order):
+            for b in order[a_i + 1:]:
+                if lo_h[b] > hi_h[a]:
+                    break
+                if lo_w[a] <= hi_w[b] and lo_w[b] <= hi_w[a] and lo_h[a] <= hi_h[b]:
+                    nbrs[a].add(int(b))
+                    nbrs[b].add(int(a))
+    return [sorted(x) for x in nbrs]
+
+
+def linear_world_to_pix(wcs_jacobian, world_center, pixel_center, world):
+    """wcs_utils.jl:14-18"""
+    return wcs_jacobian @ (np.asarray(world, float) - world_center) + pixel_center

@@ -1,0 +1,242 @@
+"""Synthetic SDSS-shaped fields: input preparation for tests and bench.
+
+Recipe, following the reference's data-free construction paths:
+  AccuracyBenchmark.make_image / make_template_images (AccuracyBenchmark.jl:553-570, 694-727):
+      constant sky and nelec_per_nmgy per band, ConstantPSFMap(render_psf(psf, (51, 51)));
+  test/SampleData.jl:30-34: identity WCS;
+  Synthetic.gen_image! (Synthetic.jl:15-47): expected nmgy = sky + sum of star / galaxy light over
+      radius-25 boxes (Model.write_star_nmgy!, write_galaxy_nmgy!, fsm_util.jl:349-400), times
+      nelec_per_nmgy, Poisson sampled, stored Float32;
+  AccuracyBenchmark.draw_source_params (AccuracyBenchmark.jl:400-452): catalog drawn from the prior.
+The reference has no in-tree numeric defaults for sky, iota and PSF width; the values below are
+builder-chosen, SDSS-like, and fixed.
+"""
+import json
+import math
+import os
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from . import cabi
+from .model import (ConstantPSFMap, Image, ImagePatch, box_around_point, get_sky_patches, make_psf, neighbor_map,
+                    render_psf)
+from .params import CatalogEntry, catalog_init_source, perturb_params
+
+SKY_NMGY = (0.20, 0.35, 0.60, 0.95, 1.40)
+NELEC_PER_NMGY = (180.0, 750.0, 820.0, 600.0, 130.0)
+PSF_ALPHA = (0.8, 0.2)
+PSF_SIGMA = (1.25, 2.6)
+PSF_BAND_SCALE = (1.10, 1.05, 1.00, 0.98, 1.00)
+PRIOR_PROBABILITY_OF_STAR = 0.28
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_prior() -> dict:
+    with open(os.path.join(_HERE, "prior_tables.json")) as f:
+        return json.load(f)
+
+
+def galaxy_prototypes():
+    """light_source_model.jl:45-75 -> (eta[2][8], nu[2][8])"""
+    dev_amp = np.array([4.26347652e-2, 2.40127183e-1, 6.85907632e-1, 1.51937350,
+                        2.83627243, 4.46467501, 5.72440830, 5.60989349])
+    dev_var = np.array([2.23759216e-4, 1.00220099e-3, 4.18731126e-3, 1.69432589e-2,
+                        6.84850479e-2, 2.87207080e-1, 1.33320254, 8.40215071])
+    exp_amp = np.array([2.34853813e-3, 3.07995260e-2, 2.23364214e-1, 1.17949102, 4.33873750, 5.99820770])
+    exp_var = np.array([1.20078965e-3, 8.84526493e-3, 3.91463084e-2, 1.39976817e-1, 4.60962500e-1, 1.50159566])
+    eta = np.zeros((2, 8)); nu = np.zeros((2, 8))
+    eta[0] = dev_amp / dev_amp.sum(); nu[0] = dev_var / 1.078031 ** 2
+    eta[1, :6] = exp_amp / exp_amp.sum(); nu[1, :6] = exp_var / 0.928896 ** 2
+    return eta, nu
+
+
+def band_psf(b: int) -> np.ndarray:
+    s = PSF_BAND_SCALE[b]
+    return make_psf(PSF_ALPHA, [(0.0, 0.0)] * 2, [np.eye(2) * (sig * s) ** 2 for sig in PSF_SIGMA])
+
+
+def blank_images(H: int, W: int) -> List[Image]:
+    images = []
+    for b in range(5):
+        psf = band_psf(b)
+        images.append(Image(pixels=np.zeros((H, W), dtype=np.float32), b=b + 1, psf=psf,
+                            sky=np.full((H, W), SKY_NMGY[b], dtype=np.float32),
+                            nelec_per_nmgy=np.full(H, NELEC_PER_NMGY[b], dtype=np.float32),
+                            psfmap=ConstantPSFMap(render_psf(psf, (51, 51)))))
+    return images
+
+
+# ---- value-only light densities (numpy; used only to paint synthetic pixels) ----------------------
+def _bspline_w(f):
+    o = 1.0 - f
+    return (o ** 3 / 6, 2.0 / 3 - f * f + f ** 3 / 2, 2.0 / 3 - o * o + o ** 3 / 2, f ** 3 / 6)
+
+
+def star_density(coef: np.ndarray, xh: np.ndarray, xw: np.ndarray) -> np.ndarray:
+    """softpluslikeinv(itp[xh, xw]) on arrays of 1-based stamp coordinates (fsm_util.jl:221-237)."""
+    ix = np.clip(np.floor(xh).astype(int), 1, 50)
+    iy = np.clip(np.floor(xw).astype(int), 1, 50)
+    wx = _bspline_w(xh - ix)
+    wy = _bspline_w(xw - iy)
+    y = np.zeros(np.broadcast(xh, xw).shape)
+    for a in range(4):
+        for b in range(4):
+            y = y + coef[ix - 1 + a, iy - 1 + b] * wx[a] * wy[b]
+    return np.where(y < 0, 1e-3 * np.exp(np.minimum(y, 0)), 1e-3 * (y + 1))
+
+
+def galaxy_density(psf: np.ndarray, m_pos, frac_dev, axis_ratio, angle, radius, hh, ww) -> np.ndarray:
+    """sum over PSF (x) prototype components (fsm_util.jl:37-65, 194-219), value only."""
+    eta, nu = galaxy_prototypes()
+    cp, sp = math.cos(angle), math.sin(angle)
+    ab = axis_ratio ** 2 - 1
+    s2 = radius ** 2
+    x11 = s2 * (1 + ab * sp * sp); x22 = s2 * (1 + ab * cp * cp); x12 = -s2 * cp * sp * ab
+    out = np.zeros(np.broadcast(hh, ww).shape)
+    for i in range(2):
+        th = frac_dev if i == 0 else 1.0 - frac_dev
+        for j in range(8 if i == 0 else 6):
+            for a, xi1, xi2, t11, t12, t22 in psf:
+                s11, s12, s22 = t11 + nu[i, j] * x11, t12 + nu[i, j] * x12, t22 + nu[i, j] * x22
+                det = s11 * s22 - s12 * s12
+                d1 = hh - (xi1 + m_pos[0]); d2 = ww - (xi2 + m_pos[1])
+                q = (s22 * d1 * d1 - 2 * s12 * d1 * d2 + s11 * d2 * d2) / det
+                out = out + th * a * eta[i, j] / (2 * math.pi * math.sqrt(det)) * np.exp(-0.5 * q)
+    return out
+
+
+def render_expected_nmgy(images: List[Image], catalog: List[CatalogEntry]) -> List[np.ndarray]:
+    """Synthetic.gen_image! with expectation=true, before the nelec scaling: sky + sources, in nmgy."""
+    out = []
+    for img in images:
+        nm = img.sky.astype(np.float64).copy()
+        coef = cabi.spline_prefilter(img.psfmap(0, 0))
+        for ce in catalog:
+            box = box_around_point(img, ce.pos, 25)
+            p = ImagePatch.from_box(img, box)
+            (h0, h1), (w0, w1) = p.box
+            if h1 < h0 or w1 < w0:
+                continue
+            hh = np.arange(h0, h1 + 1, dtype=float)[:, None]
+            ww = np.arange(w0, w1 + 1, dtype=float)[None, :]
+            m = p.wcs_jacobian @ (np.asarray(ce.pos, float) - p.world_center) + p.pixel_center
+            if ce.is_star:
+                dens = star_density(coef, hh - m[0] + 26, ww - m[1] + 26) * ce.star_fluxes[img.b - 1]
+            else:
+                dens = galaxy_density(img.psf, m, ce.gal_frac_dev, ce.gal_axis_ratio, ce.gal_angle,
+                                      ce.gal_radius_px, hh, ww) * ce.gal_fluxes[img.b - 1]
+            nm[h0 - 1:h1, w0 - 1:w1] += dens
+        out.append(nm)
+    return out
+
+
+def gen_images(images: List[Image], catalog: List[CatalogEntry], rng: np.random.Generator,
+               expectation: bool = False) -> None:
+    """Synthetic.gen_images! (Synthetic.jl:30-58)"""
+    for img, nm in zip(images, render_expected_nmgy(images, catalog)):
+        el = nm * img.nelec_per_nmgy.astype(np.float64)[:, None]
+        if not expectation:
+            el = rng.poisson(el).astype(np.float64)
+        img.pixels = el.astype(np.float32)
+
+
+# ---- catalogs -----------------------------------------------------------------------------------
+def fluxes_from_colors(r_flux: float, colors) -> np.ndarray:
+    """Synthetic.sample_fluxes (Synthetic.jl:66-77)"""
+    l = np.zeros(5)
+    l[2] = r_flux
+    l[3] = l[2] * math.exp(colors[2])
+    l[4] = l[3] * math.exp(colors[3])
+    l[1] = l[2] / math.exp(colors[1])
+    l[0] = l[1] / math.exp(colors[0])
+    return l
+
+
+def draw_source(prior: dict, rng: np.random.Generator, pos, force_star: Optional[bool] = None) -> CatalogEntry:
+    """AccuracyBenchmark.draw_source_params (AccuracyBenchmark.jl:400-452)"""
+    is_star = bool(rng.random() < PRIOR_PROBABILITY_OF_STAR) if force_star is None else force_star
+    i = 0 if is_star else 1
+    flux_r = math.exp(rng.normal(prior["flux_mean"][i], math.sqrt(prior["flux_var"][i])))
+    d = rng.choice(8, p=np.asarray(prior["k"][i]) / np.sum(prior["k"][i]))
+    cov = np.asarray(prior["color_cov"][i][d]).reshape(4, 4)
+    colors = rng.multivariate_normal(np.asarray(prior["color_mean"][i][d]), cov)
+    fl = fluxes_from_colors(flux_r, colors)
+    if is_star:
+        return CatalogEntry(np.asarray(pos, float), True, fl, fl.copy(), 0.5, 0.8, 0.0, 0.2)
+    radius = math.exp(rng.normal(prior["gal_radius_px_mean"], math.sqrt(prior["gal_radius_px_var"])))
+    angle = math.radians(rng.uniform(0, 180))
+    axis_ratio = rng.beta(2, 2)
+    frac_dev = rng.beta(0.5, 0.5)
+    return CatalogEntry(np.asarray(pos, float), False, fl.copy(), fl, float(frac_dev), float(axis_ratio),
+                        float(angle), float(radius))
+
+
+@dataclass
+class Field:
+    images: List[Image]
+    catalog: List[CatalogEntry]
+    patches: List[List[ImagePatch]]
+    neighbors: List[List[int]]
+    vp: np.ndarray          # S x 44
+    name: str = ""
+
+
+def make_field(H: int, W: int, n_sources: int, seed: int, stars_only: bool = False, perturb: bool = True,
+               nan_fraction: float = 0.0, margin: int = 26, name: str = "") -> Field:
+    """Configs 2 / 3 of SURVEY.md 8(d): uniform positions with a margin, prior-drawn sources."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    prior = load_prior()
+    images = blank_images(H, W)
+    catalog = []
+    for _ in range(n_sources):
+        pos = (rng.uniform(margin, H - margin), rng.uniform(margin, W - margin))
+        catalog.append(draw_source(prior, rng, pos, force_star=True if stars_only else None))
+    gen_images(images, catalog, rng)
+    if nan_fraction > 0:
+        for img in images:
+            mask = rng.random(img.pixels.shape) < nan_fraction
+            img.pixels[mask] = np.nan
+    patches = get_sky_patches(images, catalog)
+    nbrs = neighbor_map(patches)
+    vp = [catalog_init_source(ce) for ce in catalog]
+    if perturb:
+        perturb_params(vp)
+    return Field(images, catalog, patches, nbrs, np.stack(vp), name)
+
+
+SAMPLE_STAR_FLUXES = np.array([4.451805E+03, 1.491065E+03, 2.264545E+03, 2.027004E+03, 1.846822E+04])
+SAMPLE_GALAXY_FLUXES = np.array([1.377666E+01, 5.635334E+01, 1.258656E+02, 1.884264E+02, 2.351820E+02]) * 100
+
+
+def sample_ce(pos, is_star: bool) -> CatalogEntry:
+    """test/SampleData.jl:120-123"""
+    return CatalogEntry(np.asarray(pos, float), is_star, SAMPLE_STAR_FLUXES.copy(), SAMPLE_GALAXY_FLUXES.copy(),
+                        0.1, 0.7, math.pi / 4, 4.0)
+
+
+def make_sample_dataset(kind: str = "star", seed: int = 1, perturb: bool = True) -> Field:
+    """gen_sample_star_dataset / gen_sample_galaxy_dataset / gen_two_body_dataset /
+    gen_three_body_dataset analogues (test/SampleData.jl:161-236) on synthetic image metadata."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if kind == "star":
+        H, W, catalog = 20, 23, [sample_ce([10.1, 12.2], True)]
+    elif kind == "galaxy":
+        H, W, catalog = 20, 23, [sample_ce([8.5, 9.6], False)]
+    elif kind == "two_body":
+        H, W, catalog = 20, 23, [sample_ce([4.5, 3.6], False), sample_ce([10.1, 12.1], True)]
+    elif kind == "three_body":
+        H, W, catalog = 112, 238, [sample_ce([4.5, 3.6], False), sample_ce([60.1, 82.2], True),
+                                   sample_ce([71.3, 100.4], False)]
+    else:
+        raise ValueError(kind)
+    images = blank_images(H, W)
+    gen_images(images, catalog, rng)
+    patches = get_sky_patches(images, catalog)
+    nbrs = neighbor_map(patches)
+    vp = [catalog_init_source(ce) for ce in catalog]
+    if perturb:
+        perturb_params(vp)
+    return Field(images, catalog, patches, nbrs, np.stack(vp), kind)

@@ -1,0 +1,192 @@
+/*
+ * celeste_mi355x.h -- C ABI of the MI355X-native Celeste ELBO engine.
+ *
+ * Drop-in boundary.  Every entry point below names the
+ * reference interface (Celeste.jl, Julia 0.6, paths relative to the reference
+ * checkout) that it replaces.  Plain C types only: no torch, no HIP types in
+ * the signatures (a stream is passed as void*).
+ *
+ *   reference                                               this library
+ *   ------------------------------------------------------  --------------------------
+ *   ElboArgs(images, patches, active_sources)               celeste_ctx_create
+ *       src/deterministic_vi/elbo_args.jl:165-211
+ *   elbo(ea, vp, elbo_vars, bvn_bundle) -> SensitiveFloat    celeste_elbo_eval
+ *       src/deterministic_vi/elbo_objective.jl:482-492      celeste_elbo_eval_batch[_device]
+ *   elbo_likelihood(ea, vp, ...)                             same, without CELESTE_FLAG_KL
+ *       src/deterministic_vi/elbo_objective.jl:400-474
+ *   ImagePatch ctor: stamp conditioning + spline prefilter  celeste_spline_prefilter
+ *       src/model/imaged_sources.jl:97-107
+ *   PSF.get_psf_at_point / Model.render_psf                  celeste_psf_raster
+ *       src/PSF.jl:150-161, src/model/psf_model.jl:61-75
+ *   estimate_time (sum of active pixels)                     celeste_ctx_work_stats
+ *       src/ParallelRun.jl:45-47
+ *
+ * Conventions (all taken from the reference):
+ *   - matrices are column-major with the first index (h, image row) fastest;
+ *     element [h,w] of an H x W image is at  h-1 + H*(w-1)  (1-based h,w);
+ *   - pixel coordinates are the real pair (h, w), 1-based;
+ *   - a source's variational parameters are 44 doubles in CanonicalParams order
+ *     (src/model/param_set.jl:76-107);
+ *   - gradient d is 44 doubles, Hessian h is 44 x 44 doubles, column-major,
+ *     emitted exactly symmetric.
+ */
+#ifndef CELESTE_MI355X_H
+#define CELESTE_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CELESTE_P 44            /* length(CanonicalParams), param_set.jl:107 */
+#define CELESTE_NUM_BANDS 5
+#define CELESTE_STAMP 51        /* psfmap stamp edge, AccuracyBenchmark.jl:559 */
+#define CELESTE_COEF 53         /* padded B-spline coefficient edge */
+#define CELESTE_NUM_COLOR_COMPONENTS 8
+
+/* status codes (replace the reference's @assert / AssertionError) */
+enum {
+    CELESTE_OK = 0,
+    CELESTE_ERR_INVALID_ARG = 1,
+    CELESTE_ERR_NONFINITE_INPUT = 2,   /* elbo_objective.jl:487 */
+    CELESTE_ERR_NONFINITE_RESULT = 3,  /* elbo_args.jl:145-149 */
+    CELESTE_ERR_HIP = 4,
+    CELESTE_ERR_NO_DEVICE = 5,
+    CELESTE_ERR_ALLOC = 6
+};
+
+/* evaluation flags: has_gradient / has_hessian of the result SensitiveFloat
+ * (SensitiveFloats.jl:37-47; has_hessian implies has_gradient) and
+ * ElboArgs.include_kl (elbo_args.jl:189). */
+enum {
+    CELESTE_FLAG_GRAD = 1u,
+    CELESTE_FLAG_HESS = 2u,
+    CELESTE_FLAG_KL = 4u
+};
+
+/* Model.Image (src/model/image_model.jl:6-38).  Borrowed for the duration of
+ * celeste_ctx_create only. */
+typedef struct celeste_image_t {
+    int32_t H;                    /* rows */
+    int32_t W;                    /* columns */
+    int32_t band;                 /* 1..5 (u,g,r,i,z) */
+    int32_t reserved;
+    const float *pixels;          /* H*W electrons; NaN = masked */
+    const float *sky;             /* H*W nanomaggies (img.sky[h,w]) */
+    const float *nelec_per_nmgy;  /* H, one per row */
+} celeste_image_t;
+
+/* Model.ImagePatch (src/model/imaged_sources.jl:60-71). */
+typedef struct celeste_patch_t {
+    int32_t off_h;                /* bitmap_offset[1] = first(box[1]) - 1 */
+    int32_t off_w;                /* bitmap_offset[2] */
+    int32_t H2;                   /* size(active_pixel_bitmap, 1); may be 0 */
+    int32_t W2;
+    const uint8_t *bitmap;        /* H2*W2 column-major; NULL => !isnan(pixel) */
+    double wcs_jacobian[4];       /* 2x2 column-major */
+    double world_center[2];
+    double pixel_center[2];
+    const double *psf;            /* psf_K x {alphaBar, xiBar1, xiBar2, tauBar11, tauBar12, tauBar22} */
+    int32_t stamp;                /* index into celeste_problem_t.stamps */
+    int32_t reserved;
+} celeste_patch_t;
+
+/* Model.PriorParams (src/model/light_source_model.jl:78-132).  index 0 = star,
+ * 1 = galaxy. */
+typedef struct celeste_prior_t {
+    double is_star[2];
+    double flux_mean[2];
+    double flux_var[2];
+    double k[2][8];               /* prior.k[:, i] */
+    double color_mean[2][8][4];   /* prior.color_mean[:, d, i] */
+    double color_cov[2][8][16];   /* prior.color_cov[:, :, d, i], column-major 4x4 */
+    double gal_radius_px_mean;
+    double gal_radius_px_var;
+} celeste_prior_t;
+
+/* The whole-field problem: all images, every catalogued source's patches and
+ * the neighbour graph (Model.find_neighbors, imaged_sources.jl:232-244).
+ * Evaluating target t is the reference's
+ *     ElboArgs(images, patches[[t; neighbors(t)], :], [1])
+ * (ParallelRun.jl:468-488). */
+typedef struct celeste_problem_t {
+    int32_t n_images;
+    int32_t n_sources;
+    int32_t psf_K;                /* ElboArgs.psf_K, default 2 */
+    int32_t n_stamps;
+    const celeste_image_t *images;      /* n_images */
+    const celeste_patch_t *patches;     /* [s * n_images + n] */
+    const double *stamps;               /* n_stamps x 51 x 51, raw psfmap(...) output */
+    const int64_t *nbr_offsets;         /* n_sources + 1 (CSR) */
+    const int32_t *nbr_index;           /* 0-based source ids */
+    const celeste_prior_t *prior;       /* NULL => built-in cfg/{star,gal}_prior tables */
+} celeste_problem_t;
+
+typedef struct celeste_ctx celeste_ctx_t;
+
+/* Per-sweep work statistics. */
+typedef struct celeste_work_stats_t {
+    int64_t n_targets;
+    int64_t active_pixel_visits;    /* sum over targets, images of visited pixels */
+    int64_t patch_rows;             /* sum of H2 */
+    int64_t neighbor_links;         /* sum of K_s */
+    int64_t algorithmic_bytes;      /* 9 A + 4 R + 352 (1+K) + 200 N (1+K) + 8288 per target */
+} celeste_work_stats_t;
+
+int celeste_version(void);
+const char *celeste_strerror(int status);
+
+/* Uploads images, patch descriptors, conditioned spline coefficients and the
+ * neighbour graph to HBM of `device`.  Fails with CELESTE_ERR_NO_DEVICE when no
+ * HIP device is present: there is no CPU fallback. */
+int celeste_ctx_create(const celeste_problem_t *problem, int device, celeste_ctx_t **out);
+void celeste_ctx_destroy(celeste_ctx_t *ctx);
+
+/* elbo(ea, vp) for one target (Sa = 1, neighbours value-only).
+ * vp: n_sources x 44 host doubles (row s = source s).  Outputs may be NULL when
+ * the corresponding flag is off.  Counters: elbo_args.jl:62-63. */
+int celeste_elbo_eval(celeste_ctx_t *ctx, const double *vp, int32_t target, uint32_t flags,
+                      double *v, double *d, double *h,
+                      int64_t *n_active_px, int64_t *n_inactive_px);
+
+/* One launch for a whole batch of targets that may be evaluated together
+ * (a Cyclades batch, or every source of the field for an evaluate-only sweep).
+ * Host pointers; v[n], d[n*44], h[n*44*44], counters[n*2], status[n]. */
+int celeste_elbo_eval_batch(celeste_ctx_t *ctx, const double *vp, int32_t n_targets,
+                            const int32_t *targets, uint32_t flags,
+                            double *v, double *d, double *h,
+                            int64_t *counters, int32_t *status);
+
+/* Same, all pointers already in HBM, asynchronous on `stream` (a hipStream_t,
+ * NULL = default stream).  d_status[n] receives per-target status codes. */
+int celeste_elbo_eval_batch_device(celeste_ctx_t *ctx, const double *d_vp, int32_t n_targets,
+                                   const int32_t *d_targets, uint32_t flags,
+                                   double *d_v, double *d_d, double *d_h,
+                                   int64_t *d_counters, int32_t *d_status, void *stream);
+
+/* HIP-event timing of the kernels of the most recent batch launch, on the
+ * stream they were launched on.  Enable before the launch; read after the
+ * stream has been synchronised.  ms[0] = per-source preparation kernel,
+ * ms[1] = pixel kernel, ms[2] = 44-space lift kernel. */
+int celeste_ctx_enable_timing(celeste_ctx_t *ctx, int enable);
+int celeste_ctx_last_kernel_ms(celeste_ctx_t *ctx, float ms[3]);
+
+int celeste_ctx_work_stats(celeste_ctx_t *ctx, int32_t n_targets, const int32_t *targets,
+                           celeste_work_stats_t *out);
+
+/* ImagePatch ctor arithmetic: max(.,0), +1e-6, normalise, softpluslike, then the
+ * cubic B-spline prefilter with Line() boundaries on a padded 53x53 grid. */
+int celeste_spline_prefilter(const double *stamp51, double *coef53);
+
+/* Gaussian-mixture PSF raster sum_k alphaBar_k N(x; xiBar_k, tauBar_k) on the
+ * grid rows x cols (get_psf_at_point; render_psf uses rows = cols = -25:25).
+ * psf: K x 6 as in celeste_patch_t.  out: n_rows x n_cols column-major, host. */
+int celeste_psf_raster(int device, const double *psf, int32_t K,
+                       const double *rows, int32_t n_rows,
+                       const double *cols, int32_t n_cols, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CELESTE_MI355X_H */

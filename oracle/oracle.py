@@ -1,0 +1,142 @@
+"""ctypes wrapper of oracle/libceleste_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The problem marshalling (celeste_problem_t) is shared with the product's C ABI so that the
+oracle and the HIP engine see byte-identical inputs.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+import celeste_jl_amd  # noqa: E402,F401
+from celeste_jl_amd import cabi  # noqa: E402
+
+LIB_PATH = os.path.join(_HERE, "libceleste_oracle.so")
+P = 44
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(LIB_PATH) or \
+            os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "celeste_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        dp, ip, lp = cabi.c_double_p, cabi.c_int32_p, cabi.c_int64_p
+        L.celeste_oracle_elbo.argtypes = [C.POINTER(cabi.ProblemT), dp, C.c_int32, C.c_uint32, dp, dp, dp, lp, lp]
+        L.celeste_oracle_elbo_batch.argtypes = [C.POINTER(cabi.ProblemT), dp, C.c_int32, ip, C.c_uint32, dp, dp, dp,
+                                                lp, ip, C.c_int32]
+        L.celeste_oracle_get_bvn_cov.argtypes = [C.c_double, C.c_double, C.c_double, dp]
+        L.celeste_oracle_get_bvn_cov.restype = None
+        L.celeste_oracle_source_brightness.argtypes = [dp, dp, dp]
+        L.celeste_oracle_source_brightness.restype = None
+        L.celeste_oracle_galaxy_prototypes.argtypes = [dp, dp]
+        L.celeste_oracle_galaxy_prototypes.restype = None
+        L.celeste_oracle_spline_coefs.argtypes = [dp, dp]
+        L.celeste_oracle_spline_coefs.restype = None
+        L.celeste_oracle_spline_value.argtypes = [dp, C.c_double, C.c_double]
+        L.celeste_oracle_spline_value.restype = C.c_double
+        L.celeste_oracle_subtract_kl.argtypes = [C.POINTER(cabi.PriorT), dp, dp, dp, dp]
+        L.celeste_oracle_subtract_kl.restype = None
+        L.celeste_oracle_categorical_kl.argtypes = [dp, dp, C.c_int]
+        L.celeste_oracle_categorical_kl.restype = C.c_double
+        L.celeste_oracle_gaussian_kl.argtypes = [C.c_double] * 4
+        L.celeste_oracle_gaussian_kl.restype = C.c_double
+        L.celeste_oracle_psf_at_point.argtypes = [dp, C.c_int, C.c_double, C.c_double]
+        L.celeste_oracle_psf_at_point.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(cabi.c_double_p)
+
+
+def elbo_batch(problem: "cabi.Problem", vp, targets, flags=cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL,
+               n_threads: int = 0):
+    """Returns (v[n], d[n,44], h[n,44,44], counters[n,2], status[n]) from the CPU restatement."""
+    L = lib()
+    vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(problem.n_sources, P))
+    tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32))
+    n = tg.size
+    v = np.zeros(n); d = np.zeros((n, P)); h = np.zeros((n, P, P))
+    cnt = np.zeros((n, 2), dtype=np.int64); status = np.zeros(n, dtype=np.int32)
+    if n_threads <= 0:
+        n_threads = os.cpu_count() or 1
+    L.celeste_oracle_elbo_batch(C.byref(problem.c), _dp(vp), n, tg.ctypes.data_as(cabi.c_int32_p), flags, _dp(v),
+                                _dp(d), _dp(h), cnt.ctypes.data_as(cabi.c_int64_p),
+                                status.ctypes.data_as(cabi.c_int32_p), n_threads)
+    # h is column-major per target and symmetric (upper triangle mirrored)
+    return v, d, h.transpose(0, 2, 1).copy(), cnt, status
+
+
+def elbo_one(problem, vp, target, flags=cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL):
+    v, d, h, cnt, st = elbo_batch(problem, vp, [target], flags, n_threads=1)
+    return v[0], d[0], h[0], cnt[0], int(st[0])
+
+
+def get_bvn_cov(ab, angle, scale):
+    out = np.zeros(4)
+    lib().celeste_oracle_get_bvn_cov(ab, angle, scale, _dp(out))
+    return out.reshape(2, 2).T
+
+
+def source_brightness(vs):
+    vs = np.ascontiguousarray(vs, dtype=np.float64)
+    El = np.zeros(10); Ell = np.zeros(10)
+    lib().celeste_oracle_source_brightness(_dp(vs), _dp(El), _dp(Ell))
+    return El.reshape(2, 5).T, Ell.reshape(2, 5).T  # [b, i]
+
+
+def galaxy_prototypes():
+    eta = np.zeros(16); nu = np.zeros(16)
+    lib().celeste_oracle_galaxy_prototypes(_dp(eta), _dp(nu))
+    return eta.reshape(2, 8), nu.reshape(2, 8)
+
+
+def spline_coefs(stamp):
+    st = np.ascontiguousarray(np.asarray(stamp, dtype=np.float64).T).reshape(-1)
+    out = np.zeros(53 * 53)
+    lib().celeste_oracle_spline_coefs(_dp(st), _dp(out))
+    return out.reshape(53, 53).T.copy()
+
+
+def spline_value(coef_hw, x, y):
+    c = np.ascontiguousarray(np.asarray(coef_hw, dtype=np.float64).T).reshape(-1)
+    return lib().celeste_oracle_spline_value(_dp(c), float(x), float(y))
+
+
+def subtract_kl(vs, prior=None):
+    vs = np.ascontiguousarray(vs, dtype=np.float64)
+    v = np.zeros(1); d = np.zeros(P); h = np.zeros(P * P)
+    pr = C.byref(cabi.prior_struct(prior)) if prior is not None else None
+    lib().celeste_oracle_subtract_kl(pr, _dp(vs), _dp(v), _dp(d), _dp(h))
+    return v[0], d, h.reshape(P, P).T.copy()
+
+
+def categorical_kl(p1, p2):
+    p1 = np.ascontiguousarray(p1, dtype=np.float64); p2 = np.ascontiguousarray(p2, dtype=np.float64)
+    return lib().celeste_oracle_categorical_kl(_dp(p1), _dp(p2), p1.size)
+
+
+def gaussian_kl(mu1, var1, mu2, var2):
+    return lib().celeste_oracle_gaussian_kl(mu1, var1, mu2, var2)
+
+
+def psf_at_point(psf, row, col):
+    psf = np.ascontiguousarray(psf, dtype=np.float64)
+    return lib().celeste_oracle_psf_at_point(_dp(psf), psf.shape[0], float(row), float(col))
