@@ -1,0 +1,111 @@
+"""-m gpu: the HIP path, called through the C ABI, against the CPU oracle on identical inputs."""
+import numpy as np
+import pytest
+
+from parity_util import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+ALL = 1 | 2 | 4
+
+
+def _ctx(field, **kw):
+    import celeste_jl_amd as cel
+    return cel.FieldContext(field.images, field.patches, field.neighbors, **kw)
+
+
+@pytest.mark.parametrize("kind", ["star", "galaxy", "two_body", "three_body"])
+def test_sample_datasets(oracle, kind):
+    """config 1 analogues (test/SampleData.jl:161-236)"""
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_sample_dataset(kind)
+    ctx = _ctx(f)
+    tg = list(range(len(f.catalog)))
+    errs = assert_parity(ctx.eval_batch(f.vp, tg, ALL), oracle.elbo_batch(ctx.problem, f.vp, tg, ALL), kind)
+    print(kind, errs)
+
+
+@pytest.mark.parametrize("flags", [0, 4, 1, 1 | 4, 2, ALL])
+def test_flags(oracle, flags):
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_sample_dataset("two_body")
+    ctx = _ctx(f)
+    g = ctx.eval_batch(f.vp, [0, 1], flags)
+    r = oracle.elbo_batch(ctx.problem, f.vp, [0, 1], flags)
+    assert_parity(g, r, "flags=%d" % flags)
+
+
+def test_small_field_with_neighbors(oracle):
+    """mixed star/galaxy field, overlapping patches, 0.5 % NaN pixels (config 3b in miniature)"""
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(160, 200, 40, seed=11, nan_fraction=0.005)
+    assert sum(len(n) for n in f.neighbors) > 0
+    ctx = _ctx(f)
+    tg = list(range(len(f.catalog)))
+    errs = assert_parity(ctx.eval_batch(f.vp, tg, ALL), oracle.elbo_batch(ctx.problem, f.vp, tg, ALL), "field")
+    print(errs)
+
+
+def test_explicit_bitmaps(oracle):
+    """test_elbo.jl:64-130 manipulates active_pixel_bitmap by hand; neighbours' bitmaps gate their light"""
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_sample_dataset("two_body")
+    for n in range(5):
+        f.patches[1][n].active_pixel_bitmap[:] = False
+    f.patches[1][4].active_pixel_bitmap[9:11, 9:11] = True
+    f.patches[0][2].active_pixel_bitmap[3:7, 5] = False
+    ctx = _ctx(f)
+    assert_parity(ctx.eval_batch(f.vp, [0, 1], ALL), oracle.elbo_batch(ctx.problem, f.vp, [0, 1], ALL), "bitmaps")
+
+
+def test_batch_equals_singles():
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(128, 128, 12, seed=5)
+    ctx = _ctx(f)
+    tg = list(range(12))
+    v, d, h, cnt, st = ctx.eval_batch(f.vp, tg, ALL)
+    for t in tg:
+        v1, d1, h1, c1, s1 = ctx.eval_batch(f.vp, [t], ALL)
+        assert v1[0] == v[t] and np.array_equal(d1[0], d[t]) and np.array_equal(h1[0], h[t])
+
+
+def test_nonfinite_input_is_reported():
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_sample_dataset("two_body")
+    ctx = _ctx(f)
+    vp = f.vp.copy(); vp[1, 7] = np.nan
+    with pytest.raises(AssertionError):
+        ctx.eval_batch(vp, [0], ALL)
+    _, _, _, _, st = ctx.eval_batch(vp, [0], ALL, raise_on_error=False)
+    assert st[0] == 2
+
+
+def test_mirror_api_reads_like_the_reference(oracle):
+    """elbo(ea, vp) / elbo_likelihood(ea, vp) with ElboArgs(images, patches, [active])"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_sample_dataset("two_body")
+    ea = cel.ElboArgs(f.images, f.patches, [0])
+    sf = cel.elbo(ea, f.vp)
+    lik = cel.elbo_likelihood(ea, f.vp)
+    ov, od, oh, ocnt, _ = oracle.elbo_batch(ea._ctx.problem, f.vp, [0], ALL)
+    assert abs(sf.v - ov[0]) <= 1e-8 * abs(ov[0])
+    assert sf.has_hessian and sf.d.shape == (44,) and sf.h.shape == (44, 44)
+    assert sf.active_pixel_counter == ocnt[0, 0] and sf.inactive_pixel_counter == ocnt[0, 1]
+    # the k parameters only enter through the KL term
+    assert np.all(lik.d[28:] == 0) and np.any(sf.d[28:] != 0)
+
+
+def test_psf_raster(oracle, lib):
+    """PSF.get_psf_at_point (PSF.jl:150-161) on the default -25:25 grid"""
+    import ctypes as C
+    from celeste_jl_amd import synthetic, cabi
+    psf = np.ascontiguousarray(synthetic.band_psf(2))
+    rows = np.arange(-25.0, 26.0); cols = np.arange(-25.0, 26.0)
+    out = np.zeros(51 * 51)
+    dp = cabi.c_double_p
+    cabi.check(lib.celeste_psf_raster(0, psf.ctypes.data_as(dp), 2, rows.ctypes.data_as(dp), 51,
+                                      cols.ctypes.data_as(dp), 51, out.ctypes.data_as(dp)))
+    out = out.reshape(51, 51).T
+    ref = np.array([[oracle.psf_at_point(psf, r, c) for c in cols] for r in rows])
+    assert np.abs(out - ref).max() <= 1e-12 * ref.max()
