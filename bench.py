@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- sources/sec of the ELBO hot path (value + gradient + Hessian + KL) on MI355X.
+
+One "step" = one sweep of elbo() over every source of one synthetic 2048x1489x5 SDSS-size field
+(~2000 star+galaxy sources, BASELINE.json configs[2]), inputs resident in HBM.  With --gpus N each rank
+owns one such field (sources shard with no data-path collective; weak scaling) and the per-source results
+(value + 44-gradient) are all-gathered over RCCL at the end of every sweep (the "catalog gather").
+
+Prints ONE JSON line on rank 0 (contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FLAGS_ALL = 1 | 2 | 4
+HBM_PEAK_GBS = 8000.0
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+
+
+def build_field(H, W, n_sources, seed, cache=True):
+    import pickle
+    from celeste_jl_amd import synthetic
+    path = "/tmp/celeste_field_%d_%d_%d_%d.pkl" % (H, W, n_sources, seed)
+    if cache and os.path.exists(path):
+        try:
+            with open(path, "rb") as f:
+                return pickle.load(f)
+        except Exception:
+            pass
+    fld = synthetic.make_field(H, W, n_sources, seed=seed, name="synthetic_%dx%dx5_%dsrc" % (H, W, n_sources))
+    if cache:
+        try:
+            with open(path + ".tmp%d" % os.getpid(), "wb") as f:
+                pickle.dump(fld, f)
+            os.replace(path + ".tmp%d" % os.getpid(), path)
+        except Exception:
+            pass
+    return fld
+
+
+def cpu_baseline(problem, vp, targets, seconds_target=15.0):
+    """The oracle (dense reference-faithful C restatement, "port") on this box's host cores, bounded sample."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    probe = targets[:: max(1, len(targets) // (2 * cores))][: 2 * cores]
+    t0 = time.time()
+    oracle.elbo_batch(problem, vp, probe, FLAGS_ALL, n_threads=cores)
+    per = (time.time() - t0) / max(1, len(probe))
+    n = int(min(len(targets), max(4 * cores, seconds_target / max(per, 1e-6))))
+    sample = targets[:: max(1, len(targets) // n)][:n]
+    t0 = time.time()
+    _, _, _, _, st = oracle.elbo_batch(problem, vp, sample, FLAGS_ALL, n_threads=cores)
+    dt = time.time() - t0
+    assert (st == 0).all()
+    return {"value": len(sample) / dt, "unit": "sources/sec", "cores": cores, "kind": "port",
+            "sample": "%d of %d targets (every %d-th), value+grad+Hessian+KL, OpenMP dynamic over sources, %.1f s"
+                      % (len(sample), len(targets), max(1, len(targets) // n), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--height", type=int, default=2048)
+    ap.add_argument("--width", type=int, default=1489)
+    ap.add_argument("--sources", type=int, default=2000)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import cabi
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    # one field per rank (weak scaling): same shape, rank-dependent seed
+    fld = build_field(args.height, args.width, args.sources, args.seed + rank)
+    S = len(fld.catalog)
+    ctx = cel.FieldContext(fld.images, fld.patches, fld.neighbors, device=dev.index)
+    targets = np.arange(S, dtype=np.int32)
+    stats = ctx.work_stats(targets)
+
+    d_vp = torch.tensor(fld.vp, dtype=torch.float64, device=dev)
+    d_tg = torch.tensor(targets, dtype=torch.int32, device=dev)
+    d_v = torch.zeros(S, dtype=torch.float64, device=dev)
+    d_d = torch.zeros(S, 44, dtype=torch.float64, device=dev)
+    d_h = torch.zeros(S, 44, 44, dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(S, 2, dtype=torch.int64, device=dev)
+    d_st = torch.zeros(S, dtype=torch.int32, device=dev)
+    gather_in = torch.zeros(S, 45, dtype=torch.float64, device=dev)
+    gather_out = torch.zeros(world * S, 45, dtype=torch.float64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_ALL, d_v.data_ptr(), d_d.data_ptr(),
+                              d_h.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), stream)
+        if world > 1:
+            gather_in[:, 0] = d_v
+            gather_in[:, 1:] = d_d
+            dist.all_gather_into_tensor(gather_out, gather_in)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert int((d_st != 0).sum().item()) == 0, "non-zero per-target status"
+    pixel_visits = int(d_cnt[:, 0].sum().item())
+
+    # dominant-kernel duration: HIP events recorded by the library on the launch stream, averaged
+    ctx.enable_timing(True)
+    kms = []
+    for _ in range(min(20, max(3, args.steps))):
+        step()
+        torch.cuda.synchronize(dev)
+        kms.append(ctx.last_kernel_ms())
+    ctx.enable_timing(False)
+    kms = np.array(kms).mean(axis=0)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * S / (dt / args.steps)
+        alg_bytes = stats["algorithmic_bytes"]
+        achieved = alg_bytes / (kms[1] * 1e-3) / 1e9
+        out = {
+            "metric": "sources/sec (ELBO value+gradient+Hessian+KL per target source)",
+            "value": value, "unit": "sources/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: synthetic %dx%dx5 SDSS-size field, %d star+galaxy "
+                                   "sources per GPU, fp64, Sa=1 with value-only neighbours, psf_K=2"
+                                   % (args.height, args.width, S),
+                       "sources_per_gpu": S, "pixel_visits_per_sweep": pixel_visits,
+                       "neighbor_links": stats["neighbor_links"], "parallelism": "sources sharded, 1 field per GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pixel_kernel<2>", "kernel_ms": float(kms[1]),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "the path is FP64-VALU bound (SURVEY.md F8): see fp64_valu"},
+            "kernels_ms": {"prep": float(kms[0]), "pixel": float(kms[1]), "lift": float(kms[2])},
+            "pixel_visits_per_sec": pixel_visits / (kms[1] * 1e-3),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(ctx.problem, fld.vp, targets)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
