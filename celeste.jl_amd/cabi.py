@@ -76,7 +76,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("CELESTE_MI355X_LIB") or LIB_PATH
     if not os.path.exists(path):
         raise ImportError(
             "HIP extension %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -100,8 +100,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.celeste_spline_prefilter.argtypes = [c_double_p, c_double_p]
     lib.celeste_psf_raster.argtypes = [C.c_int, c_double_p, C.c_int32, c_double_p, C.c_int32, c_double_p,
                                        C.c_int32, c_double_p]
-    if path == LIB_PATH:
-        _lib = lib
+    _lib = lib
     return lib
 
 

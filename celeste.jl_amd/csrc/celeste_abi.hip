@@ -31,6 +31,7 @@ struct celeste_ctx {
     int device = 0;
     int N = 0, S = 0, K = 0, NC = 0, n_stamps = 0;
     int chunk_px = 1024, CH = 1;
+    int ablate = 0;  // debug: CELESTE_ABLATE bit mask, skips parts of pixel_kernel (timing experiments only)
     int max_npx = 0;
     // host mirrors (for work stats / validation)
     std::vector<DevPatch> h_patches;
@@ -49,6 +50,9 @@ struct celeste_ctx {
     SrcImg *d_srcimg = nullptr;
     Comp *d_comps = nullptr;
     SrcGeo *d_geo = nullptr;
+    int64_t *d_val_off = nullptr;   // per (source, image): offset of the patch in d_val
+    double2 *d_val = nullptr;       // pre-rendered (E_G_s.v, var_G_s.v) of neighbour sources, per patch pixel
+    int32_t *d_needed = nullptr;    // per source: is a neighbour of some target of the current batch
     // per-batch scratch (grown on demand)
     double *d_acc = nullptr;
     size_t acc_cap = 0;
@@ -204,9 +208,19 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
         CTX_TRY(dev_upload(&ds, im.sky, (size_t)im.H * im.W)); c->plane_allocs.push_back(ds);
         CTX_TRY(dev_upload(&di, im.nelec_per_nmgy, (size_t)im.H)); c->plane_allocs.push_back(di);
         d.pixels = dp; d.sky = ds; d.iota = di;
+        double *dl = nullptr, *dli = nullptr;
+        CTX_TRY(dev_upload<double>(&dl, nullptr, (size_t)im.H * im.W)); c->plane_allocs.push_back(dl);
+        CTX_TRY(dev_upload<double>(&dli, nullptr, (size_t)im.H)); c->plane_allocs.push_back(dli);
+        {
+            const size_t npix = (size_t)im.H * im.W;
+            hipLaunchKernelGGL(plane_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, nullptr, dp, di, im.H,
+                               im.W, dl, dli);
+        }
+        d.lgx = dl; d.log_iota = dli;
         c->h_images[n] = d;
     }
     CTX_TRY(dev_upload(&c->d_images, c->h_images.data(), c->h_images.size()));
+    if (hipDeviceSynchronize() != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
 
     // patches + explicit bitmaps
     c->h_patches.resize((size_t)c->S * c->N);
@@ -275,7 +289,16 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
     CTX_TRY(dev_upload<SrcImg>(&c->d_srcimg, nullptr, (size_t)c->S * c->N));
     CTX_TRY(dev_upload<Comp>(&c->d_comps, nullptr, (size_t)c->S * c->N * c->NC));
     CTX_TRY(dev_upload<SrcGeo>(&c->d_geo, nullptr, (size_t)c->S));
+    {
+        std::vector<int64_t> voff(c->h_patches.size());
+        int64_t tot = 0;
+        for (size_t q = 0; q < c->h_patches.size(); ++q) { voff[q] = tot; tot += (int64_t)c->h_patches[q].H2 * c->h_patches[q].W2; }
+        CTX_TRY(dev_upload(&c->d_val_off, voff.data(), voff.size()));
+        CTX_TRY(dev_upload<double2>(&c->d_val, nullptr, (size_t)tot));
+        CTX_TRY(dev_upload<int32_t>(&c->d_needed, nullptr, (size_t)c->S));
+    }
 
+    if (const char *env_ab = getenv("CELESTE_ABLATE")) c->ablate = atoi(env_ab);
     const char *env_chunk = getenv("CELESTE_CHUNK_PX");
     if (env_chunk && atoi(env_chunk) >= 64) c->chunk_px = (atoi(env_chunk) + 63) / 64 * 64;
     c->CH = c->max_npx > 0 ? (c->max_npx + c->chunk_px - 1) / c->chunk_px : 1;
@@ -291,7 +314,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     (void)hipSetDevice(c->device);
     for (void *p : c->plane_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -317,16 +340,24 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     hipLaunchKernelGGL(prep_kernel, dim3(c->S * c->N), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches, c->S,
                        c->N, c->K, c->d_srcimg, c->d_comps, c->d_geo);
+    HIP_TRY(hipMemsetAsync(c->d_needed, 0, (size_t)c->S * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(mark_kernel, dim3((n_targets + 255) / 256), dim3(256), 0, stream, d_targets, n_targets,
+                       c->d_nbr_off, c->d_nbr_idx, c->d_needed);
+    hipLaunchKernelGGL(value_kernel, dim3((unsigned)((size_t)c->S * c->N * c->CH)), dim3(64), 0, stream, c->d_patches,
+                       c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->d_val_off, c->N, c->NC, c->CH,
+                       c->chunk_px, c->d_val);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     const dim3 grid((unsigned)((size_t)n_targets * c->N * c->CH));
     if (derivs)
         hipLaunchKernelGGL(pixel_kernel<2>, grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,
-                           c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, d_targets, c->N, c->NC,
-                           c->CH, c->chunk_px, c->d_acc);
+                           c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off, c->d_val, d_targets,
+                           c->N, c->NC,
+                           c->CH, c->chunk_px, c->d_acc, c->ablate);
     else
         hipLaunchKernelGGL(pixel_kernel<0>, grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,
-                           c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, d_targets, c->N, c->NC,
-                           c->CH, c->chunk_px, c->d_acc);
+                           c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off, c->d_val, d_targets,
+                           c->N, c->NC,
+                           c->CH, c->chunk_px, c->d_acc, c->ablate);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
     hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                        c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->N, c->CH, c->chunk_px, flags,

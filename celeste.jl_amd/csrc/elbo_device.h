@@ -32,6 +32,9 @@ struct DevImage {
     const float *pixels;
     const float *sky;
     const float *iota;
+    // parameter-independent per-pixel / per-row terms, computed once at context creation:
+    const double *lgx;       // lgamma(pixel + 1)   (elbo_objective.jl:391), 0 for NaN pixels
+    const double *log_iota;  // Float32 log(iota[h]) widened (elbo_objective.jl:292)
 };
 
 struct DevPatch {
@@ -48,9 +51,10 @@ struct DevPatch {
 struct Comp {
     double p11, p12, p22;  // precision = inv(tauBar_k + nuBar_j XiXi)
     double mu1, mu2;       // xiBar_k + m_pos
-    double zf;             // z * gal_frac_dev_i      (f = zf * exp(...))
-    double zd;             // z * gal_frac_dev_dir    (d f / d gal_frac_dev = zd * exp(...))
-    double nu;             // nuBar_j
+    double w0;             // z * gal_frac_dev_i      (f = w0 * exp(...))
+    double wd;             // z * gal_frac_dev_dir    (d f / d gal_frac_dev = wd * exp(...))
+    double wn, wdn, wnn;   // w0 nuBar_j, wd nuBar_j, w0 nuBar_j^2
+    double pad0, pad1;     // 96-byte records: three 32-byte scalar loads
 };
 
 struct SrcImg {

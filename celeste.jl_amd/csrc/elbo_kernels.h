@@ -89,9 +89,10 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         o.p11 = s22 * idet; o.p12 = -s12 * idet; o.p22 = s11 * idet;
         o.mu1 = pc[1] + m1; o.mu2 = pc[2] + m2;
         const double dev = vs[2];
-        o.zf = z * (i == 0 ? dev : 1.0 - dev);
-        o.zd = (i == 0 ? z : -z);
-        o.nu = nu;
+        o.w0 = z * (i == 0 ? dev : 1.0 - dev);
+        o.wd = (i == 0 ? z : -z);
+        o.wn = o.w0 * nu; o.wdn = o.wd * nu; o.wnn = o.wn * nu;
+        o.pad0 = 0; o.pad1 = 0;
         comps[(size_t)sn * NC + c] = o;
     }
     if (c == 63) {
@@ -140,6 +141,20 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
 }
 
 // ---------------------------------------------------------------------------------------------
+// plane_kernel: parameter-independent terms, once per context
+// ---------------------------------------------------------------------------------------------
+__global__ void plane_kernel(const float *__restrict__ pixels, const float *__restrict__ iota, int H, int W,
+                             double *__restrict__ lgx, double *__restrict__ log_iota) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)H * W) {
+        const float x = pixels[i];
+        lgx[i] = isnan(x) ? 0.0 : lgamma((double)x + 1.0);
+    }
+    // log(iota) is a Float32 log in the reference (iota::Float32, elbo_objective.jl:292)
+    if (i < (size_t)H) log_iota[i] = (double)(float)log((double)iota[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // pixel_kernel
 // ---------------------------------------------------------------------------------------------
 __device__ inline void bspline_w(double f, double w[4]) {
@@ -151,6 +166,31 @@ __device__ inline void bspline_dw(double f, double dw[4], double ddw[4]) {
     const double o = 1.0 - f;
     dw[0] = -0.5 * o * o; dw[1] = -2 * f + 1.5 * f * f; dw[2] = 2 * o - 1.5 * o * o; dw[3] = 0.5 * f * f;
     ddw[0] = o; ddw[1] = -2 + 3 * f; ddw[2] = -2 + 3 * o; ddw[3] = f;
+}
+
+// exp(x) for x <= 0 in fp64.  x = (64 m + j) ln2/64 + r with |r| <= ln2/128, so
+// exp(x) = 2^m * 2^(j/64) * exp(r): a 64-entry table in LDS (filled by exp_table_init), a degree-5
+// Taylor polynomial (truncation 3.5e-17) and v_ldexp_f64.  About 1 ulp; 17 VALU + 1 LDS instruction
+// instead of ~31 for the library exp.  Inputs below -745 give exactly 0 like the reference's exp.
+__device__ __forceinline__ void exp_table_init(double *tab) {
+    // 2^(j/64), j = 0..63: one entry per lane of the first wavefront
+    if (threadIdx.x < 64) tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+    __syncthreads();
+}
+__device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
+    x = fmax(x, -750.0);
+    const double n = rint(x * 92.33248261689366);             // 64 / ln 2
+    double r = __builtin_fma(n, -0.010830424696450791, x);      // ln2/64, 35-bit high part: n * hi is exact for |n| < 2^17
+    r = __builtin_fma(n, 2.0164562921995537e-13, r);           // minus the low part of ln2/64 (lo = -2.0164562921995537e-13)
+    const int ni = (int)n;
+    const double tj = tab[ni & 63];
+    double p = 8.333333333333333e-03;                // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p * tj, ni >> 6);
 }
 
 // star_light_density! value only (fsm_util.jl:221-237): softpluslikeinv(itp[h - m1 + 26, w - m2 + 26])
@@ -170,16 +210,37 @@ __device__ inline double star_value(const double *__restrict__ coef, double xh, 
     return y < 0 ? 1e-3 * exp(y) : 1e-3 * (y + 1.0);
 }
 
-// value of the galaxy density sum_c zf_c exp(-0.5 d' P d) (populate_gal_fsm!, inactive branch)
-__device__ inline double galaxy_value(const Comp *__restrict__ tc, int NC, double hh, double ww) {
+// value of the galaxy density sum_c w0_c exp(-0.5 d' P d) (populate_gal_fsm!, inactive branch)
+__device__ inline double galaxy_value(const Comp *__restrict__ tc, int NC, double hh, double ww, const double *etab) {
     double v = 0;
     for (int c = 0; c < NC; ++c) {
-        const Comp k = tc[c];
+        const Comp &k = tc[c];
         const double d1 = hh - k.mu1, d2 = ww - k.mu2;
-        const double py1 = k.p11 * d1 + k.p12 * d2, py2 = k.p12 * d1 + k.p22 * d2;
-        v += k.zf * exp(-0.5 * (d1 * py1 + d2 * py2));
+        const double u = k.p11 * d1 + k.p12 * d2, vv = k.p12 * d1 + k.p22 * d2;
+        v = __builtin_fma(k.w0, exp_nonpos(-0.5 * (d1 * u + d2 * vv), etab), v);
     }
     return v;
+}
+
+// ---- cross-lane helpers (wave64; DPP quad permutes move data without touching LDS) ----------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    int lo = (int)b, hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+#define DPP_XOR1 0xB1  // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E  // quad_perm [2,3,0,1]
+
+// sum over the 16 lanes l, l^4, l^8, ... (same lane & 3): butterfly on xor 4, 8, 16, 32
+__device__ __forceinline__ double quad_class_sum(double x) {
+    x += __shfl_xor(x, 4, 64);
+    x += __shfl_xor(x, 8, 64);
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
 }
 
 __device__ inline double wave_sum(double x) {
@@ -188,15 +249,204 @@ __device__ inline double wave_sum(double x) {
     return x;
 }
 
-// MODE 0: value only; MODE 2: value + gradient + Hessian sums
-template <int MODE>
+// ---------------------------------------------------------------------------------------------
+// mark_kernel / value_kernel: value-only light of every source that is some target's neighbour
+// (is_active_source == false branch of add_pixel_term!, elbo_objective.jl:254-257), rendered once
+// per batch on the source's own patch so that the pixel kernel gathers two doubles per covering
+// neighbour instead of re-evaluating 14 psf_K exponentials per (pixel, neighbour) pair.
+// ---------------------------------------------------------------------------------------------
+__global__ void mark_kernel(const int32_t *__restrict__ targets, int n_targets, const int64_t *__restrict__ nbr_off,
+                            const int32_t *__restrict__ nbr_idx, int32_t *__restrict__ needed) {
+    const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= n_targets) return;
+    const int t = targets[ti];
+    for (int64_t q = nbr_off[t]; q < nbr_off[t + 1]; ++q) needed[nbr_idx[q]] = 1;
+}
+
 __global__ void __launch_bounds__(64)
+value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
+             const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
+             const int32_t *__restrict__ needed, const int64_t *__restrict__ val_off, int N, int NC, int CH,
+             int chunk_px, double2 *__restrict__ val) {
+    __shared__ double etab[64];
+    exp_table_init(etab);
+    const int wg = blockIdx.x;
+    const int ch = wg % CH;
+    const int sn = wg / CH;
+    const int s = sn / N;
+    if (!needed[s]) return;
+    const DevPatch &P = patches[sn];
+    const int H2 = P.H2, W2 = P.W2;
+    const int npx = H2 * (W2 - 1);  // the last column never contributes (elbo_objective.jl:349)
+    const int p0 = ch * chunk_px;
+    if (p0 >= npx) return;
+    const int p1 = min(npx, p0 + chunk_px);
+    const SrcImg si = srcimg[sn];
+    const Comp *__restrict__ tc = comps + (size_t)sn * NC;
+    const double *__restrict__ coef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
+    double2 *__restrict__ out = val + val_off[sn];
+    const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
+    for (int idx = p0 + (int)threadIdx.x; idx < p1; idx += 64) {
+        const int w2 = idx / H2, h2 = idx - w2 * H2;
+        const double hh = (double)(P.off_h + h2 + 1), ww = (double)(P.off_w + w2 + 1);
+        const double f0 = star_value(coef, hh + sh0, ww + sw0);
+        const double f1 = galaxy_value(tc, NC, hh, ww, etab);
+        const double En = si.c0 * f0 + si.c1 * f1;                      // E_G_s.v  (elbo_objective.jl:62-65)
+        const double E2n = si.q0 * (f0 * f0) + si.q1 * (f1 * f1);
+        out[idx] = make_double2(En, E2n - En * En);                     // var_G_s.v (elbo_objective.jl:204)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pixel_kernel
+// ---------------------------------------------------------------------------------------------
+// Per-pixel quantities from which every entry of the 68-double record is formed.
+struct PixelTerms {
+    double vterm, cnt_act, cnt_inact;
+    double f0, f1;
+    double alpha, beta, w2, w12;
+    double k0, k1, r0, r1;
+    double f0g0, f0g1, f0h0, f0h1, f0h2;
+    double dA0, dA1, dA2, dA3, dA4, dA5, dB0, dB1, dB2, dB3, dB4, dB5;
+    // galaxy component sums (see pixel_kernel)
+    double S0d, S1x, S1y, S1xd, S1yd, S2a, S2b, S2c, S2an, S2bn, S2cn, S2ad, S2bd, S2cd;
+    double S3a, S3b, S3c, S3d, S4a, S4b, S4c, S4d, S4e;
+};
+
+// d f1 / d(m1 m2 dev Xi11 Xi12 Xi22)
+template <int G>
+__device__ __forceinline__ double gal_g(const PixelTerms &T) {
+    if constexpr (G == 0) return T.S1x;
+    else if constexpr (G == 1) return T.S1y;
+    else if constexpr (G == 2) return T.S0d;
+    else if constexpr (G == 3) return 0.5 * T.S2an;
+    else if constexpr (G == 4) return T.S2bn;
+    else return 0.5 * T.S2cn;
+}
+// d2 f1 (upper triangle, G <= G2): Gaussian derivatives d/dm = -d/dx, d/dXi = (nu/2) d2/dx2
+template <int G, int G2>
+__device__ __forceinline__ double gal_h(const PixelTerms &T) {
+    constexpr int k = G * 6 + G2;
+    if constexpr (k == 0) return T.S2a;                 // m1 m1
+    else if constexpr (k == 1) return T.S2b;            // m1 m2
+    else if constexpr (k == 2) return T.S1xd;           // m1 dev
+    else if constexpr (k == 3) return 0.5 * T.S3a;      // m1 Xi11
+    else if constexpr (k == 4) return T.S3b;            // m1 Xi12
+    else if constexpr (k == 5) return 0.5 * T.S3c;      // m1 Xi22
+    else if constexpr (k == 7) return T.S2c;            // m2 m2
+    else if constexpr (k == 8) return T.S1yd;
+    else if constexpr (k == 9) return 0.5 * T.S3b;
+    else if constexpr (k == 10) return T.S3c;
+    else if constexpr (k == 11) return 0.5 * T.S3d;
+    else if constexpr (k == 14) return 0.0;             // dev dev
+    else if constexpr (k == 15) return 0.5 * T.S2ad;
+    else if constexpr (k == 16) return T.S2bd;
+    else if constexpr (k == 17) return 0.5 * T.S2cd;
+    else if constexpr (k == 21) return 0.25 * T.S4a;    // Xi11 Xi11
+    else if constexpr (k == 22) return 0.5 * T.S4b;
+    else if constexpr (k == 23) return 0.25 * T.S4c;
+    else if constexpr (k == 28) return T.S4c;           // Xi12 Xi12
+    else if constexpr (k == 29) return 0.5 * T.S4d;
+    else { static_assert(k == 35, "upper triangle only"); return 0.25 * T.S4e; }  // Xi22 Xi22
+}
+template <int G>
+__device__ __forceinline__ double star_g(const PixelTerms &T) {
+    if constexpr (G == 0) return T.f0g0;
+    else if constexpr (G == 1) return T.f0g1;
+    else return 0.0;
+}
+template <int G>
+__device__ __forceinline__ double dA_g(const PixelTerms &T) {
+    if constexpr (G == 0) return T.dA0; else if constexpr (G == 1) return T.dA1; else if constexpr (G == 2) return T.dA2;
+    else if constexpr (G == 3) return T.dA3; else if constexpr (G == 4) return T.dA4; else return T.dA5;
+}
+template <int G>
+__device__ __forceinline__ double dB_g(const PixelTerms &T) {
+    if constexpr (G == 0) return T.dB0; else if constexpr (G == 1) return T.dB1; else if constexpr (G == 2) return T.dB2;
+    else if constexpr (G == 3) return T.dB3; else if constexpr (G == 4) return T.dB4; else return T.dB5;
+}
+
+constexpr int hess_row(int e) {  // packed upper-triangle index (e - ACC_H0) -> row
+    int i = 0, k = e - ACC_H0;
+    while (k >= ZV - i) { k -= ZV - i; ++i; }
+    return i;
+}
+constexpr int hess_col(int e) {
+    int i = 0, k = e - ACC_H0;
+    while (k >= ZV - i) { k -= ZV - i; ++i; }
+    return i + k;
+}
+
+// entry E of the 68-double record for this pixel
+template <int E>
+__device__ __forceinline__ double record_entry(const PixelTerms &T) {
+    if constexpr (E == 0) return T.vterm;
+    else if constexpr (E == ACC_CNT) return T.cnt_act;
+    else if constexpr (E == ACC_CNT + 1) return T.cnt_inact;
+    else if constexpr (E <= ZV) {  // gradient
+        constexpr int r = E - 1;
+        if constexpr (r == 0) return T.alpha * T.f0;
+        else if constexpr (r == 1) return T.alpha * T.f1;
+        else if constexpr (r == 2) return T.w2 * T.f0 * T.f0;
+        else if constexpr (r == 3) return T.w2 * T.f1 * T.f1;
+        else return T.alpha * dA_g<r - 4>(T) + T.w2 * dB_g<r - 4>(T);
+    } else {
+        constexpr int i = hess_row(E), j = hess_col(E);
+        if constexpr (j < 2) return T.beta * (i == 0 ? T.f0 : T.f1) * (j == 0 ? T.f0 : T.f1);      // (c, c)
+        else if constexpr (i < 2 && j < 4) {                                                         // (c, q)
+            const double fi = i == 0 ? T.f0 : T.f1, fj = j == 2 ? T.f0 : T.f1;
+            return T.w12 * fi * (fj * fj);
+        } else if constexpr (j < 4) return 0.0;                                                      // (q, q)
+        else if constexpr (i < 4) {
+            constexpr int g2 = j - 4;
+            constexpr bool star = (i & 1) == 0;
+            const double fi = star ? T.f0 : T.f1;
+            double fig;
+            if constexpr (star) fig = star_g<g2>(T); else fig = gal_g<g2>(T);
+            if constexpr (i < 2) return T.alpha * fig + fi * (T.beta * dA_g<g2>(T) + T.w12 * dB_g<g2>(T));  // (c, geo)
+            else return 2.0 * T.w2 * fi * fig + T.w12 * (fi * fi) * dA_g<g2>(T);                              // (q, geo)
+        } else {                                                                                      // (geo, geo)
+            constexpr int g = i - 4, g2 = j - 4;
+            double v = T.k1 * gal_h<g, g2>(T) + T.r1 * gal_g<g>(T) * gal_g<g2>(T) + T.beta * dA_g<g>(T) * dA_g<g2>(T) +
+                       T.w12 * (dA_g<g>(T) * dB_g<g2>(T) + dB_g<g>(T) * dA_g<g2>(T));
+            if constexpr (g2 < 2) {
+                const double f0h = (g + g2 == 0) ? T.f0h0 : ((g + g2 == 1) ? T.f0h1 : T.f0h2);
+                v += T.k0 * f0h + T.r0 * star_g<g>(T) * star_g<g2>(T);
+            }
+            return v;
+        }
+    }
+}
+
+// Fold the 68 entries across each lane quad so that a lane only accumulates 17 of them: after the
+// xor-1 and xor-2 exchanges lane l holds, for its quad, the entries e = 4 j + (l & 3).
+template <int J>
+__device__ __forceinline__ void fold_entries(const PixelTerms &T, bool b0, bool b1, double *a) {
+    const double e0 = record_entry<4 * J>(T), e1 = record_entry<4 * J + 1>(T);
+    const double e2 = record_entry<4 * J + 2>(T), e3 = record_entry<4 * J + 3>(T);
+    const double t0 = (b0 ? e1 : e0) + dpp_f64<DPP_XOR1>(b0 ? e0 : e1);  // entry 4J + b0
+    const double t1 = (b0 ? e3 : e2) + dpp_f64<DPP_XOR1>(b0 ? e2 : e3);  // entry 4J + 2 + b0
+    a[J] += (b1 ? t1 : t0) + dpp_f64<DPP_XOR2>(b1 ? t0 : t1);
+    if constexpr (J + 1 < ACC_N / 4) fold_entries<J + 1>(T, b0, b1, a);
+}
+
+#define ACC_Q (ACC_N / 4)  // 17 accumulators per lane: lane l owns record entries e with e % 4 == l % 4
+
+// MODE 0: value only; MODE 2: value + gradient + Hessian sums
+#ifndef PIXEL_WAVES
+#define PIXEL_WAVES 2  // waves per SIMD the register allocator must allow (256 VGPRs, no scratch)
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(64, PIXEL_WAVES)
 pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ patches,
              const double *__restrict__ coefs, const uint8_t *__restrict__ bitmaps,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
              const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
+             const int64_t *__restrict__ val_off, const double2 *__restrict__ val,
              const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px,
-             double *__restrict__ acc) {
+             double *__restrict__ acc, int ablate) {
+    __shared__ double etab[64];
+    exp_table_init(etab);
     const int wg = blockIdx.x;
     const int ch = wg % CH;
     const int tn = wg / CH;
@@ -213,227 +463,199 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const SrcImg si = srcimg[(size_t)t * N + n];
     const Comp *__restrict__ tc = comps + ((size_t)t * N + n) * NC;
     const double *__restrict__ tcoef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
-    const int64_t nb0 = nbr_off[t], nb1 = nbr_off[t + 1];
+    const int64_t nb0 = nbr_off[t], nb1 = (ablate & 1) ? nb0 : nbr_off[t + 1];
     const double c0 = si.c0, c1 = si.c1, q0 = si.q0, q1 = si.q1;
     // index offsets of the star spline: itp[h - m1 + 26, w - m2 + 26]
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
 
-    double a[ACC_N];
+    double a[ACC_Q];
 #pragma unroll
-    for (int i = 0; i < ACC_N; ++i) a[i] = 0.0;
+    for (int i = 0; i < ACC_Q; ++i) a[i] = 0.0;
 
     for (int base = p0; base < p1; base += 64) {
-        const int idx = base + lane;
-        if (idx >= p1) continue;
-        const int w2 = idx / H2, h2 = idx - w2 * H2;  // 0-based patch coordinates, h fastest
+        const int idx = min(base + lane, p1 - 1);           // clamped: every lane stays in the loop body
+        const bool in_range = base + lane < p1;
+        const int w2 = idx / H2, h2 = idx - w2 * H2;        // 0-based patch coordinates, h fastest
         const int h = P.off_h + h2 + 1, w = P.off_w + w2 + 1;  // 1-based image coordinates
         const size_t gi = (size_t)(h - 1) + (size_t)img.H * (w - 1);
+        // coalesced (along h) loads of every per-pixel input, issued together
         const float xf = img.pixels[gi];
-        bool own_bit = true;
-        if (P.bitmap_off >= 0) own_bit = bitmaps[P.bitmap_off + h2 + (int64_t)H2 * w2] != 0;
-        if (!own_bit || isnan(xf)) continue;  // elbo_objective.jl:445,459
+        const float skyf = img.sky[gi];
+        const double lgx = img.lgx[gi];
+        const double iota = (double)img.iota[h - 1];
+        const double log_iota = img.log_iota[h - 1];
+        bool valid = in_range && !isnan(xf);                // elbo_objective.jl:459
+        if (P.bitmap_off >= 0) valid = valid && bitmaps[P.bitmap_off + h2 + (int64_t)H2 * w2] != 0;  // :445
         const double hh = (double)h, ww = (double)w;
-        double Ebar = (double)img.sky[gi];  // epsilon + neighbours
+        double Ebar = (double)skyf;  // epsilon + neighbours
         double Vbar = 0.0;
-        double n_inact = 0.0;
+        int n_inact = 0;
 
-        // ---- neighbours: value-only contributions (is_active_source == false) ----
+        // ---- neighbours: gather their pre-rendered (E_G_s.v, var_G_s.v) ----
         for (int64_t q = nb0; q < nb1; ++q) {
             const int s2 = nbr_idx[q];
             const DevPatch &Q = patches[(size_t)s2 * N + n];
             const int ph2 = h - Q.off_h, pw2 = w - Q.off_w;  // 1-based in the neighbour's patch
-            bool in = (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 < Q.W2);  // strict: elbo_objective.jl:349
+            bool in = valid & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 < Q.W2);  // strict: elbo_objective.jl:349
             if (in && Q.bitmap_off >= 0) in = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
-            const SrcImg sj = srcimg[(size_t)s2 * N + n];  // wave-uniform
             if (in) {
-                const double f0 = star_value(coefs + (size_t)Q.stamp * (CEL_COEF * CEL_COEF),
-                                             hh + (26.0 - sj.m1), ww + (26.0 - sj.m2));
-                const double f1 = galaxy_value(comps + ((size_t)s2 * N + n) * NC, NC, hh, ww);
-                const double En = sj.c0 * f0 + sj.c1 * f1;            // E_G_s.v  (elbo_objective.jl:62-65)
-                const double E2n = sj.q0 * (f0 * f0) + sj.q1 * (f1 * f1);
-                Ebar += En;
-                Vbar += E2n - En * En;                                  // var_G_s.v (elbo_objective.jl:204)
-                n_inact += 1.0;
+                const double2 ev = val[val_off[(size_t)s2 * N + n] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
+                Ebar += ev.x;
+                Vbar += ev.y;
+                n_inact += 1;
             }
         }
 
         // ---- the active source ----
-        const bool own = (w2 < W2 - 1);  // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
-        double f0 = 0, f1 = 0;
-        double f0g[2] = {0, 0}, f0h[3] = {0, 0, 0};   // d/dm, d2/dm2 (m1m1, m1m2, m2m2)
-        double g1[6] = {0, 0, 0, 0, 0, 0};            // m1 m2 dev Xi11 Xi12 Xi22
-        double h1[21];
-#pragma unroll
-        for (int i = 0; i < 21; ++i) h1[i] = 0.0;
-        if (own) {
-            // star: spline value + derivatives with respect to the index, then index = h - m + 26
-            {
-                const double xh = hh + sh0, xw = ww + sw0;
-                int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
-                int iy = (int)floor(xw); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
-                const double fx = xh - ix, fy = xw - iy;
-                double wx[4], wy[4];
-                bspline_w(fx, wx); bspline_w(fy, wy);
-                const double *cc = tcoef + (ix - 1) + CEL_COEF * (iy - 1);
-                if (MODE == 0) {
-                    double y = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const double *cb = cc + CEL_COEF * b;
-                        y += (cb[0] * wx[0] + cb[1] * wx[1] + cb[2] * wx[2] + cb[3] * wx[3]) * wy[b];
-                    }
-                    f0 = y < 0 ? 1e-3 * exp(y) : 1e-3 * (y + 1.0);
-                } else {
-                    double dwx[4], ddwx[4], dwy[4], ddwy[4];
-                    bspline_dw(fx, dwx, ddwx); bspline_dw(fy, dwy, ddwy);
-                    double y = 0, yx = 0, yy = 0, yxx = 0, yxy = 0, yyy = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const double *cb = cc + CEL_COEF * b;
-                        const double k0 = cb[0], k1 = cb[1], k2 = cb[2], k3 = cb[3];
-                        const double r = k0 * wx[0] + k1 * wx[1] + k2 * wx[2] + k3 * wx[3];
-                        const double rx = k0 * dwx[0] + k1 * dwx[1] + k2 * dwx[2] + k3 * dwx[3];
-                        const double rxx = k0 * ddwx[0] + k1 * ddwx[1] + k2 * ddwx[2] + k3 * ddwx[3];
-                        y += r * wy[b]; yx += rx * wy[b]; yxx += rxx * wy[b];
-                        yy += r * dwy[b]; yxy += rx * dwy[b]; yyy += r * ddwy[b];
-                    }
-                    // softpluslikeinv and its derivatives; not C2 at 0, branch exactly (fsm_util.jl:222)
-                    double gv, gp, gpp;
-                    if (y < 0) { gv = 1e-3 * exp(y); gp = gv; gpp = gv; }
-                    else { gv = 1e-3 * (y + 1.0); gp = 1e-3; gpp = 0.0; }
-                    f0 = gv;
-                    // d(index)/dm = -1
-                    const double ym1 = -yx, ym2 = -yy;
-                    f0g[0] = gp * ym1; f0g[1] = gp * ym2;
-                    f0h[0] = gpp * ym1 * ym1 + gp * yxx;
-                    f0h[1] = gpp * ym1 * ym2 + gp * yxy;
-                    f0h[2] = gpp * ym2 * ym2 + gp * yyy;
-                }
+        const bool own = valid && (w2 < W2 - 1);  // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
+        const double x = (double)xf;
+        if (MODE == 0) {
+            double f0 = 0, f1 = 0;
+            if (own) {
+                f0 = star_value(tcoef, hh + sh0, ww + sw0);
+                f1 = galaxy_value(tc, NC, hh, ww, etab);
             }
-            // galaxy: 14 * psf_K bivariate normals (accum_galaxy_pos!, fsm_util.jl:255-346), with the
-            // per-component (x, Sigma) -> (pos, shape) transforms hoisted out of the pixel loop
-            for (int c = 0; c < NC; ++c) {
-                const Comp k = tc[c];
+            if (valid) {
+                const double A = c0 * f0 + c1 * f1;
+                const double E = Ebar + A;
+                const double V = Vbar + ((q0 * (f0 * f0) + q1 * (f1 * f1)) - A * A);
+                const double iE = 1.0 / E;
+                a[0] += x * (log_iota + (log(E) - V * (0.5 * iE * iE))) - iota * E - lgx;
+                a[1] += own ? 1.0 : 0.0;
+                a[2] += (double)n_inact;
+            }
+            continue;
+        }
+
+        // Galaxy: 14 * psf_K bivariate normals (accum_galaxy_pos!, fsm_util.jl:255-346).  The reference's
+        // per-component chain get_bvn_derivs! -> transform_bvn_derivs! is replaced by its closed form: the
+        // derivatives of a Gaussian density with respect to its mean are Hermite polynomials in
+        // (u, v) = P (x - mu), and d/dSigma = (1/2) d2/dx2, so every quantity the Hessian needs is a
+        // weighted sum over components of spatial derivatives up to order 4 (24 sums instead of 1+6+21,
+        // and no 3x3 transforms inside the loop).  Weights: w0 = z theta_i, wd = +-z, wn = w0 nu,
+        // wdn = wd nu, wnn = w0 nu^2.
+        PixelTerms T;
+        double S0 = 0;
+        T.S0d = 0; T.S1x = 0; T.S1y = 0; T.S1xd = 0; T.S1yd = 0;
+        T.S2a = 0; T.S2b = 0; T.S2c = 0; T.S2an = 0; T.S2bn = 0; T.S2cn = 0; T.S2ad = 0; T.S2bd = 0; T.S2cd = 0;
+        T.S3a = 0; T.S3b = 0; T.S3c = 0; T.S3d = 0; T.S4a = 0; T.S4b = 0; T.S4c = 0; T.S4d = 0; T.S4e = 0;
+        if (own) {
+            for (int c = 0; c < ((ablate & 2) ? 0 : NC); ++c) {
+                const Comp &k = tc[c];
                 const double d1 = hh - k.mu1, d2 = ww - k.mu2;
-                const double py1 = k.p11 * d1 + k.p12 * d2, py2 = k.p12 * d1 + k.p22 * d2;
-                const double e = exp(-0.5 * (d1 * py1 + d2 * py2));   // eval_bvn_pdf!
-                const double f = k.zf * e;
-                f1 += f;
-                if (MODE != 0) {
-                    const double fd = k.zd * e;
-                    const double fn = f * k.nu;
-                    const double aa = py1 * py1, ab = py1 * py2, bb = py2 * py2;
-                    // get_bvn_derivs!: bvn_sig_d (BivariateNormals.jl:266-271)
-                    const double sd1 = 0.5 * (aa - k.p11), sd2 = ab - k.p12, sd3 = 0.5 * (bb - k.p22);
-                    g1[0] += f * py1; g1[1] += f * py2;   // d/dm = -d/dx = +py
-                    g1[2] += fd;
-                    g1[3] += fn * sd1; g1[4] += fn * sd2; g1[5] += fn * sd3;
-                    // (m, m): f (py py' - P)
-                    h1[0] += f * (aa - k.p11); h1[1] += f * (ab - k.p12); h1[6] += f * (bb - k.p22);
-                    // (m, dev)
-                    h1[2] += fd * py1; h1[7] += fd * py2;
-                    // (m, Xi): -(xsig_h[x, sg] - py_x sd[sg]) * nu
-                    h1[3] += fn * (py1 * sd1 - py1 * k.p11);
-                    h1[4] += fn * (py1 * sd2 - (py1 * k.p12 + py2 * k.p11));
-                    h1[5] += fn * (py1 * sd3 - py2 * k.p12);
-                    h1[8] += fn * (py2 * sd1 - py1 * k.p12);
-                    h1[9] += fn * (py2 * sd2 - (py1 * k.p22 + py2 * k.p12));
-                    h1[10] += fn * (py2 * sd3 - py2 * k.p22);
-                    // (dev, Xi)
-                    const double fdn = fd * k.nu;
-                    h1[12] += fdn * sd1; h1[13] += fdn * sd2; h1[14] += fdn * sd3;
-                    // (Xi, Xi): nu^2 f (sigsig_h + sd sd')
-                    const double fnn = fn * k.nu;
-                    h1[15] += fnn * (sd1 * sd1 - aa * k.p11 + 0.5 * k.p11 * k.p11);
-                    h1[16] += fnn * (sd1 * sd2 - ab * k.p11 - aa * k.p12 + k.p11 * k.p12);
-                    h1[17] += fnn * (sd1 * sd3 - ab * k.p12 + 0.5 * k.p12 * k.p12);
-                    h1[18] += fnn * (sd2 * sd2 - aa * k.p22 - 2.0 * ab * k.p12 - bb * k.p11 + k.p11 * k.p22 + k.p12 * k.p12);
-                    h1[19] += fnn * (sd2 * sd3 - ab * k.p22 - bb * k.p12 + k.p22 * k.p12);
-                    h1[20] += fnn * (sd3 * sd3 - bb * k.p22 + 0.5 * k.p22 * k.p22);
-                }
+                const double u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
+                const double e = exp_nonpos(-0.5 * (d1 * u + d2 * v), etab);   // eval_bvn_pdf!
+                const double f = k.w0 * e, fd = k.wd * e, fn = k.wn * e, fdn = k.wdn * e, fnn = k.wnn * e;
+                const double ha = __builtin_fma(u, u, -k.p11), hb = __builtin_fma(u, v, -k.p12),
+                             hc = __builtin_fma(v, v, -k.p22);
+                S0 += f; T.S0d += fd;
+                T.S1x = __builtin_fma(u, f, T.S1x); T.S1y = __builtin_fma(v, f, T.S1y);
+                T.S1xd = __builtin_fma(u, fd, T.S1xd); T.S1yd = __builtin_fma(v, fd, T.S1yd);
+                T.S2a = __builtin_fma(ha, f, T.S2a); T.S2b = __builtin_fma(hb, f, T.S2b); T.S2c = __builtin_fma(hc, f, T.S2c);
+                T.S2an = __builtin_fma(ha, fn, T.S2an); T.S2bn = __builtin_fma(hb, fn, T.S2bn); T.S2cn = __builtin_fma(hc, fn, T.S2cn);
+                T.S2ad = __builtin_fma(ha, fdn, T.S2ad); T.S2bd = __builtin_fma(hb, fdn, T.S2bd); T.S2cd = __builtin_fma(hc, fdn, T.S2cd);
+                // third order: u^3 - 3 p11 u, u^2 v - p11 v - 2 p12 u, u v^2 - p22 u - 2 p12 v, v^3 - 3 p22 v
+                const double tu = -2.0 * u, tv = -2.0 * v;
+                const double h3a = u * __builtin_fma(-2.0, k.p11, ha);
+                const double h3b = __builtin_fma(v, ha, tu * k.p12);
+                const double h3c = __builtin_fma(u, hc, tv * k.p12);
+                const double h3d = v * __builtin_fma(-2.0, k.p22, hc);
+                T.S3a = __builtin_fma(h3a, fn, T.S3a); T.S3b = __builtin_fma(h3b, fn, T.S3b);
+                T.S3c = __builtin_fma(h3c, fn, T.S3c); T.S3d = __builtin_fma(h3d, fn, T.S3d);
+                // fourth order
+                const double m3a = -3.0 * ha, m3c = -3.0 * hc;
+                const double h4a = __builtin_fma(u, h3a, m3a * k.p11);
+                const double h4b = __builtin_fma(v, h3a, m3a * k.p12);
+                const double h4c = __builtin_fma(u, h3c, __builtin_fma(-2.0 * hb, k.p12, -hc * k.p11));
+                const double h4d = __builtin_fma(u, h3d, m3c * k.p12);
+                const double h4e = __builtin_fma(v, h3d, m3c * k.p22);
+                T.S4a = __builtin_fma(h4a, fnn, T.S4a); T.S4b = __builtin_fma(h4b, fnn, T.S4b);
+                T.S4c = __builtin_fma(h4c, fnn, T.S4c); T.S4d = __builtin_fma(h4d, fnn, T.S4d);
+                T.S4e = __builtin_fma(h4e, fnn, T.S4e);
             }
         }
-        // h1 packed upper triangle of the 6x6 (m1 m2 dev Xi11 Xi12 Xi22):
-        // row0: 0..5, row1: 6..10, row2: 11..14 (11 = dev,dev = 0), row3: 15..17, row4: 18..19, row5: 20
+        T.f1 = S0;
+
+        // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
+        T.f0 = 0; T.f0g0 = 0; T.f0g1 = 0; T.f0h0 = 0; T.f0h1 = 0; T.f0h2 = 0;
+        if (own && !(ablate & 4)) {
+            const double xh = hh + sh0, xw = ww + sw0;
+            int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
+            int iy = (int)floor(xw); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
+            const double fx = xh - ix, fy = xw - iy;
+            double wx[4], wy[4], dwx[4], ddwx[4], dwy[4], ddwy[4];
+            bspline_w(fx, wx); bspline_w(fy, wy);
+            bspline_dw(fx, dwx, ddwx); bspline_dw(fy, dwy, ddwy);
+            const double *cc = tcoef + (ix - 1) + CEL_COEF * (iy - 1);
+            double y = 0, yx = 0, yy = 0, yxx = 0, yxy = 0, yyy = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double *cb = cc + CEL_COEF * b;
+                const double k0 = cb[0], k1 = cb[1], k2 = cb[2], k3 = cb[3];
+                const double r = k0 * wx[0] + k1 * wx[1] + k2 * wx[2] + k3 * wx[3];
+                const double rx = k0 * dwx[0] + k1 * dwx[1] + k2 * dwx[2] + k3 * dwx[3];
+                const double rxx = k0 * ddwx[0] + k1 * ddwx[1] + k2 * ddwx[2] + k3 * ddwx[3];
+                y += r * wy[b]; yx += rx * wy[b]; yxx += rxx * wy[b];
+                yy += r * dwy[b]; yxy += rx * dwy[b]; yyy += r * ddwy[b];
+            }
+            // softpluslikeinv and its derivatives; not C2 at 0, branch exactly (fsm_util.jl:222)
+            double gv, gp, gpp;
+            if (y < 0) { gv = 1e-3 * exp(y); gp = gv; gpp = gv; }
+            else { gv = 1e-3 * (y + 1.0); gp = 1e-3; gpp = 0.0; }
+            T.f0 = gv;
+            const double ym1 = -yx, ym2 = -yy;  // d(index)/dm = -1
+            T.f0g0 = gp * ym1; T.f0g1 = gp * ym2;
+            T.f0h0 = gpp * ym1 * ym1 + gp * yxx;
+            T.f0h1 = gpp * ym1 * ym2 + gp * yxy;
+            T.f0h2 = gpp * ym2 * ym2 + gp * yyy;
+        }
 
         // ---- per-pixel term (add_pixel_term!, add_elbo_log_term!) ----
-        const double A = c0 * f0 + c1 * f1;                       // E_G_s.v
-        const double B = q0 * (f0 * f0) + q1 * (f1 * f1);         // E_G2_s.v
-        const double E = Ebar + A;                                // E_G.v
-        const double V = Vbar + (B - A * A);                      // var_G.v
-        const double x = (double)xf;
-        const float iota_f = img.iota[h - 1];
-        const double iota = (double)iota_f;
-        // log(iota) is a Float32 log in the reference (iota::Float32, elbo_objective.jl:292)
-        const double log_iota = (double)(float)log(iota);
-        const double iE = 1.0 / E;
-        const double iE2 = iE * iE;
-        a[0] += x * (log_iota + (log(E) - V * (0.5 * iE2))) - iota * E - lgamma(x + 1.0);
-        a[ACC_CNT] += own ? 1.0 : 0.0;
-        a[ACC_CNT + 1] += n_inact;
-        if (MODE != 0 && own) {
-            const double iE3 = iE2 * iE;
-            const double w1 = x * (iE + V * iE3) - iota;          // dT/dE
-            const double w2 = -0.5 * x * iE2;                     // dT/dVar
-            const double w11 = -x * (iE2 + 3.0 * V * iE2 * iE2);  // d2T/dE2
-            const double w12 = x * iE3;                           // d2T/dE dVar
-            const double alpha = w1 - 2.0 * A * w2;
-            const double beta = w11 - 2.0 * w2 - 4.0 * A * w12;
-            // geometry derivatives of A and B: index g = 0..5 <-> reduced variable 4 + g
-            double dAg[6], dBg[6];
-            dAg[0] = c0 * f0g[0] + c1 * g1[0]; dAg[1] = c0 * f0g[1] + c1 * g1[1];
-            dBg[0] = 2.0 * (q0 * f0 * f0g[0] + q1 * f1 * g1[0]);
-            dBg[1] = 2.0 * (q0 * f0 * f0g[1] + q1 * f1 * g1[1]);
-#pragma unroll
-            for (int g = 2; g < 6; ++g) { dAg[g] = c1 * g1[g]; dBg[g] = 2.0 * q1 * f1 * g1[g]; }
-            // gradient
-            a[1] += alpha * f0; a[2] += alpha * f1;
-            a[3] += w2 * f0 * f0; a[4] += w2 * f1 * f1;
-#pragma unroll
-            for (int g = 0; g < 6; ++g) a[5 + g] += alpha * dAg[g] + w2 * dBg[g];
-            // Hessian: (c, c)
-            a[hidx(0, 0)] += beta * f0 * f0; a[hidx(0, 1)] += beta * f0 * f1; a[hidx(1, 1)] += beta * f1 * f1;
-            // (c, q)
-            a[hidx(0, 2)] += w12 * f0 * (f0 * f0); a[hidx(0, 3)] += w12 * f0 * (f1 * f1);
-            a[hidx(1, 2)] += w12 * f1 * (f0 * f0); a[hidx(1, 3)] += w12 * f1 * (f1 * f1);
-            // (c, geo) and (q, geo)
-            const double f0gx[6] = {f0g[0], f0g[1], 0, 0, 0, 0};
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                const double u = beta * dAg[g] + w12 * dBg[g];
-                a[hidx(0, 4 + g)] += alpha * f0gx[g] + f0 * u;
-                a[hidx(1, 4 + g)] += alpha * g1[g] + f1 * u;
-                a[hidx(2, 4 + g)] += 2.0 * w2 * f0 * f0gx[g] + w12 * (f0 * f0) * dAg[g];
-                a[hidx(3, 4 + g)] += 2.0 * w2 * f1 * g1[g] + w12 * (f1 * f1) * dAg[g];
-            }
-            // (geo, geo)
-            const double k1 = alpha * c1 + 2.0 * w2 * q1 * f1;    // multiplies d2 f1
-            const double k0 = alpha * c0 + 2.0 * w2 * q0 * f0;    // multiplies d2 f0
-            const double r1 = 2.0 * w2 * q1, r0 = 2.0 * w2 * q0;  // multiply df df'
-            int hp = 0;
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-#pragma unroll
-                for (int g2 = g; g2 < 6; ++g2, ++hp) {
-                    double v = k1 * h1[hp] + r1 * g1[g] * g1[g2] + beta * dAg[g] * dAg[g2] +
-                               w12 * (dAg[g] * dBg[g2] + dBg[g] * dAg[g2]);
-                    if (g2 < 2) {
-                        const int sp = g + g2;  // (0,0)->0 (0,1)->1 (1,1)->2
-                        v += k0 * f0h[sp] + r0 * f0g[g] * f0g[g2];
-                    }
-                    a[hidx(4 + g, 4 + g2)] += v;
-                }
-            }
+        {
+            const double A = c0 * T.f0 + c1 * T.f1;                       // E_G_s.v
+            const double B = q0 * (T.f0 * T.f0) + q1 * (T.f1 * T.f1);     // E_G2_s.v
+            const double E = valid ? Ebar + A : 1.0;                      // E_G.v
+            const double V = Vbar + (B - A * A);                          // var_G.v
+            const double iE = 1.0 / E;
+            const double iE2 = iE * iE, iE3 = iE2 * iE;
+            T.vterm = valid ? x * (log_iota + (log(E) - V * (0.5 * iE2))) - iota * E - lgx : 0.0;
+            T.cnt_act = own ? 1.0 : 0.0;
+            T.cnt_inact = (double)n_inact;
+            // derivative weights are zero unless the active source covers the pixel, which zeroes every
+            // derivative entry of the record (all lanes take part in the cross-lane exchange below)
+            const double xo = (own && !(ablate & 8)) ? x : 0.0, io = (own && !(ablate & 8)) ? iota : 0.0;
+            const double w1 = xo * (iE + V * iE3) - io;            // dT/dE
+            T.w2 = -0.5 * xo * iE2;                                // dT/dVar
+            const double w11 = -xo * (iE2 + 3.0 * V * iE2 * iE2);  // d2T/dE2
+            T.w12 = xo * iE3;                                      // d2T/dE dVar
+            T.alpha = w1 - 2.0 * A * T.w2;
+            T.beta = w11 - 2.0 * T.w2 - 4.0 * A * T.w12;
+            T.k1 = T.alpha * c1 + 2.0 * T.w2 * q1 * T.f1;          // multiplies d2 f1
+            T.k0 = T.alpha * c0 + 2.0 * T.w2 * q0 * T.f0;          // multiplies d2 f0
+            T.r1 = 2.0 * T.w2 * q1; T.r0 = 2.0 * T.w2 * q0;        // multiply df df'
+            const double q0f0 = 2.0 * q0 * T.f0, q1f1 = 2.0 * q1 * T.f1;
+            T.dA0 = c0 * T.f0g0 + c1 * gal_g<0>(T); T.dB0 = q0f0 * T.f0g0 + q1f1 * gal_g<0>(T);
+            T.dA1 = c0 * T.f0g1 + c1 * gal_g<1>(T); T.dB1 = q0f0 * T.f0g1 + q1f1 * gal_g<1>(T);
+            T.dA2 = c1 * gal_g<2>(T); T.dB2 = q1f1 * gal_g<2>(T);
+            T.dA3 = c1 * gal_g<3>(T); T.dB3 = q1f1 * gal_g<3>(T);
+            T.dA4 = c1 * gal_g<4>(T); T.dB4 = q1f1 * gal_g<4>(T);
+            T.dA5 = c1 * gal_g<5>(T); T.dB5 = q1f1 * gal_g<5>(T);
         }
+        fold_entries<0>(T, b0, b1, a);
     }
 
-    // ---- wave64 butterfly, one 68-double record per (target, image, chunk) ----
+    // ---- one 68-double record per (target, image, chunk) ----
     double *__restrict__ out = acc + (size_t)wg * ACC_N;
+    if (MODE == 0) {
+        const double s0 = wave_sum(a[0]), s1 = wave_sum(a[1]), s2 = wave_sum(a[2]);
+        if (lane == 0) { out[0] = s0; out[ACC_CNT] = s1; out[ACC_CNT + 1] = s2; }
+        return;
+    }
 #pragma unroll
-    for (int i = 0; i < ACC_N; ++i) {
-        if (MODE == 0 && i > 0 && i < ACC_CNT) continue;
-        const double s = wave_sum(a[i]);
-        if (lane == (i & 63)) out[i] = s;
+    for (int j = 0; j < ACC_Q; ++j) {
+        const double s = quad_class_sum(a[j]);
+        if (lane < 4) out[4 * j + lane] = s;
     }
 }
 
