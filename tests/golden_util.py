@@ -1,0 +1,55 @@
+"""Golden fixtures: inputs (images, catalog, vp) and expected outputs (oracle) as compressed .npz."""
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+CASES = {
+    # name: (kind, args)
+    "sample_star": ("sample", "star"),
+    "sample_galaxy": ("sample", "galaxy"),
+    "sample_two_body": ("sample", "two_body"),
+    "field_64x80_8src_nan": ("field", (64, 80, 8, 21, 0.01)),
+}
+
+
+def build_case(name):
+    from celeste_jl_amd import synthetic
+    kind, arg = CASES[name]
+    if kind == "sample":
+        return synthetic.make_sample_dataset(arg)
+    H, W, S, seed, nanf = arg
+    return synthetic.make_field(H, W, S, seed=seed, nan_fraction=nanf)
+
+
+def field_to_arrays(f):
+    cat = f.catalog
+    return dict(
+        pixels=np.stack([im.pixels for im in f.images]),
+        sky=np.array([im.sky[0, 0] for im in f.images], dtype=np.float32),
+        iota=np.array([im.nelec_per_nmgy[0] for im in f.images], dtype=np.float32),
+        pos=np.array([c.pos for c in cat]), is_star=np.array([c.is_star for c in cat]),
+        star_fluxes=np.array([c.star_fluxes for c in cat]), gal_fluxes=np.array([c.gal_fluxes for c in cat]),
+        shape=np.array([[c.gal_frac_dev, c.gal_axis_ratio, c.gal_angle, c.gal_radius_px] for c in cat]),
+        vp=f.vp)
+
+
+def arrays_to_field(z):
+    """Rebuild images / patches / neighbours from stored arrays with the package's host logic."""
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.model import get_sky_patches, neighbor_map
+    from celeste_jl_amd.params import CatalogEntry
+    _, H, W = z["pixels"].shape
+    images = synthetic.blank_images(H, W)
+    for n, im in enumerate(images):
+        assert im.sky[0, 0] == z["sky"][n] and im.nelec_per_nmgy[0] == z["iota"][n]
+        im.pixels = z["pixels"][n].copy()
+    cat = [CatalogEntry(z["pos"][s], bool(z["is_star"][s]), z["star_fluxes"][s], z["gal_fluxes"][s],
+                        *[float(x) for x in z["shape"][s]]) for s in range(len(z["pos"]))]
+    patches = get_sky_patches(images, cat)
+    return synthetic.Field(images, cat, patches, neighbor_map(patches), z["vp"].copy())
+
+
+def path(name):
+    return os.path.join(GOLDEN, name + ".npz")

@@ -1,0 +1,66 @@
+"""The C-ABI shared library loads and exports every symbol include/celeste_mi355x.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported(lib):
+    from celeste_jl_amd import cabi
+    hdr = open(os.path.join(ROOT, "include", "celeste_mi355x.h")).read()
+    declared = set(re.findall(r"\b(celeste_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(cabi.EXPORTED_SYMBOLS), declared ^ set(cabi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.celeste_version() >= 100
+    assert lib.celeste_strerror(0) == b"ok" and b"CPU fallback" in lib.celeste_strerror(cabi.ERR_NO_DEVICE)
+
+
+def test_struct_layout_matches_the_header():
+    """ctypes mirrors of the header structs (sizes on the LP64 ABI)"""
+    from celeste_jl_amd import cabi
+    assert C.sizeof(cabi.ImageT) == 16 + 3 * 8
+    assert C.sizeof(cabi.PatchT) == 16 + 8 + 8 * 8 + 8 + 8
+    assert C.sizeof(cabi.PriorT) == 8 * (6 + 16 + 64 + 256 + 2)
+    assert C.sizeof(cabi.ProblemT) == 16 + 6 * 8
+    assert C.sizeof(cabi.WorkStatsT) == 40
+
+
+def test_no_cpu_fallback(lib):
+    """Without a HIP device the engine must refuse to compute (no silent fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_sample_dataset("star")
+    with pytest.raises(cabi.CelesteError) as e:
+        cel.FieldContext(f.images, f.patches, f.neighbors)
+    assert e.value.status == cabi.ERR_NO_DEVICE
+    out = np.zeros(4); psf = np.ascontiguousarray(synthetic.band_psf(0)); g = np.zeros(2)
+    dp = cabi.c_double_p
+    st = lib.celeste_psf_raster(0, psf.ctypes.data_as(dp), 2, g.ctypes.data_as(dp), 2, g.ctypes.data_as(dp), 2,
+                                out.ctypes.data_as(dp))
+    assert st == cabi.ERR_NO_DEVICE
+
+
+def test_invalid_arguments_are_rejected(lib):
+    from celeste_jl_amd import cabi
+    h = C.c_void_p()
+    assert lib.celeste_ctx_create(None, 0, C.byref(h)) == cabi.ERR_INVALID_ARG
+    assert lib.celeste_spline_prefilter(None, None) == cabi.ERR_INVALID_ARG
+    assert lib.celeste_ctx_enable_timing(None, 1) == cabi.ERR_INVALID_ARG
+
+
+def test_product_does_not_reference_the_oracle():
+    """the oracle is test infrastructure: nothing under celeste.jl_amd/ may import, link or call it"""
+    pkg = os.path.join(ROOT, "celeste.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".inc")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oracle" not in txt.lower(), os.path.join(dirpath, fn)

@@ -1,0 +1,91 @@
+"""-m gpu: BASELINE.json configurations at full size.
+
+configs[1] (512x512x5, 100 stars): full parity against the oracle.
+configs[2] (2048x1489x5, 2000 star+galaxy sources): oracle parity on a sample of targets plus
+size-independent properties (order invariance, sharding invariance, exact symmetry, counters)."""
+import numpy as np
+import pytest
+
+from parity_util import assert_parity
+
+pytestmark = pytest.mark.gpu
+ALL = 7
+
+
+@pytest.fixture(scope="module")
+def field3():
+    from celeste_jl_amd import synthetic
+    return synthetic.make_field(2048, 1489, 2000, seed=3)
+
+
+@pytest.fixture(scope="module")
+def ctx3(field3):
+    import celeste_jl_amd as cel
+    return cel.FieldContext(field3.images, field3.patches, field3.neighbors)
+
+
+def test_config2_stars_full_parity(oracle):
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(512, 512, 100, seed=2, stars_only=True)
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    tg = list(range(100))
+    errs = assert_parity(ctx.eval_batch(f.vp, tg, ALL), oracle.elbo_batch(ctx.problem, f.vp, tg, ALL), "config2")
+    print("config2", errs)
+
+
+def test_config3_oracle_parity_on_a_sample(oracle, field3, ctx3):
+    nb = np.array([len(n) for n in field3.neighbors])
+    sample = sorted(set(list(range(0, 2000, 50)) + list(np.argsort(-nb)[:8])))  # every 50th + most crowded
+    g = ctx3.eval_batch(field3.vp, sample, ALL)
+    r = oracle.elbo_batch(ctx3.problem, field3.vp, sample, ALL)
+    errs = assert_parity(g, r, "config3 sample")
+    print("config3 sample of %d" % len(sample), errs)
+
+
+def test_config3_size_independent_properties(field3, ctx3):
+    S = 2000
+    tg = np.arange(S)
+    v, d, h, cnt, st = ctx3.eval_batch(field3.vp, tg, ALL)
+    assert (st == 0).all() and np.isfinite(v).all() and np.isfinite(d).all() and np.isfinite(h).all()
+    # exact symmetry of every Hessian
+    assert np.array_equal(h, h.transpose(0, 2, 1))
+    # counters: active pairs = sum_n H2 (W2 - 1) when nothing is masked (elbo_objective.jl:349)
+    expect = np.array([sum(p.active_pixel_bitmap.shape[0] * (p.active_pixel_bitmap.shape[1] - 1) for p in row)
+                       for row in field3.patches])
+    assert np.array_equal(cnt[:, 0], expect)
+    assert (cnt[field3_no_neighbors(field3), 1] == 0).all()
+    # order invariance: a permuted batch gives bit-identical per-target results
+    perm = np.random.default_rng(0).permutation(S)
+    v2, d2, h2, cnt2, _ = ctx3.eval_batch(field3.vp, perm, ALL)
+    assert np.array_equal(v2, v[perm]) and np.array_equal(d2, d[perm]) and np.array_equal(h2, h[perm])
+    # sharding invariance: two cost-balanced shards == one sweep
+    from celeste_jl_amd.partition import shard_targets, estimate_time
+    costs = [estimate_time(row) for row in field3.patches]
+    for shard in shard_targets(costs, 2):
+        vs, ds, hs, _, _ = ctx3.eval_batch(field3.vp, shard, ALL)
+        assert np.array_equal(vs, v[shard]) and np.array_equal(ds, d[shard]) and np.array_equal(hs, h[shard])
+    # value-only and gradient-only evaluations agree with the full one
+    v0, _, _, _, _ = ctx3.eval_batch(field3.vp, tg, 4)
+    assert np.max(np.abs(v0 - v) / np.abs(v)) <= 1e-13
+    # the k parameters have zero likelihood derivatives
+    vl, dl, hl, _, _ = ctx3.eval_batch(field3.vp, tg[:64], 3)
+    assert np.all(dl[:, 28:] == 0) and np.all(hl[:, 28:, :] == 0)
+
+
+def field3_no_neighbors(f):
+    return np.array([len(n) == 0 for n in f.neighbors])
+
+
+def test_config3_neighbor_parameters_matter(field3, ctx3):
+    """perturbing a neighbour's parameters changes the target's ELBO but not its own-parameter structure"""
+    t = int(np.argmax([len(n) for n in field3.neighbors]))
+    nb = field3.neighbors[t][0]
+    v, d, h, _, _ = ctx3.eval_batch(field3.vp, [t], ALL)
+    vp2 = field3.vp.copy(); vp2[nb, 6:8] += 0.3
+    v2, d2, h2, _, _ = ctx3.eval_batch(vp2, [t], ALL)
+    assert v2[0] != v[0]
+    iso = np.flatnonzero(field3_no_neighbors(field3))[:5]
+    a = ctx3.eval_batch(field3.vp, iso, ALL); b = ctx3.eval_batch(vp2, iso, ALL)
+    keep = [i for i, s in enumerate(iso) if s != nb]
+    assert np.array_equal(a[0][keep], b[0][keep])

@@ -1,0 +1,136 @@
+"""Host-side input preparation: boxes, patches, neighbours, initialisers, spline prefilter, sharding."""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_boxes_overlap_known_answers():
+    """test/test_imaged_sources.jl:7-12"""
+    from celeste_jl_amd.model import boxes_overlap
+    assert boxes_overlap(((1, 10), (1, 10)), ((5, 15), (5, 15)))
+    assert not boxes_overlap(((1, 10), (1, 10)), ((11, 15), (5, 15)))
+    assert not boxes_overlap(((1, 10), (1, 10)), ((5, 15), (11, 15)))
+    assert boxes_overlap(((1, 10), (1, 10)), ((10, 15), (10, 15)))
+    assert not boxes_overlap(((1, 0), (1, 10)), ((1, 10), (1, 10)))  # empty range (off-image patch)
+
+
+def test_clamp_box_and_rounding():
+    from celeste_jl_amd.model import clamp_box, julia_round
+    assert clamp_box(((-3, 7), (20, 40)), (20, 23)) == ((1, 7), (20, 23))
+    assert clamp_box(((25, 30), (1, 5)), (20, 23)) == ((21, 20), (1, 5))  # empty but legal
+    assert [julia_round(x) for x in (0.5, 1.5, 2.5, -0.5, 2.4999, 2.5001)] == [0, 2, 2, 0, 2, 3]
+
+
+def test_catalog_init_source_and_generic():
+    """DeterministicVI.jl:39-91"""
+    from celeste_jl_amd import catalog_init_source, generic_init_source, ids
+    from celeste_jl_amd.synthetic import sample_ce
+    g = generic_init_source([3.0, 4.0])
+    assert list(g[ids.pos]) == [3.0, 4.0] and g[ids.gal_radius_px] == 1.0 and np.all(g[ids.k] == 1 / 8)
+    assert g.shape == (44,) and np.all(g[ids.color_var] == 1e-2) and np.all(g[ids.flux_loc] == math.log(2.0))
+    star = catalog_init_source(sample_ce([10.1, 12.2], True))
+    assert list(star[ids.is_star]) == [0.8, 0.2] and star[ids.gal_radius_px] == 0.2 and star[ids.gal_axis_ratio] == .8
+    gal = catalog_init_source(sample_ce([8.5, 9.6], False))
+    assert list(gal[ids.is_star]) == [0.2, 0.8] and gal[ids.gal_radius_px] == 4.0 and gal[ids.gal_frac_dev] == 0.1
+    fl = sample_ce([0, 0], True).star_fluxes
+    assert star[ids.flux_loc[0]] == pytest.approx(math.log(fl[2]))
+    assert star[ids.color_mean[:, 0]] == pytest.approx([math.log(fl[c + 1] / fl[c]) for c in range(4)])
+
+
+def test_patches_and_neighbors_match_brute_force():
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.model import find_neighbors, neighbor_map, choose_patch_radius
+    f = synthetic.make_field(200, 240, 30, seed=4)
+    nm = neighbor_map(f.patches)
+    for s in range(30):
+        assert nm[s] == find_neighbors(f.patches, s)
+        for n, p in enumerate(f.patches[s]):
+            r = choose_patch_radius(f.catalog[s], f.images[n], width_scale=1.2)
+            assert 0 < r <= 25
+            (h0, h1), (w0, w1) = p.box
+            assert p.bitmap_offset == (h0 - 1, w0 - 1)
+            assert p.active_pixel_bitmap.shape == (h1 - h0 + 1, w1 - w0 + 1)
+            assert p.pixel_center[0] == (h0 + h1) / 2 and p.pixel_center[1] == (w0 + w1) / 2
+    assert nm == f.neighbors
+
+
+def test_spline_prefilter_matches_oracle_and_interpolates(lib, oracle):
+    """product prefilter (Thomas algorithm) vs oracle (dense elimination): independent implementations"""
+    from celeste_jl_amd import synthetic, cabi
+    rng = np.random.default_rng(1)
+    for stamp in (synthetic.render_psf(synthetic.band_psf(0)), rng.uniform(-0.1, 1.0, (51, 51))):
+        a = cabi.spline_prefilter(stamp)
+        b = oracle.spline_coefs(stamp)
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+        # natural boundary rows: c0 - 2 c1 + c2 = 0 along both axes
+        assert np.abs(a[0] - 2 * a[1] + a[2]).max() < 1e-12 and np.abs(a[:, -1] - 2 * a[:, -2] + a[:, -3]).max() < 1e-12
+
+
+def test_render_psf_equals_get_psf_at_point(oracle):
+    """psf_model.jl:61-75 and PSF.jl:150-161 are the same raster"""
+    from celeste_jl_amd import synthetic
+    psf = synthetic.band_psf(3)
+    st = synthetic.render_psf(psf)
+    for (i, j) in [(26, 26), (1, 1), (30, 20), (51, 2)]:
+        assert st[i - 1, j - 1] == pytest.approx(oracle.psf_at_point(psf, i - 26.0, j - 26.0), rel=1e-13)
+
+
+def test_problem_marshalling_layout():
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_sample_dataset("two_body")
+    pb = cabi.Problem(f.images, f.patches, f.neighbors)
+    assert pb.c.n_images == 5 and pb.c.n_sources == 2 and pb.c.n_stamps == 4  # bands 3 and 5 share a PSF
+    im = pb.c.images[2]
+    assert (im.H, im.W, im.band) == (20, 23, 3)
+    # column-major: element [h, w] at h + H * w
+    assert im.pixels[3 + 20 * 7] == f.images[2].pixels[3, 7]
+    p = pb.c.patches[1 * 5 + 2]
+    assert (p.off_h, p.off_w) == f.patches[1][2].bitmap_offset and not p.bitmap  # bitmap == !isnan -> NULL
+    assert list(p.wcs_jacobian) == [1.0, 0.0, 0.0, 1.0]
+    assert list(pb.nbr_off) == [0, 1, 2] and list(pb.nbr_idx[:2]) == [1, 0]
+
+
+def test_synthetic_field_is_deterministic_and_poisson_like():
+    from celeste_jl_amd import synthetic
+    a = synthetic.make_field(96, 128, 6, seed=9)
+    b = synthetic.make_field(96, 128, 6, seed=9)
+    assert all(np.array_equal(x.pixels, y.pixels) for x, y in zip(a.images, b.images))
+    assert np.array_equal(a.vp, b.vp)
+    img = a.images[2]
+    assert img.pixels.dtype == np.float32 and np.all(img.pixels >= 0) and np.all(img.pixels == np.round(img.pixels))
+    # far from any source the counts are Poisson(sky * iota)
+    assert abs(np.median(img.pixels) - 0.60 * 820) < 30
+
+
+def test_sharding_is_balanced_and_complete():
+    """load_balance_across_threads analogue (ParallelRun.jl:49-56)"""
+    from celeste_jl_amd.partition import shard_targets, estimate_time, load_balance
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(200, 240, 40, seed=4)
+    costs = [estimate_time(row) for row in f.patches]
+    for world in (1, 2, 3, 8):
+        shards = shard_targets(costs, world)
+        assert sorted(i for s in shards for i in s) == list(range(40))
+        loads = [sum(costs[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(costs)
+    assert load_balance(2, [3, 1, 1, 1]) == [3.0, 3.0]
+
+
+def test_cyclades_covers_all_sources_without_conflicts():
+    """test/test_partition.jl:56-92"""
+    from celeste_jl_amd.partition import partition_cyclades_dynamic
+    rng = np.random.default_rng(0)
+    target_sources = list(range(6, 22))
+    neighbor_map = {s: [] for s in target_sources}
+    for a, b in [(6, 7), (7, 8), (10, 15), (11, 12), (12, 13), (13, 14), (16, 21), (18, 19)]:
+        neighbor_map[a].append(b); neighbor_map[b].append(a)
+    for it in range(20):
+        batches = partition_cyclades_dynamic(target_sources, neighbor_map, batch_size=4, rng=rng)
+        assert sorted(i for b in batches for c in b for i in c) == list(range(16))
+        for b in batches:
+            for x in range(len(b)):
+                for y in range(x + 1, len(b)):
+                    for i in b[x]:
+                        for j in b[y]:
+                            assert target_sources[j] not in neighbor_map[target_sources[i]]

@@ -1,0 +1,64 @@
+"""The reference's central property test (test/test_elbo.jl:223-301): hand-written derivatives equal
+automatic differentiation of the same objective.  Here: the C oracle's value / gradient / Hessian against
+torch.autograd (fp64) on an independently written value-only restatement, plus finite differences."""
+import numpy as np
+import pytest
+
+import torch_value_model as tvm
+
+
+def _check(oracle, field, target):
+    from celeste_jl_amd import cabi
+    pb = cabi.Problem(field.images, field.patches, field.neighbors)
+    ov, od, oh, cnt, st = oracle.elbo_one(pb, field.vp, target)
+    assert st == 0
+    tv, tg, tH = tvm.value_grad_hess(field.images, field.patches, field.neighbors, field.vp, target)
+    assert abs(ov - tv) <= 1e-13 * abs(tv)
+    assert np.abs(od - tg).max() <= 1e-12 * np.abs(tg).max()
+    assert np.abs(oh - tH).max() <= 1e-12 * np.abs(tH).max()
+    # every one of the 44 parameters has a meaningful derivative check (rtol sqrt(eps) like Julia's isapprox)
+    big = np.abs(tg) > 1e-9 * np.abs(tg).max()
+    assert np.all(np.abs(od - tg)[big] <= 1.5e-8 * np.abs(tg)[big])
+
+
+def test_two_body_galaxy_target(oracle):
+    from celeste_jl_amd import synthetic
+    _check(oracle, synthetic.make_sample_dataset("two_body"), 0)
+
+
+def test_two_body_star_target(oracle):
+    from celeste_jl_amd import synthetic
+    _check(oracle, synthetic.make_sample_dataset("two_body"), 1)
+
+
+def test_kl_derivatives(oracle):
+    """subtract_kl: analytic gradient / Hessian vs autograd (the reference uses ReverseDiff / ForwardDiff)"""
+    import torch
+    from celeste_jl_amd.synthetic import load_prior, make_sample_dataset
+    prior = load_prior()
+    vs = make_sample_dataset("galaxy").vp[0]
+    v, d, h = oracle.subtract_kl(vs, prior)
+    th = torch.tensor(vs, dtype=torch.float64, requires_grad=True)
+    tv = tvm.neg_kl(th, prior)
+    g, = torch.autograd.grad(tv, th, create_graph=True)
+    H = torch.stack([torch.autograd.grad(g[i], th, retain_graph=True)[0] for i in range(44)]).numpy()
+    assert v == pytest.approx(tv.item(), rel=1e-13)
+    assert np.abs(d - g.detach().numpy()).max() <= 1e-12 * np.abs(d).max()
+    assert np.abs(h - H).max() <= 1e-12 * np.abs(H).max()
+    assert np.array_equal(h, h.T)
+
+
+def test_hessian_vector_product_matches_finite_difference(oracle):
+    """test_elbo.jl:273-301 (H 1 vs a finite difference of the gradient, 1 %); central differences here"""
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_sample_dataset("two_body")
+    pb = cabi.Problem(f.images, f.patches, f.neighbors)
+    _, d0, h0, _, _ = oracle.elbo_one(pb, f.vp, 0)
+    vp1 = f.vp.copy(); vp1[0] += 1e-5
+    vp2 = f.vp.copy(); vp2[0] -= 1e-5
+    _, d1, _, _, _ = oracle.elbo_one(pb, vp1, 0)
+    _, d2, _, _, _ = oracle.elbo_one(pb, vp2, 0)
+    hv_fd = (d1 - d2) / 2e-5
+    hv = h0.sum(axis=1)
+    for i in range(44):
+        assert abs(hv_fd[i] - hv[i]) <= 0.01 * max(abs(hv[i]), 1e-4 * np.abs(hv).max())

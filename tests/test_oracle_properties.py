@@ -1,0 +1,126 @@
+"""Property tests mirrored from test/test_elbo.jl, run on the CPU oracle (value-only evaluations)."""
+import numpy as np
+import pytest
+
+ALL = 7
+
+
+def _val(oracle, pb, vp, t=0, flags=0):
+    return oracle.elbo_one(pb, vp, t, flags)[0]
+
+
+def test_star_truth_is_most_likely(oracle):
+    """test_elbo.jl:132-170 with true_star_init (SampleData.jl:239-249)"""
+    import math
+    from celeste_jl_amd import synthetic, cabi, ids
+    f = synthetic.make_sample_dataset("star", perturb=False)
+    vp = f.vp.copy()
+    vp[0, ids.is_star] = [1.0 - 1e-4, 1e-4]
+    vp[0, ids.flux_scale] = 1e-4
+    vp[0, ids.flux_loc] = math.log(synthetic.SAMPLE_STAR_FLUXES[2]) - 0.5 * 1e-4
+    vp[0, ids.color_var] = 1e-4
+    pb = cabi.Problem(f.images, f.patches, f.neighbors)
+    best = _val(oracle, pb, vp)
+    for bad_a in (.3, .5, .9):
+        v = vp.copy(); v[0, ids.is_star] = [1 - bad_a, bad_a]
+        assert best > _val(oracle, pb, v)
+    for h2 in range(-2, 3):
+        for w2 in range(-2, 3):
+            if h2 or w2:
+                v = vp.copy(); v[0, ids.pos] += [h2 * .5, w2 * .5]
+                assert best > _val(oracle, pb, v)
+    for delta in (.7, .9, 1.1, 1.3):
+        v = vp.copy(); v[0, ids.flux_loc] += math.log(delta)
+        assert best > _val(oracle, pb, v)
+    for b in range(4):
+        for delta in (-.3, .3):
+            v = vp.copy(); v[0, ids.color_mean[b, 0]] += delta
+            assert best > _val(oracle, pb, v)
+
+
+def test_galaxy_truth_is_most_likely(oracle):
+    """test_elbo.jl:173-220"""
+    import math
+    from celeste_jl_amd import synthetic, cabi, ids
+    f = synthetic.make_sample_dataset("galaxy", perturb=False)
+    vp = f.vp.copy(); vp[0, ids.is_star] = [0.01, .99]
+    pb = cabi.Problem(f.images, f.patches, f.neighbors)
+    best = _val(oracle, pb, vp)
+    for bad_a in (.3, .5, .9):
+        v = vp.copy(); v[0, ids.is_star] = [1 - bad_a, bad_a]
+        assert best > _val(oracle, pb, v)
+    for h2 in range(-2, 3):
+        for w2 in range(-2, 3):
+            if h2 or w2:
+                v = vp.copy(); v[0, ids.pos] += [h2 * .5, w2 * .5]
+                assert best > _val(oracle, pb, v)
+    for bad_scale in (.8, 1.2):
+        v = vp.copy(); v[0, ids.flux_loc] += 2 * math.log(bad_scale)
+        assert best > _val(oracle, pb, v)
+    for name in ("gal_axis_ratio", "gal_angle", "gal_radius_px"):
+        for bad_scale in (.8, 1.2):
+            v = vp.copy(); v[0, getattr(ids, name)] *= bad_scale
+            assert best > _val(oracle, pb, v)
+    for b in range(4):
+        for delta in (-.3, .3):
+            v = vp.copy(); v[0, ids.color_mean[b, 1]] += delta
+            assert best > _val(oracle, pb, v)
+
+
+def test_inactive_source_semantics(oracle):
+    """test_elbo.jl:64-130: a neighbour with no active pixels contributes nothing; with a few active pixels it
+    changes the value only where both cover; derivatives belong to the active source only."""
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_sample_dataset("two_body")
+    for n in range(5):
+        p = f.patches[0][n]
+        assert p.bitmap_offset == (0, 0) and p.active_pixel_bitmap.shape == f.images[n].pixels.shape
+        assert p.active_pixel_bitmap.all()
+    pb_both = cabi.Problem(f.images, f.patches, f.neighbors)
+    v_both, d_both, h_both, c_both, _ = oracle.elbo_one(pb_both, f.vp, 0, 3)
+    for n in range(5):
+        f.patches[1][n].active_pixel_bitmap[:] = False
+    pb_off = cabi.Problem(f.images, f.patches, f.neighbors)
+    v_off, d_off, h_off, c_off, _ = oracle.elbo_one(pb_off, f.vp, 0, 3)
+    pb_alone = cabi.Problem(f.images, [f.patches[0]], [[]])
+    v_alone, d_alone, h_alone, c_alone, _ = oracle.elbo_one(pb_alone, f.vp[:1], 0, 3)
+    assert v_off == v_alone and np.array_equal(d_off, d_alone) and np.array_equal(h_off, h_alone)
+    assert c_off[1] == 0 and c_both[1] > 0 and c_both[0] == c_off[0]
+    assert v_both != v_off
+    f.patches[1][4].active_pixel_bitmap[9:11, 9:11] = True
+    pb_few = cabi.Problem(f.images, f.patches, f.neighbors)
+    _, _, _, c_few, _ = oracle.elbo_one(pb_few, f.vp, 0, 3)
+    assert c_few[1] == 4
+
+
+def test_last_patch_column_contributes_nothing(oracle):
+    """elbo_objective.jl:349: the counters count (pixel, source) pairs with w2 < W2"""
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_sample_dataset("star")
+    pb = cabi.Problem(f.images, f.patches, f.neighbors)
+    _, _, _, cnt, _ = oracle.elbo_one(pb, f.vp, 0, 0)
+    expect = sum(p.active_pixel_bitmap.shape[0] * (p.active_pixel_bitmap.shape[1] - 1) for p in f.patches[0])
+    assert cnt[0] == expect and cnt[1] == 0
+
+
+def test_flags_are_consistent(oracle):
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_sample_dataset("two_body")
+    pb = cabi.Problem(f.images, f.patches, f.neighbors)
+    v7, d7, h7, _, _ = oracle.elbo_one(pb, f.vp, 0, 7)
+    v3, d3, h3, _, _ = oracle.elbo_one(pb, f.vp, 0, 3)
+    v0 = _val(oracle, pb, f.vp, 0, 0)
+    v4 = _val(oracle, pb, f.vp, 0, 4)
+    kl, kd, kh = oracle.subtract_kl(f.vp[0])
+    assert v0 == v3 and v4 == v7
+    assert v7 == pytest.approx(v3 + kl, rel=1e-15)
+    assert np.allclose(d7, d3 + kd, rtol=1e-14, atol=0) and np.allclose(h7, h3 + kh, rtol=1e-13, atol=1e-9)
+    assert np.all(d3[28:] == 0)  # k enters only through the KL term
+
+
+def test_nonfinite_input_status(oracle):
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_sample_dataset("two_body")
+    pb = cabi.Problem(f.images, f.patches, f.neighbors)
+    vp = f.vp.copy(); vp[1, 3] = np.inf
+    assert oracle.elbo_one(pb, vp, 0)[4] == cabi.ERR_NONFINITE_INPUT

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz: seeded synthetic inputs and the CPU oracle's outputs for them.
+
+The reference itself cannot run here (Julia absent) and holds no numeric ELBO goldens,
+so these vectors pin *our* oracle (regression) and let the GPU tests run without the oracle."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import golden_util as gu
+from celeste_jl_amd import cabi
+from oracle import oracle
+
+for name in gu.CASES:
+    f = gu.build_case(name)
+    arrs = gu.field_to_arrays(f)
+    f2 = gu.arrays_to_field(arrs)  # the fixture must be self-contained
+    pb = cabi.Problem(f2.images, f2.patches, f2.neighbors)
+    tg = list(range(len(f2.catalog)))
+    out = {}
+    for flags in (7, 3, 0):
+        v, d, h, cnt, st = oracle.elbo_batch(pb, f2.vp, tg, flags, n_threads=1)
+        assert (st == 0).all()
+        out["v%d" % flags] = v
+        if flags:
+            out["d%d" % flags] = d; out["h%d" % flags] = h
+        out["cnt"] = cnt
+    np.savez_compressed(gu.path(name), **arrs, **out)
+    print(name, os.path.getsize(gu.path(name)), "bytes", out["v7"][:2])
