@@ -53,9 +53,8 @@ struct Comp {
     double mu1, mu2;       // xiBar_k + m_pos
     double w0;             // z * gal_frac_dev_i      (f = w0 * exp(...))
     double wd;             // z * gal_frac_dev_dir    (d f / d gal_frac_dev = wd * exp(...))
-    double wn, wdn, wnn;   // w0 nuBar_j, wd nuBar_j, w0 nuBar_j^2
-    double pad0, pad1;     // 96-byte records: three 32-byte scalar loads
-};
+    double nu;             // nuBar_j
+};                         // 64 bytes = one scalar-cache line = one s_load_dwordx16
 
 struct SrcImg {
     double m1, m2;          // linear_world_to_pix(pos)

@@ -91,8 +91,7 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         const double dev = vs[2];
         o.w0 = z * (i == 0 ? dev : 1.0 - dev);
         o.wd = (i == 0 ? z : -z);
-        o.wn = o.w0 * nu; o.wdn = o.wd * nu; o.wnn = o.wn * nu;
-        o.pad0 = 0; o.pad1 = 0;
+        o.nu = nu;
         comps[(size_t)sn * NC + c] = o;
     }
     if (c == 63) {
@@ -211,10 +210,10 @@ __device__ inline double star_value(const double *__restrict__ coef, double xh, 
 }
 
 // value of the galaxy density sum_c w0_c exp(-0.5 d' P d) (populate_gal_fsm!, inactive branch)
-__device__ inline double galaxy_value(const Comp *__restrict__ tc, int NC, double hh, double ww, const double *etab) {
+__device__ inline double galaxy_value(const Comp *tc, int NC, double hh, double ww, const double *etab) {
     double v = 0;
     for (int c = 0; c < NC; ++c) {
-        const Comp &k = tc[c];
+        const Comp k = tc[c];
         const double d1 = hh - k.mu1, d2 = ww - k.mu2;
         const double u = k.p11 * d1 + k.p12 * d2, vv = k.p12 * d1 + k.p22 * d2;
         v = __builtin_fma(k.w0, exp_nonpos(-0.5 * (d1 * u + d2 * vv), etab), v);
@@ -282,7 +281,13 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
     if (p0 >= npx) return;
     const int p1 = min(npx, p0 + chunk_px);
     const SrcImg si = srcimg[sn];
-    const Comp *__restrict__ tc = comps + (size_t)sn * NC;
+    __shared__ Comp tc[14 * CEL_MAXK];
+    {
+        const double *src = reinterpret_cast<const double *>(comps + (size_t)sn * NC);
+        double *dst = reinterpret_cast<double *>(tc);
+        for (int i = threadIdx.x; i < NC * 8; i += 64) dst[i] = src[i];
+        __syncthreads();
+    }
     const double *__restrict__ coef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
     double2 *__restrict__ out = val + val_off[sn];
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
@@ -461,7 +466,15 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const DevImage &img = images[n];
     const int lane = threadIdx.x;
     const SrcImg si = srcimg[(size_t)t * N + n];
-    const Comp *__restrict__ tc = comps + ((size_t)t * N + n) * NC;
+    // the target's components: one coalesced read into LDS, then broadcast ds_reads in the pixel loop (the
+    // scalar data cache cannot hold 8 waves x 1.8 KB per CU: 68 % of s_loads missed to L2)
+    __shared__ Comp tc[14 * CEL_MAXK];
+    {
+        const double *src = reinterpret_cast<const double *>(comps + ((size_t)t * N + n) * NC);
+        double *dst = reinterpret_cast<double *>(tc);
+        for (int i = lane; i < NC * 8; i += 64) dst[i] = src[i];
+        __syncthreads();
+    }
     const double *__restrict__ tcoef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
     const int64_t nb0 = nbr_off[t], nb1 = (ablate & 1) ? nb0 : nbr_off[t + 1];
     const double c0 = si.c0, c1 = si.c1, q0 = si.q0, q1 = si.q1;
@@ -542,11 +555,11 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         T.S3a = 0; T.S3b = 0; T.S3c = 0; T.S3d = 0; T.S4a = 0; T.S4b = 0; T.S4c = 0; T.S4d = 0; T.S4e = 0;
         if (own) {
             for (int c = 0; c < ((ablate & 2) ? 0 : NC); ++c) {
-                const Comp &k = tc[c];
+                const Comp k = tc[c];
                 const double d1 = hh - k.mu1, d2 = ww - k.mu2;
                 const double u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
                 const double e = exp_nonpos(-0.5 * (d1 * u + d2 * v), etab);   // eval_bvn_pdf!
-                const double f = k.w0 * e, fd = k.wd * e, fn = k.wn * e, fdn = k.wdn * e, fnn = k.wnn * e;
+                const double f = k.w0 * e, fd = k.wd * e, fn = f * k.nu, fdn = fd * k.nu, fnn = fn * k.nu;
                 const double ha = __builtin_fma(u, u, -k.p11), hb = __builtin_fma(u, v, -k.p12),
                              hc = __builtin_fma(v, v, -k.p22);
                 S0 += f; T.S0d += fd;
