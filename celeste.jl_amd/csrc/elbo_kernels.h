@@ -704,6 +704,79 @@ __device__ inline int bright_slot(int p) {
     return -1;
 }
 
+#define LIFT_NT 8    // images lifted concurrently per pass
+#define LIFT_NP 28   // parameters with likelihood derivatives (the k block, 28..43, only enters the KL)
+
+// Shared state of the analytic KL term (subtract_kl, elbo_kl.jl:94-154)
+struct KLShared {
+    double t[16], m[16], Ld[16][4], ml[16][4];  // per (type, colour component)
+    double ta[2], g[2], g_r[2], g_v[2], ck[2], cm[2];
+};
+
+// Hessian entry (p1 <= p2) of subtract_kl; vs = the target's parameters
+__device__ inline double kl_hess(const KLShared &K, const PriorDev *prior, const double *vs, int p1, int p2) {
+    if (p1 == 5 && p2 == 5) return -1.0 / prior->p.gal_radius_px_var;
+    if (p1 < 6 || p2 < 6) return 0.0;
+    // type of each parameter
+    auto type_of = [](int p) { return p < 10 ? ((p - 6) & 1) : (p < 26 ? (((p - 10) >> 2) & 1) : (p < 28 ? p - 26 : ((p - 28) >> 3))); };
+    const int i = type_of(p1);
+    if (type_of(p2) != i) return 0.0;
+    const double a = vs[26 + i];
+    // classes: 0 r, 1 v, 2 mu_c, 3 lambda_c, 4 a, 5 k_d
+    auto cls = [](int p) { return p < 8 ? 0 : (p < 10 ? 1 : (p < 18 ? 2 : (p < 26 ? 3 : (p < 28 ? 4 : 5)))); };
+    const int c1 = cls(p1), c2 = cls(p2);
+    const int q1 = (c1 == 2 || c1 == 3) ? ((p1 - 10) & 3) : (c1 == 5 ? ((p1 - 28) & 7) : 0);
+    const int q2 = (c2 == 2 || c2 == 3) ? ((p2 - 10) & 3) : (c2 == 5 ? ((p2 - 28) & 7) : 0);
+    if (c2 == 4) {  // (x, a_i)
+        if (c1 == 4) return -1.0 / a;
+        if (c1 == 0) return -K.g_r[i];
+        if (c1 == 1) return -K.g_v[i];
+        double s = 0;
+        for (int d = 0; d < 8; ++d) s += vs[28 + 8 * i + d] * (c1 == 2 ? K.Ld[8 * i + d][q1] : -K.ml[8 * i + d][q1]);
+        return s;
+    }
+    if (c2 == 5) {  // (x, k_id)
+        const int d = q2;
+        if (c1 == 5) return q1 == q2 ? -a / vs[p2] : 0.0;
+        if (c1 == 4) return -(K.t[8 * i + d] + 1.0 + K.m[8 * i + d]);
+        if (c1 == 2) return a * K.Ld[8 * i + d][q1];
+        if (c1 == 3) return -a * K.ml[8 * i + d][q1];
+        return 0.0;
+    }
+    if (c1 == 0 && c2 == 0) return -a / prior->p.flux_var[i];
+    if (c1 == 1 && c2 == 1) return -a * 0.5 / (vs[p1] * vs[p1]);
+    if (c1 == 3 && c2 == 3) {
+        if (q1 != q2) return 0.0;
+        double sk = 0;
+        for (int d = 0; d < 8; ++d) sk += vs[28 + 8 * i + d];
+        return -a * sk * 0.5 / (vs[p1] * vs[p1]);
+    }
+    if (c1 == 2 && c2 == 2) {
+        double s = 0;
+        for (int d = 0; d < 8; ++d) s += vs[28 + 8 * i + d] * prior->inv_cov[i][d][q1 + 4 * q2];
+        return -a * s;
+    }
+    return 0.0;
+}
+
+__device__ inline double kl_grad(const KLShared &K, const PriorDev *prior, const double *vs, int p) {
+    if (p == 5) return -(vs[5] - prior->p.gal_radius_px_mean) / prior->p.gal_radius_px_var;
+    if (p < 6) return 0.0;
+    const int i = p < 10 ? ((p - 6) & 1) : (p < 26 ? (((p - 10) >> 2) & 1) : (p < 28 ? p - 26 : ((p - 28) >> 3)));
+    const double a = vs[26 + i];
+    if (p < 8) return -a * K.g_r[i];
+    if (p < 10) return -a * K.g_v[i];
+    if (p < 26) {
+        const int c = (p - 10) & 3;
+        double s = 0;
+        for (int d = 0; d < 8; ++d) s += vs[28 + 8 * i + d] * (p < 18 ? K.Ld[8 * i + d][c] : -K.ml[8 * i + d][c]);
+        return a * s;
+    }
+    if (p < 28) return -(K.ta[i] + 1.0) - (K.ck[i] + K.g[i] + K.cm[i]);
+    const int d = (p - 28) & 7;
+    return -a * (K.t[8 * i + d] + 1.0 + K.m[8 * i + d]);
+}
+
 __global__ void __launch_bounds__(256)
 lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
@@ -712,241 +785,231 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const PriorDev *__restrict__ prior, int N, int CH, int chunk_px, uint32_t flags,
             double *__restrict__ out_v, double *__restrict__ out_d, double *__restrict__ out_h,
             int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status) {
-    __shared__ double sh_h[CEL_P * CEL_P];
-    __shared__ double sh_d[CEL_P];
-    __shared__ double sh_rec[ACC_N];
-    __shared__ double sh_jz[ZV * CEL_P];
-    __shared__ double sh_kap[10], sh_lam[10];
-    __shared__ double sh_El[2], sh_Ell[2];
+    __shared__ double sh_h[LIFT_NP * LIFT_NP];         // likelihood Hessian, upper triangle, params < 28
+    __shared__ double sh_d[LIFT_NP];
+    __shared__ double s_vs[CEL_P], s_jsh[9], s_tsh[27];
+    __shared__ double s_rec[LIFT_NT][ACC_N];
+    __shared__ double s_jz[LIFT_NT][ZV * LIFT_NP];
+    __shared__ double s_kap[LIFT_NT][10], s_lam[LIFT_NT][10], s_El[LIFT_NT][2], s_Ell[LIFT_NT][2];
+    __shared__ KLShared K;
     __shared__ double sh_v, sh_cnt[2];
-    __shared__ double sh_m[16], sh_t[16], sh_Ld[16][4], sh_ml[16][4];
     __shared__ int sh_bad;
 
-    const int ti = blockIdx.x, tid = threadIdx.x;
+    const int ti = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int t = targets[ti];
-    const double *vs = vp + (size_t)t * CEL_P;
     const bool want_grad = (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) != 0;
     const bool want_hess = (flags & CELESTE_FLAG_HESS) != 0;
-    const SrcGeo &G = geo[t];
+    const bool want_kl = (flags & CELESTE_FLAG_KL) != 0;
 
-    for (int k = tid; k < CEL_P * CEL_P; k += blockDim.x) sh_h[k] = 0.0;
-    if (tid < CEL_P) sh_d[tid] = 0.0;
+    if (tid < CEL_P) s_vs[tid] = vp[(size_t)t * CEL_P + tid];
+    else if (tid < CEL_P + 9) s_jsh[tid - CEL_P] = geo[t].jsh[tid - CEL_P];
+    else if (tid < CEL_P + 36) s_tsh[tid - CEL_P - 9] = geo[t].tsh[tid - CEL_P - 9];
+    for (int k = tid; k < LIFT_NP * LIFT_NP; k += nthr) sh_h[k] = 0.0;
+    if (tid < LIFT_NP) sh_d[tid] = 0.0;
     if (tid == 0) { sh_v = 0.0; sh_cnt[0] = 0.0; sh_cnt[1] = 0.0; sh_bad = 0; }
     __syncthreads();
+    const double *vs = s_vs;
 
-    for (int n = 0; n < N; ++n) {
-        const DevPatch &P = patches[(size_t)t * N + n];
-        const int npx = P.H2 * P.W2;
-        const int b = images[n].band - 1;
-        // sum the chunk records of this (target, image)
-        if (tid < ACC_N) {
+    // KL per (type, component) terms: 16 threads of the last wave, concurrent with the first lift pass
+    if (want_kl && tid >= 240) {
+        const int q = tid - 240, i = q >> 3, d = q & 7;
+        const celeste_prior_t &pr = prior->p;
+        const double k = vs[28 + 8 * i + d];
+        K.t[q] = log(k) - log(pr.k[i][d]);
+        double diff[4], tr = 0, sl = 0, quad = 0;
+        for (int c = 0; c < 4; ++c) diff[c] = pr.color_mean[i][d][c] - vs[10 + 4 * i + c];
+        for (int c = 0; c < 4; ++c) {
+            const double lam = vs[18 + 4 * i + c];
+            tr += prior->inv_cov[i][d][c + 4 * c] * lam; sl += log(lam);
+        }
+        for (int r = 0; r < 4; ++r) {
+            double Ld = 0;
+            for (int c = 0; c < 4; ++c) Ld += prior->inv_cov[i][d][r + 4 * c] * diff[c];
+            K.Ld[q][r] = Ld; quad += diff[r] * Ld;
+            K.ml[q][r] = 0.5 * (prior->inv_cov[i][d][r + 4 * r] - 1.0 / vs[18 + 4 * i + r]);
+        }
+        K.m[q] = 0.5 * ((tr - 4.0) + quad + (prior->logdet[i][d] - sl));
+    }
+    if (want_kl && tid >= 238 && tid < 240) {
+        const int i = tid - 238;
+        const celeste_prior_t &pr = prior->p;
+        const double a = vs[26 + i];
+        K.ta[i] = log(a) - log(pr.is_star[i]);
+        const double mu1 = vs[6 + i], var1 = vs[8 + i], mu2 = pr.flux_mean[i], var2 = pr.flux_var[i];
+        K.g[i] = .5 * (log(var2) - log(var1) + (var1 + (mu1 - mu2) * (mu1 - mu2)) / var2 - 1.0);
+        K.g_r[i] = (mu1 - mu2) / var2;
+        K.g_v[i] = .5 * (-1.0 / var1 + 1.0 / var2);
+    }
+
+    for (int n0 = 0; n0 < N; n0 += LIFT_NT) {
+        const int nt = min(LIFT_NT, N - n0);
+        // pass 1: chunk records -> per-image record; brightness moments and exponent coefficients
+        for (int k = tid; k < nt * ACC_N; k += nthr) {
+            const int i = k / ACC_N, e = k - i * ACC_N, n = n0 + i;
+            const DevPatch &P = patches[(size_t)t * N + n];
+            const int npx = P.H2 * P.W2;
             double s = 0.0;
             for (int ch = 0; ch < CH; ++ch)
-                if (ch * chunk_px < npx) s += acc[((size_t)(ti * N + n) * CH + ch) * ACC_N + tid];
-            sh_rec[tid] = s;
+                if (ch * chunk_px < npx) s += acc[((size_t)(ti * N + n) * CH + ch) * ACC_N + e];
+            s_rec[i][e] = s;
         }
-        if (tid >= 64 + 8 && tid < 64 + 8 + 10) {
-            // exponent coefficients of E_l_a[b, .] (kappa) and E_ll_a[b, .] (lambda), bids order
-            const int q = tid - 72;
-            double kap = 0, lam = 0;
-            if (q == 0) { kap = 1; lam = 2; }
-            else if (q == 1) { kap = .5; lam = 2; }
-            else {
-                const int c = (q - 2) & 3;
-                const bool is_var = q >= 6;
-                bool on; double sgn;
-                if (c == 2) { on = b >= 3; sgn = 1; }
-                else if (c == 3) { on = b >= 4; sgn = 1; }
-                else if (c == 1) { on = b <= 1; sgn = -1; }
-                else { on = b <= 0; sgn = -1; }
-                if (on) { kap = is_var ? .5 : sgn; lam = is_var ? 2 : 2 * sgn; }
+        if (want_grad) {
+            for (int k = tid; k < nt * 12; k += nthr) {
+                const int i = k / 12, q = k - i * 12;
+                const int b = images[n0 + i].band - 1;
+                if (q < 10) {
+                    // exponent coefficients of E_l_a[b, .] (kappa) and E_ll_a[b, .] (lambda), bids order
+                    double kap = 0, lam = 0;
+                    if (q == 0) { kap = 1; lam = 2; }
+                    else if (q == 1) { kap = .5; lam = 2; }
+                    else {
+                        const int c = (q - 2) & 3;
+                        const bool is_var = q >= 6;
+                        bool on; double sgn;
+                        if (c == 2) { on = b >= 3; sgn = 1; }
+                        else if (c == 3) { on = b >= 4; sgn = 1; }
+                        else if (c == 1) { on = b <= 1; sgn = -1; }
+                        else { on = b <= 0; sgn = -1; }
+                        if (on) { kap = is_var ? .5 : sgn; lam = is_var ? 2 : 2 * sgn; }
+                    }
+                    s_kap[i][q] = kap; s_lam[i][q] = lam;
+                } else {
+                    double El, Ell;
+                    brightness(vs, q - 10, b, El, Ell);
+                    s_El[i][q - 10] = El; s_Ell[i][q - 10] = Ell;
+                }
             }
-            sh_kap[q] = kap; sh_lam[q] = lam;
-        }
-        if (tid >= 96 && tid < 98) {
-            double El, Ell;
-            brightness(vs, tid - 96, b, El, Ell);
-            sh_El[tid - 96] = El; sh_Ell[tid - 96] = Ell;
         }
         __syncthreads();
-        if (tid == 0) { sh_v += sh_rec[0]; sh_cnt[0] += sh_rec[ACC_CNT]; sh_cnt[1] += sh_rec[ACC_CNT + 1]; }
+        if (tid == 0) for (int i = 0; i < nt; ++i) { sh_v += s_rec[i][0]; sh_cnt[0] += s_rec[i][ACC_CNT]; sh_cnt[1] += s_rec[i][ACC_CNT + 1]; }
         if (want_grad) {
-            // dense 10 x 44 Jacobian of the reduced variables for this image
-            for (int k = tid; k < ZV * CEL_P; k += blockDim.x) {
-                const int r = k / CEL_P, p = k - r * CEL_P;
+            // pass 2: 10 x 28 Jacobians of the reduced variables
+            for (int k = tid; k < nt * ZV * LIFT_NP; k += nthr) {
+                const int i = k / (ZV * LIFT_NP), rp = k - i * (ZV * LIFT_NP);
+                const int r = rp / LIFT_NP, p = rp - r * LIFT_NP;
                 double v = 0.0;
-                if (r >= 4 && r < 6) { if (p < 2) v = P.J[(r - 4) + 2 * p]; }
+                if (r >= 4 && r < 6) { if (p < 2) v = patches[(size_t)t * N + n0 + i].J[(r - 4) + 2 * p]; }
                 else if (r == 6) { if (p == 2) v = 1.0; }
-                else if (r >= 7) { if (p >= 3 && p < 6) v = G.jsh[(r - 7) + 3 * (p - 3)]; }
+                else if (r >= 7) { if (p >= 3 && p < 6) v = s_jsh[(r - 7) + 3 * (p - 3)]; }
                 else {
-                    const int i = r & 1;          // rows 0,1 = c_i; rows 2,3 = q_i
+                    const int ty = r & 1;          // rows 0,1 = c_i; rows 2,3 = q_i
                     const bool isq = r >= 2;
                     int st, cn, sd, cls;
                     param_rows(p, st, cn, sd, cls);
-                    if (cls == 3 + i) {
+                    if (cls == 3 + ty) {
                         const int slot = bright_slot(p);
-                        const double Ev = isq ? sh_Ell[i] : sh_El[i];
+                        const double Ev = isq ? s_Ell[i][ty] : s_El[i][ty];
                         if (slot < 0) v = Ev;
-                        else v = vs[26 + i] * Ev * (isq ? sh_lam[slot] : sh_kap[slot]);
+                        else v = vs[26 + ty] * Ev * (isq ? s_lam[i][slot] : s_kap[i][slot]);
                     }
                 }
-                sh_jz[k] = v;
+                s_jz[i][rp] = v;
             }
             __syncthreads();
-            if (tid < CEL_P) {
-                int st, cn, sd, cls;
-                param_rows(tid, st, cn, sd, cls);
-                double s = 0.0;
-                for (int a = 0; a < cn; ++a) { const int r = st + a * sd; s += sh_jz[r * CEL_P + tid] * sh_rec[1 + r]; }
-                sh_d[tid] += s;
-            }
-            if (want_hess) {
-                for (int k = tid; k < CEL_P * CEL_P; k += blockDim.x) {
-                    const int p2 = k / CEL_P, p1 = k - p2 * CEL_P;
-                    if (p1 > p2) continue;
-                    int st1, cn1, sd1, cls1, st2, cn2, sd2, cls2;
-                    param_rows(p1, st1, cn1, sd1, cls1);
-                    param_rows(p2, st2, cn2, sd2, cls2);
-                    if (cn1 == 0 || cn2 == 0) continue;
+            // pass 3: gradient and upper-triangle Hessian; every entry is owned by one thread
+            const int n_pairs = LIFT_NP * (LIFT_NP + 1) / 2;
+            for (int k = tid; k < n_pairs + LIFT_NP; k += nthr) {
+                if (k >= n_pairs) {
+                    const int p = k - n_pairs;
+                    int st, cn, sd, cls;
+                    param_rows(p, st, cn, sd, cls);
                     double s = 0.0;
+                    for (int i = 0; i < nt; ++i)
+                        for (int a = 0; a < cn; ++a) { const int r = st + a * sd; s += s_jz[i][r * LIFT_NP + p] * s_rec[i][1 + r]; }
+                    sh_d[p] += s;
+                    continue;
+                }
+                if (!want_hess) continue;
+                // unrank k -> (p1 <= p2)
+                int p2 = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
+                while ((p2 + 1) * (p2 + 2) / 2 <= k) ++p2;
+                while (p2 * (p2 + 1) / 2 > k) --p2;
+                const int p1 = k - p2 * (p2 + 1) / 2;
+                int st1, cn1, sd1, cls1, st2, cn2, sd2, cls2;
+                param_rows(p1, st1, cn1, sd1, cls1);
+                param_rows(p2, st2, cn2, sd2, cls2);
+                double s = 0.0;
+                for (int i = 0; i < nt; ++i) {
+                    const double *rec = s_rec[i];
+                    const double *jz = s_jz[i];
                     for (int a = 0; a < cn1; ++a) {
                         const int r1 = st1 + a * sd1;
-                        const double j1 = sh_jz[r1 * CEL_P + p1];
+                        const double j1 = jz[r1 * LIFT_NP + p1];
                         double inner = 0.0;
                         for (int c = 0; c < cn2; ++c) {
                             const int r2 = st2 + c * sd2;
                             const int lo = r1 < r2 ? r1 : r2, hi = r1 < r2 ? r2 : r1;
-                            inner += sh_rec[hidx(lo, hi)] * sh_jz[r2 * CEL_P + p2];
+                            inner += rec[hidx(lo, hi)] * jz[r2 * LIFT_NP + p2];
                         }
                         s += j1 * inner;
                     }
                     // second derivatives of the reduced variables
                     if (cls1 == 2 && cls2 == 2) {
-                        for (int sg = 0; sg < 3; ++sg) s += sh_rec[1 + 7 + sg] * G.tsh[sg + 3 * (p1 - 3) + 9 * (p2 - 3)];
+                        for (int sg = 0; sg < 3; ++sg) s += rec[1 + 7 + sg] * s_tsh[sg + 3 * (p1 - 3) + 9 * (p2 - 3)];
                     } else if (cls1 == cls2 && cls1 >= 3 && cls1 <= 4) {
-                        const int i = cls1 - 3;
-                        const int s1 = bright_slot(p1), s2 = bright_slot(p2);
-                        const double gc = sh_rec[1 + i], gq = sh_rec[1 + 2 + i];
-                        const double El = sh_El[i], Ell = sh_Ell[i], ai = vs[26 + i];
-                        if (s1 >= 0 && s2 >= 0)
-                            s += ai * (gc * El * sh_kap[s1] * sh_kap[s2] + gq * Ell * sh_lam[s1] * sh_lam[s2]);
-                        else if (s1 >= 0) s += gc * El * sh_kap[s1] + gq * Ell * sh_lam[s1];
-                        else if (s2 >= 0) s += gc * El * sh_kap[s2] + gq * Ell * sh_lam[s2];
+                        const int ty = cls1 - 3;
+                        const int b1 = bright_slot(p1), b2 = bright_slot(p2);
+                        const double gc = rec[1 + ty], gq = rec[1 + 2 + ty];
+                        const double El = s_El[i][ty], Ell = s_Ell[i][ty], ai = vs[26 + ty];
+                        if (b1 >= 0 && b2 >= 0)
+                            s += ai * (gc * El * s_kap[i][b1] * s_kap[i][b2] + gq * Ell * s_lam[i][b1] * s_lam[i][b2]);
+                        else if (b1 >= 0) s += gc * El * s_kap[i][b1] + gq * Ell * s_lam[i][b1];
+                        else if (b2 >= 0) s += gc * El * s_kap[i][b2] + gq * Ell * s_lam[i][b2];
                     }
-                    sh_h[p1 + CEL_P * p2] += s;
                 }
+                sh_h[p1 + LIFT_NP * p2] += s;
             }
         }
         __syncthreads();
     }
 
-    // ---- KL (subtract_kl, elbo_kl.jl:94-154), analytic derivatives ----
-    if (flags & CELESTE_FLAG_KL) {
-        const celeste_prior_t &pr = prior->p;
-        if (tid < 16) {
-            const int i = tid >> 3, d = tid & 7;
-            const double k = vs[28 + 8 * i + d];
-            sh_t[tid] = log(k) - log(pr.k[i][d]);
-            double diff[4], tr = 0, sl = 0, quad = 0;
-            for (int c = 0; c < 4; ++c) diff[c] = pr.color_mean[i][d][c] - vs[10 + 4 * i + c];
-            for (int c = 0; c < 4; ++c) {
-                const double lam = vs[18 + 4 * i + c];
-                tr += prior->inv_cov[i][d][c + 4 * c] * lam; sl += log(lam);
-            }
-            for (int r = 0; r < 4; ++r) {
-                double Ld = 0;
-                for (int c = 0; c < 4; ++c) Ld += prior->inv_cov[i][d][r + 4 * c] * diff[c];
-                sh_Ld[tid][r] = Ld; quad += diff[r] * Ld;
-                sh_ml[tid][r] = 0.5 * (prior->inv_cov[i][d][r + 4 * r] - 1.0 / vs[18 + 4 * i + r]);
-            }
-            sh_m[tid] = 0.5 * ((tr - 4.0) + quad + (prior->logdet[i][d] - sl));
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double kl = 0;
-            for (int i = 0; i < 2; ++i) {
-                const int ia = 26 + i;
-                const double a = vs[ia];
-                const double ta = log(a) - log(pr.is_star[i]);
-                kl -= a * ta;
-                sh_d[ia] -= ta + 1.0;
-                sh_h[ia + CEL_P * ia] -= 1.0 / a;
-                double ck = 0, cm = 0;
-                for (int d = 0; d < 8; ++d) {
-                    const int ik = 28 + 8 * i + d, q = 8 * i + d;
-                    const double k = vs[ik];
-                    ck += k * sh_t[q]; cm += k * sh_m[q];
-                    sh_d[ik] -= a * (sh_t[q] + 1.0) + a * sh_m[q];
-                    sh_h[ik + CEL_P * ik] -= a / k;
-                    sh_h[ia + CEL_P * ik] -= (sh_t[q] + 1.0) + sh_m[q];
-                }
-                const int ir = 6 + i, iv = 8 + i;
-                const double mu1 = vs[ir], var1 = vs[iv], mu2 = pr.flux_mean[i], var2 = pr.flux_var[i];
-                const double g = .5 * (log(var2) - log(var1) + (var1 + (mu1 - mu2) * (mu1 - mu2)) / var2 - 1.0);
-                const double g_r = (mu1 - mu2) / var2, g_v = .5 * (-1.0 / var1 + 1.0 / var2);
-                kl -= a * (ck + g + cm);
-                sh_d[ia] -= ck + g + cm;
-                sh_d[ir] -= a * g_r; sh_d[iv] -= a * g_v;
-                sh_h[ir + CEL_P * ia] -= g_r; sh_h[iv + CEL_P * ia] -= g_v;
-                sh_h[ir + CEL_P * ir] -= a / var2; sh_h[iv + CEL_P * iv] -= a * .5 / (var1 * var1);
-                for (int c = 0; c < 4; ++c) {
-                    const int im = 10 + 4 * i + c, il = 18 + 4 * i + c;
-                    const double lam = vs[il];
-                    double s_mu = 0, s_l = 0, s_k = 0;
-                    for (int d = 0; d < 8; ++d) {
-                        const int ik = 28 + 8 * i + d, q = 8 * i + d;
-                        const double k = vs[ik];
-                        const double m_mu = -sh_Ld[q][c], m_l = sh_ml[q][c];
-                        s_mu += k * m_mu; s_l += k * m_l; s_k += k;
-                        sh_h[im + CEL_P * ik] -= a * m_mu;   // im < ik: upper triangle
-                        sh_h[il + CEL_P * ik] -= a * m_l;
-                    }
-                    sh_d[im] -= a * s_mu; sh_d[il] -= a * s_l;
-                    sh_h[im + CEL_P * ia] -= s_mu; sh_h[il + CEL_P * ia] -= s_l;
-                    sh_h[il + CEL_P * il] -= a * s_k * 0.5 / (lam * lam);
-                    for (int c2 = 0; c2 <= c; ++c2) {
-                        const int im2 = 10 + 4 * i + c2;
-                        double s = 0;
-                        for (int d = 0; d < 8; ++d) s += vs[28 + 8 * i + d] * prior->inv_cov[i][d][c2 + 4 * c];
-                        sh_h[im2 + CEL_P * im] -= a * s;
-                    }
-                }
-            }
-            const double x = vs[5], mu = pr.gal_radius_px_mean, s2 = pr.gal_radius_px_var;
-            kl += -0.5 * (log(2.0 * M_PI) + log(s2) + (x - mu) * (x - mu) / s2);
-            sh_d[5] += -(x - mu) / s2;
-            sh_h[5 + CEL_P * 5] += -1.0 / s2;
-            sh_v += kl;
-        }
-        __syncthreads();
+    // ---- KL value (elbo_kl.jl:140-154) ----
+    if (want_kl && tid < 2) {
+        const int i = tid;
+        double ck = 0, cm = 0;
+        for (int d = 0; d < 8; ++d) { const double k = vs[28 + 8 * i + d]; ck += k * K.t[8 * i + d]; cm += k * K.m[8 * i + d]; }
+        K.ck[i] = ck; K.cm[i] = cm;
     }
+    __syncthreads();
+    if (want_kl && tid == 0) {
+        double kl = 0;
+        for (int i = 0; i < 2; ++i) kl -= vs[26 + i] * (K.ta[i] + K.ck[i] + K.g[i] + K.cm[i]);
+        const double x = vs[5], mu = prior->p.gal_radius_px_mean, s2 = prior->p.gal_radius_px_var;
+        kl += -0.5 * (log(2.0 * M_PI) + log(s2) + (x - mu) * (x - mu) / s2);
+        sh_v += kl;
+    }
+    __syncthreads();
 
-    // ---- finiteness (elbo_objective.jl:487,490), symmetrise, store ----
+    // ---- assemble, check finiteness (elbo_objective.jl:487,490), store exactly symmetric ----
     int bad = 0;
     if (tid == 0 && !isfinite(sh_v)) bad = 1;
-    if (want_grad && tid < CEL_P && !isfinite(sh_d[tid])) bad = 1;
-    if (want_hess)
-        for (int k = tid; k < CEL_P * CEL_P; k += blockDim.x) {
-            const int p2 = k / CEL_P, p1 = k - p2 * CEL_P;
-            if (p1 <= p2 && !isfinite(sh_h[k])) bad = 1;
+    if (want_grad && out_d && tid < CEL_P) {
+        double v = tid < LIFT_NP ? sh_d[tid] : 0.0;
+        if (want_kl) v += kl_grad(K, prior, vs, tid);
+        if (!isfinite(v)) bad = 1;
+        out_d[(size_t)ti * CEL_P + tid] = v;
+    }
+    if (want_hess && out_h) {
+        for (int k = tid; k < CEL_P * CEL_P; k += nthr) {
+            const int c2 = k / CEL_P, c1 = k - c2 * CEL_P;
+            const int p1 = c1 < c2 ? c1 : c2, p2 = c1 < c2 ? c2 : c1;
+            double v = (p2 < LIFT_NP) ? sh_h[p1 + LIFT_NP * p2] : 0.0;
+            if (want_kl) v += kl_hess(K, prior, vs, p1, p2);
+            if (!isfinite(v)) bad = 1;
+            out_h[(size_t)ti * CEL_P * CEL_P + k] = v;
         }
+    }
     if (bad) atomicOr(&sh_bad, 1);
     __syncthreads();
     if (tid == 0) {
         int st = sh_bad ? CELESTE_ERR_NONFINITE_RESULT : CELESTE_OK;
-        int fin = G.finite;
+        int fin = geo[t].finite;
         for (int64_t q = nbr_off[t]; q < nbr_off[t + 1]; ++q) fin &= geo[nbr_idx[q]].finite;
         if (!fin) st = CELESTE_ERR_NONFINITE_INPUT;
         out_status[ti] = st;
         out_v[ti] = sh_v;
         if (out_cnt) { out_cnt[2 * ti] = (int64_t)(sh_cnt[0] + 0.5); out_cnt[2 * ti + 1] = (int64_t)(sh_cnt[1] + 0.5); }
     }
-    if (want_grad && out_d && tid < CEL_P) out_d[(size_t)ti * CEL_P + tid] = sh_d[tid];
-    if (want_hess && out_h)
-        for (int k = tid; k < CEL_P * CEL_P; k += blockDim.x) {
-            const int p2 = k / CEL_P, p1 = k - p2 * CEL_P;
-            out_h[(size_t)ti * CEL_P * CEL_P + k] = (p1 <= p2) ? sh_h[k] : sh_h[p2 + CEL_P * p1];
-        }
 }
 
 // ---------------------------------------------------------------------------------------------
