@@ -30,7 +30,7 @@ static const celeste_prior_t DEFAULT_PRIOR =
 struct celeste_ctx {
     int device = 0;
     int N = 0, S = 0, K = 0, NC = 0, n_stamps = 0;
-    int chunk_px = 1024, CH = 1;
+    int chunk_px = 256, CH = 1;
     int ablate = 0;  // debug: CELESTE_ABLATE bit mask, skips parts of pixel_kernel (timing experiments only)
     int max_npx = 0;
     // host mirrors (for work stats / validation)
@@ -286,6 +286,7 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
             celeste_ctx_destroy(c); return CELESTE_ERR_HIP;
         }
     }
+    hipLaunchKernelGGL(exp_table_kernel, dim3(1), dim3(64), 0, nullptr);
     CTX_TRY(dev_upload<SrcImg>(&c->d_srcimg, nullptr, (size_t)c->S * c->N));
     CTX_TRY(dev_upload<Comp>(&c->d_comps, nullptr, (size_t)c->S * c->N * c->NC));
     CTX_TRY(dev_upload<SrcGeo>(&c->d_geo, nullptr, (size_t)c->S));
@@ -348,16 +349,14 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
                        c->chunk_px, c->d_val);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     const dim3 grid((unsigned)((size_t)n_targets * c->N * c->CH));
-    if (derivs)
-        hipLaunchKernelGGL(pixel_kernel<2>, grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,
-                           c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off, c->d_val, d_targets,
-                           c->N, c->NC,
-                           c->CH, c->chunk_px, c->d_acc, c->ablate);
-    else
-        hipLaunchKernelGGL(pixel_kernel<0>, grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,
-                           c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off, c->d_val, d_targets,
-                           c->N, c->NC,
-                           c->CH, c->chunk_px, c->d_acc, c->ablate);
+#define LAUNCH_PIXEL(MODE)                                                                                      \
+    hipLaunchKernelGGL(pixel_kernel<MODE>, grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,   \
+                       c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off, c->d_val, \
+                       d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->ablate)
+    if (flags & CELESTE_FLAG_HESS) LAUNCH_PIXEL(2);
+    else if (derivs) LAUNCH_PIXEL(1);
+    else LAUNCH_PIXEL(0);
+#undef LAUNCH_PIXEL
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
     hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                        c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->N, c->CH, c->chunk_px, flags,

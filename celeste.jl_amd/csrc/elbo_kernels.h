@@ -171,13 +171,14 @@ __device__ inline void bspline_dw(double f, double dw[4], double ddw[4]) {
 // exp(x) = 2^m * 2^(j/64) * exp(r): a 64-entry table in LDS (filled by exp_table_init), a degree-5
 // Taylor polynomial (truncation 3.5e-17) and v_ldexp_f64.  About 1 ulp; 17 VALU + 1 LDS instruction
 // instead of ~31 for the library exp.  Inputs below -745 give exactly 0 like the reference's exp.
+__device__ double g_exp2_table[64];  // 2^(j/64), filled once per context by exp_table_kernel
+__global__ void exp_table_kernel() { g_exp2_table[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0)); }
 __device__ __forceinline__ void exp_table_init(double *tab) {
-    // 2^(j/64), j = 0..63: one entry per lane of the first wavefront
-    if (threadIdx.x < 64) tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+    if (threadIdx.x < 64) tab[threadIdx.x] = g_exp2_table[threadIdx.x];  // one coalesced 512-byte read
     __syncthreads();
 }
 __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
-    x = fmax(x, -750.0);
+    // no clamp is needed: for x << -745 the integer part saturates and v_ldexp_f64 returns 0
     const double n = rint(x * 92.33248261689366);             // 64 / ln 2
     double r = __builtin_fma(n, -0.010830424696450791, x);      // ln2/64, 35-bit high part: n * hi is exact for |n| < 2^17
     r = __builtin_fma(n, 2.0164562921995537e-13, r);           // minus the low part of ln2/64 (lo = -2.0164562921995537e-13)
@@ -226,8 +227,10 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {
     const long long b = __builtin_bit_cast(long long, x);
     int lo = (int)b, hi = (int)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    // old == src: every lane of the quad is active here, so the "old" value is never selected (and no
+    // zero-initialising v_mov is needed in front of each v_mov_b32_dpp)
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 #define DPP_XOR1 0xB1  // quad_perm [1,0,3,2]
@@ -268,10 +271,11 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
              const int32_t *__restrict__ needed, const int64_t *__restrict__ val_off, int N, int NC, int CH,
              int chunk_px, double2 *__restrict__ val) {
     __shared__ double etab[64];
-    exp_table_init(etab);
-    const int wg = blockIdx.x;
-    const int ch = wg % CH;
-    const int sn = wg / CH;
+    // chunk index is the slow grid axis: all first chunks (every patch has one) are dispatched first and
+    // round-robin over the 8 XCDs, whatever CH is (with ch fastest and CH = 6, half the XCDs sat idle)
+    const int SN = gridDim.x / CH;
+    const int ch = blockIdx.x / SN;
+    const int sn = blockIdx.x - ch * SN;
     const int s = sn / N;
     if (!needed[s]) return;
     const DevPatch &P = patches[sn];
@@ -279,6 +283,7 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
     const int npx = H2 * (W2 - 1);  // the last column never contributes (elbo_objective.jl:349)
     const int p0 = ch * chunk_px;
     if (p0 >= npx) return;
+    exp_table_init(etab);
     const int p1 = min(npx, p0 + chunk_px);
     const SrcImg si = srcimg[sn];
     __shared__ Comp tc[14 * CEL_MAXK];
@@ -425,19 +430,28 @@ __device__ __forceinline__ double record_entry(const PixelTerms &T) {
 
 // Fold the 68 entries across each lane quad so that a lane only accumulates 17 of them: after the
 // xor-1 and xor-2 exchanges lane l holds, for its quad, the entries e = 4 j + (l & 3).
-template <int J>
+template <int MODE, int E>
+__device__ __forceinline__ double mode_entry(const PixelTerms &T) {
+    // MODE 1 (gradient only): Hessian entries are not formed
+    if constexpr (MODE == 1 && E > ZV && E < ACC_CNT) return 0.0;
+    else return record_entry<E>(T);
+}
+template <int MODE, int J>
 __device__ __forceinline__ void fold_entries(const PixelTerms &T, bool b0, bool b1, double *a) {
-    const double e0 = record_entry<4 * J>(T), e1 = record_entry<4 * J + 1>(T);
-    const double e2 = record_entry<4 * J + 2>(T), e3 = record_entry<4 * J + 3>(T);
-    const double t0 = (b0 ? e1 : e0) + dpp_f64<DPP_XOR1>(b0 ? e0 : e1);  // entry 4J + b0
-    const double t1 = (b0 ? e3 : e2) + dpp_f64<DPP_XOR1>(b0 ? e2 : e3);  // entry 4J + 2 + b0
-    a[J] += (b1 ? t1 : t0) + dpp_f64<DPP_XOR2>(b1 ? t0 : t1);
-    if constexpr (J + 1 < ACC_N / 4) fold_entries<J + 1>(T, b0, b1, a);
+    constexpr bool skip = (MODE == 1) && (4 * J > ZV) && (4 * J + 3 < ACC_CNT);  // group of Hessian entries only
+    if constexpr (!skip) {
+        const double e0 = mode_entry<MODE, 4 * J>(T), e1 = mode_entry<MODE, 4 * J + 1>(T);
+        const double e2 = mode_entry<MODE, 4 * J + 2>(T), e3 = mode_entry<MODE, 4 * J + 3>(T);
+        const double t0 = (b0 ? e1 : e0) + dpp_f64<DPP_XOR1>(b0 ? e0 : e1);  // entry 4J + b0
+        const double t1 = (b0 ? e3 : e2) + dpp_f64<DPP_XOR1>(b0 ? e2 : e3);  // entry 4J + 2 + b0
+        a[J] += (b1 ? t1 : t0) + dpp_f64<DPP_XOR2>(b1 ? t0 : t1);
+    }
+    if constexpr (J + 1 < ACC_N / 4) fold_entries<MODE, J + 1>(T, b0, b1, a);
 }
 
 #define ACC_Q (ACC_N / 4)  // 17 accumulators per lane: lane l owns record entries e with e % 4 == l % 4
 
-// MODE 0: value only; MODE 2: value + gradient + Hessian sums
+// MODE 0: value only; MODE 1: value + gradient sums; MODE 2: value + gradient + Hessian sums
 #ifndef PIXEL_WAVES
 #define PIXEL_WAVES 2  // waves per SIMD the register allocator must allow (256 VGPRs, no scratch)
 #endif
@@ -451,10 +465,11 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px,
              double *__restrict__ acc, int ablate) {
     __shared__ double etab[64];
-    exp_table_init(etab);
-    const int wg = blockIdx.x;
-    const int ch = wg % CH;
-    const int tn = wg / CH;
+    // chunk index is the slow grid axis (see value_kernel): heavy first chunks go first, spread over all XCDs
+    const int TN = gridDim.x / CH;
+    const int ch = blockIdx.x / TN;
+    const int tn = blockIdx.x - ch * TN;
+    const int wg = tn * CH + ch;  // record index, as the lift kernel expects
     const int ti = tn / N, n = tn - ti * N;
     const int t = targets[ti];
     const DevPatch &P = patches[(size_t)t * N + n];
@@ -462,6 +477,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const int npx = H2 * W2;
     const int p0 = ch * chunk_px;
     if (p0 >= npx) return;  // the lift kernel recomputes this predicate
+    exp_table_init(etab);
     const int p1 = min(npx, p0 + chunk_px);
     const DevImage &img = images[n];
     const int lane = threadIdx.x;
@@ -559,33 +575,36 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
                 const double d1 = hh - k.mu1, d2 = ww - k.mu2;
                 const double u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
                 const double e = exp_nonpos(-0.5 * (d1 * u + d2 * v), etab);   // eval_bvn_pdf!
-                const double f = k.w0 * e, fd = k.wd * e, fn = f * k.nu, fdn = fd * k.nu, fnn = fn * k.nu;
+                const double f = k.w0 * e, fd = k.wd * e, fn = f * k.nu;
                 const double ha = __builtin_fma(u, u, -k.p11), hb = __builtin_fma(u, v, -k.p12),
                              hc = __builtin_fma(v, v, -k.p22);
                 S0 += f; T.S0d += fd;
                 T.S1x = __builtin_fma(u, f, T.S1x); T.S1y = __builtin_fma(v, f, T.S1y);
-                T.S1xd = __builtin_fma(u, fd, T.S1xd); T.S1yd = __builtin_fma(v, fd, T.S1yd);
-                T.S2a = __builtin_fma(ha, f, T.S2a); T.S2b = __builtin_fma(hb, f, T.S2b); T.S2c = __builtin_fma(hc, f, T.S2c);
                 T.S2an = __builtin_fma(ha, fn, T.S2an); T.S2bn = __builtin_fma(hb, fn, T.S2bn); T.S2cn = __builtin_fma(hc, fn, T.S2cn);
-                T.S2ad = __builtin_fma(ha, fdn, T.S2ad); T.S2bd = __builtin_fma(hb, fdn, T.S2bd); T.S2cd = __builtin_fma(hc, fdn, T.S2cd);
-                // third order: u^3 - 3 p11 u, u^2 v - p11 v - 2 p12 u, u v^2 - p22 u - 2 p12 v, v^3 - 3 p22 v
-                const double tu = -2.0 * u, tv = -2.0 * v;
-                const double h3a = u * __builtin_fma(-2.0, k.p11, ha);
-                const double h3b = __builtin_fma(v, ha, tu * k.p12);
-                const double h3c = __builtin_fma(u, hc, tv * k.p12);
-                const double h3d = v * __builtin_fma(-2.0, k.p22, hc);
-                T.S3a = __builtin_fma(h3a, fn, T.S3a); T.S3b = __builtin_fma(h3b, fn, T.S3b);
-                T.S3c = __builtin_fma(h3c, fn, T.S3c); T.S3d = __builtin_fma(h3d, fn, T.S3d);
-                // fourth order
-                const double m3a = -3.0 * ha, m3c = -3.0 * hc;
-                const double h4a = __builtin_fma(u, h3a, m3a * k.p11);
-                const double h4b = __builtin_fma(v, h3a, m3a * k.p12);
-                const double h4c = __builtin_fma(u, h3c, __builtin_fma(-2.0 * hb, k.p12, -hc * k.p11));
-                const double h4d = __builtin_fma(u, h3d, m3c * k.p12);
-                const double h4e = __builtin_fma(v, h3d, m3c * k.p22);
-                T.S4a = __builtin_fma(h4a, fnn, T.S4a); T.S4b = __builtin_fma(h4b, fnn, T.S4b);
-                T.S4c = __builtin_fma(h4c, fnn, T.S4c); T.S4d = __builtin_fma(h4d, fnn, T.S4d);
-                T.S4e = __builtin_fma(h4e, fnn, T.S4e);
+                if (MODE == 2) {
+                    const double fdn = fd * k.nu, fnn = fn * k.nu;
+                    T.S1xd = __builtin_fma(u, fd, T.S1xd); T.S1yd = __builtin_fma(v, fd, T.S1yd);
+                    T.S2a = __builtin_fma(ha, f, T.S2a); T.S2b = __builtin_fma(hb, f, T.S2b); T.S2c = __builtin_fma(hc, f, T.S2c);
+                    T.S2ad = __builtin_fma(ha, fdn, T.S2ad); T.S2bd = __builtin_fma(hb, fdn, T.S2bd); T.S2cd = __builtin_fma(hc, fdn, T.S2cd);
+                    // third order: u^3 - 3 p11 u, u^2 v - p11 v - 2 p12 u, u v^2 - p22 u - 2 p12 v, v^3 - 3 p22 v
+                    const double tu = -2.0 * u, tv = -2.0 * v;
+                    const double h3a = u * __builtin_fma(-2.0, k.p11, ha);
+                    const double h3b = __builtin_fma(v, ha, tu * k.p12);
+                    const double h3c = __builtin_fma(u, hc, tv * k.p12);
+                    const double h3d = v * __builtin_fma(-2.0, k.p22, hc);
+                    T.S3a = __builtin_fma(h3a, fn, T.S3a); T.S3b = __builtin_fma(h3b, fn, T.S3b);
+                    T.S3c = __builtin_fma(h3c, fn, T.S3c); T.S3d = __builtin_fma(h3d, fn, T.S3d);
+                    // fourth order
+                    const double m3a = -3.0 * ha, m3c = -3.0 * hc;
+                    const double h4a = __builtin_fma(u, h3a, m3a * k.p11);
+                    const double h4b = __builtin_fma(v, h3a, m3a * k.p12);
+                    const double h4c = __builtin_fma(u, h3c, __builtin_fma(-2.0 * hb, k.p12, -hc * k.p11));
+                    const double h4d = __builtin_fma(u, h3d, m3c * k.p12);
+                    const double h4e = __builtin_fma(v, h3d, m3c * k.p22);
+                    T.S4a = __builtin_fma(h4a, fnn, T.S4a); T.S4b = __builtin_fma(h4b, fnn, T.S4b);
+                    T.S4c = __builtin_fma(h4c, fnn, T.S4c); T.S4d = __builtin_fma(h4d, fnn, T.S4d);
+                    T.S4e = __builtin_fma(h4e, fnn, T.S4e);
+                }
             }
         }
         T.f1 = S0;
@@ -655,7 +674,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             T.dA4 = c1 * gal_g<4>(T); T.dB4 = q1f1 * gal_g<4>(T);
             T.dA5 = c1 * gal_g<5>(T); T.dB5 = q1f1 * gal_g<5>(T);
         }
-        fold_entries<0>(T, b0, b1, a);
+        fold_entries<MODE, 0>(T, b0, b1, a);
     }
 
     // ---- one 68-double record per (target, image, chunk) ----
@@ -667,6 +686,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     }
 #pragma unroll
     for (int j = 0; j < ACC_Q; ++j) {
+        if (MODE == 1 && (4 * j > ZV) && (4 * j + 3 < ACC_CNT)) continue;  // Hessian-only groups are not produced
         const double s = quad_class_sum(a[j]);
         if (lane < 4) out[4 * j + lane] = s;
     }

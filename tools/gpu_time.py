@@ -18,12 +18,12 @@ for cfg in os.environ.get("CHUNKS", "1024").split(","):
     ctx.enable_timing(True)
     ms = []
     for it in range(6):
-        g = ctx.eval_batch(fld.vp, tg, 7)
+        g = ctx.eval_batch(fld.vp, tg, int(os.environ.get('FLAGS', '7')))
         ms.append(ctx.last_kernel_ms())
     ms = np.array(ms)[2:].mean(axis=0)
     if ref is None:
         ref = g
-    err = max(float(np.abs(g[i] - ref[i]).max() / np.abs(ref[i]).max()) for i in range(3))
+    err = max(float(np.abs(g[i] - ref[i]).max() / np.abs(ref[i]).max()) for i in range(3) if g[i] is not None)
     print("ablate", ab or "0", "chunk %5d: prep %.3f pixel %.3f lift %.3f ms  | visits %d inactive %d | vs first cfg %.1e"
           % (chunk, ms[0], ms[1], ms[2], g[3][:, 0].sum(), g[3][:, 1].sum(), err))
     ctx.close()
