@@ -58,6 +58,21 @@ def test_explicit_bitmaps(oracle):
     assert_parity(ctx.eval_batch(f.vp, [0, 1], ALL), oracle.elbo_batch(ctx.problem, f.vp, [0, 1], ALL), "bitmaps")
 
 
+def test_gal_frac_dev_edge_values(oracle):
+    """gal_frac_dev exactly 0 or 1 (outside catalog_init_source's clamp but legal for elbo()): the kernel's
+    per-profile partial-sum shortcut is replaced by explicit accumulation"""
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(128, 128, 12, seed=5)
+    vp = f.vp.copy()
+    vp[0::3, 2] = 0.0
+    vp[1::3, 2] = 1.0
+    vp[2::3, 2] = 1e-9
+    ctx = _ctx(f)
+    tg = list(range(12))
+    errs = assert_parity(ctx.eval_batch(vp, tg, ALL), oracle.elbo_batch(ctx.problem, vp, tg, ALL), "dev edge")
+    print(errs)
+
+
 def test_batch_equals_singles():
     from celeste_jl_amd import synthetic
     f = synthetic.make_field(128, 128, 12, seed=5)
