@@ -46,10 +46,28 @@ def build_field(H, W, n_sources, seed, cache=True):
     return fld
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / p))))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(problem, vp, targets, seconds_target=15.0):
     """The oracle (dense reference-faithful C restatement, "port") on this box's host cores, bounded sample."""
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     probe = targets[:: max(1, len(targets) // (2 * cores))][: 2 * cores]
     t0 = time.time()
     oracle.elbo_batch(problem, vp, probe, FLAGS_ALL, n_threads=cores)
@@ -61,8 +79,10 @@ def cpu_baseline(problem, vp, targets, seconds_target=15.0):
     dt = time.time() - t0
     assert (st == 0).all()
     return {"value": len(sample) / dt, "unit": "sources/sec", "cores": cores, "kind": "port",
-            "sample": "%d of %d targets (every %d-th), value+grad+Hessian+KL, OpenMP dynamic over sources, %.1f s"
-                      % (len(sample), len(targets), max(1, len(targets) // n), dt)}
+            "sample": "%d of %d targets (every %d-th), value+grad+Hessian+KL, OpenMP dynamic over sources, %d threads "
+                      "(affinity %d CPUs, cgroup quota respected), %.1f s"
+                      % (len(sample), len(targets), max(1, len(targets) // n), cores,
+                         len(os.sched_getaffinity(0)), dt)}
 
 
 def main():
@@ -87,7 +107,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    use_dist = args.gpus > 1 or world > 1 or "RANK" in os.environ   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -95,7 +116,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
 
     # one field per rank (weak scaling): same shape, rank-dependent seed
     fld = build_field(args.height, args.width, args.sources, args.seed + rank)
@@ -112,19 +133,19 @@ def main():
     d_cnt = torch.zeros(S, 2, dtype=torch.int64, device=dev)
     d_st = torch.zeros(S, dtype=torch.int32, device=dev)
     gather_in = torch.zeros(S, 45, dtype=torch.float64, device=dev)
-    gather_out = torch.zeros(world * S, 45, dtype=torch.float64, device=dev) if world > 1 else None
+    gather_out = torch.zeros(world * S, 45, dtype=torch.float64, device=dev) if use_dist else None
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
         ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_ALL, d_v.data_ptr(), d_d.data_ptr(),
                               d_h.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), stream)
-        if world > 1:
+        if use_dist:  # the catalog gather: value + 44-gradient of every source, RCCL over xGMI
             gather_in[:, 0] = d_v
             gather_in[:, 1:] = d_d
             dist.all_gather_into_tensor(gather_out, gather_in)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -136,12 +157,27 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert int((d_st != 0).sum().item()) == 0, "non-zero per-target status"
     pixel_visits = int(d_cnt[:, 0].sum().item())
+
+    # secondary figure: value + gradient only (first-order mode; the headline includes the Hessian)
+    FLAGS_GRAD = 1 | 4
+
+    def step_grad():
+        ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_GRAD, d_v.data_ptr(), d_d.data_ptr(),
+                              0, d_cnt.data_ptr(), d_st.data_ptr(), stream)
+    for _ in range(3):
+        step_grad()
+    sync()
+    tg0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_grad()
+    sync()
+    dt_grad = time.perf_counter() - tg0
 
     # dominant-kernel duration: HIP events recorded by the library on the launch stream, averaged
     ctx.enable_timing(True)
@@ -172,14 +208,16 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "pixel_kernel<2>", "kernel_ms": float(kms[1]),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "the path is FP64-VALU bound (SURVEY.md F8): see fp64_valu"},
+                         "note": "the path is FP64-VALU bound, not HBM- or MFMA-bound (SURVEY.md F8, DESIGN.md 4.3): "
+                                 "measured SQ_ACTIVE_INST_VALU / SIMD-cycles = 0.71 (profiles/)"},
             "kernels_ms": {"prep": float(kms[0]), "pixel": float(kms[1]), "lift": float(kms[2])},
             "pixel_visits_per_sec": pixel_visits / (kms[1] * 1e-3),
+            "grad_only_sources_per_sec_rank0": S / (dt_grad / args.steps),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ctx.problem, fld.vp, targets)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -5,6 +5,7 @@
 // There is deliberately no CPU evaluation path: without a HIP device every entry point
 // that computes returns CELESTE_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -52,7 +53,10 @@ struct celeste_ctx {
     SrcGeo *d_geo = nullptr;
     int64_t *d_val_off = nullptr;   // per (source, image): offset of the patch in d_val
     double2 *d_val = nullptr;       // pre-rendered (E_G_s.v, var_G_s.v) of neighbour sources, per patch pixel
-    int32_t *d_needed = nullptr;    // per source: is a neighbour of some target of the current batch
+    int32_t *d_needed = nullptr;    // per source: is a target of the current batch
+    int32_t *d_link_src = nullptr;  // per neighbour link: the source that owns it (CSR row)
+    int64_t n_links = 0;
+    int max_overlap_px = 0;
     // per-batch scratch (grown on demand)
     double *d_acc = nullptr;
     size_t acc_cap = 0;
@@ -297,6 +301,20 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
         CTX_TRY(dev_upload(&c->d_val_off, voff.data(), voff.size()));
         CTX_TRY(dev_upload<double2>(&c->d_val, nullptr, (size_t)tot));
         CTX_TRY(dev_upload<int32_t>(&c->d_needed, nullptr, (size_t)c->S));
+        std::vector<int32_t> lsrc(c->h_nbr_idx.size());
+        for (int s = 0; s < c->S; ++s)
+            for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q) {
+                lsrc[q] = s;
+                const int s2 = c->h_nbr_idx[q];
+                for (int n = 0; n < c->N; ++n) {
+                    const DevPatch &a = c->h_patches[(size_t)s * c->N + n], &b = c->h_patches[(size_t)s2 * c->N + n];
+                    const int rh = std::min(a.off_h + a.H2, b.off_h + b.H2) - std::max(a.off_h, b.off_h);
+                    const int rw = std::min(a.off_w + a.W2, b.off_w + b.W2 - 1) - std::max(a.off_w, b.off_w);
+                    if (rh > 0 && rw > 0 && rh * rw > c->max_overlap_px) c->max_overlap_px = rh * rw;
+                }
+            }
+        c->n_links = (int64_t)lsrc.size();
+        CTX_TRY(dev_upload(&c->d_link_src, lsrc.data(), lsrc.size()));
     }
 
     if (const char *env_ab = getenv("CELESTE_ABLATE")) c->ablate = atoi(env_ab);
@@ -315,7 +333,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     (void)hipSetDevice(c->device);
     for (void *p : c->plane_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -343,10 +361,13 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
                        c->N, c->K, c->d_srcimg, c->d_comps, c->d_geo);
     HIP_TRY(hipMemsetAsync(c->d_needed, 0, (size_t)c->S * sizeof(int32_t), stream));
     hipLaunchKernelGGL(mark_kernel, dim3((n_targets + 255) / 256), dim3(256), 0, stream, d_targets, n_targets,
-                       c->d_nbr_off, c->d_nbr_idx, c->d_needed);
-    hipLaunchKernelGGL(value_kernel, dim3((unsigned)((size_t)c->S * c->N * c->CH)), dim3(64), 0, stream, c->d_patches,
-                       c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->d_val_off, c->N, c->NC, c->CH,
-                       c->chunk_px, c->d_val);
+                       c->d_needed);
+    if (c->n_links > 0 && c->max_overlap_px > 0) {
+        const int chv = (c->max_overlap_px + c->chunk_px - 1) / c->chunk_px;
+        hipLaunchKernelGGL(value_kernel, dim3((unsigned)((size_t)c->n_links * c->N * chv)), dim3(64), 0, stream,
+                           c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->d_link_src, c->d_nbr_idx,
+                           c->d_val_off, c->N, c->NC, chv, c->chunk_px, c->d_val);
+    }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     const dim3 grid((unsigned)((size_t)n_targets * c->N * c->CH));
 #define LAUNCH_PIXEL(MODE)                                                                                      \

@@ -257,30 +257,40 @@ __device__ inline double wave_sum(double x) {
 // per batch on the source's own patch so that the pixel kernel gathers two doubles per covering
 // neighbour instead of re-evaluating 14 psf_K exponentials per (pixel, neighbour) pair.
 // ---------------------------------------------------------------------------------------------
-__global__ void mark_kernel(const int32_t *__restrict__ targets, int n_targets, const int64_t *__restrict__ nbr_off,
-                            const int32_t *__restrict__ nbr_idx, int32_t *__restrict__ needed) {
+__global__ void mark_kernel(const int32_t *__restrict__ targets, int n_targets, int32_t *__restrict__ is_target) {
     const int ti = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ti >= n_targets) return;
-    const int t = targets[ti];
-    for (int64_t q = nbr_off[t]; q < nbr_off[t + 1]; ++q) needed[nbr_idx[q]] = 1;
+    if (ti < n_targets) is_target[targets[ti]] = 1;
 }
 
+// One wavefront per (neighbour link t -> s2, image, chunk): renders s2's value-only light on the rectangle
+// where s2's patch (minus its last column, elbo_objective.jl:349) overlaps target t's patch, into s2's own
+// patch buffer.  Links whose source t is not a target of this batch exit immediately.  Two targets that
+// overlap the same part of s2 write identical values to the same addresses (benign).
 __global__ void __launch_bounds__(64)
 value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
-             const int32_t *__restrict__ needed, const int64_t *__restrict__ val_off, int N, int NC, int CH,
+             const int32_t *__restrict__ is_target, const int32_t *__restrict__ link_src,
+             const int32_t *__restrict__ nbr_idx, const int64_t *__restrict__ val_off, int N, int NC, int CH,
              int chunk_px, double2 *__restrict__ val) {
     __shared__ double etab[64];
-    // chunk index is the slow grid axis: all first chunks (every patch has one) are dispatched first and
+    // chunk index is the slow grid axis: all first chunks (every overlap has one) are dispatched first and
     // round-robin over the 8 XCDs, whatever CH is (with ch fastest and CH = 6, half the XCDs sat idle)
-    const int SN = gridDim.x / CH;
-    const int ch = blockIdx.x / SN;
-    const int sn = blockIdx.x - ch * SN;
-    const int s = sn / N;
-    if (!needed[s]) return;
+    const int LN = gridDim.x / CH;
+    const int ch = blockIdx.x / LN;
+    const int ln = blockIdx.x - ch * LN;
+    const int q = ln / N, n = ln - q * N;
+    const int t = link_src[q];
+    if (!is_target[t]) return;
+    const int s = nbr_idx[q];
+    const int sn = s * N + n;
     const DevPatch &P = patches[sn];
-    const int H2 = P.H2, W2 = P.W2;
-    const int npx = H2 * (W2 - 1);  // the last column never contributes (elbo_objective.jl:349)
+    const DevPatch &T = patches[(size_t)t * N + n];
+    // overlap rectangle in 0-based image coordinates [h_lo, h_hi) x [w_lo, w_hi)
+    const int h_lo = max(P.off_h, T.off_h), h_hi = min(P.off_h + P.H2, T.off_h + T.H2);
+    const int w_lo = max(P.off_w, T.off_w), w_hi = min(P.off_w + P.W2 - 1, T.off_w + T.W2);
+    const int RH = h_hi - h_lo, RW = w_hi - w_lo;
+    if (RH <= 0 || RW <= 0) return;
+    const int npx = RH * RW;
     const int p0 = ch * chunk_px;
     if (p0 >= npx) return;
     exp_table_init(etab);
@@ -297,13 +307,14 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
     double2 *__restrict__ out = val + val_off[sn];
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
     for (int idx = p0 + (int)threadIdx.x; idx < p1; idx += 64) {
-        const int w2 = idx / H2, h2 = idx - w2 * H2;
-        const double hh = (double)(P.off_h + h2 + 1), ww = (double)(P.off_w + w2 + 1);
+        const int rw = idx / RH, rh = idx - rw * RH;
+        const int h0 = h_lo + rh, w0 = w_lo + rw;  // 0-based image coordinates
+        const double hh = (double)(h0 + 1), ww = (double)(w0 + 1);
         const double f0 = star_value(coef, hh + sh0, ww + sw0);
         const double f1 = galaxy_value(tc, NC, hh, ww, etab);
         const double En = si.c0 * f0 + si.c1 * f1;                      // E_G_s.v  (elbo_objective.jl:62-65)
         const double E2n = si.q0 * (f0 * f0) + si.q1 * (f1 * f1);
-        out[idx] = make_double2(En, E2n - En * En);                     // var_G_s.v (elbo_objective.jl:204)
+        out[(h0 - P.off_h) + (int64_t)P.H2 * (w0 - P.off_w)] = make_double2(En, E2n - En * En);  // var_G_s.v (:204)
     }
 }
 
