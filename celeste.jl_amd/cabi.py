@@ -14,7 +14,7 @@ STAMP = 51
 COEF = 53
 
 OK, ERR_INVALID_ARG, ERR_NONFINITE_INPUT, ERR_NONFINITE_RESULT, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = range(7)
-FLAG_GRAD, FLAG_HESS, FLAG_KL = 1, 2, 4
+FLAG_GRAD, FLAG_HESS, FLAG_KL, FLAG_FP32 = 1, 2, 4, 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libceleste_mi355x.so")

@@ -370,14 +370,16 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     const dim3 grid((unsigned)((size_t)n_targets * c->N * c->CH));
-#define LAUNCH_PIXEL(MODE)                                                                                      \
-    hipLaunchKernelGGL(pixel_kernel<MODE>, grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,   \
+#define LAUNCH_PIXEL_T(MODE, R)                                                                                 \
+    hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,   \
                        c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off, c->d_val, \
                        d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->ablate)
+#define LAUNCH_PIXEL(MODE) do { if (flags & CELESTE_FLAG_FP32) LAUNCH_PIXEL_T(MODE, float); else LAUNCH_PIXEL_T(MODE, double); } while (0)
     if (flags & CELESTE_FLAG_HESS) LAUNCH_PIXEL(2);
     else if (derivs) LAUNCH_PIXEL(1);
-    else LAUNCH_PIXEL(0);
+    else LAUNCH_PIXEL_T(0, double);
 #undef LAUNCH_PIXEL
+#undef LAUNCH_PIXEL_T
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
     hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                        c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->N, c->CH, c->chunk_px, flags,

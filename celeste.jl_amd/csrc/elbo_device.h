@@ -50,7 +50,7 @@ struct DevPatch {
 // one PSF component (x) one galaxy prototype component (fsm_util.jl:37-65)
 struct Comp {
     double p11, p12, p22;  // precision = inv(tauBar_k + nuBar_j XiXi)
-    double mu1, mu2;       // xiBar_k + m_pos
+    double xi1, xi2;       // xiBar_k: the mean is xi + m_pos (m_pos lives in SrcImg, so coordinates stay centred)
     double w0;             // z * gal_frac_dev_i      (f = w0 * exp(...))
     double wd;             // z * gal_frac_dev_dir    (d f / d gal_frac_dev = wd * exp(...))
     double nu;             // nuBar_j

@@ -87,7 +87,7 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         const double z = (pc[0] * c_eta[8 * i + j]) / (sqrt(det) * (2.0 * M_PI));  // BvnComponent (BivariateNormals.jl:158,185)
         Comp o;
         o.p11 = s22 * idet; o.p12 = -s12 * idet; o.p22 = s11 * idet;
-        o.mu1 = pc[1] + m1; o.mu2 = pc[2] + m2;
+        o.xi1 = pc[1]; o.xi2 = pc[2];
         const double dev = vs[2];
         o.w0 = z * (i == 0 ? dev : 1.0 - dev);
         o.wd = (i == 0 ? z : -z);
@@ -211,11 +211,12 @@ __device__ inline double star_value(const double *__restrict__ coef, double xh, 
 }
 
 // value of the galaxy density sum_c w0_c exp(-0.5 d' P d) (populate_gal_fsm!, inactive branch)
-__device__ inline double galaxy_value(const Comp *tc, int NC, double hh, double ww, const double *etab) {
+// (dx, dy) = pixel - m_pos
+__device__ inline double galaxy_value(const Comp *tc, int NC, double dx, double dy, const double *etab) {
     double v = 0;
     for (int c = 0; c < NC; ++c) {
         const Comp k = tc[c];
-        const double d1 = hh - k.mu1, d2 = ww - k.mu2;
+        const double d1 = dx - k.xi1, d2 = dy - k.xi2;
         const double u = k.p11 * d1 + k.p12 * d2, vv = k.p12 * d1 + k.p22 * d2;
         v = __builtin_fma(k.w0, exp_nonpos(-0.5 * (d1 * u + d2 * vv), etab), v);
     }
@@ -311,7 +312,7 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
         const int h0 = h_lo + rh, w0 = w_lo + rw;  // 0-based image coordinates
         const double hh = (double)(h0 + 1), ww = (double)(w0 + 1);
         const double f0 = star_value(coef, hh + sh0, ww + sw0);
-        const double f1 = galaxy_value(tc, NC, hh, ww, etab);
+        const double f1 = galaxy_value(tc, NC, hh - si.m1, ww - si.m2, etab);
         const double En = si.c0 * f0 + si.c1 * f1;                      // E_G_s.v  (elbo_objective.jl:62-65)
         const double E2n = si.q0 * (f0 * f0) + si.q1 * (f1 * f1);
         out[(h0 - P.off_h) + (int64_t)P.H2 * (w0 - P.off_w)] = make_double2(En, E2n - En * En);  // var_G_s.v (:204)
@@ -460,13 +461,82 @@ __device__ __forceinline__ void fold_entries(const PixelTerms &T, bool b0, bool 
     if constexpr (J + 1 < ACC_N / 4) fold_entries<MODE, J + 1>(T, b0, b1, a);
 }
 
+// Component record in the arithmetic type of the pixel math (double, or float for CELESTE_FLAG_FP32)
+template <typename R>
+struct CompR { R p11, p12, p22, xi1, xi2, w0, wd, nu; };
+
+template <typename R> __device__ __forceinline__ R exp_np(R x, const double *tab);
+template <> __device__ __forceinline__ double exp_np<double>(double x, const double *tab) { return exp_nonpos(x, tab); }
+template <> __device__ __forceinline__ float exp_np<float>(float x, const double *) { return __expf(x); }  // v_exp_f32
+template <typename R> __device__ __forceinline__ R fma_r(R a, R b, R c);
+template <> __device__ __forceinline__ double fma_r<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float fma_r<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Galaxy: 14 * psf_K bivariate normals (accum_galaxy_pos!, fsm_util.jl:255-346).  The reference's
+// per-component chain get_bvn_derivs! -> transform_bvn_derivs! is replaced by its closed form: the
+// derivatives of a Gaussian density with respect to its mean are Hermite polynomials in
+// (u, v) = P (x - mu), and d/dSigma = (1/2) d2/dx2, so every quantity the Hessian needs is a
+// weighted sum over components of spatial derivatives up to order 4 (24 sums instead of 1+6+21,
+// and no 3x3 transforms inside the loop).  Weights: w0 = z theta_i, wd = +-z, and their products with
+// nu, nu^2.  (dx, dy) = pixel - m_pos.  Returns sum f; fills the S* members of T.
+template <int MODE, typename R>
+__device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int nc, R dx, R dy, const double *etab,
+                                              PixelTerms &T) {
+    R S0 = 0, S0d = 0, S1x = 0, S1y = 0, S1xd = 0, S1yd = 0;
+    R S2a = 0, S2b = 0, S2c = 0, S2an = 0, S2bn = 0, S2cn = 0, S2ad = 0, S2bd = 0, S2cd = 0;
+    R S3a = 0, S3b = 0, S3c = 0, S3d = 0, S4a = 0, S4b = 0, S4c = 0, S4d = 0, S4e = 0;
+    for (int c = 0; c < nc; ++c) {
+        const CompR<R> k = tc[c];
+        const R d1 = dx - k.xi1, d2 = dy - k.xi2;
+        const R u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
+        const R e = exp_np<R>((R)-0.5 * (d1 * u + d2 * v), etab);   // eval_bvn_pdf!
+        const R f = k.w0 * e, fd = k.wd * e, fn = f * k.nu;
+        const R ha = fma_r<R>(u, u, -k.p11), hb = fma_r<R>(u, v, -k.p12), hc = fma_r<R>(v, v, -k.p22);
+        S0 += f; S0d += fd;
+        S1x = fma_r<R>(u, f, S1x); S1y = fma_r<R>(v, f, S1y);
+        S2an = fma_r<R>(ha, fn, S2an); S2bn = fma_r<R>(hb, fn, S2bn); S2cn = fma_r<R>(hc, fn, S2cn);
+        if (MODE == 2) {
+            const R fdn = fd * k.nu, fnn = fn * k.nu;
+            S1xd = fma_r<R>(u, fd, S1xd); S1yd = fma_r<R>(v, fd, S1yd);
+            S2a = fma_r<R>(ha, f, S2a); S2b = fma_r<R>(hb, f, S2b); S2c = fma_r<R>(hc, f, S2c);
+            S2ad = fma_r<R>(ha, fdn, S2ad); S2bd = fma_r<R>(hb, fdn, S2bd); S2cd = fma_r<R>(hc, fdn, S2cd);
+            // third order: u^3 - 3 p11 u, u^2 v - p11 v - 2 p12 u, u v^2 - p22 u - 2 p12 v, v^3 - 3 p22 v
+            const R tu = (R)-2.0 * u, tv = (R)-2.0 * v;
+            const R h3a = u * fma_r<R>((R)-2.0, k.p11, ha);
+            const R h3b = fma_r<R>(v, ha, tu * k.p12);
+            const R h3c = fma_r<R>(u, hc, tv * k.p12);
+            const R h3d = v * fma_r<R>((R)-2.0, k.p22, hc);
+            S3a = fma_r<R>(h3a, fn, S3a); S3b = fma_r<R>(h3b, fn, S3b);
+            S3c = fma_r<R>(h3c, fn, S3c); S3d = fma_r<R>(h3d, fn, S3d);
+            // fourth order
+            const R m3a = (R)-3.0 * ha, m3c = (R)-3.0 * hc;
+            const R h4a = fma_r<R>(u, h3a, m3a * k.p11);
+            const R h4b = fma_r<R>(v, h3a, m3a * k.p12);
+            const R h4c = fma_r<R>(u, h3c, fma_r<R>((R)-2.0 * hb, k.p12, -hc * k.p11));
+            const R h4d = fma_r<R>(u, h3d, m3c * k.p12);
+            const R h4e = fma_r<R>(v, h3d, m3c * k.p22);
+            S4a = fma_r<R>(h4a, fnn, S4a); S4b = fma_r<R>(h4b, fnn, S4b);
+            S4c = fma_r<R>(h4c, fnn, S4c); S4d = fma_r<R>(h4d, fnn, S4d);
+            S4e = fma_r<R>(h4e, fnn, S4e);
+        }
+    }
+    T.S0d = S0d; T.S1x = S1x; T.S1y = S1y; T.S1xd = S1xd; T.S1yd = S1yd;
+    T.S2a = S2a; T.S2b = S2b; T.S2c = S2c; T.S2an = S2an; T.S2bn = S2bn; T.S2cn = S2cn;
+    T.S2ad = S2ad; T.S2bd = S2bd; T.S2cd = S2cd;
+    T.S3a = S3a; T.S3b = S3b; T.S3c = S3c; T.S3d = S3d;
+    T.S4a = S4a; T.S4b = S4b; T.S4c = S4c; T.S4d = S4d; T.S4e = S4e;
+    return (double)S0;
+}
+
 #define ACC_Q (ACC_N / 4)  // 17 accumulators per lane: lane l owns record entries e with e % 4 == l % 4
 
 // MODE 0: value only; MODE 1: value + gradient sums; MODE 2: value + gradient + Hessian sums
 #ifndef PIXEL_WAVES
 #define PIXEL_WAVES 2  // waves per SIMD the register allocator must allow (256 VGPRs, no scratch)
 #endif
-template <int MODE>
+// R: arithmetic type of the galaxy component loop (double; float with CELESTE_FLAG_FP32 -- everything
+// downstream of the 24 component sums, and all accumulation, stays fp64)
+template <int MODE, typename R>
 __global__ void __launch_bounds__(64, PIXEL_WAVES)
 pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ patches,
              const double *__restrict__ coefs, const uint8_t *__restrict__ bitmaps,
@@ -496,12 +566,19 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     // the target's components: one coalesced read into LDS, then broadcast ds_reads in the pixel loop (the
     // scalar data cache cannot hold 8 waves x 1.8 KB per CU: 68 % of s_loads missed to L2)
     __shared__ Comp tc[14 * CEL_MAXK];
+    __shared__ CompR<R> tcr_f[sizeof(R) == 4 ? 14 * CEL_MAXK : 1];
     {
         const double *src = reinterpret_cast<const double *>(comps + ((size_t)t * N + n) * NC);
         double *dst = reinterpret_cast<double *>(tc);
-        for (int i = lane; i < NC * 8; i += 64) dst[i] = src[i];
+        R *dstf = reinterpret_cast<R *>(tcr_f);
+        for (int i = lane; i < NC * 8; i += 64) {
+            const double v = src[i];
+            dst[i] = v;
+            if (sizeof(R) == 4) dstf[i] = (R)v;
+        }
         __syncthreads();
     }
+    const CompR<R> *tcr = sizeof(R) == 4 ? tcr_f : reinterpret_cast<const CompR<R> *>(tc);
     const double *__restrict__ tcoef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
     const int64_t nb0 = nbr_off[t], nb1 = (ablate & 1) ? nb0 : nbr_off[t + 1];
     const double c0 = si.c0, c1 = si.c1, q0 = si.q0, q1 = si.q1;
@@ -554,7 +631,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             double f0 = 0, f1 = 0;
             if (own) {
                 f0 = star_value(tcoef, hh + sh0, ww + sw0);
-                f1 = galaxy_value(tc, NC, hh, ww, etab);
+                f1 = galaxy_value(tc, NC, hh - si.m1, ww - si.m2, etab);
             }
             if (valid) {
                 const double A = c0 * f0 + c1 * f1;
@@ -568,56 +645,12 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             continue;
         }
 
-        // Galaxy: 14 * psf_K bivariate normals (accum_galaxy_pos!, fsm_util.jl:255-346).  The reference's
-        // per-component chain get_bvn_derivs! -> transform_bvn_derivs! is replaced by its closed form: the
-        // derivatives of a Gaussian density with respect to its mean are Hermite polynomials in
-        // (u, v) = P (x - mu), and d/dSigma = (1/2) d2/dx2, so every quantity the Hessian needs is a
-        // weighted sum over components of spatial derivatives up to order 4 (24 sums instead of 1+6+21,
-        // and no 3x3 transforms inside the loop).  Weights: w0 = z theta_i, wd = +-z, wn = w0 nu,
-        // wdn = wd nu, wnn = w0 nu^2.
         PixelTerms T;
         double S0 = 0;
         T.S0d = 0; T.S1x = 0; T.S1y = 0; T.S1xd = 0; T.S1yd = 0;
         T.S2a = 0; T.S2b = 0; T.S2c = 0; T.S2an = 0; T.S2bn = 0; T.S2cn = 0; T.S2ad = 0; T.S2bd = 0; T.S2cd = 0;
         T.S3a = 0; T.S3b = 0; T.S3c = 0; T.S3d = 0; T.S4a = 0; T.S4b = 0; T.S4c = 0; T.S4d = 0; T.S4e = 0;
-        if (own) {
-            for (int c = 0; c < ((ablate & 2) ? 0 : NC); ++c) {
-                const Comp k = tc[c];
-                const double d1 = hh - k.mu1, d2 = ww - k.mu2;
-                const double u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
-                const double e = exp_nonpos(-0.5 * (d1 * u + d2 * v), etab);   // eval_bvn_pdf!
-                const double f = k.w0 * e, fd = k.wd * e, fn = f * k.nu;
-                const double ha = __builtin_fma(u, u, -k.p11), hb = __builtin_fma(u, v, -k.p12),
-                             hc = __builtin_fma(v, v, -k.p22);
-                S0 += f; T.S0d += fd;
-                T.S1x = __builtin_fma(u, f, T.S1x); T.S1y = __builtin_fma(v, f, T.S1y);
-                T.S2an = __builtin_fma(ha, fn, T.S2an); T.S2bn = __builtin_fma(hb, fn, T.S2bn); T.S2cn = __builtin_fma(hc, fn, T.S2cn);
-                if (MODE == 2) {
-                    const double fdn = fd * k.nu, fnn = fn * k.nu;
-                    T.S1xd = __builtin_fma(u, fd, T.S1xd); T.S1yd = __builtin_fma(v, fd, T.S1yd);
-                    T.S2a = __builtin_fma(ha, f, T.S2a); T.S2b = __builtin_fma(hb, f, T.S2b); T.S2c = __builtin_fma(hc, f, T.S2c);
-                    T.S2ad = __builtin_fma(ha, fdn, T.S2ad); T.S2bd = __builtin_fma(hb, fdn, T.S2bd); T.S2cd = __builtin_fma(hc, fdn, T.S2cd);
-                    // third order: u^3 - 3 p11 u, u^2 v - p11 v - 2 p12 u, u v^2 - p22 u - 2 p12 v, v^3 - 3 p22 v
-                    const double tu = -2.0 * u, tv = -2.0 * v;
-                    const double h3a = u * __builtin_fma(-2.0, k.p11, ha);
-                    const double h3b = __builtin_fma(v, ha, tu * k.p12);
-                    const double h3c = __builtin_fma(u, hc, tv * k.p12);
-                    const double h3d = v * __builtin_fma(-2.0, k.p22, hc);
-                    T.S3a = __builtin_fma(h3a, fn, T.S3a); T.S3b = __builtin_fma(h3b, fn, T.S3b);
-                    T.S3c = __builtin_fma(h3c, fn, T.S3c); T.S3d = __builtin_fma(h3d, fn, T.S3d);
-                    // fourth order
-                    const double m3a = -3.0 * ha, m3c = -3.0 * hc;
-                    const double h4a = __builtin_fma(u, h3a, m3a * k.p11);
-                    const double h4b = __builtin_fma(v, h3a, m3a * k.p12);
-                    const double h4c = __builtin_fma(u, h3c, __builtin_fma(-2.0 * hb, k.p12, -hc * k.p11));
-                    const double h4d = __builtin_fma(u, h3d, m3c * k.p12);
-                    const double h4e = __builtin_fma(v, h3d, m3c * k.p22);
-                    T.S4a = __builtin_fma(h4a, fnn, T.S4a); T.S4b = __builtin_fma(h4b, fnn, T.S4b);
-                    T.S4c = __builtin_fma(h4c, fnn, T.S4c); T.S4d = __builtin_fma(h4d, fnn, T.S4d);
-                    T.S4e = __builtin_fma(h4e, fnn, T.S4e);
-                }
-            }
-        }
+        if (own) S0 = galaxy_sums<MODE, R>(tcr, (ablate & 2) ? 0 : NC, (R)(hh - si.m1), (R)(ww - si.m2), etab, T);
         T.f1 = S0;
 
         // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26

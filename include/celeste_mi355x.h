@@ -62,7 +62,10 @@ enum {
 enum {
     CELESTE_FLAG_GRAD = 1u,
     CELESTE_FLAG_HESS = 2u,
-    CELESTE_FLAG_KL = 4u
+    CELESTE_FLAG_KL = 4u,
+    /* single-precision galaxy component loop (BASELINE config 5, tolerance 1e-4 against the fp64 result);
+     * per-pixel terms, accumulation, the lift and the KL stay fp64.  No reference counterpart. */
+    CELESTE_FLAG_FP32 = 8u
 };
 
 /* Model.Image (src/model/image_model.jl:6-38).  Borrowed for the duration of

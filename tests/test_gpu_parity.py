@@ -73,6 +73,26 @@ def test_gal_frac_dev_edge_values(oracle):
     print(errs)
 
 
+def test_fp32_component_loop_within_1e4(oracle):
+    """BASELINE config 5 precision mode: float galaxy component loop, everything else fp64; compared with the
+    fp64 oracle at 1e-4 relative on v and on ||.||inf-scaled d (and h)"""
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_field(200, 240, 40, seed=4, nan_fraction=0.002)
+    ctx = _ctx(f)
+    tg = list(range(40))
+    for flags in (1 | 4 | cabi.FLAG_FP32, ALL | cabi.FLAG_FP32):
+        v, d, h, cnt, st = ctx.eval_batch(f.vp, tg, flags)
+        ov, od, oh, ocnt, ost = oracle.elbo_batch(ctx.problem, f.vp, tg, flags & 7)
+        assert (st == 0).all() and np.array_equal(cnt, ocnt)
+        ev = np.max(np.abs(v - ov) / np.abs(ov))
+        ed = max(np.abs(d[t] - od[t]).max() / np.abs(od[t]).max() for t in tg)
+        assert ev <= 1e-4 and ed <= 1e-4, (ev, ed)
+        if h is not None:
+            eh = max(np.abs(h[t] - oh[t]).max() / np.abs(oh[t]).max() for t in tg)
+            assert eh <= 1e-4, eh
+            print("fp32 errs", ev, ed, eh)
+
+
 def test_batch_equals_singles():
     from celeste_jl_amd import synthetic
     f = synthetic.make_field(128, 128, 12, seed=5)
