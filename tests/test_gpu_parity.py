@@ -93,6 +93,45 @@ def test_fp32_component_loop_within_1e4(oracle):
             print("fp32 errs", ev, ed, eh)
 
 
+def _affine_variable_psf_field(seed=7):
+    """A field whose patches carry a non-identity affine WCS Jacobian, shifted world/pixel centres and a
+    different PSF stamp per patch (variable PSF map): exercises u_d = -J' x_d, uu_h = J' xx_h J
+    (BivariateNormals.jl:424-447) and the per-patch spline (imaged_sources.jl:97-107)."""
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.model import render_psf, make_psf
+    f = synthetic.make_field(160, 200, 16, seed=seed)
+    rng = np.random.default_rng(seed)
+    J = np.array([[0.92, 0.11], [-0.07, 1.05]])
+    Jinv = np.linalg.inv(J)
+    for s, row in enumerate(f.patches):
+        for n, p in enumerate(row):
+            # world = Jinv (pix - pc) + wc, so that pix = J (world - wc) + pc keeps the source where it was
+            p.wcs_jacobian = J.copy()
+            p.world_center = np.array([3.0 + 0.1 * s, -2.0 + 0.05 * n])
+            sig = 1.2 + 0.5 * rng.random()
+            p.stamp = render_psf(make_psf((0.7, 0.3), [(0.05, -0.1), (0.0, 0.2)],
+                                          [np.eye(2) * sig ** 2, np.array([[6.0, 0.8], [0.8, 5.0]])]))
+            p.psf = make_psf((0.75, 0.25), [(0.1, -0.05), (-0.2, 0.1)],
+                             [np.array([[sig ** 2, 0.2], [0.2, 1.3 * sig ** 2]]), np.array([[6.5, -0.7], [-0.7, 5.5]])])
+        # re-express the source position in the new world coordinates
+        p0 = row[0]
+        pix = f.vp[s, 0:2].copy()
+        f.vp[s, 0:2] = Jinv @ (pix - p0.pixel_center) + p0.world_center
+        for p in row[1:]:
+            # every patch of a source must map the same world position to the same pixel position
+            p.world_center = f.vp[s, 0:2] - Jinv @ (pix - p.pixel_center)
+    return f
+
+
+def test_affine_wcs_and_variable_psf(oracle):
+    f = _affine_variable_psf_field()
+    ctx = _ctx(f)
+    assert ctx.problem.c.n_stamps == 16 * 5
+    tg = list(range(16))
+    errs = assert_parity(ctx.eval_batch(f.vp, tg, ALL), oracle.elbo_batch(ctx.problem, f.vp, tg, ALL), "affine")
+    print("affine/variable psf", errs)
+
+
 def test_batch_equals_singles():
     from celeste_jl_amd import synthetic
     f = synthetic.make_field(128, 128, 12, seed=5)

@@ -31,6 +31,13 @@ def test_two_body_star_target(oracle):
     _check(oracle, synthetic.make_sample_dataset("two_body"), 1)
 
 
+def test_affine_wcs_and_variable_psf_target(oracle):
+    """non-identity wcs_jacobian (A11: u_d = -J' x_d, uu_h = J' xx_h J) and per-patch PSF stamps"""
+    from test_gpu_parity import _affine_variable_psf_field
+    f = _affine_variable_psf_field()
+    _check(oracle, f, int(np.argmax([len(n) for n in f.neighbors])))
+
+
 def test_kl_derivatives(oracle):
     """subtract_kl: analytic gradient / Hessian vs autograd (the reference uses ReverseDiff / ForwardDiff)"""
     import torch
