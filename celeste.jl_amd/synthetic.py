@@ -207,6 +207,35 @@ def make_field(H: int, W: int, n_sources: int, seed: int, stars_only: bool = Fal
     return Field(images, catalog, patches, nbrs, np.stack(vp), name)
 
 
+def make_multifield(grid=(2, 2), H: int = 256, W: int = 256, overlap: float = 0.10, n_sources: int = 120,
+                    seed: int = 5, perturb: bool = True, margin: int = 8) -> Field:
+    """Config 5 of SURVEY.md 8(d) in miniature: a grid of overlapping fields (5 bands each) on one world
+    coordinate system (world = global pixel coordinates; each image has its own affine offset).  A source
+    has non-empty patches only in the images it overlaps; the others are the reference's empty boxes
+    (clamp_box, imaged_sources.jl:10-14)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    prior = load_prior()
+    images: List[Image] = []
+    step_h, step_w = int(round(H * (1 - overlap))), int(round(W * (1 - overlap)))
+    for gi in range(grid[0]):
+        for gj in range(grid[1]):
+            for im in blank_images(H, W):
+                im.wcs_world0 = np.array([float(gi * step_h), float(gj * step_w)])
+                images.append(im)
+    tot_h, tot_w = step_h * (grid[0] - 1) + H, step_w * (grid[1] - 1) + W
+    catalog = []
+    for _ in range(n_sources):
+        pos = (rng.uniform(margin, tot_h - margin), rng.uniform(margin, tot_w - margin))
+        catalog.append(draw_source(prior, rng, pos))
+    gen_images(images, catalog, rng)
+    patches = get_sky_patches(images, catalog)
+    nbrs = neighbor_map(patches)
+    vp = [catalog_init_source(ce) for ce in catalog]
+    if perturb:
+        perturb_params(vp)
+    return Field(images, catalog, patches, nbrs, np.stack(vp), "multifield_%dx%d" % grid)
+
+
 SAMPLE_STAR_FLUXES = np.array([4.451805E+03, 1.491065E+03, 2.264545E+03, 2.027004E+03, 1.846822E+04])
 SAMPLE_GALAXY_FLUXES = np.array([1.377666E+01, 5.635334E+01, 1.258656E+02, 1.884264E+02, 2.351820E+02]) * 100
 

@@ -132,6 +132,23 @@ def test_affine_wcs_and_variable_psf(oracle):
     print("affine/variable psf", errs)
 
 
+def test_multifield_overlapping_images(oracle):
+    """BASELINE config 5 in miniature: 2 x 2 overlapping fields (20 images); a source only has patches in the
+    images it overlaps.  fp64 parity, then the fp32 component loop at the stated 1e-4 tolerance."""
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_multifield((2, 2), 192, 192, 0.10, 60, seed=5)
+    n_img = [sum(p.active_pixel_bitmap.size > 0 for p in row) for row in f.patches]
+    assert max(n_img) >= 10 and min(n_img) >= 5      # sources in overlap regions see 2 or 4 fields
+    ctx = _ctx(f)
+    tg = list(range(len(f.catalog)))
+    ref = oracle.elbo_batch(ctx.problem, f.vp, tg, ALL)
+    errs = assert_parity(ctx.eval_batch(f.vp, tg, ALL), ref, "multifield")
+    print("multifield", errs, "images per source", min(n_img), max(n_img))
+    v, d, h, cnt, st = ctx.eval_batch(f.vp, tg, 1 | 4 | cabi.FLAG_FP32)
+    assert np.max(np.abs(v - ref[0]) / np.abs(ref[0])) <= 1e-4
+    assert max(np.abs(d[t] - ref[1][t]).max() / np.abs(ref[1][t]).max() for t in tg) <= 1e-4
+
+
 def test_batch_equals_singles():
     from celeste_jl_amd import synthetic
     f = synthetic.make_field(128, 128, 12, seed=5)
