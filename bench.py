@@ -22,7 +22,17 @@ import numpy as np  # noqa: E402
 
 FLAGS_ALL = 1 | 2 | 4
 HBM_PEAK_GBS = 8000.0
-FP64_VECTOR_PEAK_TFLOPS = 78.6
+
+
+def profiled_traffic_bytes():
+    """HBM bytes per pixel_kernel<2> launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+    separate passes, KiB -> bytes, uncorrected: see DESIGN.md 4.3).  None when no profile is present."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def build_field(H, W, n_sources, seed, cache=True):
@@ -193,6 +203,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * S / (dt / args.steps)
         alg_bytes = stats["algorithmic_bytes"]
+        traffic = profiled_traffic_bytes()
         achieved = alg_bytes / (kms[1] * 1e-3) / 1e9
         out = {
             "metric": "sources/sec (ELBO value+gradient+Hessian+KL per target source)",
@@ -205,7 +216,9 @@ def main():
                        "sources_per_gpu": S, "pixel_visits_per_sweep": pixel_visits,
                        "neighbor_links": stats["neighbor_links"], "parallelism": "sources sharded, 1 field per GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (traffic or {}).get("pixel_kernel_bytes_per_launch"),
+                         "traffic_source": (traffic or {}).get("source"),
                          "kernel": "pixel_kernel<2>", "kernel_ms": float(kms[1]),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the path is FP64-VALU bound, not HBM- or MFMA-bound (SURVEY.md F8, DESIGN.md 4.3): "
