@@ -5,7 +5,8 @@ Import as ``celeste_jl_amd`` (see celeste_jl_amd.py at the repository root).
 from . import cabi, params, model  # noqa: F401
 from .params import (ids, CatalogEntry, generic_init_source, catalog_init_source, init_sources,  # noqa: F401
                      perturb_params)
-from .elbo import ElboArgs, SensitiveFloat, FieldContext, elbo, elbo_likelihood  # noqa: F401
+from .elbo import (ElboArgs, ElboConfig, SensitiveFloat, FieldContext, elbo, elbo_likelihood,  # noqa: F401
+                   maximize)
 
-__all__ = ["ElboArgs", "SensitiveFloat", "FieldContext", "elbo", "elbo_likelihood", "ids", "CatalogEntry",
+__all__ = ["ElboArgs", "ElboConfig", "maximize", "SensitiveFloat", "FieldContext", "elbo", "elbo_likelihood", "ids", "CatalogEntry",
            "generic_init_source", "catalog_init_source", "init_sources", "perturb_params"]

@@ -56,6 +56,13 @@ class WorkStatsT(C.Structure):
                 ("neighbor_links", C.c_int64), ("algorithmic_bytes", C.c_int64)]
 
 
+class OptimConfigT(C.Structure):
+    """celeste_optim_config_t: ElboConfig defaults (ElboMaximize.jl:43-49, 95-108)"""
+    _fields_ = [("loc_width", C.c_double), ("loc_scale", C.c_double), ("max_iters", C.c_int32),
+                ("include_kl", C.c_int32), ("xtol_abs", C.c_double), ("ftol_rel", C.c_double), ("gtol", C.c_double),
+                ("initial_delta", C.c_double), ("delta_hat", C.c_double)]
+
+
 class CelesteError(RuntimeError):
     def __init__(self, status: int, msg: str):
         super().__init__("celeste_mi355x status %d: %s" % (status, msg))
@@ -67,6 +74,7 @@ EXPORTED_SYMBOLS = [
     "celeste_version", "celeste_strerror", "celeste_ctx_create", "celeste_ctx_destroy", "celeste_elbo_eval",
     "celeste_elbo_eval_batch", "celeste_elbo_eval_batch_device", "celeste_ctx_enable_timing",
     "celeste_ctx_last_kernel_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter", "celeste_psf_raster",
+    "celeste_maximize_batch",
 ]
 
 _lib = None
@@ -100,6 +108,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.celeste_spline_prefilter.argtypes = [c_double_p, c_double_p]
     lib.celeste_psf_raster.argtypes = [C.c_int, c_double_p, C.c_int32, c_double_p, C.c_int32, c_double_p,
                                        C.c_int32, c_double_p]
+    lib.celeste_maximize_batch.argtypes = [vp, c_double_p, C.c_int32, c_int32_p, C.POINTER(OptimConfigT), c_int32_p,
+                                           c_int32_p, c_double_p, c_int32_p]
     _lib = lib
     return lib
 

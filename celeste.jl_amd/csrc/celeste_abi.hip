@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "elbo_kernels.h"
+#include "optim_kernels.h"
 
 #define HIP_TRY(expr)                                                                    \
     do {                                                                                 \
@@ -340,9 +341,21 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     delete c;
 }
 
+static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
+                       uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
+                       void *stream_, bool render_neighbors);
+
 extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_vp, int32_t n_targets,
                                               const int32_t *d_targets, uint32_t flags, double *d_v, double *d_d,
                                               double *d_h, int64_t *d_counters, int32_t *d_status, void *stream_) {
+    return launch_eval(c, d_vp, n_targets, d_targets, flags, d_v, d_d, d_h, d_counters, d_status, stream_, true);
+}
+
+// render_neighbors = false keeps the neighbours' pre-rendered light of an earlier call (frozen neighbours
+// during an optimisation, ParallelRun.jl:474-488)
+static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
+                       uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
+                       void *stream_, bool render_neighbors) {
     if (!c || !d_vp || !d_targets || !d_v || !d_status || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
     if ((flags & CELESTE_FLAG_HESS) && !d_h) return CELESTE_ERR_INVALID_ARG;
     if ((flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) && !d_d) return CELESTE_ERR_INVALID_ARG;
@@ -359,6 +372,7 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     hipLaunchKernelGGL(prep_kernel, dim3(c->S * c->N), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches, c->S,
                        c->N, c->K, c->d_srcimg, c->d_comps, c->d_geo);
+    if (render_neighbors) {
     HIP_TRY(hipMemsetAsync(c->d_needed, 0, (size_t)c->S * sizeof(int32_t), stream));
     hipLaunchKernelGGL(mark_kernel, dim3((n_targets + 255) / 256), dim3(256), 0, stream, d_targets, n_targets,
                        c->d_needed);
@@ -367,6 +381,7 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
         hipLaunchKernelGGL(value_kernel, dim3((unsigned)((size_t)c->n_links * c->N * chv)), dim3(64), 0, stream,
                            c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->d_link_src, c->d_nbr_idx,
                            c->d_val_off, c->N, c->NC, chv, c->chunk_px, c->d_val);
+    }
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     const dim3 grid((unsigned)((size_t)n_targets * c->N * c->CH));
@@ -498,4 +513,84 @@ extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, cons
     }
     (void)hipFree(d_psf); (void)hipFree(d_rows); (void)hipFree(d_cols); (void)hipFree(d_out);
     return st;
+}
+
+
+// ---- maximize! for a batch of targets (ElboMaximize.jl:228-242; neighbours frozen at the input vp) ----------
+extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, int32_t n_targets, const int32_t *targets,
+                                      const celeste_optim_config_t *cfg_in, int32_t *iterations, int32_t *f_evals,
+                                      double *elbo, int32_t *status) {
+    if (!c || !vp || !targets || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
+    if (n_targets == 0) return CELESTE_OK;
+    for (int t = 0; t < n_targets; ++t) if (targets[t] < 0 || targets[t] >= c->S) return CELESTE_ERR_INVALID_ARG;
+    celeste_optim_config_t cfg = {1e-4, 1.0, 50, 1, 1e-7, 1e-6, 1e-8, 1.0, 1e9};
+    if (cfg_in) cfg = *cfg_in;
+    if (!(cfg.loc_width > 0) || !(cfg.loc_scale > 0) || cfg.max_iters < 0) return CELESTE_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    OptParams op;
+    op.loc_width = cfg.loc_width; op.loc_scale = cfg.loc_scale; op.xtol_abs = cfg.xtol_abs; op.ftol_rel = cfg.ftol_rel;
+    op.gtol = cfg.gtol; op.initial_delta = cfg.initial_delta; op.delta_hat = cfg.delta_hat; op.max_iters = cfg.max_iters;
+    op.pad = 0;
+    const uint32_t flags = CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS | (cfg.include_kl ? CELESTE_FLAG_KL : 0);
+    const size_t n = (size_t)n_targets;
+    double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_H = nullptr;
+    int32_t *d_targets = nullptr, *d_act[2] = {nullptr, nullptr}, *d_evt[2] = {nullptr, nullptr}, *d_count = nullptr,
+            *d_st = nullptr;
+    OptState *d_state = nullptr;
+    int rc = CELESTE_OK;
+#define MX_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto cleanup; } } while (0)
+    MX_TRY(hipMalloc((void **)&d_vp, (size_t)c->S * CEL_P * sizeof(double)));
+    MX_TRY(hipMalloc((void **)&d_v, n * sizeof(double)));
+    MX_TRY(hipMalloc((void **)&d_d, n * CEL_P * sizeof(double)));
+    MX_TRY(hipMalloc((void **)&d_h, n * CEL_P * CEL_P * sizeof(double)));
+    MX_TRY(hipMalloc((void **)&d_H, n * NF * NF * sizeof(double)));
+    MX_TRY(hipMalloc((void **)&d_targets, n * sizeof(int32_t)));
+    for (int k = 0; k < 2; ++k) {
+        MX_TRY(hipMalloc((void **)&d_act[k], n * sizeof(int32_t)));
+        MX_TRY(hipMalloc((void **)&d_evt[k], n * sizeof(int32_t)));
+    }
+    MX_TRY(hipMalloc((void **)&d_count, sizeof(int32_t)));
+    MX_TRY(hipMalloc((void **)&d_st, n * sizeof(int32_t)));
+    MX_TRY(hipMalloc((void **)&d_state, n * sizeof(OptState)));
+    MX_TRY(hipMemcpy(d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
+    MX_TRY(hipMemcpy(d_targets, targets, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    {
+        // neighbours are rendered once, from the input parameters, before any target moves
+        int st0 = launch_eval(c, d_vp, n_targets, d_targets, 0, d_v, nullptr, nullptr, nullptr, d_st, nullptr, true);
+        if (st0 != CELESTE_OK) { rc = st0; goto cleanup; }
+        hipLaunchKernelGGL(optim_init_kernel, dim3((n_targets + 63) / 64), dim3(64), 0, nullptr, d_vp, d_targets,
+                           n_targets, op, d_state, d_act[0]);
+        MX_TRY(hipMemcpy(d_evt[0], d_targets, n * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        int32_t n_active = n_targets;
+        int cur = 0;
+        for (int it = 0; it <= cfg.max_iters + 1 && n_active > 0; ++it) {
+            int st1 = launch_eval(c, d_vp, n_active, d_evt[cur], flags, d_v, d_d, d_h, nullptr, d_st, nullptr, false);
+            if (st1 != CELESTE_OK) { rc = st1; goto cleanup; }
+            MX_TRY(hipMemsetAsync(d_count, 0, sizeof(int32_t), nullptr));
+            hipLaunchKernelGGL(optim_step_kernel, dim3(n_active), dim3(256), 0, nullptr, d_vp, d_targets, d_act[cur],
+                               d_v, d_d, d_h, d_st, op, d_state, d_H, d_act[1 - cur], d_evt[1 - cur], d_count);
+            MX_TRY(hipMemcpy(&n_active, d_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+            cur = 1 - cur;
+        }
+        MX_TRY(hipDeviceSynchronize());
+        std::vector<OptState> hs(n);
+        MX_TRY(hipMemcpy(hs.data(), d_state, n * sizeof(OptState), hipMemcpyDeviceToHost));
+        std::vector<double> hvp((size_t)c->S * CEL_P);
+        MX_TRY(hipMemcpy(hvp.data(), d_vp, hvp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int t = 0; t < n_targets; ++t) {
+            memcpy(vp + (size_t)targets[t] * CEL_P, hvp.data() + (size_t)targets[t] * CEL_P, CEL_P * sizeof(double));
+            if (iterations) iterations[t] = hs[t].iter;
+            if (f_evals) f_evals[t] = hs[t].evals;
+            if (elbo) elbo[t] = -hs[t].f;
+            if (status) status[t] = hs[t].status;
+            if (hs[t].status != CELESTE_OK && rc == CELESTE_OK) rc = hs[t].status;
+        }
+    }
+cleanup:
+#undef MX_TRY
+    {
+        void *ptrs[] = {d_vp, d_v, d_d, d_h, d_H, d_targets, d_act[0], d_act[1], d_evt[0], d_evt[1], d_count, d_st, d_state};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+    }
+    return rc;
 }

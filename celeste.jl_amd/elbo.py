@@ -96,6 +96,25 @@ class FieldContext:
         cabi.check(self.lib.celeste_elbo_eval_batch_device(self.handle, d_vp, n_targets, d_targets, flags, d_v, d_d,
                                                            d_h, d_counters, d_status, stream), self.lib)
 
+    def maximize_batch(self, vp, targets: Sequence[int], cfg: Optional["ElboConfig"] = None, include_kl: bool = True):
+        """maximize! for every target (ElboMaximize.jl:228-242), neighbours frozen at the input vp.
+        Returns (vp_new[S,44], iterations[n], f_evals[n], elbo[n], status[n]); vp is not modified."""
+        cfg = cfg or ElboConfig()
+        vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(self.S, P)).copy()
+        tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32))
+        n = tg.size
+        its = np.zeros(n, dtype=np.int32); evals = np.zeros(n, dtype=np.int32)
+        el = np.zeros(n); status = np.zeros(n, dtype=np.int32)
+        ccfg = cfg.to_c(include_kl)
+        st = self.lib.celeste_maximize_batch(self.handle, vp.ctypes.data_as(cabi.c_double_p), n,
+                                             tg.ctypes.data_as(cabi.c_int32_p), C.byref(ccfg),
+                                             its.ctypes.data_as(cabi.c_int32_p), evals.ctypes.data_as(cabi.c_int32_p),
+                                             el.ctypes.data_as(cabi.c_double_p), status.ctypes.data_as(cabi.c_int32_p))
+        if st in (cabi.ERR_NONFINITE_INPUT, cabi.ERR_NONFINITE_RESULT):
+            raise AssertionError(self.lib.celeste_strerror(st).decode())
+        cabi.check(st, self.lib)
+        return vp, its, evals, el, status
+
     def enable_timing(self, on: bool = True):
         cabi.check(self.lib.celeste_ctx_enable_timing(self.handle, 1 if on else 0), self.lib)
 
@@ -110,6 +129,23 @@ class FieldContext:
         cabi.check(self.lib.celeste_ctx_work_stats(self.handle, tg.size, tg.ctypes.data_as(cabi.c_int32_p),
                                                    C.byref(ws)), self.lib)
         return {k: int(getattr(ws, k)) for k, _ in cabi.WorkStatsT._fields_}
+
+
+@dataclass
+class ElboConfig:
+    """ElboMaximize.ElboConfig (ElboMaximize.jl:27-61) -- the knobs maximize! exposes."""
+    loc_width: float = 1e-4
+    loc_scale: float = 1.0
+    max_iters: int = 50
+    xtol_abs: float = 1e-7
+    ftol_rel: float = 1e-6
+    gtol: float = 1e-8
+    initial_delta: float = 1.0
+    delta_hat: float = 1e9
+
+    def to_c(self, include_kl: bool) -> "cabi.OptimConfigT":
+        return cabi.OptimConfigT(self.loc_width, self.loc_scale, self.max_iters, int(include_kl), self.xtol_abs,
+                                 self.ftol_rel, self.gtol, self.initial_delta, self.delta_hat)
 
 
 class ElboArgs:
@@ -160,3 +196,13 @@ def elbo(ea: ElboArgs, vp, calculate_gradient: bool = True, calculate_hessian: b
     if ea.include_kl:
         flags |= FLAG_KL
     return _eval(ea, vp, flags)
+
+
+def maximize(ea: ElboArgs, vp, cfg: Optional[ElboConfig] = None):
+    """ElboMaximize.maximize!(ea, vp, cfg) (ElboMaximize.jl:228-242): optimises the active source in place.
+    Returns (f_evals, max_value, vp) like the reference returns (f_calls, min_value, ...)."""
+    vp_arr = np.asarray(vp, dtype=np.float64).reshape(ea.S, P)
+    new, its, evals, el, _ = ea._ctx.maximize_batch(vp_arr, ea.active_sources, cfg, include_kl=ea.include_kl)
+    a = ea.active_sources[0]
+    vp_arr[a] = new[a]
+    return int(evals[0]), float(el[0]), vp_arr

@@ -189,6 +189,32 @@ int celeste_psf_raster(int device, const double *psf, int32_t K,
                        const double *rows, int32_t n_rows,
                        const double *cols, int32_t n_cols, double *out);
 
+/* ---- the caller of the hot path ------------------------------------------
+ * ElboMaximize.ElboConfig defaults (src/deterministic_vi/ElboMaximize.jl:43-49, 95-108). */
+typedef struct celeste_optim_config_t {
+    double loc_width;      /* half-width of the position box around the initial position, 1e-4 */
+    double loc_scale;      /* 1.0 */
+    int32_t max_iters;     /* 50 */
+    int32_t include_kl;    /* ElboArgs.include_kl, 1 */
+    double xtol_abs;       /* 1e-7 */
+    double ftol_rel;       /* 1e-6 */
+    double gtol;           /* 1e-8 */
+    double initial_delta;  /* 1.0 */
+    double delta_hat;      /* 1e9 */
+} celeste_optim_config_t;
+
+/* ElboMaximize.maximize!(ea, vp, cfg) (ElboMaximize.jl:228-242) for a batch of targets, entirely on the device:
+ * enforce! / to_free! (ConstraintTransforms.jl:84-126, 225-253), then Newton trust-region iterations on the 41
+ * free parameters of every target in lock-step (one elbo() per iteration and target, propagate_derivatives!
+ * analytically, exact trust-region sub-problem in the eigenbasis), to_bound! at the end.  Every target sees its
+ * neighbours frozen at the input `vp` (ParallelRun.process_source, ParallelRun.jl:468-498); for a conflict-free
+ * Cyclades batch that is also the joint-inference semantics (ParallelRun.jl:372-397).  vp (n_sources x 44, host)
+ * is updated in place for the targets only.  cfg == NULL selects the defaults above.  Per-target outputs may be
+ * NULL. */
+int celeste_maximize_batch(celeste_ctx_t *ctx, double *vp, int32_t n_targets, const int32_t *targets,
+                           const celeste_optim_config_t *cfg, int32_t *iterations, int32_t *f_evals,
+                           double *elbo, int32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

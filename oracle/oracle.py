@@ -20,13 +20,26 @@ import celeste_jl_amd  # noqa: E402,F401
 from celeste_jl_amd import cabi  # noqa: E402
 
 LIB_PATH = os.path.join(_HERE, "libceleste_oracle.so")
+
+
+class OptCfg(C.Structure):
+    """ElboConfig defaults (ElboMaximize.jl:43-49, 95-108)"""
+    _fields_ = [("loc_width", C.c_double), ("loc_scale", C.c_double), ("max_iters", C.c_int32),
+                ("include_kl", C.c_int32), ("xtol_abs", C.c_double), ("ftol_rel", C.c_double), ("gtol", C.c_double),
+                ("initial_delta", C.c_double), ("delta_hat", C.c_double)]
+
+    def __init__(self, loc_width=1e-4, loc_scale=1.0, max_iters=50, include_kl=True, xtol_abs=1e-7, ftol_rel=1e-6,
+                 gtol=1e-8, initial_delta=1.0, delta_hat=1e9):
+        super().__init__(loc_width, loc_scale, max_iters, int(include_kl), xtol_abs, ftol_rel, gtol, initial_delta,
+                         delta_hat)
 P = 44
 _lib = None
 
 
 def build(force: bool = False) -> str:
     if force or not os.path.exists(LIB_PATH) or \
-            os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "celeste_oracle.c")):
+            os.path.getmtime(LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                             for f in ("celeste_oracle.c", "celeste_optim_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
@@ -58,6 +71,15 @@ def lib() -> C.CDLL:
         L.celeste_oracle_gaussian_kl.restype = C.c_double
         L.celeste_oracle_psf_at_point.argtypes = [dp, C.c_int, C.c_double, C.c_double]
         L.celeste_oracle_psf_at_point.restype = C.c_double
+        L.celeste_oracle_jacobi_eig.argtypes = [C.c_int, dp, dp, dp]
+        L.celeste_oracle_jacobi_eig.restype = None
+        L.celeste_oracle_solve_tr.argtypes = [C.c_int, dp, dp, C.c_double, dp, ip]
+        L.celeste_oracle_solve_tr.restype = C.c_double
+        L.celeste_oracle_constraints_roundtrip.argtypes = [dp, C.c_double, C.c_double, dp, dp, dp]
+        L.celeste_oracle_constraints_roundtrip.restype = None
+        L.celeste_oracle_propagate.argtypes = [dp, dp, C.c_double, C.c_double, dp, dp, dp, dp]
+        L.celeste_oracle_propagate.restype = None
+        L.celeste_oracle_maximize.argtypes = [C.POINTER(cabi.ProblemT), dp, C.c_int32, C.POINTER(OptCfg), dp]
         _lib = L
     return _lib
 
@@ -140,3 +162,42 @@ def gaussian_kl(mu1, var1, mu2, var2):
 def psf_at_point(psf, row, col):
     psf = np.ascontiguousarray(psf, dtype=np.float64)
     return lib().celeste_oracle_psf_at_point(_dp(psf), psf.shape[0], float(row), float(col))
+
+
+def jacobi_eig(A):
+    A = np.ascontiguousarray(A, dtype=np.float64); n = A.shape[0]
+    w = np.zeros(n); V = np.zeros(n * n)
+    lib().celeste_oracle_jacobi_eig(n, _dp(np.ascontiguousarray(A.T)), _dp(w), _dp(V))
+    return w, V.reshape(n, n).T.copy()
+
+
+def solve_tr(g, H, delta):
+    g = np.ascontiguousarray(g, dtype=np.float64); H = np.ascontiguousarray(H, dtype=np.float64); n = g.size
+    s = np.zeros(n); interior = C.c_int32(0)
+    m = lib().celeste_oracle_solve_tr(n, _dp(g), _dp(np.ascontiguousarray(H.T)), float(delta), _dp(s),
+                                      C.cast(C.byref(interior), cabi.c_int32_p))
+    return s, m, bool(interior.value)
+
+
+def constraints_roundtrip(vs, loc_width=1e-4, loc_scale=1.0):
+    vs = np.ascontiguousarray(vs, dtype=np.float64)
+    x = np.zeros(41); out = np.zeros(P); J = np.zeros(P * 41)
+    lib().celeste_oracle_constraints_roundtrip(_dp(vs), loc_width, loc_scale, _dp(x), _dp(out), _dp(J))
+    return x, out, J.reshape(41, P).T.copy()  # J[a, i]
+
+
+def propagate(x, vs0, d, h, loc_width=1e-4, loc_scale=1.0):
+    x = np.ascontiguousarray(x, dtype=np.float64); vs0 = np.ascontiguousarray(vs0, dtype=np.float64)
+    d = np.ascontiguousarray(d, dtype=np.float64); h = np.ascontiguousarray(np.asarray(h, dtype=np.float64).T)
+    gf = np.zeros(41); Hf = np.zeros(41 * 41)
+    lib().celeste_oracle_propagate(_dp(x), _dp(vs0), loc_width, loc_scale, _dp(d), _dp(h), _dp(gf), _dp(Hf))
+    return gf, Hf.reshape(41, 41).T.copy()
+
+
+def maximize(problem, vp, target, cfg=None):
+    """maximize! for one target (neighbours frozen); returns (vp_new, iterations, f_evals, elbo, status)"""
+    cfg = cfg or OptCfg()
+    vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(problem.n_sources, P)).copy()
+    stats = np.zeros(3)
+    st = lib().celeste_oracle_maximize(C.byref(problem.c), _dp(vp), int(target), C.byref(cfg), _dp(stats))
+    return vp, int(stats[0]), int(stats[1]), float(stats[2]), int(st)

@@ -1,0 +1,81 @@
+"""-m gpu: maximize! on the device (celeste_maximize_batch) against the CPU restatement of the same algorithm
+and against the reference's recovery tolerances (test/test_optimization.jl)."""
+import numpy as np
+import pytest
+
+from test_oracle_optimizer import _verify_sample_galaxy
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(f):
+    import celeste_jl_amd as cel
+    return cel.FieldContext(f.images, f.patches, f.neighbors)
+
+
+def test_galaxy_optimization_matches_reference_tolerances_and_oracle(oracle):
+    """test_optimization.jl:54-59"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_sample_dataset("galaxy")
+    ctx = _ctx(f)
+    cfg = cel.ElboConfig(loc_width=3.0)
+    vp, its, evals, elbo, st = ctx.maximize_batch(f.vp, [0], cfg, include_kl=False)
+    assert st[0] == 0 and evals[0] == its[0] + 1
+    _verify_sample_galaxy(vp[0], [8.5, 9.6])
+    ovp, oit, oev, oelbo, ost = oracle.maximize(ctx.problem, f.vp, 0, oracle.OptCfg(loc_width=3.0, include_kl=False))
+    print("gpu", its[0], elbo[0], "oracle", oit, oelbo)
+    assert abs(elbo[0] - oelbo) <= 1e-6 * abs(oelbo)
+    # same deterministic algorithm on both sides: the optima agree far inside the reference's tolerances
+    assert np.abs(vp[0, :28] - ovp[0, :28]).max() <= 1e-3
+
+
+def test_full_elbo_optimization(oracle):
+    """test_optimization.jl:62-68 (KL on, loc_width 1.0, x_tol 0)"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_sample_dataset("galaxy")
+    ea = cel.ElboArgs(f.images, f.patches, [0])
+    vp = f.vp.copy()
+    evals, best, vp = cel.maximize(ea, vp, cel.ElboConfig(loc_width=1.0, xtol_abs=0.0))
+    _verify_sample_galaxy(vp[0], [8.5, 9.6])
+    assert best > cel.elbo(ea, f.vp).v
+    assert cel.elbo(ea, vp).v == pytest.approx(best, rel=1e-10)
+
+
+def test_only_the_active_source_moves():
+    """test_optimization.jl:36-51"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_sample_dataset("three_body")
+    ea = cel.ElboArgs(f.images, f.patches, [1], include_kl=False)
+    vp = f.vp.copy()
+    cel.maximize(ea, vp, cel.ElboConfig(loc_width=1.0))
+    assert not np.array_equal(vp[1], f.vp[1])
+    assert np.array_equal(vp[0], f.vp[0]) and np.array_equal(vp[2], f.vp[2])
+
+
+def test_batch_with_frozen_neighbours_matches_oracle(oracle):
+    """every target of a crowded field at once; each one sees its neighbours at their input values
+    (ParallelRun.process_source, ParallelRun.jl:468-498) exactly as the per-target CPU optimiser does"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(160, 200, 24, seed=11)
+    ctx = _ctx(f)
+    tg = list(range(24))
+    cfg = cel.ElboConfig(max_iters=12)
+    vp, its, evals, elbo, st = ctx.maximize_batch(f.vp, tg, cfg)
+    assert (st == 0).all()
+    v0 = ctx.eval_batch(f.vp, tg, 4)[0]
+    assert np.all(elbo > v0)
+    worst = 0.0
+    for t in (0, 5, 11, 17, 23):
+        ovp, oit, oev, oelbo, ost = oracle.maximize(ctx.problem, f.vp, t, oracle.OptCfg(max_iters=12))
+        assert ost == 0
+        assert abs(elbo[t] - oelbo) <= 1e-7 * abs(oelbo), (t, elbo[t], oelbo, its[t], oit)
+        worst = max(worst, np.abs(vp[t] - ovp[t]).max())
+    print("max |vp_gpu - vp_oracle| after 12 iterations:", worst)
+    assert worst <= 1e-4
+    # sources that were not targets keep their parameters
+    vp2, *_ = ctx.maximize_batch(f.vp, [3], cfg)
+    assert np.array_equal(np.delete(vp2, 3, axis=0), np.delete(f.vp, 3, axis=0))
