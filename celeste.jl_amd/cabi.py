@@ -108,8 +108,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.celeste_spline_prefilter.argtypes = [c_double_p, c_double_p]
     lib.celeste_psf_raster.argtypes = [C.c_int, c_double_p, C.c_int32, c_double_p, C.c_int32, c_double_p,
                                        C.c_int32, c_double_p]
-    lib.celeste_maximize_batch.argtypes = [vp, c_double_p, C.c_int32, c_int32_p, C.POINTER(OptimConfigT), c_int32_p,
-                                           c_int32_p, c_double_p, c_int32_p]
+    lib.celeste_maximize_batch.argtypes = [vp, c_double_p, c_double_p, c_double_p, C.c_int32, c_int32_p,
+                                           C.POINTER(OptimConfigT), c_int32_p, c_int32_p, c_double_p, c_int32_p]
     _lib = lib
     return lib
 

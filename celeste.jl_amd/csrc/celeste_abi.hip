@@ -517,7 +517,8 @@ extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, cons
 
 
 // ---- maximize! for a batch of targets (ElboMaximize.jl:228-242; neighbours frozen at the input vp) ----------
-extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, int32_t n_targets, const int32_t *targets,
+extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double *vp_neighbors,
+                                      const double *pos_centers, int32_t n_targets, const int32_t *targets,
                                       const celeste_optim_config_t *cfg_in, int32_t *iterations, int32_t *f_evals,
                                       double *elbo, int32_t *status) {
     if (!c || !vp || !targets || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
@@ -533,7 +534,7 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, int32_t n_ta
     op.pad = 0;
     const uint32_t flags = CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS | (cfg.include_kl ? CELESTE_FLAG_KL : 0);
     const size_t n = (size_t)n_targets;
-    double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_H = nullptr;
+    double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_H = nullptr, *d_pos = nullptr;
     int32_t *d_targets = nullptr, *d_act[2] = {nullptr, nullptr}, *d_evt[2] = {nullptr, nullptr}, *d_count = nullptr,
             *d_st = nullptr;
     OptState *d_state = nullptr;
@@ -552,14 +553,19 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, int32_t n_ta
     MX_TRY(hipMalloc((void **)&d_count, sizeof(int32_t)));
     MX_TRY(hipMalloc((void **)&d_st, n * sizeof(int32_t)));
     MX_TRY(hipMalloc((void **)&d_state, n * sizeof(OptState)));
-    MX_TRY(hipMemcpy(d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
     MX_TRY(hipMemcpy(d_targets, targets, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (pos_centers) {
+        MX_TRY(hipMalloc((void **)&d_pos, n * 2 * sizeof(double)));
+        MX_TRY(hipMemcpy(d_pos, pos_centers, n * 2 * sizeof(double), hipMemcpyHostToDevice));
+    }
     {
-        // neighbours are rendered once, from the input parameters, before any target moves
+        // neighbours are rendered once, from their frozen parameters, before any target moves
+        MX_TRY(hipMemcpy(d_vp, vp_neighbors ? vp_neighbors : vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
         int st0 = launch_eval(c, d_vp, n_targets, d_targets, 0, d_v, nullptr, nullptr, nullptr, d_st, nullptr, true);
         if (st0 != CELESTE_OK) { rc = st0; goto cleanup; }
+        if (vp_neighbors) MX_TRY(hipMemcpy(d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(optim_init_kernel, dim3((n_targets + 63) / 64), dim3(64), 0, nullptr, d_vp, d_targets,
-                           n_targets, op, d_state, d_act[0]);
+                           n_targets, op, d_state, d_act[0], d_pos);
         MX_TRY(hipMemcpy(d_evt[0], d_targets, n * sizeof(int32_t), hipMemcpyDeviceToDevice));
         int32_t n_active = n_targets;
         int cur = 0;
@@ -589,7 +595,7 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, int32_t n_ta
 cleanup:
 #undef MX_TRY
     {
-        void *ptrs[] = {d_vp, d_v, d_d, d_h, d_H, d_targets, d_act[0], d_act[1], d_evt[0], d_evt[1], d_count, d_st, d_state};
+        void *ptrs[] = {d_vp, d_v, d_d, d_h, d_H, d_pos, d_targets, d_act[0], d_act[1], d_evt[0], d_evt[1], d_count, d_st, d_state};
         for (void *p : ptrs) if (p) (void)hipFree(p);
     }
     return rc;

@@ -82,12 +82,15 @@ __device__ inline void to_bound_dev(const double *x, const double *pos0, const O
 
 // enforce! + to_free! + first trial point; one thread per target
 __global__ void optim_init_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, int n_targets,
-                                  OptParams op, OptState *__restrict__ st, int32_t *__restrict__ active) {
+                                  OptParams op, OptState *__restrict__ st, int32_t *__restrict__ active,
+                                  const double *__restrict__ pos_centers) {
     const int ti = blockIdx.x * blockDim.x + threadIdx.x;
     if (ti >= n_targets) return;
     double *vs = vp + (size_t)targets[ti] * CEL_P;
     OptState &S = st[ti];
-    S.pos0[0] = vs[0]; S.pos0[1] = vs[1];
+    // the position box stays where the first ElboConfig put it (ParallelRun.jl:96-100); default: current position
+    S.pos0[0] = pos_centers ? pos_centers[2 * ti] : vs[0];
+    S.pos0[1] = pos_centers ? pos_centers[2 * ti + 1] : vs[1];
     for (int i = 0; i < 26; ++i) {
         double lo, hi, sc;
         box_bounds(i, S.pos0, op, lo, hi, sc);

@@ -96,8 +96,10 @@ class FieldContext:
         cabi.check(self.lib.celeste_elbo_eval_batch_device(self.handle, d_vp, n_targets, d_targets, flags, d_v, d_d,
                                                            d_h, d_counters, d_status, stream), self.lib)
 
-    def maximize_batch(self, vp, targets: Sequence[int], cfg: Optional["ElboConfig"] = None, include_kl: bool = True):
-        """maximize! for every target (ElboMaximize.jl:228-242), neighbours frozen at the input vp.
+    def maximize_batch(self, vp, targets: Sequence[int], cfg: Optional["ElboConfig"] = None, include_kl: bool = True,
+                       vp_neighbors=None, pos_centers=None):
+        """maximize! for every target (ElboMaximize.jl:228-242), neighbours frozen at `vp_neighbors` (default: the
+        input vp); `pos_centers` [n,2] pins the position boxes (default: the current positions).
         Returns (vp_new[S,44], iterations[n], f_evals[n], elbo[n], status[n]); vp is not modified."""
         cfg = cfg or ElboConfig()
         vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(self.S, P)).copy()
@@ -106,7 +108,12 @@ class FieldContext:
         its = np.zeros(n, dtype=np.int32); evals = np.zeros(n, dtype=np.int32)
         el = np.zeros(n); status = np.zeros(n, dtype=np.int32)
         ccfg = cfg.to_c(include_kl)
-        st = self.lib.celeste_maximize_batch(self.handle, vp.ctypes.data_as(cabi.c_double_p), n,
+        nb = None if vp_neighbors is None else np.ascontiguousarray(
+            np.asarray(vp_neighbors, dtype=np.float64).reshape(self.S, P))
+        pc = None if pos_centers is None else np.ascontiguousarray(np.asarray(pos_centers, dtype=np.float64).reshape(n, 2))
+        st = self.lib.celeste_maximize_batch(self.handle, vp.ctypes.data_as(cabi.c_double_p),
+                                             nb.ctypes.data_as(cabi.c_double_p) if nb is not None else None,
+                                             pc.ctypes.data_as(cabi.c_double_p) if pc is not None else None, n,
                                              tg.ctypes.data_as(cabi.c_int32_p), C.byref(ccfg),
                                              its.ctypes.data_as(cabi.c_int32_p), evals.ctypes.data_as(cabi.c_int32_p),
                                              el.ctypes.data_as(cabi.c_double_p), status.ctypes.data_as(cabi.c_int32_p))

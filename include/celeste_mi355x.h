@@ -209,11 +209,15 @@ typedef struct celeste_optim_config_t {
  * analytically, exact trust-region sub-problem in the eigenbasis), to_bound! at the end.  Every target sees its
  * neighbours frozen at the input `vp` (ParallelRun.process_source, ParallelRun.jl:468-498); for a conflict-free
  * Cyclades batch that is also the joint-inference semantics (ParallelRun.jl:372-397).  vp (n_sources x 44, host)
- * is updated in place for the targets only.  cfg == NULL selects the defaults above.  Per-target outputs may be
- * NULL. */
-int celeste_maximize_batch(celeste_ctx_t *ctx, double *vp, int32_t n_targets, const int32_t *targets,
-                           const celeste_optim_config_t *cfg, int32_t *iterations, int32_t *f_evals,
-                           double *elbo, int32_t *status);
+ * is updated in place for the targets only.  vp_neighbors (n_sources x 44, may be NULL = vp) holds the frozen
+ * parameters under which every source acts as a *neighbour* (single inference starts targets at
+ * generic_init_source while their neighbours sit at catalog_init_source, DeterministicVI.jl:94-103).
+ * pos_centers (n_targets x 2, may be NULL = current position) are the centres of the position boxes, which the
+ * reference keeps fixed across repeated maximize! calls (ParallelRun.jl:96-100).  cfg == NULL selects the
+ * defaults above.  Per-target outputs may be NULL. */
+int celeste_maximize_batch(celeste_ctx_t *ctx, double *vp, const double *vp_neighbors, const double *pos_centers,
+                           int32_t n_targets, const int32_t *targets, const celeste_optim_config_t *cfg,
+                           int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status);
 
 #ifdef __cplusplus
 }

@@ -79,3 +79,49 @@ def test_batch_with_frozen_neighbours_matches_oracle(oracle):
     # sources that were not targets keep their parameters
     vp2, *_ = ctx.maximize_batch(f.vp, [3], cfg)
     assert np.array_equal(np.delete(vp2, 3, axis=0), np.delete(f.vp, 3, axis=0))
+
+
+def test_joint_objective_helper_matches_single_active_elbo(oracle):
+    """the multi-active score (test_infer.jl:9-29) reduces to elbo_likelihood for one active source"""
+    from celeste_jl_amd import synthetic, cabi
+    from joint_objective import joint_objective
+    f = synthetic.make_sample_dataset("two_body")
+    pb = cabi.Problem(f.images, f.patches, f.neighbors)
+    for t in (0, 1):
+        assert joint_objective(f.images, f.patches, f.vp, {t}) == pytest.approx(oracle.elbo_one(pb, f.vp, t, 0)[0], rel=1e-12)
+
+
+def test_joint_beats_single_on_overlapping_sources():
+    """test_infer.jl:49-70: joint (Cyclades, 3 sweeps) objective > single-source objective"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.infer import one_node_single_infer, one_node_joint_infer
+    from joint_objective import joint_objective
+    f = synthetic.make_field(72, 72, 7, seed=23, margin=14)
+    assert sum(len(n) for n in f.neighbors) >= 6
+    ctx = _ctx(f)
+    tg = list(range(len(f.catalog)))
+    cfg = cel.ElboConfig(loc_width=1.0)
+    vs_single = one_node_single_infer(ctx, f.catalog, tg, cfg)
+    vs_joint = one_node_joint_infer(ctx, f.catalog, tg, f.neighbors, cfg, batch_size=4)
+    assert np.all(np.isfinite(vs_single)) and np.all(np.isfinite(vs_joint))
+    s_single = joint_objective(f.images, f.patches, vs_single, set(tg))
+    s_joint = joint_objective(f.images, f.patches, vs_joint, set(tg))
+    print("single", s_single, "joint", s_joint)
+    assert s_joint > s_single
+
+
+def test_single_infer_neighbours_sit_at_catalog_init(oracle):
+    """one_node_single_infer == per-target maximize! with init_sources([1], cat_local) (DeterministicVI.jl:94-103)"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, catalog_init_source, generic_init_source
+    from celeste_jl_amd.infer import one_node_single_infer
+    f = synthetic.make_field(72, 72, 7, seed=23, margin=14)
+    ctx = _ctx(f)
+    cfg = cel.ElboConfig(max_iters=6)
+    out = one_node_single_infer(ctx, f.catalog, list(range(7)), cfg)
+    base = np.stack([catalog_init_source(ce) for ce in f.catalog])
+    for t in (0, 3, 6):
+        vp = base.copy(); vp[t] = generic_init_source(f.catalog[t].pos)
+        ovp, *_ = oracle.maximize(ctx.problem, vp, t, oracle.OptCfg(max_iters=6))
+        assert np.abs(out[t] - ovp[t]).max() <= 1e-6
