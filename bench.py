@@ -227,6 +227,17 @@ def main():
             "pixel_visits_per_sec": pixel_visits / (kms[1] * 1e-3),
             "grad_only_sources_per_sec_rank0": S / (dt_grad / args.steps),
         }
+        if world == 1:
+            # secondary, end-to-end figure: ElboMaximize.maximize! (Newton trust region, <= 50 iterations, KL on)
+            # for every source of the field, neighbours frozen; wall time includes H2D/D2H and allocations
+            import celeste_jl_amd as _cel
+            ctx.maximize_batch(fld.vp, targets[:64], _cel.ElboConfig(max_iters=3))  # warm-up
+            t1 = time.perf_counter()
+            _, its, evals, _, ost = ctx.maximize_batch(fld.vp, targets, _cel.ElboConfig())
+            dt_opt = time.perf_counter() - t1
+            out["optimizer"] = {"optimized_sources_per_sec": S / dt_opt, "seconds": dt_opt,
+                                "mean_newton_iterations": float(its.mean()), "elbo_evaluations": int(evals.sum()),
+                                "failed": int((ost != 0).sum())}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ctx.problem, fld.vp, targets)
         print(json.dumps(out))

@@ -9,7 +9,7 @@
 //                                                                   of the transform instead of nested ForwardDiff)
 //   ElboMaximize.maximize! -> Optim.optimize(NewtonTrustRegion)     optim_step_kernel + host loop in celeste_abi.hip
 //       (ElboMaximize.jl:228-242; Optim.jl is third-party, unvendored: restated from its published algorithm,
-//        Nocedal & Wright Alg. 4.1 / section 4.3 -- see oracle/celeste_optim_oracle.c for the same statement)
+//        Nocedal & Wright Alg. 4.1 / section 4.3)
 //
 // One 256-thread workgroup per target and Newton iteration: chain rule to the 41 free parameters, accept /
 // reject + radius update, then the next trust-region sub-problem solved exactly in the eigenbasis of the
