@@ -74,7 +74,7 @@ EXPORTED_SYMBOLS = [
     "celeste_version", "celeste_strerror", "celeste_ctx_create", "celeste_ctx_destroy", "celeste_elbo_eval",
     "celeste_elbo_eval_batch", "celeste_elbo_eval_batch_device", "celeste_ctx_enable_timing",
     "celeste_ctx_last_kernel_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter", "celeste_psf_raster",
-    "celeste_maximize_batch",
+    "celeste_maximize_batch", "celeste_render_expected",
 ]
 
 _lib = None
@@ -110,6 +110,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                        C.c_int32, c_double_p]
     lib.celeste_maximize_batch.argtypes = [vp, c_double_p, c_double_p, c_double_p, C.c_int32, c_int32_p,
                                            C.POINTER(OptimConfigT), c_int32_p, c_int32_p, c_double_p, c_int32_p]
+    lib.celeste_render_expected.argtypes = [vp, c_double_p, C.c_int32, c_double_p]
     _lib = lib
     return lib
 

@@ -600,3 +600,28 @@ cleanup:
     }
     return rc;
 }
+
+
+// ---- expected-image renderer (bin/write_celeste_expectation.jl:112-156, fsm_util.jl:349-400) ------------
+extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32_t image, double *out_plane) {
+    if (!c || !vp || !out_plane || image < 0 || image >= c->N) return CELESTE_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    const DevImage &im = c->h_images[image];
+    const size_t npix = (size_t)im.H * im.W;
+    double *d_plane = nullptr;
+    if (!c->d_vp) HIP_TRY(hipMalloc((void **)&c->d_vp, (size_t)c->S * CEL_P * sizeof(double)));
+    HIP_TRY(hipMemcpy(c->d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&d_plane, npix * sizeof(double)));
+    int rc = CELESTE_OK;
+    if (hipMemset(d_plane, 0, npix * sizeof(double)) != hipSuccess) rc = CELESTE_ERR_HIP;
+    if (rc == CELESTE_OK) {
+        hipLaunchKernelGGL(prep_kernel, dim3(c->S * c->N), dim3(64), 0, nullptr, c->d_vp, c->d_images, c->d_patches,
+                           c->S, c->N, c->K, c->d_srcimg, c->d_comps, c->d_geo);
+        hipLaunchKernelGGL(render_kernel, dim3((unsigned)((size_t)c->S * c->CH)), dim3(64), 0, nullptr, c->d_patches,
+                           c->d_coefs, c->d_bitmaps, im.pixels, c->d_srcimg, c->d_comps, (int)image, c->N, c->NC,
+                           c->CH, c->chunk_px, im.H, d_plane);
+        if (hipMemcpy(out_plane, d_plane, npix * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = CELESTE_ERR_HIP;
+    }
+    (void)hipFree(d_plane);
+    return rc;
+}

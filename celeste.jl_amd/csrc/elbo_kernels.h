@@ -1077,6 +1077,50 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
 }
 
 // ---------------------------------------------------------------------------------------------
+// render_kernel: expected light of every source on one image, sum_s E_G_s.v in nanomaggies (the value-only
+// add_pixel_term! sweep of bin/write_celeste_expectation.jl:112-156).  One wavefront per (source, chunk);
+// contributions are added to the image plane with fp64 atomics (summation order, hence the last bits, is
+// not deterministic).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+render_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
+              const uint8_t *__restrict__ bitmaps, const float *__restrict__ pixels, const SrcImg *__restrict__ srcimg,
+              const Comp *__restrict__ comps, int n, int N, int NC, int CH, int chunk_px, int imgH,
+              double *__restrict__ plane) {
+    __shared__ double etab[64];
+    const int S = gridDim.x / CH;
+    const int ch = blockIdx.x / S;
+    const int s = blockIdx.x - ch * S;
+    const int sn = s * N + n;
+    const DevPatch &P = patches[sn];
+    const int H2 = P.H2, W2 = P.W2;
+    const int npx = H2 * (W2 - 1);
+    const int p0 = ch * chunk_px;
+    if (p0 >= npx) return;
+    exp_table_init(etab);
+    const int p1 = min(npx, p0 + chunk_px);
+    const SrcImg si = srcimg[sn];
+    __shared__ Comp tc[14 * CEL_MAXK];
+    {
+        const double *src = reinterpret_cast<const double *>(comps + (size_t)sn * NC);
+        double *dst = reinterpret_cast<double *>(tc);
+        for (int i = threadIdx.x; i < NC * 8; i += 64) dst[i] = src[i];
+        __syncthreads();
+    }
+    const double *__restrict__ coef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
+    for (int idx = p0 + (int)threadIdx.x; idx < p1; idx += 64) {
+        const int w2 = idx / H2, h2 = idx - w2 * H2;
+        const size_t gi = (size_t)(P.off_h + h2) + (size_t)imgH * (P.off_w + w2);
+        bool act = P.bitmap_off >= 0 ? bitmaps[P.bitmap_off + h2 + (int64_t)H2 * w2] != 0 : !isnan(pixels[gi]);
+        if (!act) continue;
+        const double hh = (double)(P.off_h + h2 + 1), ww = (double)(P.off_w + w2 + 1);
+        const double f0 = star_value(coef, hh + (26.0 - si.m1), ww + (26.0 - si.m2));
+        const double f1 = galaxy_value(tc, NC, hh - si.m1, ww - si.m2, etab);
+        atomicAdd(&plane[gi], si.c0 * f0 + si.c1 * f1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // psf_raster_kernel: get_psf_at_point (PSF.jl:150-161)
 // ---------------------------------------------------------------------------------------------
 __global__ void psf_raster_kernel(const double *__restrict__ psf, int K, const double *__restrict__ rows, int nr,

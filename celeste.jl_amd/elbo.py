@@ -122,6 +122,16 @@ class FieldContext:
         cabi.check(st, self.lib)
         return vp, its, evals, el, status
 
+    def render_expected(self, vp, image: int) -> np.ndarray:
+        """sum_s E[G_s] in nanomaggies on image `image` (bin/write_celeste_expectation.jl:112-156); H x W array."""
+        vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(self.S, P))
+        img = self.problem.images[image]
+        H, W = img.pixels.shape
+        out = np.zeros(H * W)
+        cabi.check(self.lib.celeste_render_expected(self.handle, vp.ctypes.data_as(cabi.c_double_p), image,
+                                                    out.ctypes.data_as(cabi.c_double_p)), self.lib)
+        return out.reshape(W, H).T.copy()
+
     def enable_timing(self, on: bool = True):
         cabi.check(self.lib.celeste_ctx_enable_timing(self.handle, 1 if on else 0), self.lib)
 

@@ -219,6 +219,12 @@ int celeste_maximize_batch(celeste_ctx_t *ctx, double *vp, const double *vp_neig
                            int32_t n_targets, const int32_t *targets, const celeste_optim_config_t *cfg,
                            int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status);
 
+/* Expected light of all sources on image `image` (0-based): out[h,w] = sum_s E_G_s.v in nanomaggies, i.e.
+ * elbo_vars.E_G.v - sky of the value-only add_pixel_term! sweep in bin/write_celeste_expectation.jl:112-156
+ * (every source contributes on its own patch, last column and inactive pixels excluded).  out: H x W doubles,
+ * column-major, host. */
+int celeste_render_expected(celeste_ctx_t *ctx, const double *vp, int32_t image, double *out_plane);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,14 @@ from celeste_jl_amd import cabi
 DT = torch.float64
 
 
-def joint_objective(images, patches, vp, active):
+def expected_planes(images, patches, vp):
+    """(E - sky) per image: sum over sources of E[G_s] on their own patches (value-only add_pixel_term!)"""
+    out = []
+    joint_objective(images, patches, vp, set(), planes=out)
+    return out
+
+
+def joint_objective(images, patches, vp, active, planes=None):
     vp = torch.tensor(np.asarray(vp), dtype=DT)
     total = 0.0
     S = len(patches)
@@ -47,6 +54,8 @@ def joint_objective(images, patches, vp, active):
                 cov = bm[:, :W2 - 1].to(DT)
                 E[h0:h0 + H2, w0:w0 + W2 - 1] += cov * Es
                 V[h0:h0 + H2, w0:w0 + W2 - 1] += cov * (E2s - Es * Es)
+            if planes is not None:
+                planes.append((E - torch.tensor(img.sky.astype(np.float64))).numpy())
             x = torch.tensor(img.pixels.astype(np.float64))
             visit &= ~torch.isnan(x)
             x = torch.nan_to_num(x)

@@ -149,6 +149,20 @@ def test_multifield_overlapping_images(oracle):
     assert max(np.abs(d[t] - ref[1][t]).max() / np.abs(ref[1][t]).max() for t in tg) <= 1e-4
 
 
+def test_expected_image_renderer():
+    """celeste_render_expected vs an independent numpy/torch rendering (write_celeste_expectation.jl:112-156)"""
+    from celeste_jl_amd import synthetic
+    from joint_objective import expected_planes
+    f = synthetic.make_field(160, 200, 30, seed=11, nan_fraction=0.004)
+    ctx = _ctx(f)
+    ref = expected_planes(f.images, f.patches, f.vp)
+    for n in (0, 2, 4):
+        got = ctx.render_expected(f.vp, n)
+        assert got.shape == ref[n].shape
+        assert np.abs(got - ref[n]).max() <= 1e-12 * np.abs(ref[n]).max()
+        assert (got > 0).sum() > 1000
+
+
 def test_batch_equals_singles():
     from celeste_jl_amd import synthetic
     f = synthetic.make_field(128, 128, 12, seed=5)
