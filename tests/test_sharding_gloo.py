@@ -29,7 +29,16 @@ def _worker(rank, world, port, out_dir):
         return v, d
 
     v, d = sharded_sweep(evaluate, list(range(24)), costs, rank, world)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), v=v, d=d)
+
+    # the optimiser shards the same way (single inference: neighbours frozen => shards are independent)
+    from celeste_jl_amd.parallel import sharded_maximize
+    opt_targets = [2, 7, 11, 19]
+
+    def maximize(tg):
+        return np.stack([oracle.maximize(pb, f.vp, t, oracle.OptCfg(max_iters=2))[0][t] for t in tg])
+
+    vs = sharded_maximize(maximize, opt_targets, [costs[t] for t in opt_targets], rank, world)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), v=v, d=d, vs=vs)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -42,6 +51,8 @@ def test_two_rank_sweep_equals_single_rank(tmp_path, oracle):
     f = synthetic.make_field(160, 200, 24, seed=11)
     pb = cabi.Problem(f.images, f.patches, f.neighbors)
     v, d, _, _, _ = oracle.elbo_batch(pb, f.vp, list(range(24)), 7, n_threads=2)
+    vs = np.stack([oracle.maximize(pb, f.vp, t, oracle.OptCfg(max_iters=2))[0][t] for t in (2, 7, 11, 19)])
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         assert np.array_equal(z["v"], v) and np.array_equal(z["d"], d)
+        assert np.array_equal(z["vs"], vs)
