@@ -558,24 +558,26 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const int npx = H2 * W2;
     const int p0 = ch * chunk_px;
     if (p0 >= npx) return;  // the lift kernel recomputes this predicate
-    exp_table_init(etab);
     const int p1 = min(npx, p0 + chunk_px);
     const DevImage &img = images[n];
     const int lane = threadIdx.x;
     const SrcImg si = srcimg[(size_t)t * N + n];
-    // the target's components: one coalesced read into LDS, then broadcast ds_reads in the pixel loop (the
-    // scalar data cache cannot hold 8 waves x 1.8 KB per CU: 68 % of s_loads missed to L2)
+    // Workgroup prologue: the exp table and the target's components (64-byte records) are staged in LDS with
+    // one coalesced read each and a single barrier (the scalar data cache cannot hold 8 waves x 1.8 KB per CU:
+    // 68 % of per-component s_loads missed to L2).
     __shared__ Comp tc[14 * CEL_MAXK];
     __shared__ CompR<R> tcr_f[sizeof(R) == 4 ? 14 * CEL_MAXK : 1];
     {
         const double *src = reinterpret_cast<const double *>(comps + ((size_t)t * N + n) * NC);
         double *dst = reinterpret_cast<double *>(tc);
         R *dstf = reinterpret_cast<R *>(tcr_f);
+        const double tabv = g_exp2_table[lane];
         for (int i = lane; i < NC * 8; i += 64) {
             const double v = src[i];
             dst[i] = v;
             if (sizeof(R) == 4) dstf[i] = (R)v;
         }
+        etab[lane] = tabv;
         __syncthreads();
     }
     const CompR<R> *tcr = sizeof(R) == 4 ? tcr_f : reinterpret_cast<const CompR<R> *>(tc);
