@@ -68,6 +68,50 @@ class ConstantPSFMap:
 
 
 @dataclass
+class SDSSBackground:
+    """src/SDSSIO.jl:56-99: the sky plane of an SDSS frame, bilinear interpolation of a small sky image at the
+    per-row / per-column coordinates sky_x / sky_y (constant extrapolation), times the per-row calibration.
+    All arithmetic in Float32 like the reference (including its weight convention: the fractional offset
+    xw0 = sky_x - floor(sky_x) multiplies the *lower* sample).  `materialize()` gives the H x W float32 plane
+    that celeste_image_t.sky expects."""
+    sky_small: np.ndarray
+    sky_x: np.ndarray
+    sky_y: np.ndarray
+    calibration: np.ndarray
+
+    def __post_init__(self):
+        self.sky_small = np.asarray(self.sky_small, dtype=np.float32)
+        self.sky_x = np.asarray(self.sky_x, dtype=np.float32)
+        self.sky_y = np.asarray(self.sky_y, dtype=np.float32)
+        self.calibration = np.asarray(self.calibration, dtype=np.float32)
+        assert self.calibration.shape == self.sky_x.shape
+
+    @property
+    def shape(self):
+        return (self.sky_x.size, self.sky_y.size)
+
+    def materialize(self) -> np.ndarray:
+        nx, ny = self.sky_small.shape
+        one = np.float32(1.0)
+        x0 = np.floor(self.sky_x).astype(np.int64); xw0 = (self.sky_x - x0.astype(np.float32)).astype(np.float32)
+        y0 = np.floor(self.sky_y).astype(np.int64); yw0 = (self.sky_y - y0.astype(np.float32)).astype(np.float32)
+        xw1 = (one - xw0).astype(np.float32); yw1 = (one - yw0).astype(np.float32)
+        x1 = np.clip(x0 + 1, 1, nx) - 1; x0 = np.clip(x0, 1, nx) - 1
+        y1 = np.clip(y0 + 1, 1, ny) - 1; y0 = np.clip(y0, 1, ny) - 1
+        s = self.sky_small
+        dns = ((xw0[:, None] * yw0[None, :]).astype(np.float32) * s[np.ix_(x0, y0)]
+               + (xw1[:, None] * yw0[None, :]).astype(np.float32) * s[np.ix_(x1, y0)]
+               + (xw0[:, None] * yw1[None, :]).astype(np.float32) * s[np.ix_(x0, y1)]
+               + (xw1[:, None] * yw1[None, :]).astype(np.float32) * s[np.ix_(x1, y1)]).astype(np.float32)
+        return (dns * self.calibration[:, None]).astype(np.float32)
+
+    def __getitem__(self, ij):
+        i, j = ij   # 1-based like the reference
+        return SDSSBackground(self.sky_small, self.sky_x[i - 1:i], self.sky_y[j - 1:j],
+                              self.calibration[i - 1:i]).materialize()[0, 0]
+
+
+@dataclass
 class Image:
     """image_model.jl:6-38.  pixels/sky are H x W (first index = row h), float32."""
     pixels: np.ndarray

@@ -163,6 +163,37 @@ def test_expected_image_renderer():
         assert (got > 0).sum() > 1000
 
 
+def test_random_parameters_inside_the_constraint_boxes(oracle):
+    """stress: variational parameters drawn uniformly from the optimiser's constraint boxes
+    (ElboMaximize.jl:63-93), i.e. everything maximize! can ever hand to elbo()"""
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(200, 240, 40, seed=4)
+    rng = np.random.default_rng(123)
+    S = len(f.catalog)
+    lo = np.array([0, 0, 1e-2, 1e-2, -10, .1] + [-1] * 2 + [1e-4] * 2 + [-10] * 8 + [1e-4] * 8)
+    hi = np.array([0, 0, .99, .99, 10, 70] + [10] * 2 + [.1] * 2 + [10] * 8 + [1.0] * 8)
+    ctx = _ctx(f)
+    worst = {}
+    for trial in range(3):
+        vp = f.vp.copy()
+        u = rng.random((S, 26))
+        vp[:, 2:26] = (lo + u * (hi - lo))[:, 2:]
+        vp[:, 0:2] += rng.uniform(-1.5, 1.5, (S, 2))
+        vp[:, 5] = np.exp(rng.uniform(np.log(0.1), np.log(70.0), S))          # radius: log-uniform
+        vp[:, 10:18] = rng.uniform(-3, 3, (S, 8))                              # colours: keep fluxes finite
+        a = rng.uniform(0.005, 0.995, S); vp[:, 26] = a; vp[:, 27] = 1 - a
+        for i in range(2):
+            k = rng.dirichlet(np.ones(8), S) * (1 - 0.01) + 0.01 / 8
+            vp[:, 28 + 8 * i:36 + 8 * i] = k
+        tg = list(range(S))
+        g = ctx.eval_batch(vp, tg, ALL)
+        r = oracle.elbo_batch(ctx.problem, vp, tg, ALL)
+        errs = assert_parity(g, r, "random trial %d" % trial)
+        for k2, v2 in errs.items():
+            worst[k2] = max(worst.get(k2, 0), v2)
+    print("random-parameter parity", worst)
+
+
 def test_batch_equals_singles():
     from celeste_jl_amd import synthetic
     f = synthetic.make_field(128, 128, 12, seed=5)

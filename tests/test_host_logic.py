@@ -15,6 +15,23 @@ def test_boxes_overlap_known_answers():
     assert not boxes_overlap(((1, 0), (1, 10)), ((1, 10), (1, 10)))  # empty range (off-image patch)
 
 
+def test_sdss_background_known_answers():
+    """test/test_sdssio.jl:12-40 (data-free known answers of the bilinear sky)"""
+    from celeste_jl_amd.model import SDSSBackground
+    small = np.array([[1., 2., 3., 4.], [5., 6., 7., 8.], [9., 10., 11., 12.]])
+    sky = SDSSBackground(small, [0.1, 2.5], [0.5, 2.5, 4.], np.ones(2))
+    assert sky.shape == (2, 3)
+    expect = {(1, 1): 1.0, (2, 1): 7.0, (1, 2): 2.5, (2, 2): 8.5, (1, 3): 4.0, (2, 3): 10.0}
+    for ij, v in expect.items():
+        assert sky[ij] == pytest.approx(v, rel=1e-6)
+    plane = sky.materialize()
+    assert plane.dtype == np.float32 and plane[1, 1] == pytest.approx(8.5)
+    oob = SDSSBackground(small, [-5.0, 4.0], [-4.0, 5.0], np.ones(2))
+    assert (oob[1, 1], oob[1, 2], oob[2, 1], oob[2, 2]) == (1.0, 4.0, 9.0, 12.0)
+    cal = SDSSBackground(small, [0.1, 2.5], [0.5, 2.5, 4.], [2.0, 0.5])
+    assert cal[2, 2] == pytest.approx(4.25)
+
+
 def test_clamp_box_and_rounding():
     from celeste_jl_amd.model import clamp_box, julia_round
     assert clamp_box(((-3, 7), (20, 40)), (20, 23)) == ((1, 7), (20, 23))
