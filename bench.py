@@ -199,6 +199,31 @@ def main():
     ctx.enable_timing(False)
     kms = np.array(kms).mean(axis=0)
 
+    # split variant: per-pixel records to HBM, then the streaming per-patch sum -- the one
+    # HBM-bound kernel of the path; a measurement aid next to the fused throughput configuration
+    split = None
+    if world == 1:
+        def step_split():
+            ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_ALL | cabi.FLAG_SPLIT, d_v.data_ptr(),
+                                  d_d.data_ptr(), d_h.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), stream)
+        ctx.enable_timing(True)
+        sm = []
+        for i in range(8):
+            step_split()
+            torch.cuda.synchronize(dev)
+            if i >= 2:
+                sm.append(ctx.last_kernel_ms() + [ctx.last_record_sum_ms()])
+        ctx.enable_timing(False)
+        sm = np.array(sm).mean(axis=0)
+        rb = stats["record_bytes"]
+        split = {"kernel": "record_sum_kernel", "bound": "hbm", "kernel_ms": float(sm[3]),
+                 "algorithmic_bytes_per_launch": rb, "achieved": rb / (sm[3] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": rb / (sm[3] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "stored_record_bytes": stats["record_tiles"] * 68 * 64 * 8,
+                 "record_write_kernel_ms": float(sm[1]), "lift_ms": float(sm[2]),
+                 "note": "544 B (68 f64) per visited pixel + one 544 B result per patch; fused kernel stays the "
+                         "throughput configuration"}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * S / (dt / args.steps)
@@ -227,6 +252,8 @@ def main():
             "pixel_visits_per_sec": pixel_visits / (kms[1] * 1e-3),
             "grad_only_sources_per_sec_rank0": S / (dt_grad / args.steps),
         }
+        if split is not None:
+            out["split_variant"] = split
         if world == 1:
             # secondary, end-to-end figure: ElboMaximize.maximize! (Newton trust region, <= 50 iterations, KL on)
             # for every source of the field, neighbours frozen; wall time includes H2D/D2H and allocations

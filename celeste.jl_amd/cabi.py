@@ -14,7 +14,7 @@ STAMP = 51
 COEF = 53
 
 OK, ERR_INVALID_ARG, ERR_NONFINITE_INPUT, ERR_NONFINITE_RESULT, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = range(7)
-FLAG_GRAD, FLAG_HESS, FLAG_KL, FLAG_FP32 = 1, 2, 4, 8
+FLAG_GRAD, FLAG_HESS, FLAG_KL, FLAG_FP32, FLAG_SPLIT = 1, 2, 4, 8, 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libceleste_mi355x.so")
@@ -53,7 +53,8 @@ class ProblemT(C.Structure):
 
 class WorkStatsT(C.Structure):
     _fields_ = [("n_targets", C.c_int64), ("active_pixel_visits", C.c_int64), ("patch_rows", C.c_int64),
-                ("neighbor_links", C.c_int64), ("algorithmic_bytes", C.c_int64)]
+                ("neighbor_links", C.c_int64), ("algorithmic_bytes", C.c_int64), ("record_bytes", C.c_int64),
+                ("record_tiles", C.c_int64)]
 
 
 class OptimConfigT(C.Structure):
@@ -73,7 +74,7 @@ class CelesteError(RuntimeError):
 EXPORTED_SYMBOLS = [
     "celeste_version", "celeste_strerror", "celeste_ctx_create", "celeste_ctx_destroy", "celeste_elbo_eval",
     "celeste_elbo_eval_batch", "celeste_elbo_eval_batch_device", "celeste_ctx_enable_timing",
-    "celeste_ctx_last_kernel_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter", "celeste_psf_raster",
+    "celeste_ctx_last_kernel_ms", "celeste_ctx_last_record_sum_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter", "celeste_psf_raster",
     "celeste_maximize_batch", "celeste_render_expected",
 ]
 
@@ -104,6 +105,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.celeste_elbo_eval_batch_device.argtypes = [vp, vp, C.c_int32, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
     lib.celeste_ctx_enable_timing.argtypes = [vp, C.c_int]
     lib.celeste_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.celeste_ctx_last_record_sum_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.celeste_ctx_work_stats.argtypes = [vp, C.c_int32, c_int32_p, C.POINTER(WorkStatsT)]
     lib.celeste_spline_prefilter.argtypes = [c_double_p, c_double_p]
     lib.celeste_psf_raster.argtypes = [C.c_int, c_double_p, C.c_int32, c_double_p, C.c_int32, c_double_p,

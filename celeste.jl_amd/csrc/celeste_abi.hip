@@ -58,6 +58,14 @@ struct celeste_ctx {
     int32_t *d_link_src = nullptr;  // per neighbour link: the source that owns it (CSR row)
     int64_t n_links = 0;
     int max_overlap_px = 0;
+    // split variant: per (source, image) first 64-pixel tile in d_rec, allocated on first use
+    std::vector<int64_t> h_tile_off;
+    int64_t *d_tile_off = nullptr;
+    int64_t n_tiles = 0;
+    int sum_tiles = 4, RCH = 1;   // record_sum_kernel: tiles per workgroup, parts per patch
+    double *d_rec = nullptr;
+    double *d_acc_split = nullptr;
+    size_t acc_split_cap = 0;
     // per-batch scratch (grown on demand)
     double *d_acc = nullptr;
     size_t acc_cap = 0;
@@ -70,7 +78,8 @@ struct celeste_ctx {
     size_t stage_cap = 0;
     // timing
     int timing = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int ev_split = 0;
     int ev_valid = 0;
 };
 
@@ -322,7 +331,18 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
     const char *env_chunk = getenv("CELESTE_CHUNK_PX");
     if (env_chunk && atoi(env_chunk) >= 64) c->chunk_px = (atoi(env_chunk) + 63) / 64 * 64;
     c->CH = c->max_npx > 0 ? (c->max_npx + c->chunk_px - 1) / c->chunk_px : 1;
-    for (int i = 0; i < 4; ++i)
+    {
+        c->h_tile_off.resize(c->h_patches.size());
+        int64_t tot = 0;
+        for (size_t q = 0; q < c->h_patches.size(); ++q) {
+            c->h_tile_off[q] = tot;
+            tot += ((int64_t)c->h_patches[q].H2 * c->h_patches[q].W2 + 63) / 64;
+        }
+        c->n_tiles = tot;
+        if (const char *e = getenv("CELESTE_SUM_TILES")) if (atoi(e) > 0) c->sum_tiles = atoi(e);
+        c->RCH = std::max(1, ((c->max_npx + 63) / 64 + c->sum_tiles - 1) / c->sum_tiles);
+    }
+    for (int i = 0; i < 5; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
 #undef CTX_TRY
     *out = c;
@@ -334,10 +354,10 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     (void)hipSetDevice(c->device);
     for (void *p : c->plane_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
 
@@ -369,6 +389,22 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         c->acc_cap = need;
     }
     const bool derivs = (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) != 0;
+    const bool split = (flags & CELESTE_FLAG_SPLIT) != 0;
+    if (split) {
+        if (!(flags & CELESTE_FLAG_HESS)) return CELESTE_ERR_INVALID_ARG;
+        if (!c->d_rec) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (dev_upload(&c->d_tile_off, c->h_tile_off.data(), c->h_tile_off.size()) != CELESTE_OK) return CELESTE_ERR_HIP;
+            if (hipMalloc((void **)&c->d_rec, (size_t)std::max<int64_t>(c->n_tiles, 1) * ACC_N * 64 * sizeof(double)) != hipSuccess)
+                return CELESTE_ERR_ALLOC;
+        }
+        const size_t need_s = (size_t)n_targets * c->N * c->RCH * ACC_N;
+        if (need_s > c->acc_split_cap) {
+            if (c->d_acc_split) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_acc_split)); c->d_acc_split = nullptr; }
+            HIP_TRY(hipMalloc((void **)&c->d_acc_split, need_s * sizeof(double)));
+            c->acc_split_cap = need_s;
+        }
+    }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     hipLaunchKernelGGL(prep_kernel, dim3(c->S * c->N), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches, c->S,
                        c->N, c->K, c->d_srcimg, c->d_comps, c->d_geo);
@@ -388,14 +424,26 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
 #define LAUNCH_PIXEL_T(MODE, R)                                                                                 \
     hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,   \
                        c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off, c->d_val, \
-                       d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->ablate)
+                       d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->ablate, c->d_tile_off, c->d_rec)
 #define LAUNCH_PIXEL(MODE) do { if (flags & CELESTE_FLAG_FP32) LAUNCH_PIXEL_T(MODE, float); else LAUNCH_PIXEL_T(MODE, double); } while (0)
-    if (flags & CELESTE_FLAG_HESS) LAUNCH_PIXEL(2);
+    if (split) LAUNCH_PIXEL(3);
+    else if (flags & CELESTE_FLAG_HESS) LAUNCH_PIXEL(2);
     else if (derivs) LAUNCH_PIXEL(1);
     else LAUNCH_PIXEL_T(0, double);
 #undef LAUNCH_PIXEL
 #undef LAUNCH_PIXEL_T
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
+    c->ev_split = 0;
+    if (split) {
+        // per-patch sums of the records, then the lift reads one record per (target, image): CH = 1
+        hipLaunchKernelGGL(record_sum_kernel, dim3((unsigned)((size_t)n_targets * c->N * c->RCH)), dim3(RSUM_NT), 0,
+                           stream, c->d_patches, d_targets, c->d_tile_off, reinterpret_cast<const double2 *>(c->d_rec),
+                           c->N, c->RCH, c->sum_tiles, c->d_acc_split);
+        if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], stream)); c->ev_split = 1; }
+        hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
+                           c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->N, c->RCH, c->sum_tiles * 64, flags,
+                           d_v, d_d, d_h, d_counters, d_status);
+    } else
     hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                        c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->N, c->CH, c->chunk_px, flags,
                        d_v, d_d, d_h, d_counters, d_status);
@@ -469,6 +517,14 @@ extern "C" int celeste_ctx_last_kernel_ms(celeste_ctx_t *c, float ms[3]) {
     if (!c || !ms || !c->ev_valid) return CELESTE_ERR_INVALID_ARG;
     HIP_TRY(hipEventSynchronize(c->ev[3]));
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    if (c->ev_split) HIP_TRY(hipEventElapsedTime(&ms[2], c->ev[4], c->ev[3]));  // lift alone
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_ctx_last_record_sum_ms(celeste_ctx_t *c, float *ms) {
+    if (!c || !ms || !c->ev_valid || !c->ev_split) return CELESTE_ERR_INVALID_ARG;
+    HIP_TRY(hipEventSynchronize(c->ev[3]));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev[2], c->ev[4]));
     return CELESTE_OK;
 }
 
@@ -485,6 +541,10 @@ extern "C" int celeste_ctx_work_stats(celeste_ctx_t *c, int32_t n_targets, const
             const DevPatch &p = c->h_patches[(size_t)t * c->N + n];
             A += (int64_t)p.H2 * p.W2;  // upper bound of visited pixels (NaN / masked pixels are skipped)
             R += p.H2;
+            if (p.H2 * p.W2 > 0) {
+                out->record_bytes += (int64_t)ACC_N * 8 * ((int64_t)p.H2 * p.W2 + 1);
+                out->record_tiles += ((int64_t)p.H2 * p.W2 + 63) / 64;
+            }
         }
         const int64_t Kn = c->h_nbr_off[t + 1] - c->h_nbr_off[t];
         out->active_pixel_visits += A;

@@ -461,6 +461,14 @@ __device__ __forceinline__ void fold_entries(const PixelTerms &T, bool b0, bool 
     if constexpr (J + 1 < ACC_N / 4) fold_entries<MODE, J + 1>(T, b0, b1, a);
 }
 
+// Split variant (CELESTE_FLAG_SPLIT): instead of folding, every pixel's 68-entry record goes to HBM, entry-major
+// inside a 64-pixel tile (rec[e * 64 + lane]) so that each store instruction writes one contiguous 512-byte row.
+template <int E>
+__device__ __forceinline__ void store_entries(const PixelTerms &T, double *__restrict__ tile_lane) {
+    __builtin_nontemporal_store(record_entry<E>(T), tile_lane + E * 64);
+    if constexpr (E + 1 < ACC_N) store_entries<E + 1>(T, tile_lane);
+}
+
 // Component record in the arithmetic type of the pixel math (double, or float for CELESTE_FLAG_FP32)
 template <typename R>
 struct CompR { R p11, p12, p22, xi1, xi2, w0, wd, nu; };
@@ -530,7 +538,8 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int nc, R dx, 
 
 #define ACC_Q (ACC_N / 4)  // 17 accumulators per lane: lane l owns record entries e with e % 4 == l % 4
 
-// MODE 0: value only; MODE 1: value + gradient sums; MODE 2: value + gradient + Hessian sums
+// MODE 0: value only; MODE 1: value + gradient sums; MODE 2: value + gradient + Hessian sums;
+// MODE 3: as MODE 2 but the per-pixel records are written to HBM for record_sum_kernel (split variant)
 #ifndef PIXEL_WAVES
 #define PIXEL_WAVES 2  // waves per SIMD the register allocator must allow (256 VGPRs, no scratch)
 #endif
@@ -544,7 +553,8 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
              const int64_t *__restrict__ val_off, const double2 *__restrict__ val,
              const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px,
-             double *__restrict__ acc, int ablate) {
+             double *__restrict__ acc, int ablate, const int64_t *__restrict__ tile_off, double *__restrict__ rec) {
+    constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
     __shared__ double etab[64];
     // chunk index is the slow grid axis (see value_kernel): heavy first chunks go first, spread over all XCDs
     const int TN = gridDim.x / CH;
@@ -652,7 +662,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         T.S0d = 0; T.S1x = 0; T.S1y = 0; T.S1xd = 0; T.S1yd = 0;
         T.S2a = 0; T.S2b = 0; T.S2c = 0; T.S2an = 0; T.S2bn = 0; T.S2cn = 0; T.S2ad = 0; T.S2bd = 0; T.S2cd = 0;
         T.S3a = 0; T.S3b = 0; T.S3c = 0; T.S3d = 0; T.S4a = 0; T.S4b = 0; T.S4c = 0; T.S4d = 0; T.S4e = 0;
-        if (own) S0 = galaxy_sums<MODE, R>(tcr, (ablate & 2) ? 0 : NC, (R)(hh - si.m1), (R)(ww - si.m2), etab, T);
+        if (own) S0 = galaxy_sums<GM, R>(tcr, (ablate & 2) ? 0 : NC, (R)(hh - si.m1), (R)(ww - si.m2), etab, T);
         T.f1 = S0;
 
         // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
@@ -720,8 +730,12 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             T.dA4 = c1 * gal_g<4>(T); T.dB4 = q1f1 * gal_g<4>(T);
             T.dA5 = c1 * gal_g<5>(T); T.dB5 = q1f1 * gal_g<5>(T);
         }
-        fold_entries<MODE, 0>(T, b0, b1, a);
+        if constexpr (MODE == 3)
+            store_entries<0>(T, rec + (size_t)(tile_off[(size_t)t * N + n] + (base >> 6)) * (ACC_N * 64) + lane);
+        else
+            fold_entries<MODE, 0>(T, b0, b1, a);
     }
+    if (MODE == 3) return;
 
     // ---- one 68-double record per (target, image, chunk) ----
     double *__restrict__ out = acc + (size_t)wg * ACC_N;
@@ -735,6 +749,55 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         if (MODE == 1 && (4 * j > ZV) && (4 * j + 3 < ACC_CNT)) continue;  // Hessian-only groups are not produced
         const double s = quad_class_sum(a[j]);
         if (lane < 4) out[4 * j + lane] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// record_sum_kernel (split variant): the per-patch sum of the per-pixel records -- the reference's
+// accumulation of add_pixel_term! results into elbo_vars.elbo (elbo_objective.jl:330-392, 452-466) as a pure
+// HBM-streaming segmented sum.  One workgroup of 128 threads per (target, image); a 64-pixel tile is
+// 68 rows x 512 B; thread t reads the double2 at row t/32 + 4k, column pair t%32 (16 B per lane, each wave
+// instruction covers two whole rows = 1 KiB contiguous), 17 independent loads per tile.
+// ---------------------------------------------------------------------------------------------
+typedef double d2v __attribute__((ext_vector_type(2)));
+#define RSUM_NT 128
+#define RSUM_K (ACC_N * 32 / RSUM_NT)  // 17
+__global__ void __launch_bounds__(RSUM_NT)
+record_sum_kernel(const DevPatch *__restrict__ patches, const int32_t *__restrict__ targets,
+                  const int64_t *__restrict__ tile_off, const double2 *__restrict__ rec, int N, int RCH,
+                  int sum_tiles, double *__restrict__ acc) {
+    // part index is the slow grid axis: every patch's first part is launched before any second part
+    const int TN = gridDim.x / RCH;
+    const int part = blockIdx.x / TN;
+    const int tn = blockIdx.x - part * TN;
+    const int ti = tn / N, n = tn - ti * N;
+    const int t = targets[ti];
+    const DevPatch &P = patches[(size_t)t * N + n];
+    const int npx = P.H2 * P.W2;
+    const int tile0 = part * sum_tiles;
+    const int ntiles = min(sum_tiles, ((npx + 63) >> 6) - tile0);
+    if (ntiles <= 0) return;  // the lift kernel recomputes this predicate (part * sum_tiles * 64 < npx)
+    const int tid = threadIdx.x;
+    const d2v *__restrict__ src = reinterpret_cast<const d2v *>(rec) +
+                                  (size_t)(tile_off[(size_t)t * N + n] + tile0) * (ACC_N * 32) + tid;
+    d2v a[RSUM_K];
+#pragma unroll
+    for (int k = 0; k < RSUM_K; ++k) a[k] = (d2v)(0.0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        d2v v[RSUM_K];
+#pragma unroll
+        for (int k = 0; k < RSUM_K; ++k) v[k] = __builtin_nontemporal_load(src + k * RSUM_NT);
+#pragma unroll
+        for (int k = 0; k < RSUM_K; ++k) a[k] += v[k];
+        src += ACC_N * 32;
+    }
+    double *__restrict__ out = acc + ((size_t)tn * RCH + part) * ACC_N;
+    const int row0 = tid >> 5;
+#pragma unroll
+    for (int k = 0; k < RSUM_K; ++k) {
+        double s = a[k].x + a[k].y;
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+        if ((tid & 31) == 0) out[row0 + 4 * k] = s;
     }
 }
 

@@ -140,6 +140,12 @@ class FieldContext:
         cabi.check(self.lib.celeste_ctx_last_kernel_ms(self.handle, ms), self.lib)
         return [float(x) for x in ms]
 
+    def last_record_sum_ms(self) -> float:
+        """FLAG_SPLIT launches: duration of the streaming per-patch record sum."""
+        ms = C.c_float()
+        cabi.check(self.lib.celeste_ctx_last_record_sum_ms(self.handle, C.byref(ms)), self.lib)
+        return float(ms.value)
+
     def work_stats(self, targets: Sequence[int]) -> dict:
         tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32))
         ws = cabi.WorkStatsT()

@@ -65,7 +65,12 @@ enum {
     CELESTE_FLAG_KL = 4u,
     /* single-precision galaxy component loop (BASELINE config 5, tolerance 1e-4 against the fp64 result);
      * per-pixel terms, accumulation, the lift and the KL stay fp64.  No reference counterpart. */
-    CELESTE_FLAG_FP32 = 8u
+    CELESTE_FLAG_FP32 = 8u,
+    /* split variant of the pixel sum (measurement aid): the pixel kernel writes one
+     * 68-double record per visited pixel to HBM and a separate streaming kernel forms the per-patch sums
+     * (the accumulation of add_pixel_term! into elbo_vars.elbo, elbo_objective.jl:330-392,452-466).
+     * Requires CELESTE_FLAG_HESS; distinct targets in the batch.  Same results up to summation order. */
+    CELESTE_FLAG_SPLIT = 16u
 };
 
 /* Model.Image (src/model/image_model.jl:6-38).  Borrowed for the duration of
@@ -135,6 +140,8 @@ typedef struct celeste_work_stats_t {
     int64_t patch_rows;             /* sum of H2 */
     int64_t neighbor_links;         /* sum of K_s */
     int64_t algorithmic_bytes;      /* 9 A + 4 R + 352 (1+K) + 200 N (1+K) + 8288 per target */
+    int64_t record_bytes;           /* split variant: 544 A + 544 per non-empty (target, image) patch */
+    int64_t record_tiles;           /* split variant: 64-pixel record tiles actually stored / re-read */
 } celeste_work_stats_t;
 
 int celeste_version(void);
@@ -174,6 +181,9 @@ int celeste_elbo_eval_batch_device(celeste_ctx_t *ctx, const double *d_vp, int32
  * ms[1] = pixel kernel, ms[2] = 44-space lift kernel. */
 int celeste_ctx_enable_timing(celeste_ctx_t *ctx, int enable);
 int celeste_ctx_last_kernel_ms(celeste_ctx_t *ctx, float ms[3]);
+/* CELESTE_FLAG_SPLIT launches only: duration of the record-sum kernel (ms[1] above is then the
+ * record-writing pixel kernel alone, ms[2] the lift alone). */
+int celeste_ctx_last_record_sum_ms(celeste_ctx_t *ctx, float *ms);
 
 int celeste_ctx_work_stats(celeste_ctx_t *ctx, int32_t n_targets, const int32_t *targets,
                            celeste_work_stats_t *out);

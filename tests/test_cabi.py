@@ -27,7 +27,7 @@ def test_struct_layout_matches_the_header():
     assert C.sizeof(cabi.PatchT) == 16 + 8 + 8 * 8 + 8 + 8
     assert C.sizeof(cabi.PriorT) == 8 * (6 + 16 + 64 + 256 + 2)
     assert C.sizeof(cabi.ProblemT) == 16 + 6 * 8
-    assert C.sizeof(cabi.WorkStatsT) == 40
+    assert C.sizeof(cabi.WorkStatsT) == 56
 
 
 def test_no_cpu_fallback(lib):

@@ -46,6 +46,23 @@ def test_small_field_with_neighbors(oracle):
     print(errs)
 
 
+def test_split_variant_record_sum(oracle):
+    """CELESTE_FLAG_SPLIT: per-pixel records to HBM + streaming per-patch sum gives the
+    same SensitiveFloat as the fused kernel; partial tiles, NaN pixels, neighbours, a subset of targets"""
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_field(160, 200, 40, seed=11, nan_fraction=0.005)
+    ctx = _ctx(f)
+    for tg in (list(range(len(f.catalog))), [7, 3, 21]):
+        ref = oracle.elbo_batch(ctx.problem, f.vp, tg, ALL)
+        g = ctx.eval_batch(f.vp, tg, ALL | cabi.FLAG_SPLIT)
+        errs = assert_parity(g, ref, "split")
+        fused = ctx.eval_batch(f.vp, tg, ALL)
+        assert np.max(np.abs(g[0] - fused[0]) / np.abs(fused[0])) < 1e-12
+        print("split", errs)
+    with pytest.raises(cabi.CelesteError):
+        ctx.eval_batch(f.vp, [0], 1 | cabi.FLAG_SPLIT)   # needs HESS
+
+
 def test_explicit_bitmaps(oracle):
     """test_elbo.jl:64-130 manipulates active_pixel_bitmap by hand; neighbours' bitmaps gate their light"""
     from celeste_jl_amd import synthetic
