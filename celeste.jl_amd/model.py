@@ -68,6 +68,30 @@ class ConstantPSFMap:
 
 
 @dataclass
+class SDSSPSFMap:
+    """src/SDSSIO.jl:239-299: spatially variable PSF = eigen-images (columns of rrows, each a flattened
+    rnrow x rncol stamp, column-major) weighted by polynomials
+    w_k(x, y) = sum_ij cmat[i, j, k] (RCS (x - 1))^i (RCS (y - 1))^j, RCS = 0.001, x / y one-based pixel coordinates."""
+    rrows: np.ndarray   # (rnrow * rncol) x nk
+    rnrow: int
+    rncol: int
+    cmat: np.ndarray    # ni x nj x nk
+
+    def __post_init__(self):
+        self.rrows = np.asarray(self.rrows, dtype=np.float64)
+        self.cmat = np.asarray(self.cmat, dtype=np.float64)
+        assert self.rrows.shape[0] == self.rnrow * self.rncol
+        assert self.rrows.shape[1] == self.cmat.shape[2]
+
+    def __call__(self, x, y):
+        RCS = 0.001
+        px = (RCS * (x - 1.0)) ** np.arange(self.cmat.shape[0])
+        py = (RCS * (y - 1.0)) ** np.arange(self.cmat.shape[1])
+        w = np.einsum("ijk,i,j->k", self.cmat, px, py)
+        return (self.rrows @ w).reshape(self.rncol, self.rnrow).T.copy()   # column-major stamp
+
+
+@dataclass
 class SDSSBackground:
     """src/SDSSIO.jl:56-99: the sky plane of an SDSS frame, bilinear interpolation of a small sky image at the
     per-row / per-column coordinates sky_x / sky_y (constant extrapolation), times the per-row calibration.
@@ -119,7 +143,7 @@ class Image:
     psf: np.ndarray              # K x 6
     sky: np.ndarray              # H x W float32, nmgy
     nelec_per_nmgy: np.ndarray   # H float32
-    psfmap: ConstantPSFMap
+    psfmap: object               # ConstantPSFMap or SDSSPSFMap: (x, y) -> 51 x 51 raw stamp
     wcs_jacobian: np.ndarray = field(default_factory=lambda: np.eye(2))  # affine WCS: pix = J (world - w0) + p0
     wcs_world0: np.ndarray = field(default_factory=lambda: np.zeros(2))
     wcs_pix0: np.ndarray = field(default_factory=lambda: np.zeros(2))

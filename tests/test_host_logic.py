@@ -32,6 +32,30 @@ def test_sdss_background_known_answers():
     assert cal[2, 2] == pytest.approx(4.25)
 
 
+def test_sdss_psf_map_polynomial_weights():
+    """SDSSIO.jl:262-299 restated as an explicit loop; a map with only the constant coefficient is position independent"""
+    from celeste_jl_amd.model import SDSSPSFMap
+    rng = np.random.default_rng(5)
+    nk, nr, nc = 3, 51, 51
+    rrows = rng.normal(size=(nr * nc, nk)); cmat = rng.normal(size=(4, 5, nk))
+    m = SDSSPSFMap(rrows, nr, nc, cmat)
+    x, y = 812.3, 1403.9
+    stamp = np.zeros(nr * nc)
+    for k in range(nk):
+        w = 0.0
+        for j in range(5):
+            for i in range(4):
+                w += cmat[i, j, k] * (0.001 * (x - 1.0)) ** i * (0.001 * (y - 1.0)) ** j
+        stamp += w * rrows[:, k]
+    got = m(x, y)
+    assert got.shape == (nr, nc)
+    assert np.allclose(got, stamp.reshape(nc, nr).T, rtol=1e-13, atol=1e-13)
+    c0 = np.zeros((4, 5, nk)); c0[0, 0] = [1.0, 0.5, -0.25]
+    const = SDSSPSFMap(rrows, nr, nc, c0)
+    assert np.allclose(const(1, 1), const(2000, 1400))
+    assert np.allclose(const(1, 1).T.ravel(), rrows @ c0[0, 0])
+
+
 def test_clamp_box_and_rounding():
     from celeste_jl_amd.model import clamp_box, julia_round
     assert clamp_box(((-3, 7), (20, 40)), (20, 23)) == ((1, 7), (20, 23))
