@@ -75,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "celeste_version", "celeste_strerror", "celeste_ctx_create", "celeste_ctx_destroy", "celeste_elbo_eval",
     "celeste_elbo_eval_batch", "celeste_elbo_eval_batch_device", "celeste_ctx_enable_timing",
     "celeste_ctx_last_kernel_ms", "celeste_ctx_last_record_sum_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter", "celeste_psf_raster",
-    "celeste_maximize_batch", "celeste_render_expected",
+    "celeste_maximize_batch", "celeste_render_expected", "celeste_optim_stats",
 ]
 
 _lib = None
@@ -112,6 +112,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                        C.c_int32, c_double_p]
     lib.celeste_maximize_batch.argtypes = [vp, c_double_p, c_double_p, c_double_p, C.c_int32, c_int32_p,
                                            C.POINTER(OptimConfigT), c_int32_p, c_int32_p, c_double_p, c_int32_p]
+    lib.celeste_optim_stats.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.celeste_render_expected.argtypes = [vp, c_double_p, C.c_int32, c_double_p]
     _lib = lib
     return lib

@@ -591,7 +591,10 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double
     OptParams op;
     op.loc_width = cfg.loc_width; op.loc_scale = cfg.loc_scale; op.xtol_abs = cfg.xtol_abs; op.ftol_rel = cfg.ftol_rel;
     op.gtol = cfg.gtol; op.initial_delta = cfg.initial_delta; op.delta_hat = cfg.delta_hat; op.max_iters = cfg.max_iters;
-    op.pad = 0;
+    // CELESTE_TR_SOLVER=eig: full eigen-decomposition for every sub-problem (cross-check of the default
+    // tridiagonal-space solve)
+    const char *env_solver = getenv("CELESTE_TR_SOLVER");
+    op.solver = (env_solver && strcmp(env_solver, "eig") == 0) ? 1 : 0;
     const uint32_t flags = CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS | (cfg.include_kl ? CELESTE_FLAG_KL : 0);
     const size_t n = (size_t)n_targets;
     double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_H = nullptr, *d_pos = nullptr;
@@ -633,7 +636,7 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double
             int st1 = launch_eval(c, d_vp, n_active, d_evt[cur], flags, d_v, d_d, d_h, nullptr, d_st, nullptr, false);
             if (st1 != CELESTE_OK) { rc = st1; goto cleanup; }
             MX_TRY(hipMemsetAsync(d_count, 0, sizeof(int32_t), nullptr));
-            hipLaunchKernelGGL(optim_step_kernel, dim3(n_active), dim3(256), 0, nullptr, d_vp, d_targets, d_act[cur],
+            hipLaunchKernelGGL(optim_step_kernel, dim3(n_active), dim3(64), 0, nullptr, d_vp, d_targets, d_act[cur],
                                d_v, d_d, d_h, d_st, op, d_state, d_H, d_act[1 - cur], d_evt[1 - cur], d_count);
             MX_TRY(hipMemcpy(&n_active, d_count, sizeof(int32_t), hipMemcpyDeviceToHost));
             cur = 1 - cur;
@@ -661,6 +664,16 @@ cleanup:
     return rc;
 }
 
+
+extern "C" int celeste_optim_stats(int reset, uint64_t out[5]) {
+    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    if (out) {
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_optim_stats), sizeof h));
+        for (int i = 0; i < 5; ++i) out[i] = h[i];
+    }
+    if (reset) { unsigned long long z[5] = {0, 0, 0, 0, 0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_optim_stats), z, sizeof z)); }
+    return CELESTE_OK;
+}
 
 // ---- expected-image renderer (bin/write_celeste_expectation.jl:112-156, fsm_util.jl:349-400) ------------
 extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32_t image, double *out_plane) {

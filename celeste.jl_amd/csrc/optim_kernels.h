@@ -11,16 +11,22 @@
 //       (ElboMaximize.jl:228-242; Optim.jl is third-party, unvendored: restated from its published algorithm,
 //        Nocedal & Wright Alg. 4.1 / section 4.3)
 //
-// One 256-thread workgroup per target and Newton iteration: chain rule to the 41 free parameters, accept /
-// reject + radius update, then the next trust-region sub-problem solved exactly in the eigenbasis of the
-// 41 x 41 Hessian (parallel round-robin Jacobi rotations in LDS, secular equation by safeguarded Newton).
+// One wavefront (64-thread workgroup) per target and Newton iteration: chain rule to the 41 free parameters,
+// accept / reject + radius update, then the next trust-region sub-problem (N&W section 4.3).  The exact
+// solution p(lambda) = -(H + lambda I)^-1 g only needs H up to an orthogonal change of basis, so H is reduced to
+// tridiagonal form T = Q' H Q by Householder reflections (lanes = rows, 13 KB of LDS) and everything else runs
+// in O(n) per lambda: extreme eigenvalues of T by 64-way Sturm multisection, (T + lambda I) y = -Q'g by LDL',
+// the secular equation by safeguarded Newton, p = Q y.  Same step as the eigen-decomposition Optim.jl uses, to
+// the tolerance of the secular solve, at a fraction of its latency (the hard case included: lowest eigenvectors
+// by inverse iteration); OptParams.solver = 1 takes the full eigen-decomposition (implicit-shift QL) instead.
+// Sub-problem rules: see oracle/celeste_optim_oracle.c (celeste_oracle_solve_tr).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "elbo_device.h"
 #include "../../include/celeste_mi355x.h"
 
 #define NF 41
-#define NJ 42  // Jacobi works on an even order; index 41 is an inert dummy
+#define LDA 45  // leading dimension of the LDS matrix (holds the 44 x 44 bound-space Hessian first; odd: no bank conflicts)
 
 struct OptState {                 // per target slot
     double x[NF], xt[NF], g[NF];
@@ -31,7 +37,7 @@ struct OptState {                 // per target slot
 
 struct OptParams {
     double loc_width, loc_scale, xtol_abs, ftol_rel, gtol, initial_delta, delta_hat;
-    int32_t max_iters, pad;
+    int32_t max_iters, solver;    // 0: tridiagonal-space solve (default), 1: eigen-decomposition always
 };
 
 __device__ __forceinline__ void box_bounds(int i, const double *pos0, const OptParams &op, double &lo, double &hi,
@@ -121,23 +127,397 @@ __global__ void optim_init_kernel(double *__restrict__ vp, const int32_t *__rest
     active[ti] = ti;
 }
 
+__device__ __forceinline__ double lane_bcast(double x, int src) { return __shfl(x, src, 64); }
+
+// wave sum by DPP row operations (no LDS traffic): quad butterflies, row mirrors, row broadcasts; the total
+// ends in lane 63 and is handed to every lane through a scalar register pair
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_add_f64(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    return x + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double x) {
+    x = dpp_add_f64<0xB1, 0xF>(x);    // quad_perm [1,0,3,2]
+    x = dpp_add_f64<0x4E, 0xF>(x);    // quad_perm [2,3,0,1]
+    x = dpp_add_f64<0x141, 0xF>(x);   // row_half_mirror
+    x = dpp_add_f64<0x140, 0xF>(x);   // row_mirror: every lane holds its 16-lane row sum
+    x = dpp_add_f64<0x142, 0xA>(x);   // row_bcast15 into rows 1, 3
+    x = dpp_add_f64<0x143, 0xC>(x);   // row_bcast31 into rows 2, 3: lane 63 holds the total
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Householder reduction of the symmetric NF x NF matrix A (LDS, column-major, full storage) to tridiagonal
+// form.  On exit: row i of A (columns < i) holds the Householder vector u_i, hv[i] = |u_i|^2 / 2 (0: no
+// reflection), e[i] the sub-diagonal entry (i - 1, i), A(i, i) the diagonal.  q: NF doubles of scratch.
+__device__ inline void tred_wave(double *A, double *hv, double *e, double *q, int ln) {
+    for (int i = NF - 1; i >= 1; --i) {
+        const int l = i - 1;
+        const bool act = ln <= l;
+        double x = act ? A[i + LDA * ln] : 0.0;            // row i left of the diagonal
+        if (l == 0) { e[i] = lane_bcast(x, 0); hv[i] = 0.0; continue; }
+        const double scale = wave_sum_dpp(fabs(x));
+        if (scale == 0.0) { e[i] = 0.0; hv[i] = 0.0; continue; }
+        x /= scale;
+        double h = wave_sum_dpp(x * x);
+        const double f = lane_bcast(x, l);
+        const double g = f >= 0 ? -sqrt(h) : sqrt(h);
+        h -= f * g;
+        const double u = (ln == l) ? f - g : x;           // Householder vector (0 beyond l)
+        if (act) A[i + LDA * ln] = u;
+        e[i] = scale * g; hv[i] = h;
+        __syncthreads();
+        double acc = 0.0;
+        if (act) for (int k = 0; k <= l; ++k) acc += A[ln + LDA * k] * A[i + LDA * k];
+        const double p = acc / h;
+        const double hh = wave_sum_dpp(p * u) / (h + h);
+        const double qv = p - hh * u;
+        if (act) q[ln] = qv;
+        __syncthreads();
+        if (act) for (int k = 0; k <= l; ++k) A[ln + LDA * k] -= u * q[k] + qv * A[i + LDA * k];
+        __syncthreads();
+    }
+    hv[0] = 0.0; e[0] = 0.0;
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Full symmetric eigen-decomposition by one wavefront: tred_wave, accumulation of the transformation,
+// implicit-shift QL.  On exit w = eigenvalues (unordered), column i of A = eigenvector i.  Lane j owns row j
+// (QL) or column j (accumulation); every lane carries the scalar recurrences redundantly, so all control flow
+// is wave-uniform and the QL phase needs no barrier.
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline void eig_sym_wave(double *A, double *w, double *e, double *q, int ln) {
+    tred_wave(A, w, e, q, ln);
+    for (int i = 1; i < NF; ++i) {   // column i above the diagonal: u_i / h_i, as the accumulation expects
+        const double h = w[i];
+        if (h != 0.0 && ln < i) A[ln + LDA * i] = A[i + LDA * ln] / h;
+    }
+    __syncthreads();
+    for (int i = 0; i < NF; ++i) {
+        const int l = i - 1;
+        const double hi = w[i];
+        if (l >= 0 && hi != 0.0 && ln <= l) {
+            double g = 0.0;
+            for (int k = 0; k <= l; ++k) g += A[i + LDA * k] * A[k + LDA * ln];
+            for (int k = 0; k <= l; ++k) A[k + LDA * ln] -= g * A[k + LDA * i];
+        }
+        __syncthreads();
+        const double dii = A[i + LDA * i];
+        __syncthreads();
+        w[i] = dii;
+        if (ln == 0) A[i + LDA * i] = 1.0;
+        if (ln <= l) { A[ln + LDA * i] = 0.0; A[i + LDA * ln] = 0.0; }
+        __syncthreads();
+    }
+    // implicit-shift QL on (w, e); rotations are applied to row ln of the eigenvector matrix
+    {
+        const double ev = (ln >= 1 && ln < NF) ? e[ln] : 0.0;
+        __syncthreads();
+        if (ln >= 1 && ln < NF) e[ln - 1] = ev;
+        if (ln == 0) e[NF - 1] = 0.0;
+        __syncthreads();
+    }
+    const bool row = ln < NF;
+    for (int l = 0; l < NF; ++l) {
+        for (int iter = 0; iter < 60; ++iter) {
+            int m = l;
+            for (; m < NF - 1; ++m) {
+                const double dd = fabs(w[m]) + fabs(w[m + 1]);
+                if (fabs(e[m]) + dd == dd) break;
+            }
+            if (m == l) break;
+            double g = (w[l + 1] - w[l]) / (2.0 * e[l]);
+            double r = sqrt(g * g + 1.0);
+            g = w[m] - w[l] + e[l] / (g + (g >= 0 ? r : -r));
+            double s = 1.0, c = 1.0, p = 0.0;
+            bool underflow = false;
+            double zc = row ? A[ln + LDA * m] : 0.0;        // z(ln, col), carried from one rotation to the next
+            int col = m;
+            for (int i = m - 1; i >= l; --i) {
+                const double ei = e[i];
+                const double f = s * ei, b = c * ei;
+                const double r2 = f * f + g * g;
+                if (r2 == 0.0) { e[i + 1] = 0.0; w[i + 1] -= p; e[m] = 0.0; underflow = true; break; }
+                const double ir = 1.0 / sqrt(r2);
+                e[i + 1] = r2 * ir;
+                s = f * ir; c = g * ir;
+                g = w[i + 1] - p;
+                r = (w[i] - g) * s + 2.0 * c * b;
+                p = s * r;
+                w[i + 1] = g + p;
+                g = c * r - b;
+                if (row) {
+                    const double zi = A[ln + LDA * i];
+                    A[ln + LDA * (i + 1)] = s * zi + c * zc;
+                    zc = c * zi - s * zc;
+                }
+                col = i;
+            }
+            if (row) A[ln + LDA * col] = zc;
+            if (underflow) continue;
+            w[l] -= p; e[l] = g; e[m] = 0.0;
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tridiagonal-space pieces of the trust-region solve.  td / te: diagonal and sub-diagonal (te[k] couples k-1, k).
+// The serial recurrences are carried redundantly by every lane (uniform values, identical LDS writes).
+// ---------------------------------------------------------------------------------------------------------
+// Both serial recurrences below run on the characteristic polynomials P_k of the leading k x k blocks
+// (P_{k+1} = (d_k - x) P_k - e_k^2 P_{k-1}, rescaled by a power of two at every step) instead of on their ratios:
+// the chain then holds two FMAs and an exponent fix per step, no division.
+__device__ __forceinline__ void poly_rescale(double &pm, double &pc) {
+    const int ex = __builtin_amdgcn_frexp_exp(fmax(fabs(pc), fabs(pm)));
+    pm = __builtin_ldexp(pm, -ex); pc = __builtin_ldexp(pc, -ex);
+}
+// LDL' of T + lam I (positive definite by construction of lam): ip[k] = 1 / pivot k = P_k / P_{k+1} (one division
+// per lane, in parallel), mk[k] = multiplier
+__device__ __forceinline__ void tri_factor(const double *__restrict__ td, const double *__restrict__ te,
+                                           const double *__restrict__ te2, double lam, double *__restrict__ ip,
+                                           double *__restrict__ mk, double *__restrict__ pa, double *__restrict__ pb,
+                                           int ln) {
+    double pm = 1.0, pc = td[0] + lam;
+    pa[0] = pm; pb[0] = pc;
+    for (int k = 1; k < NF; ++k) {
+        const double pn = __builtin_fma(td[k] + lam, pc, -te2[k] * pm);
+        pa[k] = pc; pb[k] = pn;
+        pm = pc; pc = pn;
+        poly_rescale(pm, pc);
+    }
+    __syncthreads();
+    double inv = 0.0;
+    if (ln < NF) { inv = pa[ln] / pb[ln]; ip[ln] = inv; }
+    __syncthreads();
+    if (ln >= 1 && ln < NF) mk[ln] = te[ln] * ip[ln - 1];
+    __syncthreads();
+}
+// y = (T + lam I)^-1 (sign * rhs)
+__device__ __forceinline__ void tri_solve(const double *__restrict__ te, const double *__restrict__ ip,
+                                          const double *__restrict__ mk, const double *__restrict__ rhs, double sign,
+                                          double *__restrict__ r, double *__restrict__ y) {
+    double prev = sign * rhs[0];
+    r[0] = prev;
+    for (int k = 1; k < NF; ++k) { prev = __builtin_fma(-mk[k], prev, sign * rhs[k]); r[k] = prev; }
+    double yn = prev * ip[NF - 1];
+    y[NF - 1] = yn;
+    for (int k = NF - 2; k >= 0; --k) { yn = __builtin_fma(-te[k + 1], yn, r[k]) * ip[k]; y[k] = yn; }
+    __syncthreads();
+}
+// Sturm count #{eigenvalues of T < x} = number of sign changes in P_0 .. P_n (an exact zero counts as a change)
+__device__ __forceinline__ int sturm_count(const double *__restrict__ td, const double *__restrict__ te2, double x) {
+    double pm = 1.0, pc = td[0] - x;
+    if (pc == 0.0) pc = -1e-300;
+    bool negp = pc < 0;
+    int c = negp;
+    for (int k = 1; k < NF; ++k) {
+        double pn = __builtin_fma(td[k] - x, pc, -te2[k] * pm);
+        if (pn == 0.0) pn = pc > 0 ? -1e-300 : 1e-300;
+        pm = pc; pc = pn;
+        poly_rescale(pm, pc);
+        const bool neg = pc < 0;
+        c += neg != negp;
+        negp = neg;
+    }
+    return c;
+}
+// Smallest (thr = 1) or largest (thr = NF) eigenvalue of T inside [a, b] by 64-way multisection on the Sturm count
+__device__ inline double tri_extreme(const double *__restrict__ td, const double *__restrict__ te2, double a, double b,
+                                     int thr, int passes, int ln, double &lower) {
+    for (int pass = 0; pass < passes; ++pass) {
+        const double x = a + (b - a) * ((double)(ln + 1) * (1.0 / 65.0));
+        const int c = sturm_count(td, te2, x);
+        const unsigned long long mask = __ballot(c >= thr);
+        double na, nb;
+        if (mask) {
+            const int jb = __ffsll((long long)mask) - 1;
+            nb = lane_bcast(x, jb);
+            const double below = lane_bcast(x, jb > 0 ? jb - 1 : 0);
+            na = jb > 0 ? below : a;
+        } else { na = lane_bcast(x, 63); nb = b; }
+        a = na; b = nb;
+        if (b - a <= 8.881784197001252e-16 * fmax(fabs(a), fabs(b))) break;
+    }
+    lower = a;
+    return 0.5 * (a + b);
+}
+
+// diagnostics: sub-problems solved as interior Newton steps / on the boundary / hard case, total and maximum
+// number of secular-equation iterations (celeste_optim_stats)
+__device__ unsigned long long g_optim_stats[5];
+
+#define TRI_MAXC 6   // largest cluster of lowest eigenvalues the hard-case test handles in the tridiagonal basis
+struct TriLds { double *A, *hv, *td, *te, *te2, *ip, *mk, *r, *y, *gt, *q, *gq, *zc, *pa, *pb; };
+
+// Trust-region step in the tridiagonal basis.  In: L.A = H (destroyed), g (lane register), delta.
+// Out: step p (lane register), model decrease m, interior flag.  Returns false in the hard case (caller falls
+// back to the eigen-decomposition).
+__device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int ln, double &p_out, double &m_out,
+                                    int &interior_out) {
+    const bool fr = ln < NF;
+    tred_wave(L.A, L.hv, L.te, L.q, ln);
+    if (fr) { const double ek = L.te[ln]; L.td[ln] = L.A[ln + LDA * ln]; L.te2[ln] = ek * ek; }
+    // gt = Q' g: reflections n-1 ... 2 in turn
+    double v = fr ? g : 0.0;
+    for (int i = NF - 1; i >= 2; --i) {
+        const double h = L.hv[i];
+        if (h == 0.0) continue;
+        const double u = ln < i ? L.A[i + LDA * ln] : 0.0;
+        v -= (wave_sum_dpp(u * v) / h) * u;
+    }
+    if (fr) L.gt[ln] = v;
+    __syncthreads();
+    // Gershgorin interval, extreme eigenvalues
+    double wmin, wmax, wmin_lower, norm_bound;
+    {
+        const double ea = fr ? fabs(L.te[ln]) : 0.0, eb = (ln + 1 < NF) ? fabs(L.te[ln + 1]) : 0.0;
+        const double dk = fr ? L.td[ln] : 0.0;
+        double lo = fr ? dk - ea - eb : INFINITY, hi = fr ? dk + ea + eb : -INFINITY;
+        for (int o = 32; o >= 1; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+        const double pad = 4.440892098500626e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300;
+        lo -= pad; hi += pad;
+        double unused;
+        norm_bound = fmax(fabs(lo), fabs(hi));
+        wmin = tri_extreme(L.td, L.te2, lo, hi, 1, 12, ln, wmin_lower);
+        wmax = tri_extreme(L.td, L.te2, lo, hi, NF, 3, ln, unused);
+    }
+    const double d2 = delta * delta;
+    int interior = 0;
+    double y = 0.0;
+    if (wmin >= 1e-8) {
+        tri_factor(L.td, L.te, L.te2, 0.0, L.ip, L.mk, L.pa, L.pb, ln);
+        tri_solve(L.te, L.ip, L.mk, L.gt, -1.0, L.r, L.y);
+        y = fr ? L.y[ln] : 0.0;
+        interior = wave_sum_dpp(y * y) <= d2;
+    }
+    if (!interior) {
+        const double lambda_lb = -wmin + fmax(1e-8, 1e-8 * (wmax - wmin));
+        double lambda = lambda_lb;
+        bool hard = false;
+        if (wmin < 0) {
+            // Hard-case candidate: g orthogonal (1e-10) to the eigenvectors of every eigenvalue within 1e-10 of the
+            // smallest.  Their number is a Sturm count; an orthonormal basis z_0 .. z_{mc-1} of their span comes
+            // from inverse iteration with the shift just below the smallest eigenvalue (the Sturm count at
+            // wmin_lower is 0, so T - shift I is positive definite) and Gram-Schmidt.
+            int mc = sturm_count(L.td, L.te2, wmin + 1e-10);
+            if (mc < 1) mc = 1;
+            if (mc > TRI_MAXC) { if (ln == 0) atomicAdd(&g_optim_stats[2], 1ull); return false; }
+            const double shift = wmin_lower - 4.440892098500626e-16 * norm_bound;
+            tri_factor(L.td, L.te, L.te2, -shift, L.ip, L.mk, L.pa, L.pb, ln);
+            bool orth = true;
+            for (int j = 0; j < mc && orth; ++j) {
+                double z = fr ? 1.0 + 0.5 * sin(1.7 * ln + 0.3 + 2.1 * j) : 0.0;
+                for (int it = 0; it < 4; ++it) {
+                    if (fr) L.q[ln] = z;
+                    __syncthreads();
+                    tri_solve(L.te, L.ip, L.mk, L.q, 1.0, L.r, L.gq);
+                    z = fr ? L.gq[ln] : 0.0;
+                    for (int jj = 0; jj < j; ++jj) {
+                        const double zo = fr ? L.zc[jj * NF + ln] : 0.0;
+                        z -= wave_sum_dpp(z * zo) * zo;
+                    }
+                    z *= 1.0 / sqrt(wave_sum_dpp(z * z));
+                }
+                if (fabs(wave_sum_dpp(fr ? z * L.gt[ln] : 0.0)) > 1e-10) orth = false;
+                if (fr) L.zc[j * NF + ln] = z;
+                __syncthreads();
+            }
+            if (orth) {
+                tri_factor(L.td, L.te, L.te2, lambda, L.ip, L.mk, L.pa, L.pb, ln);
+                tri_solve(L.te, L.ip, L.mk, L.gt, -1.0, L.r, L.y);
+                y = fr ? L.y[ln] : 0.0;
+                for (int j = 0; j < mc; ++j) {
+                    const double zo = fr ? L.zc[j * NF + ln] : 0.0;
+                    y -= wave_sum_dpp(y * zo) * zo;
+                }
+                const double p2 = wave_sum_dpp(y * y);
+                if (p2 <= d2) {   // N&W (4.45): to the boundary along the lowest eigenvector
+                    hard = true;
+                    y += sqrt(d2 - p2) * (fr ? L.zc[ln] : 0.0);
+                    if (fr) L.y[ln] = y;
+                    __syncthreads();
+                    if (ln == 0) atomicAdd(&g_optim_stats[2], 1ull);
+                }
+            }
+        }
+        if (!hard) {
+        int it = 0;
+        for (; it < 20; ++it) {
+            tri_factor(L.td, L.te, L.te2, lambda, L.ip, L.mk, L.pa, L.pb, ln);
+            tri_solve(L.te, L.ip, L.mk, L.gt, -1.0, L.r, L.y);
+            y = fr ? L.y[ln] : 0.0;
+            const double q2 = wave_sum_dpp(y * y);
+            tri_solve(L.te, L.ip, L.mk, L.y, 1.0, L.r, L.q);     // (T + lambda)^-1 y
+            const double q3 = wave_sum_dpp(fr ? y * L.q[ln] : 0.0);
+            const double prev = lambda;
+            lambda += q2 * (sqrt(q2) - delta) / (delta * q3);
+            if (lambda < lambda_lb) lambda = 0.5 * (prev - lambda_lb) + lambda_lb;
+            if (fabs(lambda - prev) < 1e-10 || lambda <= prev) break;
+        }
+        if (ln == 0) {
+            atomicAdd(&g_optim_stats[1], 1ull); atomicAdd(&g_optim_stats[3], (unsigned long long)it);
+            atomicMax(&g_optim_stats[4], (unsigned long long)it);
+        }
+        }
+    }
+    // model value g'p + p'Hp / 2 in the tridiagonal basis
+    {
+        double ty = 0.0;
+        if (fr) {
+            ty = L.td[ln] * y;
+            if (ln > 0) ty += L.te[ln] * L.y[ln - 1];
+            if (ln + 1 < NF) ty += L.te[ln + 1] * L.y[ln + 1];
+        }
+        m_out = wave_sum_dpp(fr ? L.gt[ln] * y + 0.5 * y * ty : 0.0);
+    }
+    // p = Q y: reflections 2 ... n-1 in turn
+    for (int i = 2; i < NF; ++i) {
+        const double h = L.hv[i];
+        if (h == 0.0) continue;
+        const double u = ln < i ? L.A[i + LDA * ln] : 0.0;
+        y -= (wave_sum_dpp(u * y) / h) * u;
+    }
+    if (interior && ln == 0) atomicAdd(&g_optim_stats[0], 1ull);
+    p_out = y;
+    interior_out = interior;
+    return true;
+}
+
+// to_bound! by one wavefront: x (41, LDS) -> vs (44)
+__device__ inline void to_bound_wave(const double *x, const double *pos0, const OptParams &op, double *vs, int ln) {
+    if (ln < 26) {
+        double lo, hi, sc;
+        box_bounds(ln, pos0, op, lo, hi, sc);
+        vs[ln] = (1.0 / (1.0 + exp(-x[ln] / sc))) * (hi - lo) + lo;
+    } else if (ln < 29) {
+        const int g = ln - 26;
+        double p[8];
+        simplex_probs(x, g, p);
+        const int n = c_simplex_n[g];
+        const double lo = c_simplex_lo[g];
+        for (int i = 0; i < n; ++i) vs[c_simplex_b0[g] + i] = (1 - n * lo) * p[i] + lo;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // optim_step_kernel
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, const int32_t *__restrict__ active,
                   const double *__restrict__ ev_v, const double *__restrict__ ev_d, const double *__restrict__ ev_h,
                   const int32_t *__restrict__ ev_status, OptParams op, OptState *__restrict__ st,
                   double *__restrict__ Hstate, int32_t *__restrict__ next_active, int32_t *__restrict__ next_targets,
                   int32_t *__restrict__ next_count) {
-    __shared__ double sA[NJ * NJ];        // Hessian being diagonalised (column-major)
-    __shared__ double sV[NJ * NJ];        // eigenvectors
-    __shared__ double sHt[NF * NF];       // trial-point Hessian (negated, free space)
-    __shared__ double sd[CEL_P], sx[NF], sg[NF], sgt[NF], sJb[26], sHb[26], sp[3][8];
-    __shared__ double sc_[21], ss_[21];   // rotation cos / sin of the current round
-    __shared__ int spq[21][2];
-    __shared__ double sw[NJ], sqg[NJ], scv[NJ], sred[8];
-    __shared__ int s_flag[4];             // 0: accept, 1: done, 2: jacobi converged
+    __shared__ double sA[LDA * CEL_P];    // bound-space Hessian -> trial-point Hessian (negated, free space) -> solver
+    __shared__ double sd[CEL_P], sx[NF], sg[NF], sgt[NF], sJb[26], sHb[26], sp[3][8], sJs[3][8][7];
+    __shared__ double sw[NF], se[NF], sq[NF], scv[NF];
+    __shared__ double std_[NF], ste2[NF], sip[NF], smk[NF], sr[NF], sy[NF], sgt2[NF], szc[TRI_MAXC * NF], spa[NF], spb[NF];
+    __shared__ int s_flag[2];             // 0: accept, 1: done
 
     const int li = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int slot = active[li];
@@ -158,208 +538,194 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         sHb[tid] = w * s * (1 - s) * (1 - 2 * s) / (sc * sc);
     } else if (tid < 29) simplex_probs(sx, tid - 26, sp[tid - 26]);
     __syncthreads();
-    // Jacobian entry d bound_a / d free_i (0 outside the parameter's own constraint group)
-    auto jac = [&](int a, int i) -> double {
-        if (i < 26) return a == i ? sJb[i] : 0.0;
-        const int g = i < 27 ? 0 : (i < 34 ? 1 : 2);
-        const int b0 = c_simplex_b0[g], n = c_simplex_n[g], j = i - c_simplex_f0[g];
-        if (a < b0 || a >= b0 + n) return 0.0;
-        const double *p = sp[g];
-        return (1 - n * c_simplex_lo[g]) * p[a - b0] * (((a - b0) == j) - p[j]);
-    };
-    auto group_lo = [&](int i) { return i < 26 ? i : c_simplex_b0[i < 27 ? 0 : (i < 34 ? 1 : 2)]; };
-    auto group_n = [&](int i) { return i < 26 ? 1 : c_simplex_n[i < 27 ? 0 : (i < 34 ? 1 : 2)]; };
-    if (tid < NF) {
-        double s = 0;
-        const int a0 = group_lo(tid), na = group_n(tid);
-        for (int a = a0; a < a0 + na; ++a) s += jac(a, tid) * sd[a];
+    // simplex Jacobians d bound_{b0+a} / d free_{f0+j} = (1 - n lo) p_a ((a == j) - p_j)
+    for (int k = tid; k < 3 * 56; k += nthr) {
+        const int g = k / 56, r = k - g * 56, a = r / 7, j = r - a * 7;
+        const int n = c_simplex_n[g];
+        sJs[g][a][j] = (a < n && j < n - 1) ? (1 - n * c_simplex_lo[g]) * sp[g][a] * ((a == j) - sp[g][j]) : 0.0;
+    }
+    // the 44 x 44 bound-space Hessian into LDS
+    for (int k = tid; k < CEL_P * CEL_P; k += nthr) { const int b = k / CEL_P, a = k - b * CEL_P; sA[a + LDA * b] = h[k]; }
+    __syncthreads();
+    if (tid < NF) {   // gradient: J' d
+        double s;
+        if (tid < 26) s = sJb[tid] * sd[tid];
+        else {
+            const int g = tid < 27 ? 0 : (tid < 34 ? 1 : 2), j = tid - c_simplex_f0[g];
+            s = 0;
+            for (int a = 0; a < c_simplex_n[g]; ++a) s += sJs[g][a][j] * sd[c_simplex_b0[g] + a];
+        }
         sgt[tid] = -s;  // minimise -elbo
     }
-    for (int k = tid; k < NF * NF; k += nthr) {
-        const int j = k / NF, i = k - j * NF;
-        if (i > j) continue;
-        const int a0 = group_lo(i), na = group_n(i), b0 = group_lo(j), nb = group_n(j);
-        double s = 0;
-        for (int a = a0; a < a0 + na; ++a) {
-            const double ja = jac(a, i);
-            double inner = 0;
-            for (int b = b0; b < b0 + nb; ++b) inner += h[a + CEL_P * b] * jac(b, j);
-            s += ja * inner;
-        }
-        // second derivatives of the transform, contracted with the bound gradient
-        if (i < 26) { if (i == j) s += sd[i] * sHb[i]; }
-        else if (a0 == b0) {
-            const int g = i < 27 ? 0 : (i < 34 ? 1 : 2);
-            const int n = c_simplex_n[g], f0 = c_simplex_f0[g], jj = i - f0, kk = j - f0;
-            const double *p = sp[g];
-            const double scl = 1 - n * c_simplex_lo[g];
-            for (int a = 0; a < n; ++a) {
-                const double d2 = p[a] * (((a == jj) - p[jj]) * ((a == kk) - p[kk]) - p[jj] * ((jj == kk) - p[kk]));
-                s += sd[a0 + a] * scl * d2;
+    // J' H J in place, J block diagonal (26 scalars + simplex blocks 2x1, 8x7, 8x7): rows (lane = row) ...
+    if (tid < CEL_P) {
+        for (int i = 0; i < 26; ++i) sA[tid + LDA * i] *= sJb[i];
+        for (int g = 0; g < 3; ++g) {
+            const int n = c_simplex_n[g], b0 = c_simplex_b0[g], f0 = c_simplex_f0[g];
+            double hv[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) hv[b] = b < n ? sA[tid + LDA * (b0 + b)] : 0.0;
+            for (int j = 0; j < n - 1; ++j) {
+                double o = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) o += hv[b] * sJs[g][b][j];
+                sA[tid + LDA * (f0 + j)] = o;
             }
         }
-        sHt[i + NF * j] = -s; sHt[j + NF * i] = -s;
     }
+    __syncthreads();
+    // ... then columns (lane = column), plus the second derivatives of the transform contracted with the bound
+    // gradient, negated (minimise -elbo)
+    if (tid < NF) {
+        double *col = sA + LDA * tid;
+        for (int i = 0; i < 26; ++i) col[i] = -(col[i] * sJb[i]);
+        if (tid < 26) col[tid] -= sd[tid] * sHb[tid];
+        for (int g = 0; g < 3; ++g) {
+            const int n = c_simplex_n[g], b0 = c_simplex_b0[g], f0 = c_simplex_f0[g];
+            double mv[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) mv[a] = a < n ? col[b0 + a] : 0.0;
+            const int kk = tid - f0;
+            const bool own = kk >= 0 && kk < n - 1;
+            const double *pp = sp[g];
+            const double scl = 1 - n * c_simplex_lo[g];
+            for (int jj = 0; jj < n - 1; ++jj) {
+                double o = 0;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) o += sJs[g][a][jj] * mv[a];
+                if (own) {
+                    for (int a = 0; a < n; ++a) {
+                        const double d2 = pp[a] * (((a == jj) - pp[jj]) * ((a == kk) - pp[kk]) - pp[jj] * ((jj == kk) - pp[kk]));
+                        o += sd[b0 + a] * scl * d2;
+                    }
+                }
+                col[f0 + jj] = -o;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < NF) for (int i = 0; i < tid; ++i) sA[tid + LDA * i] = sA[i + LDA * tid];   // exactly symmetric
     __syncthreads();
 
     // ---- accept / reject, radius update, convergence (N&W Alg. 4.1 as in Optim.jl's NewtonTrustRegion) ----
-    if (tid == 0) {
-        const double ft = -ev_v[li];
-        int accept = 1, done = 0;
-        S.evals += 1;
-        if (ev_status[li] != CELESTE_OK) { S.status = ev_status[li]; accept = 0; done = 1; }
-        else if (S.iter >= 0) {
-            const double m = S.m;
-            double rho;
-            if (fabs(m) <= 2.220446049250313e-16) rho = 1.0;
-            else if (m > 0) rho = 0.25 - 1.0;
-            else rho = (S.f - ft) / (0 - m);
-            if (rho < 0.25) S.delta *= 0.25;
-            else if (rho > 0.75 && !S.interior) S.delta = fmin(2 * S.delta, op.delta_hat);
-            accept = rho > 0.1;
-            if (accept) {
-                double dx = 0, gmax = 0;
-                for (int i = 0; i < NF; ++i) { dx = fmax(dx, fabs(sx[i] - S.x[i])); gmax = fmax(gmax, fabs(sgt[i])); }
-                if (dx <= op.xtol_abs || fabs(ft - S.f) <= op.ftol_rel * fabs(ft) || gmax <= op.gtol) done = 1;
+    {
+        const double dxl = tid < NF ? fabs(sx[tid] - S.x[tid]) : 0.0, gl = tid < NF ? fabs(sgt[tid]) : 0.0;
+        double dx = dxl, gmax = gl;
+        for (int o = 32; o >= 1; o >>= 1) { dx = fmax(dx, __shfl_xor(dx, o, 64)); gmax = fmax(gmax, __shfl_xor(gmax, o, 64)); }
+        if (tid == 0) {
+            const double ft = -ev_v[li];
+            int accept = 1, done = 0;
+            S.evals += 1;
+            if (ev_status[li] != CELESTE_OK) { S.status = ev_status[li]; accept = 0; done = 1; }
+            else if (S.iter >= 0) {
+                const double m = S.m;
+                double rho;
+                if (fabs(m) <= 2.220446049250313e-16) rho = 1.0;
+                else if (m > 0) rho = 0.25 - 1.0;
+                else rho = (S.f - ft) / (0 - m);
+                if (rho < 0.25) S.delta *= 0.25;
+                else if (rho > 0.75 && !S.interior) S.delta = fmin(2 * S.delta, op.delta_hat);
+                accept = rho > 0.1;
+                if (accept && (dx <= op.xtol_abs || fabs(ft - S.f) <= op.ftol_rel * fabs(ft) || gmax <= op.gtol)) done = 1;
             }
+            if (accept) S.f = ft;
+            S.iter += 1;
+            if (S.iter >= op.max_iters) done = 1;
+            s_flag[0] = accept; s_flag[1] = done;
         }
-        if (accept) S.f = ft;
-        S.iter += 1;
-        if (S.iter >= op.max_iters) done = 1;
-        s_flag[0] = accept; s_flag[1] = done;
     }
     __syncthreads();
     const int accept = s_flag[0], done = s_flag[1];
     if (accept) {
         if (tid < NF) { S.x[tid] = sx[tid]; S.g[tid] = sgt[tid]; sg[tid] = sgt[tid]; }
-        for (int k = tid; k < NF * NF; k += nthr) Hs[k] = sHt[k];
+        if (!done) for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; Hs[k] = sA[(k - j * NF) + LDA * j]; }
     } else {
         if (tid < NF) { sx[tid] = S.x[tid]; sg[tid] = S.g[tid]; }
-        for (int k = tid; k < NF * NF; k += nthr) sHt[k] = Hs[k];
+        if (!done) for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hs[k]; }
     }
     __syncthreads();
     if (done) {
-        if (tid == 0) { S.done = 1; to_bound_dev(S.x, S.pos0, op, vp + (size_t)t * CEL_P); }
+        if (tid == 0) S.done = 1;
+        to_bound_wave(sx, S.pos0, op, vp + (size_t)t * CEL_P, tid);
         return;
     }
 
-    // ---- trust-region sub-problem at the accepted point: eigen-decomposition by parallel Jacobi ----
-    for (int k = tid; k < NJ * NJ; k += nthr) {
-        const int j = k / NJ, i = k - j * NJ;
-        sA[k] = (i < NF && j < NF) ? sHt[i + NF * j] : 0.0;
-        sV[k] = (i == j) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        // convergence: off-diagonal mass against the diagonal
-        double off = 0, dg = 0;
-        for (int k = tid; k < NF * NF; k += nthr) {
-            const int j = k / NF, i = k - j * NF;
-            const double a = sA[i + NJ * j];
-            if (i == j) dg += a * a; else off += a * a;
-        }
-        for (int o = 32; o >= 1; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
-        if ((tid & 63) == 0) { sred[tid >> 6] = off; sred[4 + (tid >> 6)] = dg; }
-        __syncthreads();
-        if (tid == 0) {
-            const double o = sred[0] + sred[1] + sred[2] + sred[3], d = sred[4] + sred[5] + sred[6] + sred[7];
-            s_flag[2] = (o <= 1e-30 * (o + d)) || o == 0.0;
-        }
-        __syncthreads();
-        if (s_flag[2]) break;
-        for (int r = 0; r < NJ - 1; ++r) {
-            // round-robin pairing: player 41 (the dummy) is fixed; its pair is skipped
-            if (tid < 20) {
-                const int k = tid + 1;
-                int p = (r + k) % (NJ - 1), q = (r - k + (NJ - 1)) % (NJ - 1);
-                if (p > q) { const int u = p; p = q; q = u; }
-                const double apq = sA[p + NJ * q];
-                double c = 1.0, s = 0.0;
-                if (apq != 0.0) {
-                    const double theta = (sA[q + NJ * q] - sA[p + NJ * p]) / (2 * apq);
-                    const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-                    c = 1 / sqrt(tt * tt + 1); s = tt * c;
-                }
-                sc_[tid] = c; ss_[tid] = s; spq[tid][0] = p; spq[tid][1] = q;
-            }
-            __syncthreads();
-            for (int k = tid; k < 20 * NF; k += nthr) {  // rows p, q
-                const int pr = k / NF, col = k - pr * NF;
-                const int p = spq[pr][0], q = spq[pr][1];
-                const double c = sc_[pr], s = ss_[pr];
-                const double ap = sA[p + NJ * col], aq = sA[q + NJ * col];
-                sA[p + NJ * col] = c * ap - s * aq; sA[q + NJ * col] = s * ap + c * aq;
-            }
-            __syncthreads();
-            for (int k = tid; k < 20 * NF; k += nthr) {  // columns p, q of A and of V
-                const int pr = k / NF, row = k - pr * NF;
-                const int p = spq[pr][0], q = spq[pr][1];
-                const double c = sc_[pr], s = ss_[pr];
-                const double ap = sA[row + NJ * p], aq = sA[row + NJ * q];
-                sA[row + NJ * p] = c * ap - s * aq; sA[row + NJ * q] = s * ap + c * aq;
-                const double vp_ = sV[row + NJ * p], vq = sV[row + NJ * q];
-                sV[row + NJ * p] = c * vp_ - s * vq; sV[row + NJ * q] = s * vp_ + c * vq;
-            }
+    // ---- trust-region sub-problem at the accepted point (N&W section 4.3) ----
+    const bool fr = tid < NF;
+    double step = 0.0, m = 0.0;
+    int interior = 0;
+    bool solved = false;
+    if (op.solver != 1) {
+        const TriLds L = {sA, sw, std_, se, ste2, sip, smk, sr, sy, sgt2, sq, scv, szc, spa, spb};
+        solved = tri_tr_solve(L, fr ? sg[tid] : 0.0, S.delta, tid, step, m, interior);
+        if (!solved) {   // hard case: restore H and diagonalise it
+            for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hs[k]; }
             __syncthreads();
         }
     }
-    if (tid < NF) {
-        sw[tid] = sA[tid + NJ * tid];
-        double q = 0;
-        for (int k = 0; k < NF; ++k) q += sV[k + NJ * tid] * sg[k];
-        sqg[tid] = q;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        // exact sub-problem solution in the eigenbasis (N&W section 4.3), hard case included
-        double wmin = sw[0], wmax = sw[0];
-        int imin = 0;
-        for (int i = 1; i < NF; ++i) { if (sw[i] < wmin) { wmin = sw[i]; imin = i; } wmax = fmax(wmax, sw[i]); }
+    if (!solved) {
+        eig_sym_wave(sA, sw, se, sq, tid);
+        double qg = 0.0;
+        if (fr) for (int k = 0; k < NF; ++k) qg += sA[k + LDA * tid] * sg[k];
+        const double wi = fr ? sw[tid] : 0.0;
+        // extreme eigenvalues (and the lane of the smallest)
+        double wmin = fr ? wi : INFINITY, wmax = fr ? wi : -INFINITY;
+        int imin = tid;
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double om = __shfl_xor(wmin, o, 64);
+            const int oi = __shfl_xor(imin, o, 64);
+            if (om < wmin || (om == wmin && oi < imin)) { wmin = om; imin = oi; }
+            wmax = fmax(wmax, __shfl_xor(wmax, o, 64));
+        }
         const double delta = S.delta, d2 = delta * delta;
-        int interior = 0;
+        interior = 0;
         if (wmin >= 1e-8) {
-            double p2 = 0;
-            for (int i = 0; i < NF; ++i) p2 += (sqg[i] / sw[i]) * (sqg[i] / sw[i]);
-            interior = p2 <= d2;
+            const double r = fr ? qg / wi : 0.0;
+            interior = wave_sum(r * r) <= d2;
         }
-        if (interior) {
-            for (int i = 0; i < NF; ++i) scv[i] = -sqg[i] / sw[i];
-        } else {
+        double cv;
+        if (interior) cv = fr ? -qg / wi : 0.0;
+        else {
             const double lambda_lb = -wmin + fmax(1e-8, 1e-8 * (wmax - wmin));
-            double lambda = fmax(lambda_lb, 0.0), p2 = 0;
-            for (int i = 0; i < NF; ++i) { const double r = sqg[i] / (sw[i] + lambda); p2 += r * r; }
-            if (p2 < d2) {
-                for (int i = 0; i < NF; ++i) scv[i] = -sqg[i] / (sw[i] + lambda);
-                const double tau = sqrt(d2 - p2);
-                scv[imin] += (scv[imin] >= 0 ? tau : -tau);
-            } else {
-                for (int it = 0; it < 100; ++it) {
-                    double q2 = 0, q3 = 0;
-                    for (int i = 0; i < NF; ++i) { const double r = sqg[i] / (sw[i] + lambda); q2 += r * r; q3 += r * r / (sw[i] + lambda); }
-                    const double nrm = sqrt(q2);
-                    double ln = lambda + (q2 / q3) * (nrm - delta) / delta;
-                    if (ln < lambda_lb) ln = 0.5 * (lambda + lambda_lb);
-                    const bool conv = fabs(ln - lambda) <= 1e-12 * fmax(1.0, fabs(ln));
-                    lambda = ln;
-                    if (conv) break;
+            double lambda = lambda_lb;
+            bool hard = false;
+            cv = 0.0;
+            if (wmin < 0) {
+                const bool low = fr && fabs(wi - wmin) <= 1e-10;          // eigenvalues tied with the smallest
+                if (__ballot(low && fabs(qg) > 1e-10) == 0ull) {          // g orthogonal to all their eigenvectors
+                    const double r = (fr && !low) ? qg / (wi + lambda) : 0.0;
+                    const double p2 = wave_sum(r * r);
+                    if (p2 <= d2) {   // N&W (4.45): to the boundary along the lowest eigenvector
+                        hard = true;
+                        cv = tid == imin ? sqrt(d2 - p2) : -r;
+                    }
                 }
-                for (int i = 0; i < NF; ++i) scv[i] = -sqg[i] / (sw[i] + lambda);
+            }
+            if (!hard) {
+                for (int it = 0; it < 20; ++it) {
+                    cv = fr ? -qg / (wi + lambda) : 0.0;
+                    const double q2 = wave_sum(cv * cv), q3 = wave_sum(fr ? cv * cv / (wi + lambda) : 0.0);
+                    const double prev = lambda;
+                    lambda += q2 * (sqrt(q2) - delta) / (delta * q3);
+                    if (lambda < lambda_lb) lambda = 0.5 * (prev - lambda_lb) + lambda_lb;
+                    if (fabs(lambda - prev) < 1e-10 || lambda <= prev) break;
+                }
             }
         }
-        double m = 0;
-        for (int i = 0; i < NF; ++i) m += sqg[i] * scv[i] + 0.5 * sw[i] * scv[i] * scv[i];
-        S.m = m; S.interior = interior;
+
+        m = wave_sum(fr ? qg * cv + 0.5 * wi * cv * cv : 0.0);
+        if (fr) scv[tid] = cv;
+        __syncthreads();
+        if (fr) for (int i = 0; i < NF; ++i) step += sA[tid + LDA * i] * scv[i];
     }
-    __syncthreads();
-    if (tid < NF) {
-        double s = 0;
-        for (int i = 0; i < NF; ++i) s += sV[tid + NJ * i] * scv[i];
-        const double xn = sx[tid] + s;
+    if (tid == 0) { S.m = m; S.interior = interior; }
+    if (fr) {
+        const double xn = sx[tid] + step;
         S.xt[tid] = xn; sx[tid] = xn;
     }
     __syncthreads();
+    to_bound_wave(sx, S.pos0, op, vp + (size_t)t * CEL_P, tid);   // next evaluation point
     if (tid == 0) {
-        to_bound_dev(sx, S.pos0, op, vp + (size_t)t * CEL_P);   // next evaluation point
         const int pos = atomicAdd(next_count, 1);
         next_active[pos] = slot; next_targets[pos] = t;
     }

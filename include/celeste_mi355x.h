@@ -229,6 +229,11 @@ int celeste_maximize_batch(celeste_ctx_t *ctx, double *vp, const double *vp_neig
                            int32_t n_targets, const int32_t *targets, const celeste_optim_config_t *cfg,
                            int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status);
 
+/* Diagnostics of the trust-region sub-problems solved since the last reset, summed over all contexts of the
+ * process: out[0] interior Newton steps, out[1] boundary solutions, out[2] hard cases, out[3] total and out[4]
+ * maximum number of secular-equation iterations. */
+int celeste_optim_stats(int reset, uint64_t out[5]);
+
 /* Expected light of all sources on image `image` (0-based): out[h,w] = sum_s E_G_s.v in nanomaggies, i.e.
  * elbo_vars.E_G.v - sky of the value-only add_pixel_term! sweep in bin/write_celeste_expectation.jl:112-156
  * (every source contributes on its own patch, last column and inactive pixels excluded).  out: H x W doubles,

@@ -175,7 +175,17 @@ void celeste_oracle_jacobi_eig(int n, const double *A_in, double *w, double *V) 
     free(A);
 }
 
-/* ---- trust-region sub-problem: min g's + 0.5 s'Hs, |s| <= delta (N&W section 4.3), exact in the eigenbasis */
+/* ---- trust-region sub-problem: min g's + 0.5 s'Hs, |s| <= delta.
+ * Optim.jl (third-party, not vendored under /root/reference; Celeste's REQUIRE asks for Optim >= 0.7.4) solves it
+ * in solve_tr_subproblem! of its NewtonTrustRegion method.  Restated from that published routine (N&W section
+ * 4.3, Alg. 4.3): eigen-decomposition; the unconstrained Newton step when the smallest eigenvalue is >= 1e-8 and
+ * the step fits; otherwise lambda starts at lambda_lb = -w_min + max(1e-8, 1e-8 (w_max - w_min)); the hard case
+ * only when w_min < 0 and g is orthogonal (1e-10) to every eigenvector whose eigenvalue is within 1e-10 of w_min;
+ * else Newton iterations on lambda (tolerance 1e-10, halving towards lambda_lb when the update undershoots it),
+ * the step being the one of the last factorisation.  Optim stops after max_iters = 5 such iterations whether or
+ * not they converged; here they run to convergence (<= 20; the iterates increase monotonically from the left of
+ * the root, so a non-increasing update means the rounding floor is reached).  parity unpinned: Optim's source is
+ * not available here; pinned only through the reference's recovery tolerances (test/test_optimization.jl). */
 /* returns model value m; interior flag; s */
 double celeste_oracle_solve_tr(int n, const double *g, const double *H, double delta, double *s, int *interior_out) {
     double *w = (double *)malloc(sizeof(double) * n), *V = (double *)malloc(sizeof(double) * n * n);
@@ -184,7 +194,6 @@ double celeste_oracle_solve_tr(int n, const double *g, const double *H, double d
     for (int i = 0; i < n; ++i) { double t = 0; for (int k = 0; k < n; ++k) t += V[k + n * i] * g[k]; qg[i] = t; }
     const double wmin = w[0], wmax = w[n - 1], d2 = delta * delta;
     int interior = 0;
-    double lambda = 0;
     if (wmin >= 1e-8) {
         double p2 = 0; for (int i = 0; i < n; ++i) p2 += (qg[i] / w[i]) * (qg[i] / w[i]);
         if (p2 <= d2) interior = 1;
@@ -193,26 +202,30 @@ double celeste_oracle_solve_tr(int n, const double *g, const double *H, double d
         for (int i = 0; i < n; ++i) c[i] = -qg[i] / w[i];
     } else {
         const double lambda_lb = -wmin + fmax(1e-8, 1e-8 * (wmax - wmin));
-        lambda = fmax(lambda_lb, 0.0);
-        double p2 = 0; for (int i = 0; i < n; ++i) p2 += (qg[i] / (w[i] + lambda)) * (qg[i] / (w[i] + lambda));
-        if (p2 < d2) {
-            /* hard case: even the smallest admissible ridge gives a step inside the region; move along the
-             * eigenvector of the smallest eigenvalue to the boundary (N&W (4.45)) */
-            for (int i = 0; i < n; ++i) c[i] = -qg[i] / (w[i] + lambda);
-            const double tau = sqrt(d2 - p2);
-            c[0] += (c[0] >= 0 ? tau : -tau);
-        } else {
-            for (int it = 0; it < 100; ++it) {
-                double q2 = 0, q3 = 0;
-                for (int i = 0; i < n; ++i) { const double r = qg[i] / (w[i] + lambda); q2 += r * r; q3 += r * r / (w[i] + lambda); }
-                const double nrm = sqrt(q2);
-                double upd = (q2 / q3) * (nrm - delta) / delta;   /* Newton on 1/|p| - 1/delta */
-                double ln = lambda + upd;
-                if (ln < lambda_lb) ln = 0.5 * (lambda + lambda_lb);
-                if (fabs(ln - lambda) <= 1e-12 * fmax(1.0, fabs(ln))) { lambda = ln; break; }
-                lambda = ln;
+        double lambda = lambda_lb;
+        int hard = 0;
+        if (wmin < 0) {
+            int cand = 1, idx = 0;
+            while (idx < n && fabs(w[0] - w[idx]) <= 1e-10) { if (fabs(qg[idx]) > 1e-10) { cand = 0; break; } ++idx; }
+            if (cand) {
+                double p2 = 0;
+                for (int i = idx; i < n; ++i) p2 += (qg[i] / (w[i] + lambda)) * (qg[i] / (w[i] + lambda));
+                if (p2 <= d2) {   /* N&W (4.45): to the boundary along the lowest eigenvector */
+                    hard = 1;
+                    for (int i = 0; i < n; ++i) c[i] = i < idx ? 0.0 : -qg[i] / (w[i] + lambda);
+                    c[0] = sqrt(d2 - p2);
+                }
             }
-            for (int i = 0; i < n; ++i) c[i] = -qg[i] / (w[i] + lambda);
+        }
+        if (!hard) {
+            for (int it = 0; it < 20; ++it) {
+                double q2 = 0, q3 = 0;
+                for (int i = 0; i < n; ++i) { c[i] = -qg[i] / (w[i] + lambda); q2 += c[i] * c[i]; q3 += c[i] * c[i] / (w[i] + lambda); }
+                const double prev = lambda;
+                lambda += q2 * (sqrt(q2) - delta) / (delta * q3);
+                if (lambda < lambda_lb) lambda = 0.5 * (prev - lambda_lb) + lambda_lb;
+                if (fabs(lambda - prev) < 1e-10 || lambda <= prev) break;
+            }
         }
     }
     double m = 0;

@@ -70,7 +70,7 @@ def test_trust_region_subproblem_kkt(oracle):
         g = rng.normal(size=41)
         for delta in (1e-2, 1.0, 1e2):
             s, m, interior = oracle.solve_tr(g, H, delta)
-            assert np.linalg.norm(s) <= delta * (1 + 1e-9)
+            assert np.linalg.norm(s) <= delta * (1 + 1e-7)
             assert m == pytest.approx(g @ s + 0.5 * s @ H @ s, rel=1e-9, abs=1e-9)
             if interior:
                 assert np.abs(H @ s + g).max() < 1e-8
@@ -78,7 +78,7 @@ def test_trust_region_subproblem_kkt(oracle):
                 lam = -(s @ (H @ s + g)) / (s @ s)
                 assert lam > -1e-8 and np.abs((H + lam * np.eye(41)) @ s + g).max() < 1e-6 * max(1, np.abs(g).max())
                 assert np.linalg.eigvalsh(H)[0] + lam > -1e-7
-                assert abs(np.linalg.norm(s) - delta) <= 1e-8 * delta
+                assert abs(np.linalg.norm(s) - delta) <= 1e-7 * delta
     # hard case: gradient orthogonal to the eigenvector of the smallest (negative) eigenvalue
     H = np.diag(np.concatenate([[-1.0], np.linspace(1, 3, 40)])); g = np.zeros(41); g[1:] = 0.01
     s, m, interior = oracle.solve_tr(g, H, 1.0)
