@@ -19,7 +19,11 @@
 // the secular equation by safeguarded Newton, p = Q y.  Same step as the eigen-decomposition Optim.jl uses, to
 // the tolerance of the secular solve, at a fraction of its latency (the hard case included: lowest eigenvectors
 // by inverse iteration); OptParams.solver = 1 takes the full eigen-decomposition (implicit-shift QL) instead.
-// Sub-problem rules: see oracle/celeste_optim_oracle.c (celeste_oracle_solve_tr).
+// Sub-problem rules (Optim.jl's solve_tr_subproblem!, restated; Optim is third-party and not vendored): the plain
+// Newton step when the smallest eigenvalue is >= 1e-8 and the step fits; otherwise lambda starts at
+// lambda_lb = -w_min + max(1e-8, 1e-8 (w_max - w_min)); the hard case only when w_min < 0 and g is orthogonal
+// (1e-10) to every eigenvector whose eigenvalue lies within 1e-10 of w_min; else Newton on lambda (tolerance 1e-10,
+// halving towards lambda_lb on undershoot) run to convergence, the step being the last factorisation's.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "elbo_device.h"
