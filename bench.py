@@ -220,6 +220,7 @@ def main():
                  "algorithmic_bytes_per_launch": rb, "achieved": rb / (sm[3] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": rb / (sm[3] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "stored_record_bytes": stats["record_tiles"] * 68 * 64 * 8,
+                 "traffic": (profiled_traffic_bytes() or {}).get("record_sum_bytes_per_launch"),
                  "record_write_kernel_ms": float(sm[1]), "lift_ms": float(sm[2]),
                  "note": "544 B (68 f64) per visited pixel + one 544 B result per patch; fused kernel stays the "
                          "throughput configuration"}
@@ -246,8 +247,10 @@ def main():
                          "traffic_source": (traffic or {}).get("source"),
                          "kernel": "pixel_kernel<2>", "kernel_ms": float(kms[1]),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "the path is FP64-VALU bound, not HBM- or MFMA-bound (SURVEY.md F8, DESIGN.md 4.3): "
-                                 "measured SQ_ACTIVE_INST_VALU / SIMD-cycles = 0.71 (profiles/)"},
+                         "valu_utilization": (traffic or {}).get("pixel_kernel_valu_utilization"),
+                         "note": "the fused kernel is FP64-VALU bound, not HBM- or MFMA-bound (SURVEY.md F8, DESIGN.md 4.3): "
+                                 "valu_utilization = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles from the committed PMC pass; "
+                                 "the HBM-bound kernel of the path is split_variant.kernel"},
             "kernels_ms": {"prep": float(kms[0]), "pixel": float(kms[1]), "lift": float(kms[2])},
             "pixel_visits_per_sec": pixel_visits / (kms[1] * 1e-3),
             "grad_only_sources_per_sec_rank0": S / (dt_grad / args.steps),

@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage (through gpurun): tools/profile_round.sh <tag>
 # Writes gpurun_out/<tag>/: bench.json, kernel-trace stats (csv) of the same bench command, and the
-# HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes, guide section "HBM").
+# HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes, guide section "HBM") plus one SQ pass.
+# Summarise locally afterwards with: python tools/summarize_profile.py <tag>
 TAG=${1:-r01}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
@@ -11,13 +12,8 @@ python $ROOT/bench.py --steps 30 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
-python - <<PY
-import pandas as pd, glob, json
-for f in glob.glob("$OUT/trace/*kernel_stats.csv"):
-    print(open(f).read()[:3000])
-for tag in ("fetch", "write"):
-    for f in glob.glob("$OUT/pmc_%s/*counter_collection.csv" % tag):
-        df = pd.read_csv(f)
-        print(tag, df.groupby(["Kernel_Name", "Counter_Name"]).Counter_Value.mean().to_string()[:2000])
-PY
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o sq -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq.err
+# keep the merged output small: drop the per-dispatch traces of the PMC passes' kernel-trace
+find $OUT -name "*kernel_trace.csv" -path "*pmc_*" -delete
+ls -la $OUT $OUT/trace | head -30
 cat $OUT/bench.json

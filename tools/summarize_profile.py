@@ -1,0 +1,84 @@
+"""Summarise a tools/profile_round.sh run: python tools/summarize_profile.py <tag>
+Reads gpurun_out/<tag>/, writes profiles/<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_pmc_summary.md and
+refreshes profiles/hbm_traffic.json (the `traffic` figure bench.py reports)."""
+import glob, json, os, shutil, sys
+import pandas as pd
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
+stats = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
+
+
+def short(name):
+    name = name.split("(")[0].replace("void ", "")
+    return name
+
+
+def means(sub):
+    out = {}
+    for f in glob.glob(os.path.join(src, sub, "*counter_collection.csv")):
+        df = pd.read_csv(f)
+        df["k"] = df.Kernel_Name.map(short)
+        # the bench's optimiser leg launches the same kernels on shrinking batches: keep full-batch dispatches only
+        df = df[df.Grid_Size == df.groupby("k").Grid_Size.transform("max")]
+        for (k, c), v in df.groupby(["k", "Counter_Name"]).Counter_Value.mean().items():
+            out.setdefault(k, {})[c] = float(v)
+    return out
+
+
+fetch, write, sq = means("pmc_fetch"), means("pmc_write"), means("pmc_sq")
+kt = pd.read_csv(glob.glob(os.path.join(src, "trace", "*kernel_trace.csv"))[0])
+kt["k"] = kt.Kernel_Name.map(short)
+kt["ns"] = kt.End_Timestamp - kt.Start_Timestamp
+kt = kt[kt.Grid_Size_X == kt.groupby("k").Grid_Size_X.transform("max")]
+ks = kt.groupby("k").ns.mean().reset_index().rename(columns={"ns": "AverageNs"})
+lines = ["# %s PMC summary (rocprofv3 --pmc, separate passes; per-launch means; workload = bench.py config 3)" % tag, "",
+         "Command: tools/profile_round.sh %s (FETCH_SIZE, WRITE_SIZE and SQ counters each in their own pass, "
+         "--kernel-trace only).  FETCH_SIZE / WRITE_SIZE are KiB as reported; on gfx950 FETCH_SIZE counts half the "
+         "bytes of a >= 16 B/lane coalesced streaming read (guide, HBM section), so the corrected column doubles it "
+         "for record_sum_kernel (16 B/lane loads); the pixel kernel's loads are 4-8 B/lane and stay uncorrected." % tag, "",
+         "| kernel | avg us (kernel-trace, full-batch launches) | FETCH_SIZE KiB | WRITE_SIZE KiB | fetch bytes (corrected) | write bytes |",
+         "|---|---|---|---|---|---|"]
+traffic = {}
+for k in sorted(set(fetch) | set(write)):
+    if k.startswith("at::") or k.startswith("__amd") or "elementwise" in k or "reduce_kernel" in k:
+        continue
+    f = fetch.get(k, {}).get("FETCH_SIZE", 0.0); w = write.get(k, {}).get("WRITE_SIZE", 0.0)
+    corr = 2.0 if k.startswith("record_sum_kernel") else 1.0
+    row = ks[ks.k == k]
+    avg = float(row.AverageNs.iloc[0]) / 1e3 if len(row) else float("nan")
+    lines.append("| %s | %.1f | %.0f | %.0f | %.0f | %.0f |" % (k, avg, f, w, f * 1024 * corr, w * 1024))
+    traffic[k] = {"fetch_bytes": f * 1024 * corr, "write_bytes": w * 1024, "avg_us": avg}
+lines += ["", "## SQ counters (per launch)", "", "```"]
+for k in sorted(sq):
+    if k.startswith("at::") or k.startswith("__amd") or "elementwise" in k:
+        continue
+    c = sq[k]
+    util = c.get("SQ_ACTIVE_INST_VALU", 0) / max(c.get("SQ_BUSY_CYCLES", 1) * 4.0 / 1.0, 1)
+    lines.append("%-28s %s" % (k, {n: round(v) for n, v in c.items()}))
+lines += ["```", ""]
+pk = sq.get("pixel_kernel<2, double>", {})
+valu_util = None
+if pk:
+    simd_cycles = pk["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+    valu_util = pk["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
+    lines += ["## Reading (pixel_kernel<2>, one launch = one sweep of the bench field)", "",
+              "* GRBM_GUI_ACTIVE / 8 XCDs = %.3g cycles; x 1024 SIMDs = %.3g SIMD-cycles." % (pk["GRBM_GUI_ACTIVE"] / 8, simd_cycles),
+              "* SQ_ACTIVE_INST_VALU = %.3g quad-cycles -> **%.0f %% of all SIMD issue cycles are VALU** (FP64-bound)."
+              % (pk["SQ_ACTIVE_INST_VALU"], 100 * valu_util),
+              "* SQ_WAVE_CYCLES / SIMD-cycles = %.2f resident waves per SIMD." % (pk["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles), ""]
+open(os.path.join(dst, tag + "_pmc_summary.md"), "w").write("\n".join(lines))
+px = traffic.get("pixel_kernel<2, double>", {})
+rs = traffic.get("record_sum_kernel", {})
+json.dump({"pixel_kernel_bytes_per_launch": px.get("fetch_bytes", 0) + px.get("write_bytes", 0),
+           "fetch_bytes": px.get("fetch_bytes"), "write_bytes": px.get("write_bytes"),
+           "record_sum_bytes_per_launch": (rs.get("fetch_bytes", 0) + rs.get("write_bytes", 0)) or None,
+           "pixel_kernel_valu_utilization": valu_util,
+           "source": "profiles/%s_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KiB x 1024; "
+                     "record_sum FETCH_SIZE doubled per the gfx950 16 B/lane correction, pixel kernel uncorrected)" % tag},
+          open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+print("\n".join(lines))
