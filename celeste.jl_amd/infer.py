@@ -15,12 +15,13 @@ sources of one component are optimised one after another.  On the GPU the j-th s
 batch form one launch ("layer"): no two of them are neighbours, so optimising them simultaneously is exactly
 the reference's schedule.
 """
-from typing import List, Optional, Sequence
+from typing import Callable, List, Optional, Sequence
 
 import numpy as np
 
 from .elbo import ElboConfig, FieldContext
 from .params import catalog_init_source, generic_init_source
+from .parallel import sharded_maximize
 from .partition import partition_cyclades_dynamic
 
 NUM_JOINT_VI_ITERS = 3   # Config.num_joint_vi_iters (src/config.jl:17-25)
@@ -37,15 +38,18 @@ def one_node_single_infer(ctx: FieldContext, catalog, target_sources: Sequence[i
     return new[list(target_sources)]
 
 
-def one_node_joint_infer(ctx: FieldContext, catalog, target_sources: Sequence[int], neighbors: List[List[int]],
-                         cfg: Optional[ElboConfig] = None, batch_size: int = 400, n_iters: int = NUM_JOINT_VI_ITERS,
-                         rng: Optional[np.random.Generator] = None) -> np.ndarray:
-    """Cyclades-batched joint inference; returns the optimised parameters, one row per target."""
-    targets = list(target_sources)
+def joint_infer_sweeps(maximize_layer: Callable, vp: np.ndarray, targets: Sequence[int], neighbors: List[List[int]],
+                       batch_size: int = 400, n_iters: int = NUM_JOINT_VI_ITERS,
+                       rng: Optional[np.random.Generator] = None, rank: int = 0, world: int = 1,
+                       costs: Optional[Sequence[float]] = None, all_gather: Optional[Callable] = None) -> np.ndarray:
+    """The joint-inference schedule, independent of who optimises a layer.
+
+    maximize_layer(vp, layer, pos_centers) -> [len(layer), 44] optimises the sources of `layer` (no two of them are
+    neighbours) against the shared table `vp` and returns their new rows.  With world > 1 every rank holds the
+    whole table, optimises its cost-balanced shard of each layer and the updated rows are all-gathered (352 B per
+    target and layer: SURVEY.md 8(e)) -- the only exchange of the path.  vp is updated in place and returned."""
+    targets = list(targets)
     tset = set(targets)
-    vp = np.stack([catalog_init_source(ce) for ce in catalog])
-    for t in targets:
-        vp[t] = generic_init_source(catalog[t].pos)
     centers = {t: vp[t, 0:2].copy() for t in targets}        # boxes stay at the initial positions
     nmap = {t: [n for n in neighbors[t] if n in tset] for t in targets}
     batches = partition_cyclades_dynamic(targets, nmap, batch_size=batch_size,
@@ -55,6 +59,31 @@ def one_node_joint_infer(ctx: FieldContext, catalog, target_sources: Sequence[in
             depth = max(len(c) for c in components)
             for j in range(depth):
                 layer = [targets[c[j]] for c in components if len(c) > j]
-                pc = np.stack([centers[t] for t in layer])
-                vp, _, _, _, st = ctx.maximize_batch(vp, layer, cfg, pos_centers=pc)
+
+                def run(local):
+                    pc = np.stack([centers[t] for t in local])
+                    return maximize_layer(vp, list(local), pc)
+                if world == 1:
+                    vp[layer] = run(layer)
+                else:
+                    lc = [1.0 if costs is None else costs[t] for t in layer]
+                    vp[layer] = sharded_maximize(run, layer, lc, rank, world, all_gather)
+    return vp
+
+
+def one_node_joint_infer(ctx: FieldContext, catalog, target_sources: Sequence[int], neighbors: List[List[int]],
+                         cfg: Optional[ElboConfig] = None, batch_size: int = 400, n_iters: int = NUM_JOINT_VI_ITERS,
+                         rng: Optional[np.random.Generator] = None, rank: int = 0, world: int = 1,
+                         costs: Optional[Sequence[float]] = None, all_gather: Optional[Callable] = None) -> np.ndarray:
+    """Cyclades-batched joint inference; returns the optimised parameters, one row per target.  rank / world > 1:
+    one process per GPU, images replicated (every rank builds the same FieldContext), layers sharded."""
+    targets = list(target_sources)
+    vp = np.stack([catalog_init_source(ce) for ce in catalog])
+    for t in targets:
+        vp[t] = generic_init_source(catalog[t].pos)
+
+    def maximize_layer(table, layer, pc):
+        return ctx.maximize_batch(table, layer, cfg, pos_centers=pc)[0][layer]
+    vp = joint_infer_sweeps(maximize_layer, vp, targets, neighbors, batch_size, n_iters, rng, rank, world, costs,
+                            all_gather)
     return vp[targets]

@@ -9,6 +9,23 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+JOINT_TARGETS = [0, 3, 5, 8, 13, 21]
+
+
+def _joint(f, pb, oracle, rank, world, costs):
+    from celeste_jl_amd.infer import joint_infer_sweeps
+
+    def maximize_layer(vp, layer, pc):
+        rows = []
+        for t, c in zip(layer, pc):   # first sweep: the position boxes are centred on the current positions
+            assert np.array_equal(c, vp[t, 0:2])
+            rows.append(oracle.maximize(pb, vp, t, oracle.OptCfg(max_iters=2))[0][t])
+        return np.stack(rows)
+    vp = f.vp.copy()
+    return joint_infer_sweeps(maximize_layer, vp, JOINT_TARGETS, f.neighbors, batch_size=3, n_iters=1,
+                              rng=np.random.default_rng(5), rank=rank, world=world, costs=costs)[JOINT_TARGETS]
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -38,7 +55,10 @@ def _worker(rank, world, port, out_dir):
         return np.stack([oracle.maximize(pb, f.vp, t, oracle.OptCfg(max_iters=2))[0][t] for t in tg])
 
     vs = sharded_maximize(maximize, opt_targets, [costs[t] for t in opt_targets], rank, world)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), v=v, d=d, vs=vs)
+    # joint inference: every layer of every Cyclades batch is sharded, updated rows all-gathered per layer
+    from celeste_jl_amd.infer import joint_infer_sweeps
+    vj = _joint(f, pb, oracle, rank, world, costs)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), v=v, d=d, vs=vs, vj=vj)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,3 +76,9 @@ def test_two_rank_sweep_equals_single_rank(tmp_path, oracle):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         assert np.array_equal(z["v"], v) and np.array_equal(z["d"], d)
         assert np.array_equal(z["vs"], vs)
+    from celeste_jl_amd.partition import estimate_time
+    vj = _joint(f, pb, oracle, 0, 1, [estimate_time(row) for row in f.patches])
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert np.array_equal(z["vj"], vj)
+    assert not np.array_equal(vj, f.vp[JOINT_TARGETS])
