@@ -651,11 +651,12 @@ static void calculate_G_s(const double *vs, ElboVars *ev, const SourceBrightness
     }
 }
 
-/* add_sources_sf! for Sa = 1 (SensitiveFloats.jl:215-250) */
-static void add_sources_sf(SF *all, const SF *s, int has_grad, int has_hess) {
+/* add_sources_sf! (SensitiveFloats.jl:215-250): the single-source SF goes into block `sa` of the all-sources SF */
+static void add_sources_sf(SF *all, const SF *s, int sa, int has_grad, int has_hess) {
     all->v += s->v;
-    if (has_grad) for (int k = 0; k < P; ++k) all->d[k] = all->d[k] + s->d[k];
-    if (has_hess) for (int k = 0; k < P * P; ++k) all->h[k] += s->h[k];
+    const int o = P * sa;
+    if (has_grad) for (int k = 0; k < P; ++k) all->d[o + k] = all->d[o + k] + s->d[k];
+    if (has_hess) for (int j = 0; j < P; ++j) for (int i = 0; i < P; ++i) H_(all, o + i, o + j) += s->h[i + P * j];
 }
 
 /* add_elbo_log_term! (elbo_objective.jl:274-327) */
@@ -669,15 +670,17 @@ static void add_elbo_log_term(ElboVars *ev, float x_nbm, float iota) {
     double g_d[2] = {-0.5 / (E * E), 1 / E + V / (E * E * E)};
     double g_h[4] = {0, 1 / (E * E * E), 1 / (E * E * E), -(1 / (E * E) + 3 * V / (E * E * E * E))};
     combine_sfs(&ev->var_G, &ev->E_G, &ev->elbo_log_term, log_term, g_d, g_h, 1, ev->has_hess);
-    for (int k = 0; k < P; ++k) ev->elbo.d[k] += (double)x_nbm * ev->elbo_log_term.d[k];
-    if (ev->has_hess) for (int k = 0; k < P * P; ++k) ev->elbo.h[k] += (double)x_nbm * ev->elbo_log_term.h[k];
+    const int pt = ev->elbo.p;
+    for (int k = 0; k < pt; ++k) ev->elbo.d[k] += (double)x_nbm * ev->elbo_log_term.d[k];
+    if (ev->has_hess) for (int k = 0; k < pt * pt; ++k) ev->elbo.h[k] += (double)x_nbm * ev->elbo_log_term.h[k];
 }
 
 /* add_scaled_sfs! (SensitiveFloats.jl:185-208) */
 static void add_scaled_sfs(SF *a, const SF *b, double scale, int has_grad, int has_hess) {
     a->v += scale * b->v;
-    if (has_grad) for (int k = 0; k < P; ++k) a->d[k] += scale * b->d[k];
-    if (has_hess) for (int i2 = 0; i2 < P; ++i2) for (int i1 = 0; i1 <= i2; ++i1) {
+    const int pt = a->p;
+    if (has_grad) for (int k = 0; k < pt; ++k) a->d[k] += scale * b->d[k];
+    if (has_hess) for (int i2 = 0; i2 < pt; ++i2) for (int i1 = 0; i1 <= i2; ++i1) {
         H_(a, i1, i2) += scale * H_(b, i1, i2);
         H_(a, i2, i1) = H_(a, i1, i2);
     }
@@ -816,22 +819,37 @@ double celeste_oracle_psf_at_point(const double *psf, int K, double row, double 
     return s;
 }
 
-/* ---- elbo_likelihood + elbo for Sa = 1 (elbo_objective.jl:400-492) ---------- */
+/* ---- elbo_likelihood + elbo (elbo_objective.jl:400-492) ---------------------- */
 /* coefs_all: n_stamps x 53 x 53 spline coefficients (ImagePatch.itp_psf is built
- * once per patch at construction time, not per elbo() call) */
-static int oracle_elbo_impl(const celeste_problem_t *pr, const double *coefs_all, const double *vp, int32_t target,
-                            uint32_t flags, double *v, double *d, double *h, int64_t *n_active_px,
-                            int64_t *n_inactive_px) {
-    if (!pr || !vp || target < 0 || target >= pr->n_sources) return CELESTE_ERR_INVALID_ARG;
+ * once per patch at construction time, not per elbo() call).
+ * active[0..Sa-1]: ElboArgs.active_sources.  The local source list (ElboArgs.S) is the active sources followed by
+ * every neighbour of an active source that is not itself active.  d: P x Sa, h: (P Sa) x (P Sa), col-major. */
+static int oracle_elbo_multi(const celeste_problem_t *pr, const double *coefs_all, const double *vp, int Sa,
+                             const int32_t *active_src, uint32_t flags, double *v, double *d, double *h,
+                             int64_t *n_active_px, int64_t *n_inactive_px) {
+    if (!pr || !vp || Sa < 1 || !active_src) return CELESTE_ERR_INVALID_ARG;
+    for (int a = 0; a < Sa; ++a) {
+        if (active_src[a] < 0 || active_src[a] >= pr->n_sources) return CELESTE_ERR_INVALID_ARG;
+        for (int a2 = 0; a2 < a; ++a2) if (active_src[a2] == active_src[a]) return CELESTE_ERR_INVALID_ARG;
+    }
     const int N = pr->n_images, K = pr->psf_K;
     const int has_hess = (flags & CELESTE_FLAG_HESS) != 0;
     const int has_grad = has_hess || (flags & CELESTE_FLAG_GRAD) != 0;
-    /* local source list: [target; neighbors] */
-    int64_t nb0 = pr->nbr_offsets ? pr->nbr_offsets[target] : 0, nb1 = pr->nbr_offsets ? pr->nbr_offsets[target + 1] : 0;
-    int S = 1 + (int)(nb1 - nb0);
-    int *src = (int *)malloc(sizeof(int) * S);
-    src[0] = target;
-    for (int q = 1; q < S; ++q) src[q] = pr->nbr_index[nb0 + q - 1];
+    const int PT = P * Sa;
+    /* local source list: [active...; neighbours of the active sources] */
+    int cap = Sa;
+    for (int a = 0; a < Sa; ++a)
+        if (pr->nbr_offsets) cap += (int)(pr->nbr_offsets[active_src[a] + 1] - pr->nbr_offsets[active_src[a]]);
+    int *src = (int *)malloc(sizeof(int) * cap);
+    int S = 0;
+    for (int a = 0; a < Sa; ++a) src[S++] = active_src[a];
+    for (int a = 0; a < Sa && pr->nbr_offsets; ++a)
+        for (int64_t q = pr->nbr_offsets[active_src[a]]; q < pr->nbr_offsets[active_src[a] + 1]; ++q) {
+            const int c = pr->nbr_index[q];
+            int seen = 0;
+            for (int k = 0; k < S; ++k) if (src[k] == c) { seen = 1; break; }
+            if (!seen) src[S++] = c;
+        }
     for (int q = 0; q < S; ++q) for (int k = 0; k < P; ++k)
         if (!isfinite(vp[(size_t)src[q] * P + k])) { free(src); return CELESTE_ERR_NONFINITE_INPUT; }
 
@@ -839,10 +857,10 @@ static int oracle_elbo_impl(const celeste_problem_t *pr, const double *coefs_all
     ev.has_grad = has_grad; ev.has_hess = has_hess;
     ev.fs0m = sf_new(2); ev.fs1m = sf_new(6);
     ev.E_G_s = sf_new(P); ev.E_G2_s = sf_new(P); ev.var_G_s = sf_new(P);
-    ev.E_G = sf_new(P); ev.var_G = sf_new(P); ev.elbo_log_term = sf_new(P); ev.elbo = sf_new(P);
+    ev.E_G = sf_new(PT); ev.var_G = sf_new(PT); ev.elbo_log_term = sf_new(PT); ev.elbo = sf_new(PT);
 
     SourceBrightness *sbs = (SourceBrightness *)malloc(sizeof(SourceBrightness) * S);
-    for (int q = 0; q < S; ++q) sb_load(&sbs[q], vp + (size_t)src[q] * P, q == 0 && has_grad);
+    for (int q = 0; q < S; ++q) sb_load(&sbs[q], vp + (size_t)src[q] * P, q < Sa && has_grad);
     GalComp *mcs = (GalComp *)malloc(sizeof(GalComp) * S * K * 16);
     const double **coefs = (const double **)malloc(sizeof(double *) * S);
     BvnDerivs bd; memset(&bd, 0, sizeof bd);
@@ -853,13 +871,21 @@ static int oracle_elbo_impl(const celeste_problem_t *pr, const double *coefs_all
         for (int q = 0; q < S; ++q) {
             const celeste_patch_t *p = &pr->patches[(size_t)src[q] * N + n];
             load_bvn_mixtures_source(mcs + (size_t)q * K * 16, p, K, vp + (size_t)src[q] * P,
-                                     has_grad && q == 0, has_hess);
+                                     has_grad && q < Sa, has_hess);
             coefs[q] = coefs_all + (size_t)p->stamp * 53 * 53;
         }
-        const celeste_patch_t *pa = &pr->patches[(size_t)target * N + n];
+        /* pixels of several active patches are visited once (elbo_objective.jl:430-470) */
+        unsigned char *visited = Sa > 1 ? (unsigned char *)calloc((size_t)img->H * img->W, 1) : NULL;
+        for (int sa = 0; sa < Sa; ++sa) {
+        const celeste_patch_t *pa = &pr->patches[(size_t)src[sa] * N + n];
         for (int w2 = 1; w2 <= pa->W2; ++w2) for (int h2 = 1; h2 <= pa->H2; ++h2) {
             int hh = pa->off_h + h2, ww = pa->off_w + w2; /* 1-based image coords */
             if (!patch_bitmap(pr, n, pa, h2, w2)) continue;
+            if (visited) {
+                unsigned char *vis = &visited[(hh - 1) + (size_t)img->H * (ww - 1)];
+                if (*vis) continue;
+                *vis = 1;
+            }
             float x_nbm = img->pixels[(hh - 1) + (size_t)img->H * (ww - 1)];
             if (isnan(x_nbm)) continue;
             /* add_pixel_term! (elbo_objective.jl:330-392) */
@@ -869,7 +895,7 @@ static int oracle_elbo_impl(const celeste_problem_t *pr, const double *coefs_all
                 int ph2 = hh - p->off_h, pw2 = ww - p->off_w;
                 if (!(1 <= ph2 && ph2 <= p->H2 && 1 <= pw2 && pw2 < p->W2)) continue;
                 if (!patch_bitmap(pr, n, p, ph2, pw2)) continue;
-                int active = (q == 0);
+                int active = (q < Sa);
                 if (active) ev.active_px++; else ev.inactive_px++;
                 const double *vs = vp + (size_t)src[q] * P;
                 star_light_density(&ev.fs0m, p, coefs[q], hh, ww, vs + ID_POS, active, has_grad, has_hess);
@@ -877,8 +903,8 @@ static int oracle_elbo_impl(const celeste_problem_t *pr, const double *coefs_all
                 /* accumulate_source_pixel_brightness! (elbo_objective.jl:240-259) */
                 calculate_G_s(vs, &ev, &sbs[q], b, active);
                 if (active) {
-                    add_sources_sf(&ev.E_G, &ev.E_G_s, has_grad, has_hess);
-                    add_sources_sf(&ev.var_G, &ev.var_G_s, has_grad, has_hess);
+                    add_sources_sf(&ev.E_G, &ev.E_G_s, q, has_grad, has_hess);
+                    add_sources_sf(&ev.var_G, &ev.var_G_s, q, has_grad, has_hess);
                 } else { ev.E_G.v += ev.E_G_s.v; ev.var_G.v += ev.var_G_s.v; }
             }
             ev.E_G.v += (double)img->sky[(hh - 1) + (size_t)img->H * (ww - 1)];
@@ -887,22 +913,26 @@ static int oracle_elbo_impl(const celeste_problem_t *pr, const double *coefs_all
             add_scaled_sfs(&ev.elbo, &ev.E_G, -(double)iota, has_grad, has_hess);
             ev.elbo.v -= lgamma((double)x_nbm + 1.0);
         }
+        }
+        free(visited);
     }
     if (flags & CELESTE_FLAG_KL) { /* subtract_kl_all_sources! (elbo_kl.jl:214-225) */
         double kv; double *kd = (double *)malloc(sizeof(double) * P), *kh = (double *)malloc(sizeof(double) * P * P);
-        celeste_oracle_subtract_kl(pr->prior, vp + (size_t)target * P, &kv, kd, kh);
-        ev.elbo.v += kv;
-        if (has_grad) for (int k = 0; k < P; ++k) ev.elbo.d[k] += kd[k];
-        if (has_hess) for (int k = 0; k < P * P; ++k) ev.elbo.h[k] += kh[k];
+        for (int sa = 0; sa < Sa; ++sa) {
+            celeste_oracle_subtract_kl(pr->prior, vp + (size_t)src[sa] * P, &kv, kd, kh);
+            ev.elbo.v += kv;
+            if (has_grad) for (int k = 0; k < P; ++k) ev.elbo.d[P * sa + k] += kd[k];
+            if (has_hess) for (int j = 0; j < P; ++j) for (int i = 0; i < P; ++i) H_(&ev.elbo, P * sa + i, P * sa + j) += kh[i + P * j];
+        }
         free(kd); free(kh);
     }
     int status = CELESTE_OK;
     if (!isfinite(ev.elbo.v)) status = CELESTE_ERR_NONFINITE_RESULT;
-    if (has_grad) for (int k = 0; k < P; ++k) if (!isfinite(ev.elbo.d[k])) status = CELESTE_ERR_NONFINITE_RESULT;
-    if (has_hess) for (int k = 0; k < P * P; ++k) if (!isfinite(ev.elbo.h[k])) status = CELESTE_ERR_NONFINITE_RESULT;
+    if (has_grad) for (int k = 0; k < PT; ++k) if (!isfinite(ev.elbo.d[k])) status = CELESTE_ERR_NONFINITE_RESULT;
+    if (has_hess) for (int k = 0; k < PT * PT; ++k) if (!isfinite(ev.elbo.h[k])) status = CELESTE_ERR_NONFINITE_RESULT;
     if (v) *v = ev.elbo.v;
-    if (d && has_grad) memcpy(d, ev.elbo.d, sizeof(double) * P);
-    if (h && has_hess) memcpy(h, ev.elbo.h, sizeof(double) * P * P);
+    if (d && has_grad) memcpy(d, ev.elbo.d, sizeof(double) * PT);
+    if (h && has_hess) memcpy(h, ev.elbo.h, sizeof(double) * PT * PT);
     if (n_active_px) *n_active_px = ev.active_px;
     if (n_inactive_px) *n_inactive_px = ev.inactive_px;
 
@@ -911,6 +941,13 @@ static int oracle_elbo_impl(const celeste_problem_t *pr, const double *coefs_all
     sf_free(&ev.fs0m); sf_free(&ev.fs1m); sf_free(&ev.E_G_s); sf_free(&ev.E_G2_s); sf_free(&ev.var_G_s);
     sf_free(&ev.E_G); sf_free(&ev.var_G); sf_free(&ev.elbo_log_term); sf_free(&ev.elbo);
     return status;
+}
+
+static int oracle_elbo_impl(const celeste_problem_t *pr, const double *coefs_all, const double *vp, int32_t target,
+                            uint32_t flags, double *v, double *d, double *h, int64_t *n_active_px,
+                            int64_t *n_inactive_px) {
+    if (!pr || !vp || target < 0 || target >= pr->n_sources) return CELESTE_ERR_INVALID_ARG;
+    return oracle_elbo_multi(pr, coefs_all, vp, 1, &target, flags, v, d, h, n_active_px, n_inactive_px);
 }
 
 static double *all_coefs(const celeste_problem_t *pr) {
@@ -924,6 +961,17 @@ int celeste_oracle_elbo(const celeste_problem_t *pr, const double *vp, int32_t t
     if (!pr) return CELESTE_ERR_INVALID_ARG;
     double *c = all_coefs(pr);
     int st = oracle_elbo_impl(pr, c, vp, target, flags, v, d, h, n_active_px, n_inactive_px);
+    free(c);
+    return st;
+}
+
+/* elbo() with several active sources (ElboArgs.active_sources, Sa >= 1): d is P x Sa, h (P Sa) x (P Sa) */
+int celeste_oracle_elbo_multi(const celeste_problem_t *pr, const double *vp, int32_t n_active, const int32_t *active,
+                              uint32_t flags, double *v, double *d, double *h, int64_t *n_active_px,
+                              int64_t *n_inactive_px) {
+    if (!pr) return CELESTE_ERR_INVALID_ARG;
+    double *c = all_coefs(pr);
+    int st = oracle_elbo_multi(pr, c, vp, n_active, active, flags, v, d, h, n_active_px, n_inactive_px);
     free(c);
     return st;
 }

@@ -53,6 +53,8 @@ def lib() -> C.CDLL:
         L.celeste_oracle_elbo.argtypes = [C.POINTER(cabi.ProblemT), dp, C.c_int32, C.c_uint32, dp, dp, dp, lp, lp]
         L.celeste_oracle_elbo_batch.argtypes = [C.POINTER(cabi.ProblemT), dp, C.c_int32, ip, C.c_uint32, dp, dp, dp,
                                                 lp, ip, C.c_int32]
+        L.celeste_oracle_elbo_multi.argtypes = [C.POINTER(cabi.ProblemT), dp, C.c_int32, ip, C.c_uint32,
+                                                C.POINTER(C.c_double), dp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.celeste_oracle_get_bvn_cov.argtypes = [C.c_double, C.c_double, C.c_double, dp]
         L.celeste_oracle_get_bvn_cov.restype = None
         L.celeste_oracle_source_brightness.argtypes = [dp, dp, dp]
@@ -104,6 +106,19 @@ def elbo_batch(problem: "cabi.Problem", vp, targets, flags=cabi.FLAG_GRAD | cabi
                                 status.ctypes.data_as(cabi.c_int32_p), n_threads)
     # h is column-major per target and symmetric (upper triangle mirrored)
     return v, d, h.transpose(0, 2, 1).copy(), cnt, status
+
+
+def elbo_multi(problem, vp, active, flags=cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL):
+    """elbo() with the active sources `active` (ElboArgs.active_sources, in that order).
+    Returns (v, d [Sa, 44], h [44 Sa, 44 Sa], counters[2], status)."""
+    vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(problem.n_sources, P))
+    act = np.ascontiguousarray(np.asarray(active, dtype=np.int32))
+    sa = act.size
+    v = C.c_double(); d = np.zeros(sa * P); h = np.zeros((sa * P, sa * P))
+    na = C.c_int64(); ni = C.c_int64()
+    st = lib().celeste_oracle_elbo_multi(C.byref(problem.c), _dp(vp), sa, act.ctypes.data_as(cabi.c_int32_p), flags,
+                                         C.byref(v), _dp(d), _dp(h), C.byref(na), C.byref(ni))
+    return v.value, d.reshape(sa, P), h.T.copy(), np.array([na.value, ni.value]), int(st)
 
 
 def elbo_one(problem, vp, target, flags=cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL):

@@ -18,10 +18,36 @@ def expected_planes(images, patches, vp):
 
 
 def joint_objective(images, patches, vp, active, planes=None):
+    with torch.no_grad():
+        return float(joint_objective_tensor(images, patches, torch.tensor(np.asarray(vp), dtype=DT), active, planes))
+
+
+def joint_value_grad_hess(images, patches, vp, active, include_kl=True):
+    """elbo() with the active sources `active` (in that order): value, d [Sa, 44], h [44 Sa, 44 Sa] by autograd"""
     vp = torch.tensor(np.asarray(vp), dtype=DT)
+    active = list(active)
+    theta0 = torch.cat([vp[a] for a in active]).clone().requires_grad_(True)
+
+    def f(theta):
+        rows = [vp[s] for s in range(vp.shape[0])]
+        for k, a in enumerate(active):
+            rows[a] = theta[44 * k:44 * (k + 1)]
+        val = joint_objective_tensor(images, patches, torch.stack(rows), set(active))
+        if include_kl:
+            prior = tvm.load_prior()
+            for k in range(len(active)):
+                val = val + tvm.neg_kl(theta[44 * k:44 * (k + 1)], prior)
+        return val
+    v = f(theta0)
+    g, = torch.autograd.grad(v, theta0, create_graph=True)
+    H = torch.stack([torch.autograd.grad(g[i], theta0, retain_graph=True)[0] for i in range(theta0.numel())])
+    return v.item(), g.detach().numpy().reshape(len(active), 44), H.detach().numpy()
+
+
+def joint_objective_tensor(images, patches, vp, active, planes=None):
     total = 0.0
     S = len(patches)
-    with torch.no_grad():
+    if True:
         for n, img in enumerate(images):
             H, W = img.pixels.shape
             E = torch.tensor(img.sky.astype(np.float64))
@@ -52,10 +78,11 @@ def joint_objective(images, patches, vp, active, planes=None):
                     Es = Es + vs[26 + i] * El * fi
                     E2s = E2s + vs[26 + i] * Ell * fi * fi
                 cov = bm[:, :W2 - 1].to(DT)
-                E[h0:h0 + H2, w0:w0 + W2 - 1] += cov * Es
-                V[h0:h0 + H2, w0:w0 + W2 - 1] += cov * (E2s - Es * Es)
+                pad = (w0, W - (w0 + W2 - 1), h0, H - (h0 + H2))
+                E = E + torch.nn.functional.pad(cov * Es, pad)
+                V = V + torch.nn.functional.pad(cov * (E2s - Es * Es), pad)
             if planes is not None:
-                planes.append((E - torch.tensor(img.sky.astype(np.float64))).numpy())
+                planes.append((E - torch.tensor(img.sky.astype(np.float64))).detach().numpy())
             x = torch.tensor(img.pixels.astype(np.float64))
             visit &= ~torch.isnan(x)
             x = torch.nan_to_num(x)
@@ -63,5 +90,5 @@ def joint_objective(images, patches, vp, active, planes=None):
             iota = torch.tensor(iota32.astype(np.float64))[:, None]
             log_iota = torch.tensor(np.log(iota32.astype(np.float64)).astype(np.float32).astype(np.float64))[:, None]
             term = x * (log_iota + torch.log(E) - V / (2 * E * E)) - iota * E - torch.lgamma(x + 1)
-            total += float((term * visit.to(DT)).sum())
+            total = total + (term * visit.to(DT)).sum()
     return total

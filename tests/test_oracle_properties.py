@@ -124,3 +124,50 @@ def test_nonfinite_input_status(oracle):
     pb = cabi.Problem(f.images, f.patches, f.neighbors)
     vp = f.vp.copy(); vp[1, 3] = np.inf
     assert oracle.elbo_one(pb, vp, 0)[4] == cabi.ERR_NONFINITE_INPUT
+
+
+# ---- several active sources (ElboArgs.active_sources with Sa > 1) ----------------------------------------------
+
+def _two_body():
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_sample_dataset("two_body")
+    # every other source is a neighbour (ElboArgs: all S local sources contribute to any pixel they cover)
+    nb = [[1], [0]]
+    return f, cabi.Problem(f.images, f.patches, nb)
+
+
+def test_multi_active_matches_autograd(oracle):
+    """Sa = 2: value, both gradient columns and the full 88 x 88 Hessian (diagonal and cross blocks) against
+    torch.autograd of the independently written joint objective"""
+    from joint_objective import joint_value_grad_hess
+    f, pb = _two_body()
+    v, d, h, cnt, st = oracle.elbo_multi(pb, f.vp, [0, 1])
+    assert st == 0
+    tv, td, th = joint_value_grad_hess(f.images, f.patches, f.vp, [0, 1])
+    assert abs(v - tv) <= 1e-12 * abs(tv)
+    assert np.abs(d - td).max() <= 1e-10 * np.abs(td).max()
+    assert np.abs(h - th).max() <= 1e-10 * np.abs(th).max()
+    assert np.abs(h[:44, 44:]).max() > 0 and np.allclose(h, h.T, rtol=1e-12, atol=1e-9 * np.abs(h).max())
+
+
+def test_multi_active_swap_invariance_and_single_source_blocks(oracle):
+    """test_elbo.jl:107-129: swapping the two active sources permutes d and h; the diagonal blocks and gradient
+    columns are those of the single-active-source evaluations; an inactive second source has no derivatives"""
+    f, pb = _two_body()
+    v01, d01, h01, c01, _ = oracle.elbo_multi(pb, f.vp, [0, 1])
+    v10, d10, h10, c10, _ = oracle.elbo_multi(pb, f.vp, [1, 0])
+    assert abs(v01 - v10) <= 1e-13 * abs(v01) and np.array_equal(c01, c10)
+    assert np.allclose(d01[0], d10[1], rtol=1e-12, atol=0) and np.allclose(d01[1], d10[0], rtol=1e-12, atol=0)
+    sc = np.abs(h01).max()
+    assert np.abs(h01[:44, :44] - h10[44:, 44:]).max() <= 1e-12 * sc
+    assert np.abs(h01[:44, 44:] - h10[44:, :44]).max() <= 1e-12 * sc
+    for k, t in enumerate((0, 1)):
+        v1, d1, h1, _, _ = oracle.elbo_one(pb, f.vp, t)
+        assert np.allclose(d1, d01[k], rtol=1e-11, atol=1e-9 * np.abs(d1).max())
+        assert np.abs(h1 - h01[44 * k:44 * (k + 1), 44 * k:44 * (k + 1)]).max() <= 1e-11 * np.abs(h1).max()
+    # the joint value visits the union of the two patches once
+    from joint_objective import joint_objective
+    from torch_value_model import neg_kl, load_prior
+    import torch
+    kl = sum(float(neg_kl(torch.tensor(f.vp[t]), load_prior())) for t in (0, 1))
+    assert v01 == pytest.approx(joint_objective(f.images, f.patches, f.vp, {0, 1}) + kl, rel=1e-12)
