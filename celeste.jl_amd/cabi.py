@@ -73,7 +73,7 @@ class CelesteError(RuntimeError):
 # every symbol include/celeste_mi355x.h declares
 EXPORTED_SYMBOLS = [
     "celeste_version", "celeste_strerror", "celeste_ctx_create", "celeste_ctx_destroy", "celeste_elbo_eval",
-    "celeste_elbo_eval_batch", "celeste_elbo_eval_batch_device", "celeste_ctx_enable_timing",
+    "celeste_elbo_eval_batch", "celeste_elbo_eval_multi", "celeste_elbo_eval_batch_device", "celeste_ctx_enable_timing",
     "celeste_ctx_last_kernel_ms", "celeste_ctx_last_record_sum_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter", "celeste_psf_raster",
     "celeste_maximize_batch", "celeste_render_expected", "celeste_optim_stats",
 ]
@@ -105,6 +105,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.celeste_elbo_eval_batch_device.argtypes = [vp, vp, C.c_int32, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
     lib.celeste_ctx_enable_timing.argtypes = [vp, C.c_int]
     lib.celeste_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.celeste_elbo_eval_multi.argtypes = [vp, c_double_p, C.c_int32, c_int32_p, C.c_uint32, C.POINTER(C.c_double),
+                                            c_double_p, c_double_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.celeste_ctx_last_record_sum_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.celeste_ctx_work_stats.argtypes = [vp, C.c_int32, c_int32_p, C.POINTER(WorkStatsT)]
     lib.celeste_spline_prefilter.argtypes = [c_double_p, c_double_p]

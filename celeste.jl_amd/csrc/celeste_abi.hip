@@ -363,7 +363,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
 
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
-                       void *stream_, bool render_neighbors);
+                       void *stream_, bool render_neighbors, const int32_t *d_active_rank = nullptr);
 
 extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_vp, int32_t n_targets,
                                               const int32_t *d_targets, uint32_t flags, double *d_v, double *d_d,
@@ -375,7 +375,7 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
 // during an optimisation, ParallelRun.jl:474-488)
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
-                       void *stream_, bool render_neighbors) {
+                       void *stream_, bool render_neighbors, const int32_t *d_active_rank) {
     if (!c || !d_vp || !d_targets || !d_v || !d_status || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
     if ((flags & CELESTE_FLAG_HESS) && !d_h) return CELESTE_ERR_INVALID_ARG;
     if ((flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) && !d_d) return CELESTE_ERR_INVALID_ARG;
@@ -424,7 +424,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
 #define LAUNCH_PIXEL_T(MODE, R)                                                                                 \
     hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,   \
                        c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off, c->d_val, \
-                       d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->ablate, c->d_tile_off, c->d_rec)
+                       d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->ablate, c->d_tile_off, c->d_rec, d_active_rank)
 #define LAUNCH_PIXEL(MODE) do { if (flags & CELESTE_FLAG_FP32) LAUNCH_PIXEL_T(MODE, float); else LAUNCH_PIXEL_T(MODE, double); } while (0)
     if (split) LAUNCH_PIXEL(3);
     else if (flags & CELESTE_FLAG_HESS) LAUNCH_PIXEL(2);
@@ -504,6 +504,109 @@ extern "C" int celeste_elbo_eval(celeste_ctx_t *c, const double *vp, int32_t tar
     if (n_active_px) *n_active_px = cnt[0];
     if (n_inactive_px) *n_inactive_px = cnt[1];
     return st;
+}
+
+// ---- elbo() with several active sources (ElboArgs.active_sources, elbo_args.jl:165-211) -------------------
+extern "C" int celeste_elbo_eval_multi(celeste_ctx_t *c, const double *vp, int32_t n_active, const int32_t *active,
+                                       uint32_t flags, double *v, double *d, double *h, int64_t *n_active_px,
+                                       int64_t *n_inactive_px) {
+    if (!c || !vp || !active || n_active < 1 || (flags & CELESTE_FLAG_SPLIT)) return CELESTE_ERR_INVALID_ARG;
+    const int Sa = n_active;
+    for (int a = 0; a < Sa; ++a) {
+        if (active[a] < 0 || active[a] >= c->S) return CELESTE_ERR_INVALID_ARG;
+        for (int b = 0; b < a; ++b) if (active[b] == active[a]) return CELESTE_ERR_INVALID_ARG;
+    }
+    const bool want_hess = (flags & CELESTE_FLAG_HESS) != 0;
+    const bool want_grad = want_hess || (flags & CELESTE_FLAG_GRAD) != 0;
+    if ((want_grad && !d) || (want_hess && !h)) return CELESTE_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t PT = (size_t)CEL_P * Sa;
+    std::vector<double> hv(Sa), hd((size_t)Sa * CEL_P), hh(want_hess ? (size_t)Sa * CEL_P * CEL_P : 0);
+    std::vector<int64_t> hcnt((size_t)Sa * 2);
+    std::vector<int32_t> hst(Sa), rank((size_t)c->S, -1);
+    for (int a = 0; a < Sa; ++a) rank[active[a]] = a;
+    // pairs of active sources that light common pixels; the first of a pair must list the second as a neighbour
+    std::vector<int32_t> pa, pb, pia, pib;
+    if (want_hess)
+        for (int ia = 0; ia < Sa; ++ia) for (int ib = ia + 1; ib < Sa; ++ib) {
+            auto lists = [&](int s, int t) {
+                for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q) if (c->h_nbr_idx[q] == t) return true;
+                return false;
+            };
+            if (lists(active[ia], active[ib])) { pa.push_back(active[ia]); pb.push_back(active[ib]); pia.push_back(ia); pib.push_back(ib); }
+            else if (lists(active[ib], active[ia])) { pa.push_back(active[ib]); pb.push_back(active[ia]); pia.push_back(ib); pib.push_back(ia); }
+        }
+    const size_t np = pa.size();
+    double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_rec = nullptr, *d_x = nullptr;
+    int32_t *d_t = nullptr, *d_st = nullptr, *d_rank = nullptr, *d_pa = nullptr, *d_pb = nullptr;
+    int64_t *d_cnt = nullptr;
+    int rc = CELESTE_OK;
+    std::vector<double> hx(np * LIFT_NP * LIFT_NP);
+#define MU_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto done; } } while (0)
+    MU_TRY(hipMalloc((void **)&d_vp, (size_t)c->S * CEL_P * sizeof(double)));
+    MU_TRY(hipMalloc((void **)&d_v, Sa * sizeof(double)));
+    MU_TRY(hipMalloc((void **)&d_d, (size_t)Sa * CEL_P * sizeof(double)));
+    MU_TRY(hipMalloc((void **)&d_h, (size_t)Sa * CEL_P * CEL_P * sizeof(double)));
+    MU_TRY(hipMalloc((void **)&d_t, Sa * sizeof(int32_t)));
+    MU_TRY(hipMalloc((void **)&d_st, Sa * sizeof(int32_t)));
+    MU_TRY(hipMalloc((void **)&d_cnt, (size_t)Sa * 2 * sizeof(int64_t)));
+    MU_TRY(hipMalloc((void **)&d_rank, (size_t)c->S * sizeof(int32_t)));
+    MU_TRY(hipMemcpy(d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
+    MU_TRY(hipMemcpy(d_t, active, Sa * sizeof(int32_t), hipMemcpyHostToDevice));
+    MU_TRY(hipMemcpy(d_rank, rank.data(), (size_t)c->S * sizeof(int32_t), hipMemcpyHostToDevice));
+    rc = launch_eval(c, d_vp, Sa, d_t, flags, d_v, d_d, d_h, d_cnt, d_st, nullptr, true, d_rank);
+    if (rc != CELESTE_OK) goto done;
+    if (np > 0) {
+        MU_TRY(hipMalloc((void **)&d_pa, np * sizeof(int32_t)));
+        MU_TRY(hipMalloc((void **)&d_pb, np * sizeof(int32_t)));
+        MU_TRY(hipMalloc((void **)&d_rec, np * c->N * ZV * ZV * sizeof(double)));
+        MU_TRY(hipMalloc((void **)&d_x, np * LIFT_NP * LIFT_NP * sizeof(double)));
+        MU_TRY(hipMemcpy(d_pa, pa.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+        MU_TRY(hipMemcpy(d_pb, pb.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(cross_kernel, dim3((unsigned)(np * c->N)), dim3(64), 0, nullptr, c->d_images, c->d_patches,
+                           c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off,
+                           c->d_val, d_pa, d_pb, c->N, c->NC, d_rec);
+        hipLaunchKernelGGL(cross_lift_kernel, dim3((unsigned)np), dim3(256), 0, nullptr, d_vp, c->d_images, c->d_patches,
+                           c->d_geo, d_pa, d_pb, d_rec, c->N, d_x);
+        MU_TRY(hipMemcpy(hx.data(), d_x, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    MU_TRY(hipDeviceSynchronize());
+    MU_TRY(hipMemcpy(hv.data(), d_v, Sa * sizeof(double), hipMemcpyDeviceToHost));
+    MU_TRY(hipMemcpy(hst.data(), d_st, Sa * sizeof(int32_t), hipMemcpyDeviceToHost));
+    MU_TRY(hipMemcpy(hcnt.data(), d_cnt, hcnt.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (want_grad) MU_TRY(hipMemcpy(hd.data(), d_d, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (want_hess) MU_TRY(hipMemcpy(hh.data(), d_h, hh.size() * sizeof(double), hipMemcpyDeviceToHost));
+    {
+        double vs = 0; int64_t na = 0, ni = 0;
+        for (int a = 0; a < Sa; ++a) {
+            vs += hv[a]; na += hcnt[2 * a]; ni += hcnt[2 * a + 1];
+            if (hst[a] != CELESTE_OK && rc == CELESTE_OK) rc = hst[a];
+        }
+        if (v) *v = vs;
+        if (n_active_px) *n_active_px = na;
+        if (n_inactive_px) *n_inactive_px = ni;
+        if (want_grad) memcpy(d, hd.data(), hd.size() * sizeof(double));   // P x Sa, column per active source
+        if (want_hess) {
+            memset(h, 0, PT * PT * sizeof(double));
+            for (int a = 0; a < Sa; ++a)
+                for (int j = 0; j < CEL_P; ++j) for (int i = 0; i < CEL_P; ++i)
+                    h[(CEL_P * a + i) + PT * (CEL_P * a + j)] = hh[(size_t)a * CEL_P * CEL_P + i + CEL_P * j];
+            for (size_t k = 0; k < np; ++k)
+                for (int p2 = 0; p2 < LIFT_NP; ++p2) for (int p1 = 0; p1 < LIFT_NP; ++p1) {
+                    const double x = hx[k * LIFT_NP * LIFT_NP + p1 + LIFT_NP * p2];   // d2 / d theta_a[p1] d theta_b[p2]
+                    if (!std::isfinite(x) && rc == CELESTE_OK) rc = CELESTE_ERR_NONFINITE_RESULT;
+                    h[(CEL_P * pia[k] + p1) + PT * (CEL_P * pib[k] + p2)] = x;
+                    h[(CEL_P * pib[k] + p2) + PT * (CEL_P * pia[k] + p1)] = x;
+                }
+        }
+    }
+done:
+#undef MU_TRY
+    {
+        void *ptrs[] = {d_vp, d_v, d_d, d_h, d_rec, d_x, d_t, d_st, d_rank, d_pa, d_pb, d_cnt};
+        for (void *q : ptrs) if (q) (void)hipFree(q);
+    }
+    return rc;
 }
 
 extern "C" int celeste_ctx_enable_timing(celeste_ctx_t *c, int enable) {

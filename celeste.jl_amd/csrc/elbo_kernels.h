@@ -553,7 +553,8 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
              const int64_t *__restrict__ val_off, const double2 *__restrict__ val,
              const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px,
-             double *__restrict__ acc, int ablate, const int64_t *__restrict__ tile_off, double *__restrict__ rec) {
+             double *__restrict__ acc, int ablate, const int64_t *__restrict__ tile_off, double *__restrict__ rec,
+             const int32_t *__restrict__ active_rank) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
     __shared__ double etab[64];
     // chunk index is the slow grid axis (see value_kernel): heavy first chunks go first, spread over all XCDs
@@ -593,6 +594,9 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const CompR<R> *tcr = sizeof(R) == 4 ? tcr_f : reinterpret_cast<const CompR<R> *>(tc);
     const double *__restrict__ tcoef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
     const int64_t nb0 = nbr_off[t], nb1 = (ablate & 1) ? nb0 : nbr_off[t + 1];
+    // several active sources (celeste_elbo_eval_multi): a pixel of two active patches is visited by the earlier
+    // one only (elbo_objective.jl:430-470) -- its value term and inactive-source count are dropped here
+    const int my_rank = active_rank ? active_rank[t] : 0;
     const double c0 = si.c0, c1 = si.c1, q0 = si.q0, q1 = si.q1;
     // index offsets of the star spline: itp[h - m1 + 26, w - m2 + 26]
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
@@ -620,6 +624,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         double Ebar = (double)skyf;  // epsilon + neighbours
         double Vbar = 0.0;
         int n_inact = 0;
+        bool dup = false;
 
         // ---- neighbours: gather their pre-rendered (E_G_s.v, var_G_s.v) ----
         for (int64_t q = nb0; q < nb1; ++q) {
@@ -628,13 +633,23 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             const int ph2 = h - Q.off_h, pw2 = w - Q.off_w;  // 1-based in the neighbour's patch
             bool in = valid & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 < Q.W2);  // strict: elbo_objective.jl:349
             if (in && Q.bitmap_off >= 0) in = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
+            int r2 = -1;
+            if (active_rank) {
+                r2 = active_rank[s2];
+                if (r2 >= 0 && r2 < my_rank) {   // does the earlier active source visit this pixel (last column included)?
+                    bool vis = valid & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 <= Q.W2);
+                    if (vis && Q.bitmap_off >= 0) vis = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
+                    dup |= vis;
+                }
+            }
             if (in) {
                 const double2 ev = val[val_off[(size_t)s2 * N + n] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
                 Ebar += ev.x;
                 Vbar += ev.y;
-                n_inact += 1;
+                n_inact += r2 < 0;
             }
         }
+        if (dup) n_inact = 0;
 
         // ---- the active source ----
         const bool own = valid && (w2 < W2 - 1);  // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
@@ -650,7 +665,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
                 const double E = Ebar + A;
                 const double V = Vbar + ((q0 * (f0 * f0) + q1 * (f1 * f1)) - A * A);
                 const double iE = 1.0 / E;
-                a[0] += x * (log_iota + (log(E) - V * (0.5 * iE * iE))) - iota * E - lgx;
+                if (!dup) a[0] += x * (log_iota + (log(E) - V * (0.5 * iE * iE))) - iota * E - lgx;
                 a[1] += own ? 1.0 : 0.0;
                 a[2] += (double)n_inact;
             }
@@ -707,7 +722,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             const double V = Vbar + (B - A * A);                          // var_G.v
             const double iE = 1.0 / E;
             const double iE2 = iE * iE, iE3 = iE2 * iE;
-            T.vterm = valid ? x * (log_iota + (log(E) - V * (0.5 * iE2))) - iota * E - lgx : 0.0;
+            T.vterm = (valid && !dup) ? x * (log_iota + (log(E) - V * (0.5 * iE2))) - iota * E - lgx : 0.0;
             T.cnt_act = own ? 1.0 : 0.0;
             T.cnt_inact = (double)n_inact;
             // derivative weights are zero unless the active source covers the pixel, which zeroes every
@@ -831,6 +846,23 @@ __device__ inline int bright_slot(int p) {
     if (p < 18) return 2 + ((p - 10) & 3);
     if (p < 26) return 6 + ((p - 18) & 3);
     return -1;
+}
+
+// exponent coefficients of E_l_a[b, .] (kappa) and E_ll_a[b, .] (lambda) for brightness slot q (bids order), band b
+__device__ inline void bright_coef(int q, int b, double &kap, double &lam) {
+    kap = 0; lam = 0;
+    if (q == 0) { kap = 1; lam = 2; }
+    else if (q == 1) { kap = .5; lam = 2; }
+    else {
+        const int c = (q - 2) & 3;
+        const bool is_var = q >= 6;
+        bool on; double sgn;
+        if (c == 2) { on = b >= 3; sgn = 1; }
+        else if (c == 3) { on = b >= 4; sgn = 1; }
+        else if (c == 1) { on = b <= 1; sgn = -1; }
+        else { on = b <= 0; sgn = -1; }
+        if (on) { kap = is_var ? .5 : sgn; lam = is_var ? 2 : 2 * sgn; }
+    }
 }
 
 #define LIFT_NT 8    // images lifted concurrently per pass
@@ -987,20 +1019,8 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
                 const int i = k / 12, q = k - i * 12;
                 const int b = images[n0 + i].band - 1;
                 if (q < 10) {
-                    // exponent coefficients of E_l_a[b, .] (kappa) and E_ll_a[b, .] (lambda), bids order
-                    double kap = 0, lam = 0;
-                    if (q == 0) { kap = 1; lam = 2; }
-                    else if (q == 1) { kap = .5; lam = 2; }
-                    else {
-                        const int c = (q - 2) & 3;
-                        const bool is_var = q >= 6;
-                        bool on; double sgn;
-                        if (c == 2) { on = b >= 3; sgn = 1; }
-                        else if (c == 3) { on = b >= 4; sgn = 1; }
-                        else if (c == 1) { on = b <= 1; sgn = -1; }
-                        else { on = b <= 0; sgn = -1; }
-                        if (on) { kap = is_var ? .5 : sgn; lam = is_var ? 2 : 2 * sgn; }
-                    }
+                    double kap, lam;
+                    bright_coef(q, b, kap, lam);
                     s_kap[i][q] = kap; s_lam[i][q] = lam;
                 } else {
                     double El, Ell;
@@ -1139,6 +1159,193 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         out_v[ti] = sh_v;
         if (out_cnt) { out_cnt[2 * ti] = (int64_t)(sh_cnt[0] + 0.5); out_cnt[2 * ti + 1] = (int64_t)(sh_cnt[1] + 0.5); }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Several active sources (ElboArgs.active_sources, Sa > 1; add_sources_sf!, SensitiveFloats.jl:215-250).
+// Gradient columns and diagonal Hessian blocks are the single-active evaluations (every other source value-only);
+// the cross block of two active sources a, b collects, over the pixels both cover,
+//     d2T/dE2 dE_a dE_b' + d2T/dE dVar (dE_a dVar_b' + dVar_a dE_b')        (d2T/dVar2 = 0)
+// first in the reduced variables (cross_kernel: one 10 x 10 record per pair and image), then in the canonical
+// parameters (cross_lift_kernel: J_a' M J_b).  A test-level path of the reference: written for clarity, not speed.
+// ---------------------------------------------------------------------------------------------
+struct FirstOrder { double A, B, gE[ZV], gB[ZV]; };  // E_G_s.v, E_G2_s.v and their gradients in the reduced variables
+
+__device__ inline void source_first_order(const SrcImg &si, const Comp *comps, int NC, const double *tcoef, double hh,
+                                          double ww, const double *etab, FirstOrder &F) {
+    PixelTerms T;
+    T.S0d = 0; T.S1x = 0; T.S1y = 0; T.S2an = 0; T.S2bn = 0; T.S2cn = 0;
+    const double f1 = galaxy_sums<1, double>(reinterpret_cast<const CompR<double> *>(comps), NC, hh - si.m1, ww - si.m2,
+                                             etab, T);
+    // star: natural bicubic spline value and first derivatives with respect to the position
+    const double xh = hh + (26.0 - si.m1), xw = ww + (26.0 - si.m2);
+    int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
+    int iy = (int)floor(xw); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
+    double wx[4], wy[4], dwx[4], ddwx[4], dwy[4], ddwy[4];
+    bspline_w(xh - ix, wx); bspline_w(xw - iy, wy);
+    bspline_dw(xh - ix, dwx, ddwx); bspline_dw(xw - iy, dwy, ddwy);
+    const double *cc = tcoef + (ix - 1) + CEL_COEF * (iy - 1);
+    double y = 0, yx = 0, yy = 0;
+    for (int b = 0; b < 4; ++b) {
+        const double *cb = cc + CEL_COEF * b;
+        const double r = cb[0] * wx[0] + cb[1] * wx[1] + cb[2] * wx[2] + cb[3] * wx[3];
+        const double rx = cb[0] * dwx[0] + cb[1] * dwx[1] + cb[2] * dwx[2] + cb[3] * dwx[3];
+        y += r * wy[b]; yx += rx * wy[b]; yy += r * dwy[b];
+    }
+    double f0, gp;
+    if (y < 0) { f0 = 1e-3 * exp(y); gp = f0; } else { f0 = 1e-3 * (y + 1.0); gp = 1e-3; }
+    const double f0g0 = -gp * yx, f0g1 = -gp * yy;   // d(index)/dm = -1
+    const double c0 = si.c0, c1 = si.c1, q0 = si.q0, q1 = si.q1;
+    F.A = c0 * f0 + c1 * f1;
+    F.B = q0 * (f0 * f0) + q1 * (f1 * f1);
+    const double gg[6] = {gal_g<0>(T), gal_g<1>(T), gal_g<2>(T), gal_g<3>(T), gal_g<4>(T), gal_g<5>(T)};
+    F.gE[0] = f0; F.gE[1] = f1; F.gE[2] = 0; F.gE[3] = 0;
+    F.gB[0] = 0; F.gB[1] = 0; F.gB[2] = f0 * f0; F.gB[3] = f1 * f1;
+    for (int k = 0; k < 6; ++k) {
+        const double sg = k == 0 ? f0g0 : (k == 1 ? f0g1 : 0.0);
+        F.gE[4 + k] = c0 * sg + c1 * gg[k];
+        F.gB[4 + k] = 2.0 * q0 * f0 * sg + 2.0 * q1 * f1 * gg[k];
+    }
+}
+
+__global__ void __launch_bounds__(64)
+cross_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
+             const uint8_t *__restrict__ bitmaps, const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
+             const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
+             const int64_t *__restrict__ val_off, const double2 *__restrict__ val, const int32_t *__restrict__ pair_a,
+             const int32_t *__restrict__ pair_b, int N, int NC, double *__restrict__ out) {
+    __shared__ double etab[64];
+    __shared__ double sX[2 * ZV][64], sY[2 * ZV][64];
+    const int pair = blockIdx.x / N, n = blockIdx.x - pair * N;
+    const int a = pair_a[pair], b = pair_b[pair];
+    const int lane = threadIdx.x;
+    etab[lane] = g_exp2_table[lane];
+    const DevPatch &Pa = patches[(size_t)a * N + n], &Pb = patches[(size_t)b * N + n];
+    const DevImage &img = images[n];
+    // pixels both sources light up: rows of both patches, columns of both minus each one's last
+    const int h_lo = max(Pa.off_h, Pb.off_h), h_hi = min(Pa.off_h + Pa.H2, Pb.off_h + Pb.H2);
+    const int w_lo = max(Pa.off_w, Pb.off_w), w_hi = min(Pa.off_w + Pa.W2 - 1, Pb.off_w + Pb.W2 - 1);
+    const int rh = h_hi - h_lo, rw = w_hi - w_lo;
+    double acc0 = 0.0, acc1 = 0.0;
+    const int e0 = lane, e1 = lane + 64;                   // entries r1 * 10 + r2 owned by this lane
+    __syncthreads();
+    if (rh > 0 && rw > 0) {
+        const SrcImg sa = srcimg[(size_t)a * N + n], sb = srcimg[(size_t)b * N + n];
+        const Comp *ca = comps + ((size_t)a * N + n) * NC, *cb = comps + ((size_t)b * N + n) * NC;
+        const double *ta = coefs + (size_t)Pa.stamp * (CEL_COEF * CEL_COEF), *tb = coefs + (size_t)Pb.stamp * (CEL_COEF * CEL_COEF);
+        const int npx = rh * rw;
+        for (int base = 0; base < npx; base += 64) {
+            const int idx = min(base + lane, npx - 1);
+            const int wq = idx / rh, hq = idx - wq * rh;
+            const int h = h_lo + hq + 1, w = w_lo + wq + 1;     // 1-based image coordinates
+            const size_t gi = (size_t)(h - 1) + (size_t)img.H * (w - 1);
+            const float xf = img.pixels[gi];
+            bool ok = (base + lane < npx) && !isnan(xf);
+            const int ah = h - Pa.off_h, aw = w - Pa.off_w, bh = h - Pb.off_h, bw = w - Pb.off_w;
+            if (ok && Pa.bitmap_off >= 0) ok = bitmaps[Pa.bitmap_off + (ah - 1) + (int64_t)Pa.H2 * (aw - 1)] != 0;
+            if (ok && Pb.bitmap_off >= 0) ok = bitmaps[Pb.bitmap_off + (bh - 1) + (int64_t)Pb.H2 * (bw - 1)] != 0;
+            FirstOrder Fa, Fb;
+            source_first_order(sa, ca, NC, ta, (double)h, (double)w, etab, Fa);
+            source_first_order(sb, cb, NC, tb, (double)h, (double)w, etab, Fb);
+            // totals over every source covering the pixel: a itself + a's neighbours (b among them)
+            double E = (double)img.sky[gi] + Fa.A, V = Fa.B - Fa.A * Fa.A;
+            for (int64_t q = nbr_off[a]; q < nbr_off[a + 1]; ++q) {
+                const int s2 = nbr_idx[q];
+                const DevPatch &Q = patches[(size_t)s2 * N + n];
+                const int ph2 = h - Q.off_h, pw2 = w - Q.off_w;
+                bool in = ok & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 < Q.W2);
+                if (in && Q.bitmap_off >= 0) in = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
+                if (in) {
+                    const double2 ev = val[val_off[(size_t)s2 * N + n] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
+                    E += ev.x; V += ev.y;
+                }
+            }
+            const double x = ok ? (double)xf : 0.0;
+            const double iE = 1.0 / E, iE2 = iE * iE;
+            const double w11 = -x * (iE2 + 3.0 * V * iE2 * iE2), w12 = x * iE2 * iE;
+            for (int r = 0; r < ZV; ++r) {
+                const double gVa = Fa.gB[r] - 2.0 * Fa.A * Fa.gE[r], gVb = Fb.gB[r] - 2.0 * Fb.A * Fb.gE[r];
+                sX[r][lane] = ok ? w11 * Fa.gE[r] + w12 * gVa : 0.0;
+                sX[ZV + r][lane] = ok ? w12 * Fa.gE[r] : 0.0;
+                sY[r][lane] = ok ? Fb.gE[r] : 0.0;
+                sY[ZV + r][lane] = ok ? gVb : 0.0;
+            }
+            __syncthreads();
+            {
+                const int r1 = e0 / ZV, r2 = e0 - r1 * ZV;
+                for (int px = 0; px < 64; ++px) acc0 += sX[r1][px] * sY[r2][px] + sX[ZV + r1][px] * sY[ZV + r2][px];
+                if (e1 < ZV * ZV) {
+                    const int q1 = e1 / ZV, q2 = e1 - q1 * ZV;
+                    for (int px = 0; px < 64; ++px) acc1 += sX[q1][px] * sY[q2][px] + sX[ZV + q1][px] * sY[ZV + q2][px];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    double *o = out + (size_t)blockIdx.x * (ZV * ZV);
+    o[e0] = acc0;
+    if (e1 < ZV * ZV) o[e1] = acc1;
+}
+
+// d z_r / d theta_p of one source on one image (the entries lift_kernel tabulates in s_jz)
+__device__ inline double zjac_entry(int r, int p, const double *vs, const DevPatch &P, const double *jsh, int band0) {
+    if (r >= 4 && r < 6) return p < 2 ? P.J[(r - 4) + 2 * p] : 0.0;
+    if (r == 6) return p == 2 ? 1.0 : 0.0;
+    if (r >= 7) return (p >= 3 && p < 6) ? jsh[(r - 7) + 3 * (p - 3)] : 0.0;
+    const int ty = r & 1;
+    const bool isq = r >= 2;
+    int st, cn, sd, cls;
+    param_rows(p, st, cn, sd, cls);
+    if (cls != 3 + ty) return 0.0;
+    double El, Ell;
+    brightness(vs, ty, band0, El, Ell);
+    const double Ev = isq ? Ell : El;
+    const int slot = bright_slot(p);
+    if (slot < 0) return Ev;
+    double kap, lam;
+    bright_coef(slot, band0, kap, lam);
+    return vs[26 + ty] * Ev * (isq ? lam : kap);
+}
+
+// one workgroup per pair: out[pair][p1 + 28 p2] = sum_n sum_{r1, r2} J_a[r1, p1] M_n[r1, r2] J_b[r2, p2]
+__global__ void __launch_bounds__(256)
+cross_lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
+                  const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
+                  const int32_t *__restrict__ pair_a, const int32_t *__restrict__ pair_b,
+                  const double *__restrict__ rec, int N, double *__restrict__ out) {
+    __shared__ double sJa[ZV * LIFT_NP], sJb[ZV * LIFT_NP], sM[ZV * ZV], sva[CEL_P], svb[CEL_P];
+    const int pair = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int a = pair_a[pair], b = pair_b[pair];
+    if (tid < CEL_P) { sva[tid] = vp[(size_t)a * CEL_P + tid]; svb[tid] = vp[(size_t)b * CEL_P + tid]; }
+    double hacc[(LIFT_NP * LIFT_NP + 255) / 256];
+    for (int k = 0; k < (LIFT_NP * LIFT_NP + 255) / 256; ++k) hacc[k] = 0.0;
+    __syncthreads();
+    for (int n = 0; n < N; ++n) {
+        const int band0 = images[n].band - 1;
+        for (int k = tid; k < ZV * LIFT_NP; k += nthr) {
+            const int r = k / LIFT_NP, p = k - r * LIFT_NP;
+            sJa[k] = zjac_entry(r, p, sva, patches[(size_t)a * N + n], geo[a].jsh, band0);
+            sJb[k] = zjac_entry(r, p, svb, patches[(size_t)b * N + n], geo[b].jsh, band0);
+        }
+        for (int k = tid; k < ZV * ZV; k += nthr) sM[k] = rec[((size_t)pair * N + n) * (ZV * ZV) + k];
+        __syncthreads();
+        for (int k = tid, slot = 0; k < LIFT_NP * LIFT_NP; k += nthr, ++slot) {
+            const int p2 = k / LIFT_NP, p1 = k - p2 * LIFT_NP;
+            int st1, cn1, sd1, cls1, st2, cn2, sd2, cls2;
+            param_rows(p1, st1, cn1, sd1, cls1);
+            param_rows(p2, st2, cn2, sd2, cls2);
+            double s = 0.0;
+            for (int i = 0; i < cn1; ++i) {
+                const int r1 = st1 + i * sd1;
+                double inner = 0.0;
+                for (int j = 0; j < cn2; ++j) { const int r2 = st2 + j * sd2; inner += sM[r1 * ZV + r2] * sJb[r2 * LIFT_NP + p2]; }
+                s += sJa[r1 * LIFT_NP + p1] * inner;
+            }
+            hacc[slot] += s;
+        }
+        __syncthreads();
+    }
+    for (int k = tid, slot = 0; k < LIFT_NP * LIFT_NP; k += nthr, ++slot) out[(size_t)pair * LIFT_NP * LIFT_NP + k] = hacc[slot];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@
 
 Same names, argument meaning and error behaviour: non-finite parameters or results raise
 AssertionError like the reference's @assert (elbo_objective.jl:487, elbo_args.jl:145-149).
-Only Sa = 1 (the production configuration) is implemented in the device path.
+Sa = 1 is the production configuration (batched, tuned); Sa > 1 goes through celeste_elbo_eval_multi.
 """
 import ctypes as C
 from dataclasses import dataclass
@@ -89,6 +89,27 @@ class FieldContext:
             cabi.check(st, self.lib)
         # h is symmetric, so column-major == row-major
         return v, d, h, cnt, status
+
+    def eval_multi(self, vp, active: Sequence[int], flags: int = FLAG_GRAD | FLAG_HESS | FLAG_KL):
+        """elbo() with several active sources: returns (v, d[44, Sa], h[44 Sa, 44 Sa], counters[2]); d / h are None
+        when not requested.  Column a of d and block a of h belong to active[a] (SensitiveFloats.jl:29-31)."""
+        vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(self.S, P))
+        act = np.ascontiguousarray(np.asarray(active, dtype=np.int32))
+        sa = act.size
+        want_h = bool(flags & FLAG_HESS)
+        want_d = want_h or bool(flags & FLAG_GRAD)
+        v = C.c_double()
+        d = np.zeros(sa * P) if want_d else None
+        h = np.zeros((sa * P, sa * P)) if want_h else None
+        na = C.c_int64(); ni = C.c_int64()
+        dp = cabi.c_double_p
+        st = self.lib.celeste_elbo_eval_multi(self.handle, vp.ctypes.data_as(dp), sa, act.ctypes.data_as(cabi.c_int32_p),
+                                              flags, C.byref(v), d.ctypes.data_as(dp) if want_d else None,
+                                              h.ctypes.data_as(dp) if want_h else None, C.byref(na), C.byref(ni))
+        if st in (cabi.ERR_NONFINITE_INPUT, cabi.ERR_NONFINITE_RESULT):
+            raise AssertionError(self.lib.celeste_strerror(st).decode())
+        cabi.check(st, self.lib)
+        return (v.value, d.reshape(sa, P).T.copy() if want_d else None, h, np.array([na.value, ni.value]))
 
     # -- device-pointer API (torch tensors or raw pointers) -----------------------------------
     def eval_batch_device(self, d_vp: int, n_targets: int, d_targets: int, flags: int, d_v: int, d_d: int,
@@ -185,23 +206,24 @@ class ElboArgs:
         self.N = len(images)
         assert all(len(row) == self.N for row in patches)
         assert psf_K > 0
-        if self.Sa != 1:
-            raise NotImplementedError("the MI355X engine evaluates Sa = 1 (production configuration, "
-                                      "ParallelRun.jl:482); got %d active sources" % self.Sa)
+        assert self.Sa >= 1 and len(set(active_sources)) == self.Sa
         self.psf_K = psf_K
         self.images = images
         self.patches = patches
         self.active_sources = list(active_sources)
         self.include_kl = include_kl
-        a = self.active_sources[0]
         nbrs = [[] for _ in range(self.S)]
-        nbrs[a] = [s for s in range(self.S) if s != a]  # every other local source is a neighbour
+        for a in self.active_sources:   # every other local source is a neighbour of every active source
+            nbrs[a] = [s for s in range(self.S) if s != a]
         self._ctx = FieldContext(images, patches, nbrs, psf_K=psf_K, prior=prior, device=device)
 
 
 def _eval(ea: ElboArgs, vp, flags: int) -> SensitiveFloat:
     vp = np.asarray(vp, dtype=np.float64).reshape(ea.S, P)
     assert np.all(np.isfinite(vp)), "vp contains NaNs or Infs"
+    if ea.Sa > 1:   # d is P x Sa, h is (P Sa) x (P Sa), as in SensitiveFloats.jl:29-31
+        v, d, h, cnt = ea._ctx.eval_multi(vp, ea.active_sources, flags)
+        return SensitiveFloat(float(v), d, h, int(cnt[0]), int(cnt[1]))
     v, d, h, cnt, _ = ea._ctx.eval_batch(vp, ea.active_sources, flags)
     return SensitiveFloat(float(v[0]), None if d is None else d[0].copy(), None if h is None else h[0].copy(),
                           int(cnt[0, 0]), int(cnt[0, 1]))
@@ -225,6 +247,8 @@ def maximize(ea: ElboArgs, vp, cfg: Optional[ElboConfig] = None):
     """ElboMaximize.maximize!(ea, vp, cfg) (ElboMaximize.jl:228-242): optimises the active source in place.
     Returns (f_evals, max_value, vp) like the reference returns (f_calls, min_value, ...)."""
     vp_arr = np.asarray(vp, dtype=np.float64).reshape(ea.S, P)
+    if ea.Sa != 1:
+        raise NotImplementedError("maximize! on the device optimises one active source (ParallelRun.jl:482)")
     new, its, evals, el, _ = ea._ctx.maximize_batch(vp_arr, ea.active_sources, cfg, include_kl=ea.include_kl)
     a = ea.active_sources[0]
     vp_arr[a] = new[a]

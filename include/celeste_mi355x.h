@@ -168,6 +168,16 @@ int celeste_elbo_eval_batch(celeste_ctx_t *ctx, const double *vp, int32_t n_targ
                             double *v, double *d, double *h,
                             int64_t *counters, int32_t *status);
 
+/* elbo() with several active sources (ElboArgs.active_sources with Sa > 1, elbo_args.jl:165-211; the layout of
+ * SensitiveFloats.jl:29-31): d is P x Sa column-major (column a = active[a]), h is (P Sa) x (P Sa) column-major
+ * with the cross blocks of add_sources_sf! / combine_sfs_hessian!, exactly symmetric.  Every other source of the
+ * context that is a neighbour of an active source contributes value-only.  A pixel of several active patches is
+ * visited once (elbo_objective.jl:430-470).  Production always uses Sa = 1 (ParallelRun.jl:482): this entry point
+ * serves the reference's multi-source tests and is not tuned. */
+int celeste_elbo_eval_multi(celeste_ctx_t *ctx, const double *vp, int32_t n_active, const int32_t *active,
+                            uint32_t flags, double *v, double *d, double *h,
+                            int64_t *n_active_px, int64_t *n_inactive_px);
+
 /* Same, all pointers already in HBM, asynchronous on `stream` (a hipStream_t,
  * NULL = default stream).  d_status[n] receives per-target status codes. */
 int celeste_elbo_eval_batch_device(celeste_ctx_t *ctx, const double *d_vp, int32_t n_targets,

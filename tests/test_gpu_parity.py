@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from parity_util import assert_parity
+from parity_util import assert_parity, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -209,6 +209,44 @@ def test_random_parameters_inside_the_constraint_boxes(oracle):
         for k2, v2 in errs.items():
             worst[k2] = max(worst.get(k2, 0), v2)
     print("random-parameter parity", worst)
+
+
+def test_multiple_active_sources(oracle):
+    """ElboArgs with Sa > 1 (test_elbo.jl:64-130): value on the union of the active patches, gradient columns,
+    diagonal and cross Hessian blocks; swap invariance; a third, inactive source contributes value-only"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    for kind, acts in (("two_body", ([0, 1], [1, 0])), ("three_body", ([0, 2], [2, 1, 0], [1]))):
+        f = synthetic.make_sample_dataset(kind)
+        S = len(f.catalog)
+        for act in acts:
+            ea = cel.ElboArgs(f.images, f.patches, act)
+            sf = cel.elbo(ea, f.vp)
+            pb = cabi.Problem(f.images, f.patches, [[s for s in range(S) if s != a] if a in act else [] for a in range(S)])
+            for flags in (ALL, 1 | 4, 0):
+                ov, od, oh, ocnt, ost = oracle.elbo_multi(pb, f.vp, act, flags)
+                assert ost == 0
+                if len(act) == 1:
+                    break
+                v, d, h, cnt = ea._ctx.eval_multi(f.vp, act, flags)
+                assert abs(v - ov) <= 1e-8 * abs(ov) and np.array_equal(cnt, ocnt), (kind, act, flags, v, ov, cnt, ocnt)
+                if flags & 3:
+                    assert max(rel_err(d[:, k], od[k]) for k in range(len(act))) <= 1e-8
+                if flags & 2:
+                    assert np.array_equal(h, h.T)
+                    e = rel_err(h, oh)
+                    assert e <= 1e-8, (kind, act, e)
+                    print(kind, act, "multi-active errs", abs(v - ov) / abs(ov), e, "cross block max", np.abs(h[:44, 44:88]).max())
+                    if kind == "two_body":
+                        assert np.abs(h[:44, 44:88]).max() > 0
+        # swap invariance (test_elbo.jl:107-129)
+        if kind == "two_body":
+            a01 = cel.elbo(cel.ElboArgs(f.images, f.patches, [0, 1]), f.vp)
+            a10 = cel.elbo(cel.ElboArgs(f.images, f.patches, [1, 0]), f.vp)
+            assert a01.v == pytest.approx(a10.v, rel=1e-13)
+            assert np.allclose(a01.d[:, 0], a10.d[:, 1], rtol=1e-11) and np.allclose(a01.h[:44, 44:], a10.h[44:, :44], rtol=1e-9, atol=1e-9 * np.abs(a01.h).max())
+            one = cel.elbo(cel.ElboArgs(f.images, f.patches, [0]), f.vp)
+            assert np.allclose(one.h, a01.h[:44, :44], rtol=1e-9, atol=1e-10 * np.abs(one.h).max())
 
 
 def test_batch_equals_singles():
