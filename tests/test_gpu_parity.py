@@ -249,6 +249,69 @@ def test_multiple_active_sources(oracle):
             assert np.allclose(one.h, a01.h[:44, :44], rtol=1e-9, atol=1e-10 * np.abs(one.h).max())
 
 
+@pytest.mark.parametrize("K", [1, 3, 4])
+def test_psf_K_other_than_two(oracle, K):
+    """ElboArgs.psf_K (elbo_args.jl:197) other than the SDSS default: 14 K galaxy components per source"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    from celeste_jl_amd.model import get_sky_patches, neighbor_map, ConstantPSFMap, render_psf
+    f = synthetic.make_sample_dataset("two_body")
+    rng = np.random.default_rng(K)
+    for img in f.images:
+        w = rng.dirichlet(np.ones(K) * 4)
+        comps = []
+        for k in range(K):
+            s = 1.1 + 0.9 * k + 0.2 * rng.random()
+            comps.append([w[k], 0.3 * rng.normal(), 0.3 * rng.normal(), s * s, 0.1 * s * s * rng.normal(), s * s * (1 + 0.2 * rng.random())])
+        img.psf = np.array(comps)
+        img.psfmap = ConstantPSFMap(render_psf(img.psf, (51, 51)))
+    patches = get_sky_patches(f.images, f.catalog)
+    nbrs = neighbor_map(patches)
+    ctx = cel.FieldContext(f.images, patches, nbrs, psf_K=K)
+    errs = assert_parity(ctx.eval_batch(f.vp, [0, 1], ALL), oracle.elbo_batch(ctx.problem, f.vp, [0, 1], ALL), "psf_K=%d" % K)
+    print("psf_K", K, errs)
+
+
+def test_edge_cases(oracle):
+    """empty target list; a target without a single active pixel (ELBO = -KL, derivatives of the KL only); a source
+    whose box misses every image (clamp_box, imaged_sources.jl:10-14); the last-column rule on a 1-column patch"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_sample_dataset("three_body")
+    ctx = _ctx(f)
+    v, d, h, cnt, st = ctx.eval_batch(f.vp, [], ALL)
+    assert v.size == 0 and st.size == 0
+    # no active pixel at all for source 1
+    for n in range(5):
+        f.patches[1][n].active_pixel_bitmap[:] = False
+    # source 2: one-column patches (contributes nothing: 1 <= w2 < W2 is empty), still visited
+    for n in range(5):
+        p = f.patches[2][n]
+        keep = p.active_pixel_bitmap[:, :1].copy()
+        (h0, h1), (w0, w1) = p.box
+        p.box = ((h0, h1), (w0, w0))
+        p.active_pixel_bitmap = keep
+    ctx = _ctx(f)
+    g = ctx.eval_batch(f.vp, [0, 1, 2], ALL)
+    r = oracle.elbo_batch(ctx.problem, f.vp, [0, 1, 2], ALL)
+    assert_parity(g, r, "edge")
+    assert g[3][1, 0] == 0 and g[3][2, 0] == 0 and g[3][0, 0] > 0
+    kl_only = ctx.eval_batch(f.vp, [1], ALL)[0][0]
+    from torch_value_model import neg_kl, load_prior
+    import torch
+    assert kl_only == pytest.approx(float(neg_kl(torch.tensor(f.vp[1]), load_prior())), rel=1e-12)
+    # a source far outside every image: empty boxes everywhere
+    from celeste_jl_amd.model import get_sky_patches, neighbor_map
+    from celeste_jl_amd.params import catalog_init_source
+    ce = synthetic.sample_ce([4000.0, -900.0], True)
+    cat = list(f.catalog) + [ce]
+    patches = get_sky_patches(f.images, cat)
+    assert all(p.active_pixel_bitmap.size == 0 for p in patches[3])
+    vp = np.vstack([f.vp, catalog_init_source(ce)])
+    ctx = cel.FieldContext(f.images, patches, neighbor_map(patches))
+    assert_parity(ctx.eval_batch(vp, [3, 0], ALL), oracle.elbo_batch(ctx.problem, vp, [3, 0], ALL), "outside")
+
+
 def test_batch_equals_singles():
     from celeste_jl_amd import synthetic
     f = synthetic.make_field(128, 128, 12, seed=5)
