@@ -58,6 +58,15 @@ struct celeste_ctx {
     int32_t *d_link_src = nullptr;  // per neighbour link: the source that owns it (CSR row)
     int64_t n_links = 0;
     int max_overlap_px = 0;
+    // visit lists: the images each source has a non-empty patch in (grids run over these, tables stay S x N)
+    std::vector<int32_t> h_vis_off, h_vis_img, h_vis_src;
+    int32_t *d_vis_off = nullptr, *d_vis_img = nullptr, *d_vis_src = nullptr;
+    int32_t *d_link_img = nullptr;   // [link * M + j]: image of the j-th visit of the link's target (-1: none)
+    int32_t *d_items = nullptr;      // [ti * M + j] of the current batch
+    size_t items_cap = 0;
+    int M = 1;        // largest number of images one source appears in
+    bool dense = false;
+    int64_t V = 0;    // visits in total
     // split variant: per (source, image) first 64-pixel tile in d_rec, allocated on first use
     std::vector<int64_t> h_tile_off;
     int64_t *d_tile_off = nullptr;
@@ -327,6 +336,37 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
         CTX_TRY(dev_upload(&c->d_link_src, lsrc.data(), lsrc.size()));
     }
 
+    c->h_vis_off.assign((size_t)c->S + 1, 0);
+    for (int s = 0; s < c->S; ++s) {
+        for (int n = 0; n < c->N; ++n) {
+            const DevPatch &q = c->h_patches[(size_t)s * c->N + n];
+            if (q.H2 * q.W2 > 0) { c->h_vis_img.push_back(n); c->h_vis_src.push_back(s); }
+        }
+        c->h_vis_off[s + 1] = (int32_t)c->h_vis_img.size();
+        c->M = std::max(c->M, c->h_vis_off[s + 1] - c->h_vis_off[s]);
+    }
+    // single-field problems (every source in every image, or nearly: M == N): list all N images for every source
+    // and let the kernels map (target, j) -> image j directly
+    c->dense = c->M == c->N && !getenv("CELESTE_FORCE_VISIT_LISTS");   // (the variable exists for testing)
+    if (c->dense) {
+        c->h_vis_img.clear(); c->h_vis_src.clear();
+        for (int s = 0; s < c->S; ++s) {
+            for (int n = 0; n < c->N; ++n) { c->h_vis_img.push_back(n); c->h_vis_src.push_back(s); }
+            c->h_vis_off[s + 1] = (int32_t)c->h_vis_img.size();
+        }
+    }
+    c->V = (int64_t)c->h_vis_img.size();
+    CTX_TRY(dev_upload(&c->d_vis_off, c->h_vis_off.data(), c->h_vis_off.size()));
+    CTX_TRY(dev_upload(&c->d_vis_img, c->h_vis_img.data(), c->h_vis_img.size()));
+    CTX_TRY(dev_upload(&c->d_vis_src, c->h_vis_src.data(), c->h_vis_src.size()));
+    {
+        std::vector<int32_t> li((size_t)c->n_links * c->M, -1);
+        for (int s = 0; s < c->S; ++s)
+            for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q)
+                for (int j = 0; j < c->h_vis_off[s + 1] - c->h_vis_off[s]; ++j) li[(size_t)q * c->M + j] = c->h_vis_img[c->h_vis_off[s] + j];
+        if (!c->dense) CTX_TRY(dev_upload(&c->d_link_img, li.data(), li.size()));
+    }
+
     if (const char *env_ab = getenv("CELESTE_ABLATE")) c->ablate = atoi(env_ab);
     const char *env_chunk = getenv("CELESTE_CHUNK_PX");
     if (env_chunk && atoi(env_chunk) >= 64) c->chunk_px = (atoi(env_chunk) + 63) / 64 * 64;
@@ -354,7 +394,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     (void)hipSetDevice(c->device);
     for (void *p : c->plane_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_link_img, c->d_items, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -382,11 +422,16 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     if (n_targets == 0) return CELESTE_OK;
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t need = (size_t)n_targets * c->N * c->CH * ACC_N;
+    const size_t need = (size_t)n_targets * c->M * c->CH * ACC_N;
     if (need > c->acc_cap) {
         if (c->d_acc) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_acc)); c->d_acc = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_acc, need * sizeof(double)));
         c->acc_cap = need;
+    }
+    if (!c->dense && (size_t)n_targets * c->M > c->items_cap) {
+        if (c->d_items) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_items)); c->d_items = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_items, (size_t)n_targets * c->M * sizeof(int32_t)));
+        c->items_cap = (size_t)n_targets * c->M;
     }
     const bool derivs = (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) != 0;
     const bool split = (flags & CELESTE_FLAG_SPLIT) != 0;
@@ -398,7 +443,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
             if (hipMalloc((void **)&c->d_rec, (size_t)std::max<int64_t>(c->n_tiles, 1) * ACC_N * 64 * sizeof(double)) != hipSuccess)
                 return CELESTE_ERR_ALLOC;
         }
-        const size_t need_s = (size_t)n_targets * c->N * c->RCH * ACC_N;
+        const size_t need_s = (size_t)n_targets * c->M * c->RCH * ACC_N;
         if (need_s > c->acc_split_cap) {
             if (c->d_acc_split) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_acc_split)); c->d_acc_split = nullptr; }
             HIP_TRY(hipMalloc((void **)&c->d_acc_split, need_s * sizeof(double)));
@@ -406,46 +451,62 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         }
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
-    hipLaunchKernelGGL(prep_kernel, dim3(c->S * c->N), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches, c->S,
-                       c->N, c->K, c->d_srcimg, c->d_comps, c->d_geo);
+    if (c->V > 0)
+        hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches,
+                           c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps);
+    if (render_neighbors) HIP_TRY(hipMemsetAsync(c->d_needed, 0, (size_t)c->S * sizeof(int32_t), stream));
+    {
+        const size_t nthreads = std::max<size_t>((size_t)c->S, (size_t)n_targets * (c->dense ? 1 : c->M));
+        hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, d_vp, c->S, c->d_geo,
+                           d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
+                           render_neighbors ? c->d_needed : nullptr);
+    }
     if (render_neighbors) {
-    HIP_TRY(hipMemsetAsync(c->d_needed, 0, (size_t)c->S * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(mark_kernel, dim3((n_targets + 255) / 256), dim3(256), 0, stream, d_targets, n_targets,
-                       c->d_needed);
     if (c->n_links > 0 && c->max_overlap_px > 0) {
         const int chv = (c->max_overlap_px + c->chunk_px - 1) / c->chunk_px;
-        hipLaunchKernelGGL(value_kernel, dim3((unsigned)((size_t)c->n_links * c->N * chv)), dim3(64), 0, stream,
+        hipLaunchKernelGGL(value_kernel, dim3((unsigned)((size_t)c->n_links * c->M * chv)), dim3(64), 0, stream,
                            c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->d_link_src, c->d_nbr_idx,
-                           c->d_val_off, c->N, c->NC, chv, c->chunk_px, c->d_val);
+                           c->d_val_off, c->d_link_img, c->N, c->M, c->NC, chv, c->chunk_px, c->d_val);
     }
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
-    const dim3 grid((unsigned)((size_t)n_targets * c->N * c->CH));
-#define LAUNCH_PIXEL_T(MODE, R)                                                                                 \
-    hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, c->d_images, c->d_patches, c->d_coefs,   \
-                       c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off, c->d_val, \
-                       d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->ablate, c->d_tile_off, c->d_rec, d_active_rank)
+    const dim3 grid((unsigned)((size_t)n_targets * c->M * c->CH));
+#define PIXEL_ARGS                                                                                                \
+    c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx,       \
+    c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->ablate, c->d_tile_off, c->d_rec, \
+    d_active_rank, c->d_items, c->M
+#define LAUNCH_PIXEL_T(MODE, R) hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, PIXEL_ARGS)
+#define LAUNCH_PIXEL_M(MODE) hipLaunchKernelGGL((pixel_kernel<MODE, double, true>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL(MODE) do { if (flags & CELESTE_FLAG_FP32) LAUNCH_PIXEL_T(MODE, float); else LAUNCH_PIXEL_T(MODE, double); } while (0)
-    if (split) LAUNCH_PIXEL(3);
+    if (d_active_rank) {   // several active sources: fp64, fused
+        if (flags & CELESTE_FLAG_HESS) LAUNCH_PIXEL_M(2);
+        else if (derivs) LAUNCH_PIXEL_M(1);
+        else LAUNCH_PIXEL_M(0);
+    }
+    else if (split) LAUNCH_PIXEL(3);
     else if (flags & CELESTE_FLAG_HESS) LAUNCH_PIXEL(2);
     else if (derivs) LAUNCH_PIXEL(1);
     else LAUNCH_PIXEL_T(0, double);
 #undef LAUNCH_PIXEL
+#undef LAUNCH_PIXEL_M
+#undef PIXEL_ARGS
 #undef LAUNCH_PIXEL_T
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
     c->ev_split = 0;
     if (split) {
         // per-patch sums of the records, then the lift reads one record per (target, image): CH = 1
-        hipLaunchKernelGGL(record_sum_kernel, dim3((unsigned)((size_t)n_targets * c->N * c->RCH)), dim3(RSUM_NT), 0,
+        hipLaunchKernelGGL(record_sum_kernel, dim3((unsigned)((size_t)n_targets * c->M * c->RCH)), dim3(RSUM_NT), 0,
                            stream, c->d_patches, d_targets, c->d_tile_off, reinterpret_cast<const double2 *>(c->d_rec),
-                           c->N, c->RCH, c->sum_tiles, c->d_acc_split);
+                           c->d_items, c->N, c->M, c->RCH, c->sum_tiles, c->d_acc_split);
         if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], stream)); c->ev_split = 1; }
         hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
-                           c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->N, c->RCH, c->sum_tiles * 64, flags,
+                           c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M,
+                           c->RCH, c->sum_tiles * 64, flags,
                            d_v, d_d, d_h, d_counters, d_status);
     } else
     hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
-                       c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->N, c->CH, c->chunk_px, flags,
+                       c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH,
+                       c->chunk_px, flags,
                        d_v, d_d, d_h, d_counters, d_status);
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[3], stream)); c->ev_valid = 1; }
     HIP_TRY(hipGetLastError());
@@ -791,8 +852,9 @@ extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32
     int rc = CELESTE_OK;
     if (hipMemset(d_plane, 0, npix * sizeof(double)) != hipSuccess) rc = CELESTE_ERR_HIP;
     if (rc == CELESTE_OK) {
-        hipLaunchKernelGGL(prep_kernel, dim3(c->S * c->N), dim3(64), 0, nullptr, c->d_vp, c->d_images, c->d_patches,
-                           c->S, c->N, c->K, c->d_srcimg, c->d_comps, c->d_geo);
+        if (c->V > 0)
+            hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, nullptr, c->d_vp, c->d_images,
+                               c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps);
         hipLaunchKernelGGL(render_kernel, dim3((unsigned)((size_t)c->S * c->CH)), dim3(64), 0, nullptr, c->d_patches,
                            c->d_coefs, c->d_bitmaps, im.pixels, c->d_srcimg, c->d_comps, (int)image, c->N, c->NC,
                            c->CH, c->chunk_px, im.H, d_plane);

@@ -61,11 +61,13 @@ __device__ inline void brightness(const double *vs, int i, int b, double &El, do
 
 __global__ void __launch_bounds__(64)
 prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
-            const DevPatch *__restrict__ patches, int S, int N, int K,
-            SrcImg *__restrict__ srcimg, Comp *__restrict__ comps, SrcGeo *__restrict__ geo) {
+            const DevPatch *__restrict__ patches, const int32_t *__restrict__ vis_src,
+            const int32_t *__restrict__ vis_img, int N, int K,
+            SrcImg *__restrict__ srcimg, Comp *__restrict__ comps) {
     const int NC = 14 * K;
-    const int sn = blockIdx.x;  // s * N + n
-    const int s = sn / N, n = sn - s * N;
+    // one workgroup per visit = (source, image) pair with a non-empty patch; the tables stay dense (s * N + n)
+    const int s = vis_src[blockIdx.x], n = vis_img[blockIdx.x];
+    const int sn = s * N + n;
     const int c = threadIdx.x;
     const double *vs = vp + (size_t)s * CEL_P;
     const DevPatch &p = patches[sn];
@@ -106,7 +108,13 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         o.pad0 = 0; o.pad1 = 0;
         srcimg[sn] = o;
     }
-    if (n == 0 && c == 62) {
+}
+
+// per-source shape derivatives and the finiteness flag of its parameters
+__device__ inline void source_geo(const double *vp, int s, SrcGeo *geo) {
+    const double *vs = vp + (size_t)s * CEL_P;
+    double x11, x12, x22;
+    bvn_cov(vs[3], vs[4], vs[5], x11, x12, x22);
         // GalaxySigmaDerivs without nuBar (BivariateNormals.jl:346-397); argument order there is
         // (angle, axis_ratio, radius); columns are (axis_ratio, angle, radius)
         SrcGeo g;
@@ -136,7 +144,6 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         for (int q = 0; q < CEL_P; ++q) fin &= (int)isfinite(vs[q]);
         g.finite = fin; g.pad = 0;
         geo[s] = g;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -258,9 +265,39 @@ __device__ inline double wave_sum(double x) {
 // per batch on the source's own patch so that the pixel kernel gathers two doubles per covering
 // neighbour instead of re-evaluating 14 psf_K exponentials per (pixel, neighbour) pair.
 // ---------------------------------------------------------------------------------------------
+// items[ti * M + j] = image of the j-th visit of target ti (-1: none), so that the pixel kernels find their
+// (target, image) with two independent loads instead of a chain through the visit lists
+__global__ void visit_items_kernel(const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
+                                   const int32_t *__restrict__ vis_img, int M, int32_t *__restrict__ items) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_targets * M) return;
+    const int ti = k / M, j = k - ti * M;
+    const int t = targets[ti];
+    const int vo = vis_off[t];
+    items[k] = j < vis_off[t + 1] - vo ? vis_img[vo + j] : -1;
+}
+
 __global__ void mark_kernel(const int32_t *__restrict__ targets, int n_targets, int32_t *__restrict__ is_target) {
     const int ti = blockIdx.x * blockDim.x + threadIdx.x;
     if (ti < n_targets) is_target[targets[ti]] = 1;
+}
+
+// One launch for the per-batch bookkeeping: SrcGeo of every source, the visit items of the batch (unless every
+// source is listed in every image), the target flags (is_target == nullptr: keep an earlier rendering)
+__device__ inline void source_geo(const double *vp, int s, SrcGeo *geo);
+__global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo,
+                             const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
+                             const int32_t *__restrict__ vis_img, int M, int32_t *__restrict__ items,
+                             int32_t *__restrict__ is_target) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < S) source_geo(vp, k, geo);
+    if (items && k < n_targets * M) {
+        const int ti = k / M, j = k - ti * M;
+        const int t = targets[ti];
+        const int vo = vis_off[t];
+        items[k] = j < vis_off[t + 1] - vo ? vis_img[vo + j] : -1;
+    }
+    if (is_target && k < n_targets) is_target[targets[k]] = 1;
 }
 
 // One wavefront per (neighbour link t -> s2, image, chunk): renders s2's value-only light on the rectangle
@@ -271,7 +308,8 @@ __global__ void __launch_bounds__(64)
 value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
              const int32_t *__restrict__ is_target, const int32_t *__restrict__ link_src,
-             const int32_t *__restrict__ nbr_idx, const int64_t *__restrict__ val_off, int N, int NC, int CH,
+             const int32_t *__restrict__ nbr_idx, const int64_t *__restrict__ val_off,
+             const int32_t *__restrict__ link_img, int N, int M, int NC, int CH,
              int chunk_px, double2 *__restrict__ val) {
     __shared__ double etab[64];
     // chunk index is the slow grid axis: all first chunks (every overlap has one) are dispatched first and
@@ -279,7 +317,9 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
     const int LN = gridDim.x / CH;
     const int ch = blockIdx.x / LN;
     const int ln = blockIdx.x - ch * LN;
-    const int q = ln / N, n = ln - q * N;
+    const int q = ln / M;                   // ln = q * M + j: link, j-th image the link's target appears in
+    const int n = link_img ? link_img[ln] : ln - q * M;
+    if (n < 0) return;
     const int t = link_src[q];
     if (!is_target[t]) return;
     const int s = nbr_idx[q];
@@ -545,7 +585,9 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int nc, R dx, 
 #endif
 // R: arithmetic type of the galaxy component loop (double; float with CELESTE_FLAG_FP32 -- everything
 // downstream of the 24 component sums, and all accumulation, stays fp64)
-template <int MODE, typename R>
+// MULTI: several active sources (celeste_elbo_eval_multi) -- compiled separately so that the production
+// instantiation carries none of its per-neighbour bookkeeping
+template <int MODE, typename R, bool MULTI = false>
 __global__ void __launch_bounds__(64, PIXEL_WAVES)
 pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ patches,
              const double *__restrict__ coefs, const uint8_t *__restrict__ bitmaps,
@@ -554,15 +596,17 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const int64_t *__restrict__ val_off, const double2 *__restrict__ val,
              const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px,
              double *__restrict__ acc, int ablate, const int64_t *__restrict__ tile_off, double *__restrict__ rec,
-             const int32_t *__restrict__ active_rank) {
+             const int32_t *__restrict__ active_rank, const int32_t *__restrict__ items, int M) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
     __shared__ double etab[64];
     // chunk index is the slow grid axis (see value_kernel): heavy first chunks go first, spread over all XCDs
     const int TN = gridDim.x / CH;
     const int ch = blockIdx.x / TN;
     const int tn = blockIdx.x - ch * TN;
-    const int wg = tn * CH + ch;  // record index, as the lift kernel expects
-    const int ti = tn / N, n = tn - ti * N;
+    const int wg = tn * CH + ch;  // record index, as the lift kernel expects: ((ti * M + j) * CH + ch)
+    const int ti = tn / M;                     // tn = ti * M + j: target, j-th image it appears in (tables stay dense)
+    const int n = items ? items[tn] : tn - ti * M;   // items == nullptr: every source is listed in all M = N images
+    if (n < 0) return;
     const int t = targets[ti];
     const DevPatch &P = patches[(size_t)t * N + n];
     const int H2 = P.H2, W2 = P.W2;
@@ -596,7 +640,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const int64_t nb0 = nbr_off[t], nb1 = (ablate & 1) ? nb0 : nbr_off[t + 1];
     // several active sources (celeste_elbo_eval_multi): a pixel of two active patches is visited by the earlier
     // one only (elbo_objective.jl:430-470) -- its value term and inactive-source count are dropped here
-    const int my_rank = active_rank ? active_rank[t] : 0;
+    const int my_rank = MULTI ? active_rank[t] : 0;
     const double c0 = si.c0, c1 = si.c1, q0 = si.q0, q1 = si.q1;
     // index offsets of the star spline: itp[h - m1 + 26, w - m2 + 26]
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
@@ -634,7 +678,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             bool in = valid & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 < Q.W2);  // strict: elbo_objective.jl:349
             if (in && Q.bitmap_off >= 0) in = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
             int r2 = -1;
-            if (active_rank) {
+            if (MULTI) {
                 r2 = active_rank[s2];
                 if (r2 >= 0 && r2 < my_rank) {   // does the earlier active source visit this pixel (last column included)?
                     bool vis = valid & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 <= Q.W2);
@@ -646,10 +690,10 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
                 const double2 ev = val[val_off[(size_t)s2 * N + n] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
                 Ebar += ev.x;
                 Vbar += ev.y;
-                n_inact += r2 < 0;
+                n_inact += MULTI ? (r2 < 0) : 1;
             }
         }
-        if (dup) n_inact = 0;
+        if (MULTI && dup) n_inact = 0;
 
         // ---- the active source ----
         const bool own = valid && (w2 < W2 - 1);  // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
@@ -665,7 +709,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
                 const double E = Ebar + A;
                 const double V = Vbar + ((q0 * (f0 * f0) + q1 * (f1 * f1)) - A * A);
                 const double iE = 1.0 / E;
-                if (!dup) a[0] += x * (log_iota + (log(E) - V * (0.5 * iE * iE))) - iota * E - lgx;
+                if (!(MULTI && dup)) a[0] += x * (log_iota + (log(E) - V * (0.5 * iE * iE))) - iota * E - lgx;
                 a[1] += own ? 1.0 : 0.0;
                 a[2] += (double)n_inact;
             }
@@ -722,7 +766,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             const double V = Vbar + (B - A * A);                          // var_G.v
             const double iE = 1.0 / E;
             const double iE2 = iE * iE, iE3 = iE2 * iE;
-            T.vterm = (valid && !dup) ? x * (log_iota + (log(E) - V * (0.5 * iE2))) - iota * E - lgx : 0.0;
+            T.vterm = (valid && !(MULTI && dup)) ? x * (log_iota + (log(E) - V * (0.5 * iE2))) - iota * E - lgx : 0.0;
             T.cnt_act = own ? 1.0 : 0.0;
             T.cnt_inact = (double)n_inact;
             // derivative weights are zero unless the active source covers the pixel, which zeroes every
@@ -779,13 +823,16 @@ typedef double d2v __attribute__((ext_vector_type(2)));
 #define RSUM_K (ACC_N * 32 / RSUM_NT)  // 17
 __global__ void __launch_bounds__(RSUM_NT)
 record_sum_kernel(const DevPatch *__restrict__ patches, const int32_t *__restrict__ targets,
-                  const int64_t *__restrict__ tile_off, const double2 *__restrict__ rec, int N, int RCH,
-                  int sum_tiles, double *__restrict__ acc) {
+                  const int64_t *__restrict__ tile_off, const double2 *__restrict__ rec,
+                  const int32_t *__restrict__ items, int N, int M, int RCH, int sum_tiles,
+                  double *__restrict__ acc) {
     // part index is the slow grid axis: every patch's first part is launched before any second part
     const int TN = gridDim.x / RCH;
     const int part = blockIdx.x / TN;
     const int tn = blockIdx.x - part * TN;
-    const int ti = tn / N, n = tn - ti * N;
+    const int ti = tn / M;
+    const int n = items ? items[tn] : tn - ti * M;
+    if (n < 0) return;
     const int t = targets[ti];
     const DevPatch &P = patches[(size_t)t * N + n];
     const int npx = P.H2 * P.W2;
@@ -943,7 +990,8 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
             const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
             const int32_t *__restrict__ targets, const double *__restrict__ acc,
-            const PriorDev *__restrict__ prior, int N, int CH, int chunk_px, uint32_t flags,
+            const PriorDev *__restrict__ prior, const int32_t *__restrict__ vis_off,
+            const int32_t *__restrict__ vis_img, int N, int M, int CH, int chunk_px, uint32_t flags,
             double *__restrict__ out_v, double *__restrict__ out_d, double *__restrict__ out_h,
             int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status) {
     __shared__ double sh_h[LIFT_NP * LIFT_NP];         // likelihood Hessian, upper triangle, params < 28
@@ -1002,22 +1050,24 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         K.g_v[i] = .5 * (-1.0 / var1 + 1.0 / var2);
     }
 
-    for (int n0 = 0; n0 < N; n0 += LIFT_NT) {
-        const int nt = min(LIFT_NT, N - n0);
+    // the images the target appears in (its visit list), LIFT_NT at a time
+    const int vo = vis_off[t], n_vis = vis_off[t + 1] - vo;
+    for (int n0 = 0; n0 < n_vis; n0 += LIFT_NT) {
+        const int nt = min(LIFT_NT, n_vis - n0);
         // pass 1: chunk records -> per-image record; brightness moments and exponent coefficients
         for (int k = tid; k < nt * ACC_N; k += nthr) {
-            const int i = k / ACC_N, e = k - i * ACC_N, n = n0 + i;
+            const int i = k / ACC_N, e = k - i * ACC_N, n = vis_img[vo + n0 + i];
             const DevPatch &P = patches[(size_t)t * N + n];
             const int npx = P.H2 * P.W2;
             double s = 0.0;
             for (int ch = 0; ch < CH; ++ch)
-                if (ch * chunk_px < npx) s += acc[((size_t)(ti * N + n) * CH + ch) * ACC_N + e];
+                if (ch * chunk_px < npx) s += acc[((size_t)(ti * M + n0 + i) * CH + ch) * ACC_N + e];
             s_rec[i][e] = s;
         }
         if (want_grad) {
             for (int k = tid; k < nt * 12; k += nthr) {
                 const int i = k / 12, q = k - i * 12;
-                const int b = images[n0 + i].band - 1;
+                const int b = images[vis_img[vo + n0 + i]].band - 1;
                 if (q < 10) {
                     double kap, lam;
                     bright_coef(q, b, kap, lam);
@@ -1037,7 +1087,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
                 const int i = k / (ZV * LIFT_NP), rp = k - i * (ZV * LIFT_NP);
                 const int r = rp / LIFT_NP, p = rp - r * LIFT_NP;
                 double v = 0.0;
-                if (r >= 4 && r < 6) { if (p < 2) v = patches[(size_t)t * N + n0 + i].J[(r - 4) + 2 * p]; }
+                if (r >= 4 && r < 6) { if (p < 2) v = patches[(size_t)t * N + vis_img[vo + n0 + i]].J[(r - 4) + 2 * p]; }
                 else if (r == 6) { if (p == 2) v = 1.0; }
                 else if (r >= 7) { if (p >= 3 && p < 6) v = s_jsh[(r - 7) + 3 * (p - 3)]; }
                 else {
@@ -1113,6 +1163,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
     }
 
     // ---- KL value (elbo_kl.jl:140-154) ----
+    __syncthreads();   // the per-component KL terms were written by other threads (a target may have no visit at all)
     if (want_kl && tid < 2) {
         const int i = tid;
         double ck = 0, cm = 0;

@@ -89,3 +89,45 @@ def test_config3_neighbor_parameters_matter(field3, ctx3):
     a = ctx3.eval_batch(field3.vp, iso, ALL); b = ctx3.eval_batch(vp2, iso, ALL)
     keep = [i for i, s in enumerate(iso) if s != nb]
     assert np.array_equal(a[0][keep], b[0][keep])
+
+
+def test_config5_overlapping_fields_fp32(oracle):
+    """BASELINE configs[4] scaled to one GPU's share: a 2 x 4 grid of overlapping fields (40 images), 1500 sources each
+    seen by 5-20 images, fp32 component loop against the fp64 oracle at 1e-4 (sampled) and against the fp64 device
+    path (all sources); sharding invariance across 8 cost-balanced shards"""
+    import time
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    from celeste_jl_amd.partition import shard_targets, estimate_time
+    t0 = time.time()
+    f = synthetic.make_multifield(grid=(2, 4), H=400, W=400, overlap=0.10, n_sources=1500, seed=5)
+    S, N = len(f.catalog), len(f.images)
+    seen = np.array([sum(p.active_pixel_bitmap.size > 0 for p in row) for row in f.patches])
+    assert N == 40 and seen.min() >= 5 and seen.max() >= 10
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    t1 = time.time()
+    tg = np.arange(S)
+    fl32 = ALL | cabi.FLAG_FP32
+    v64, d64, h64, cnt64, st64 = ctx.eval_batch(f.vp, tg, ALL)
+    t2 = time.time()
+    v32, d32, h32, cnt32, st32 = ctx.eval_batch(f.vp, tg, fl32)
+    t3 = time.time()
+    print("config5/8: build %.1f s, ctx %.1f s, fp64 sweep %.3f s, fp32 sweep %.3f s (host API incl. D2H of %d Hessians)"
+          % (t1 - t0, t2 - t1 - (t3 - t2), t2 - t1, t3 - t2, S))
+    assert (st64 == 0).all() and (st32 == 0).all() and np.array_equal(cnt32, cnt64)
+    ev = np.max(np.abs(v32 - v64) / np.abs(v64))
+    ed = max(np.abs(d32[t] - d64[t]).max() / np.abs(d64[t]).max() for t in tg)
+    eh = max(np.abs(h32[t] - h64[t]).max() / np.abs(h64[t]).max() for t in tg)
+    print("fp32 vs fp64 device:", ev, ed, eh)
+    assert ev <= 1e-4 and ed <= 1e-4 and eh <= 1e-4
+    sample = sorted(set(list(range(0, S, 60)) + list(np.argsort(-seen)[:6])))
+    ov, od, oh, ocnt, ost = oracle.elbo_batch(ctx.problem, f.vp, sample, ALL)
+    assert np.array_equal(cnt32[sample], ocnt)
+    assert np.max(np.abs(v32[sample] - ov) / np.abs(ov)) <= 1e-4
+    assert max(np.abs(d32[t] - od[k]).max() / np.abs(od[k]).max() for k, t in enumerate(sample)) <= 1e-4
+    errs = assert_parity((v64[sample], d64[sample], h64[sample], cnt64[sample], st64[sample]), (ov, od, oh, ocnt, ost), "config5 fp64")
+    print("config5 fp64 sample of %d" % len(sample), errs)
+    costs = [estimate_time(row) for row in f.patches]
+    for shard in shard_targets(costs, 8):
+        vs, ds, _, _, _ = ctx.eval_batch(f.vp, shard, 1 | 4 | cabi.FLAG_FP32)
+        assert np.array_equal(vs, v32[shard]) and np.array_equal(ds, d32[shard])

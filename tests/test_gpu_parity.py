@@ -310,6 +310,14 @@ def test_edge_cases(oracle):
     vp = np.vstack([f.vp, catalog_init_source(ce)])
     ctx = cel.FieldContext(f.images, patches, neighbor_map(patches))
     assert_parity(ctx.eval_batch(vp, [3, 0], ALL), oracle.elbo_batch(ctx.problem, vp, [3, 0], ALL), "outside")
+    # the same in a multi-field problem (sparse visit lists: sources appear in a subset of the images)
+    f = synthetic.make_multifield(grid=(1, 2), H=96, W=96, n_sources=10, seed=9)
+    cat = list(f.catalog) + [ce]
+    patches = get_sky_patches(f.images, cat)
+    vp = np.vstack([f.vp, catalog_init_source(ce)])
+    ctx = cel.FieldContext(f.images, patches, neighbor_map(patches))
+    tg = [10, 0, 4, 9]
+    assert_parity(ctx.eval_batch(vp, tg, ALL), oracle.elbo_batch(ctx.problem, vp, tg, ALL), "outside, multi-field")
 
 
 def test_batch_equals_singles():
