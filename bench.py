@@ -4,7 +4,8 @@
 One "step" = one sweep of elbo() over every source of one synthetic 2048x1489x5 SDSS-size field
 (~2000 star+galaxy sources, BASELINE.json configs[2]), inputs resident in HBM.  With --gpus N each rank
 owns one such field (sources shard with no data-path collective; weak scaling) and the per-source results
-(value + 44-gradient) are all-gathered over RCCL at the end of every sweep (the "catalog gather").
+(value + 44-gradient) are all-gathered over RCCL after every sweep (the "catalog gather"), on a second stream
+so that the gather of sweep k overlaps the kernels of sweep k + 1; every gather is complete before the clock stops.
 
 Prints ONE JSON line on rank 0 (contract in the task description).
 """
@@ -137,25 +138,45 @@ def main():
 
     d_vp = torch.tensor(fld.vp, dtype=torch.float64, device=dev)
     d_tg = torch.tensor(targets, dtype=torch.int32, device=dev)
-    d_v = torch.zeros(S, dtype=torch.float64, device=dev)
-    d_d = torch.zeros(S, 44, dtype=torch.float64, device=dev)
+    # value / gradient outputs are double-buffered so that the catalog gather of sweep k (RCCL, on its own stream)
+    # overlaps the kernels of sweep k + 1
+    d_vs = [torch.zeros(S, dtype=torch.float64, device=dev) for _ in range(2)]
+    d_ds = [torch.zeros(S, 44, dtype=torch.float64, device=dev) for _ in range(2)]
+    d_v, d_d = d_vs[0], d_ds[0]
     d_h = torch.zeros(S, 44, 44, dtype=torch.float64, device=dev)
     d_cnt = torch.zeros(S, 2, dtype=torch.int64, device=dev)
     d_st = torch.zeros(S, dtype=torch.int32, device=dev)
-    gather_in = torch.zeros(S, 45, dtype=torch.float64, device=dev)
-    gather_out = torch.zeros(world * S, 45, dtype=torch.float64, device=dev) if use_dist else None
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    compute_stream = torch.cuda.current_stream(dev)
+    stream = compute_stream.cuda_stream
+    if use_dist:
+        comm_stream = torch.cuda.Stream(dev)
+        gather_in = [torch.zeros(S, 45, dtype=torch.float64, device=dev) for _ in range(2)]
+        gather_out = torch.zeros(world * S, 45, dtype=torch.float64, device=dev)
+        buf_free = [torch.cuda.Event(), torch.cuda.Event()]
+        for e in buf_free:
+            e.record(compute_stream)
+    step_no = [0]
 
     def step():
-        ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_ALL, d_v.data_ptr(), d_d.data_ptr(),
+        k = step_no[0] % 2
+        step_no[0] += 1
+        if use_dist:
+            compute_stream.wait_event(buf_free[k])      # the gather that last read this buffer pair is through
+        ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_ALL, d_vs[k].data_ptr(), d_ds[k].data_ptr(),
                               d_h.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), stream)
         if use_dist:  # the catalog gather: value + 44-gradient of every source, RCCL over xGMI
-            gather_in[:, 0] = d_v
-            gather_in[:, 1:] = d_d
-            dist.all_gather_into_tensor(gather_out, gather_in)
+            done = torch.cuda.Event()
+            done.record(compute_stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(done)
+                gather_in[k][:, 0] = d_vs[k]
+                gather_in[k][:, 1:] = d_ds[k]
+                dist.all_gather_into_tensor(gather_out, gather_in[k])
+                buf_free[k].record(comm_stream)
 
     def sync():
         if use_dist:
+            comm_stream.synchronize()
             dist.barrier()
         torch.cuda.synchronize(dev)
 
