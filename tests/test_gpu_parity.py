@@ -320,6 +320,56 @@ def test_edge_cases(oracle):
     assert_parity(ctx.eval_batch(vp, tg, ALL), oracle.elbo_batch(ctx.problem, vp, tg, ALL), "outside, multi-field")
 
 
+def test_invalid_arguments_are_refused():
+    """status codes instead of the reference's assertion failures (include/celeste_mi355x.h)"""
+    import ctypes as C
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    lib = cabi.load_library()
+    f = synthetic.make_sample_dataset("two_body")
+
+    def create(mutate, **kw):
+        pb = cabi.Problem(f.images, f.patches, f.neighbors, **kw)
+        mutate(pb)
+        h = C.c_void_p()
+        st = lib.celeste_ctx_create(C.byref(pb.c), 0, C.byref(h))
+        if st == 0:
+            lib.celeste_ctx_destroy(h)
+        return st
+
+    assert create(lambda pb: None) == cabi.OK
+    assert create(lambda pb: setattr(pb.c, "psf_K", 5)) == cabi.ERR_INVALID_ARG           # 14 K components must fit
+    assert create(lambda pb: setattr(pb.c, "n_sources", 0)) == cabi.ERR_INVALID_ARG
+
+    def patch_outside(pb):
+        pb.c.patches[0].off_h = 15      # 15 + H2 > H = 20
+    assert create(patch_outside) == cabi.ERR_INVALID_ARG
+
+    def bad_stamp(pb):
+        pb.c.patches[1].stamp = 99
+    assert create(bad_stamp) == cabi.ERR_INVALID_ARG
+
+    def bad_band(pb):
+        pb.c.images[2].band = 6
+    assert create(bad_band) == cabi.ERR_INVALID_ARG
+    assert lib.celeste_ctx_create(C.byref(cabi.Problem(f.images, f.patches, f.neighbors).c), 64, C.byref(C.c_void_p())) == cabi.ERR_INVALID_ARG
+
+    ctx = _ctx(f)
+    with pytest.raises(cabi.CelesteError):
+        ctx.eval_batch(f.vp, [2], ALL)            # target out of range
+    with pytest.raises(cabi.CelesteError):
+        ctx.eval_batch(f.vp, [-1], ALL)
+    with pytest.raises(cabi.CelesteError):
+        ctx.eval_multi(f.vp, [0, 0], ALL)         # duplicate active source
+    with pytest.raises(cabi.CelesteError):
+        ctx.maximize_batch(f.vp, [0], cel.ElboConfig(loc_width=-1.0))
+    v = np.zeros(1)
+    assert lib.celeste_elbo_eval_batch(ctx.handle, None, 1, None, 7, v.ctypes.data_as(cabi.c_double_p), None, None, None,
+                                       None) == cabi.ERR_INVALID_ARG
+    # the context survives all of the above
+    assert ctx.eval_batch(f.vp, [0, 1], ALL)[4].tolist() == [0, 0]
+
+
 def test_batch_equals_singles():
     from celeste_jl_amd import synthetic
     f = synthetic.make_field(128, 128, 12, seed=5)
