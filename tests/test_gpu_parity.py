@@ -320,6 +320,37 @@ def test_edge_cases(oracle):
     assert_parity(ctx.eval_batch(vp, tg, ALL), oracle.elbo_batch(ctx.problem, vp, tg, ALL), "outside, multi-field")
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_randomised_small_fields(oracle, seed):
+    """fuzz: random image size, source count, NaN fraction, explicit bitmaps, target subset / order, flag set, and
+    either evaluation path (fused / split / visit lists forced by giving one source no patch in one image)"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(60, 140)), int(rng.integers(60, 140))
+    S = int(rng.integers(1, 14))
+    f = synthetic.make_field(H, W, S, seed=2000 + seed, nan_fraction=float(rng.choice([0.0, 0.01, 0.05])), margin=int(rng.integers(3, 27)))
+    for s_ in range(S):
+        if rng.random() < 0.3:      # punch holes into some patches' bitmaps
+            p = f.patches[s_][int(rng.integers(5))]
+            if p.active_pixel_bitmap.size:
+                p.active_pixel_bitmap &= rng.random(p.active_pixel_bitmap.shape) > 0.2
+    if S > 2 and rng.random() < 0.5:  # one source loses its patch in one image: visit lists become ragged
+        p = f.patches[int(rng.integers(S))][int(rng.integers(5))]
+        (h0, h1), (w0, w1) = p.box
+        p.box = ((h0, h0 - 1), (w0, w0 - 1))
+        p.active_pixel_bitmap = np.zeros((0, 0), dtype=bool)
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    tg = rng.permutation(S)[:int(rng.integers(1, S + 1))].tolist()
+    flags = int(rng.choice([0, 4, 1, 5, 3, 7, 7, 7]))
+    g = ctx.eval_batch(f.vp, tg, flags)
+    r = oracle.elbo_batch(ctx.problem, f.vp, tg, flags)
+    errs = assert_parity(g, r, "fuzz %d" % seed)
+    if flags & 2:
+        assert_parity(ctx.eval_batch(f.vp, tg, flags | cabi.FLAG_SPLIT), r, "fuzz %d split" % seed)
+    print("fuzz", seed, (H, W, S), "targets", len(tg), "flags", flags, errs)
+
+
 def test_invalid_arguments_are_refused():
     """status codes instead of the reference's assertion failures (include/celeste_mi355x.h)"""
     import ctypes as C
