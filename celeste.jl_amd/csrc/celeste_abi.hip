@@ -85,6 +85,14 @@ struct celeste_ctx {
     int64_t *d_cnt = nullptr;
     int32_t *d_status = nullptr;
     size_t stage_cap = 0;
+    // buffers of celeste_maximize_batch, kept between calls (grown on demand)
+    struct OptBuffers {
+        size_t cap = 0;
+        double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_H = nullptr, *d_pos = nullptr;
+        int32_t *d_targets = nullptr, *d_act[2] = {nullptr, nullptr}, *d_evt[2] = {nullptr, nullptr}, *d_count = nullptr,
+                *d_st = nullptr;
+        void *d_state = nullptr;
+    } opt;
     // timing
     int timing = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -397,6 +405,12 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
                     c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_link_img, c->d_items, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    {
+        auto &o = c->opt;
+        void *optr[] = {o.d_vp, o.d_v, o.d_d, o.d_h, o.d_H, o.d_pos, o.d_targets, o.d_act[0], o.d_act[1], o.d_evt[0], o.d_evt[1],
+                        o.d_count, o.d_st, o.d_state};
+        for (void *q : optr) if (q) (void)hipFree(q);
+    }
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
@@ -761,30 +775,33 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double
     op.solver = (env_solver && strcmp(env_solver, "eig") == 0) ? 1 : 0;
     const uint32_t flags = CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS | (cfg.include_kl ? CELESTE_FLAG_KL : 0);
     const size_t n = (size_t)n_targets;
-    double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_H = nullptr, *d_pos = nullptr;
-    int32_t *d_targets = nullptr, *d_act[2] = {nullptr, nullptr}, *d_evt[2] = {nullptr, nullptr}, *d_count = nullptr,
-            *d_st = nullptr;
-    OptState *d_state = nullptr;
+    auto &ob = c->opt;
     int rc = CELESTE_OK;
 #define MX_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto cleanup; } } while (0)
-    MX_TRY(hipMalloc((void **)&d_vp, (size_t)c->S * CEL_P * sizeof(double)));
-    MX_TRY(hipMalloc((void **)&d_v, n * sizeof(double)));
-    MX_TRY(hipMalloc((void **)&d_d, n * CEL_P * sizeof(double)));
-    MX_TRY(hipMalloc((void **)&d_h, n * CEL_P * CEL_P * sizeof(double)));
-    MX_TRY(hipMalloc((void **)&d_H, n * NF * NF * sizeof(double)));
-    MX_TRY(hipMalloc((void **)&d_targets, n * sizeof(int32_t)));
-    for (int k = 0; k < 2; ++k) {
-        MX_TRY(hipMalloc((void **)&d_act[k], n * sizeof(int32_t)));
-        MX_TRY(hipMalloc((void **)&d_evt[k], n * sizeof(int32_t)));
+    if (n > ob.cap) {   // (re)allocate every per-target buffer at the new capacity
+        void **grow[] = {(void **)&ob.d_v, (void **)&ob.d_d, (void **)&ob.d_h, (void **)&ob.d_H, (void **)&ob.d_pos,
+                         (void **)&ob.d_targets, (void **)&ob.d_act[0], (void **)&ob.d_act[1], (void **)&ob.d_evt[0],
+                         (void **)&ob.d_evt[1], (void **)&ob.d_st, &ob.d_state};
+        const size_t bytes[] = {sizeof(double), CEL_P * sizeof(double), CEL_P * CEL_P * sizeof(double), NF * NF * sizeof(double),
+                                2 * sizeof(double), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t),
+                                sizeof(int32_t), sizeof(int32_t), sizeof(OptState)};
+        ob.cap = 0;
+        for (int k = 0; k < 12; ++k) {
+            if (*grow[k]) { (void)hipFree(*grow[k]); *grow[k] = nullptr; }
+            MX_TRY(hipMalloc(grow[k], n * bytes[k]));
+        }
+        ob.cap = n;
     }
-    MX_TRY(hipMalloc((void **)&d_count, sizeof(int32_t)));
-    MX_TRY(hipMalloc((void **)&d_st, n * sizeof(int32_t)));
-    MX_TRY(hipMalloc((void **)&d_state, n * sizeof(OptState)));
+    if (!ob.d_vp) MX_TRY(hipMalloc((void **)&ob.d_vp, (size_t)c->S * CEL_P * sizeof(double)));
+    if (!ob.d_count) MX_TRY(hipMalloc((void **)&ob.d_count, sizeof(int32_t)));
+    {
+    double *const d_vp = ob.d_vp, *const d_v = ob.d_v, *const d_d = ob.d_d, *const d_h = ob.d_h, *const d_H = ob.d_H;
+    double *const d_pos = pos_centers ? ob.d_pos : nullptr;
+    int32_t *const d_targets = ob.d_targets, *const d_count = ob.d_count, *const d_st = ob.d_st;
+    int32_t *const *d_act = ob.d_act, *const *d_evt = ob.d_evt;
+    OptState *const d_state = (OptState *)ob.d_state;
     MX_TRY(hipMemcpy(d_targets, targets, n * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (pos_centers) {
-        MX_TRY(hipMalloc((void **)&d_pos, n * 2 * sizeof(double)));
-        MX_TRY(hipMemcpy(d_pos, pos_centers, n * 2 * sizeof(double), hipMemcpyHostToDevice));
-    }
+    if (pos_centers) MX_TRY(hipMemcpy(d_pos, pos_centers, n * 2 * sizeof(double), hipMemcpyHostToDevice));
     {
         // neighbours are rendered once, from their frozen parameters, before any target moves
         MX_TRY(hipMemcpy(d_vp, vp_neighbors ? vp_neighbors : vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
@@ -819,12 +836,9 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double
             if (hs[t].status != CELESTE_OK && rc == CELESTE_OK) rc = hs[t].status;
         }
     }
+    }
 cleanup:
 #undef MX_TRY
-    {
-        void *ptrs[] = {d_vp, d_v, d_d, d_h, d_H, d_pos, d_targets, d_act[0], d_act[1], d_evt[0], d_evt[1], d_count, d_st, d_state};
-        for (void *p : ptrs) if (p) (void)hipFree(p);
-    }
     return rc;
 }
 
