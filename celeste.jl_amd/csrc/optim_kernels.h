@@ -132,6 +132,12 @@ __global__ void optim_init_kernel(double *__restrict__ vp, const int32_t *__rest
 }
 
 __device__ __forceinline__ double lane_bcast(double x, int src) { return __shfl(x, src, 64); }
+// the same for a wave-uniform source lane: v_readlane into a scalar register pair instead of an LDS permute
+__device__ __forceinline__ double lane_bcast_u(double x, int src) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)b, src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 
 // wave sum by DPP row operations (no LDS traffic): quad butterflies, row mirrors, row broadcasts; the total
 // ends in lane 63 and is handed to every lane through a scalar register pair
@@ -161,23 +167,32 @@ __device__ inline void tred_wave(double *A, double *hv, double *e, double *q, in
     for (int i = NF - 1; i >= 1; --i) {
         const int l = i - 1;
         const bool act = ln <= l;
-        double x = act ? A[i + LDA * ln] : 0.0;            // row i left of the diagonal
-        if (l == 0) { e[i] = lane_bcast(x, 0); hv[i] = 0.0; continue; }
-        const double scale = wave_sum_dpp(fabs(x));
-        if (scale == 0.0) { e[i] = 0.0; hv[i] = 0.0; continue; }
-        x /= scale;
-        double h = wave_sum_dpp(x * x);
-        const double f = lane_bcast(x, l);
+        const double x = act ? A[i + LDA * ln] : 0.0;     // row i left of the diagonal
+        if (l == 0) { e[i] = lane_bcast_u(x, 0); hv[i] = 0.0; continue; }
+        // (no rescaling of the row: the entries are curvatures of an O(1e7) objective in O(1) free parameters, far
+        // from the overflow / underflow range the classical algorithm guards against)
+        const double f = lane_bcast_u(x, l);
+        const double hoff = wave_sum_dpp(ln < l ? x * x : 0.0);
+        if (hoff == 0.0) { e[i] = f; hv[i] = 0.0; continue; }   // nothing left of column l: already tridiagonal here
+        double h = hoff + f * f;
         const double g = f >= 0 ? -sqrt(h) : sqrt(h);
         h -= f * g;
         const double u = (ln == l) ? f - g : x;           // Householder vector (0 beyond l)
         if (act) A[i + LDA * ln] = u;
-        e[i] = scale * g; hv[i] = h;
+        e[i] = g; hv[i] = h;
         __syncthreads();
-        double acc = 0.0;
-        if (act) for (int k = 0; k <= l; ++k) acc += A[ln + LDA * k] * A[i + LDA * k];
-        const double p = acc / h;
-        const double hh = wave_sum_dpp(p * u) / (h + h);
+        double acc0 = 0.0, acc1 = 0.0;                    // two chains: the FMA latency is the critical path here
+        if (act) {
+            int k = 0;
+            for (; k + 1 <= l; k += 2) {
+                acc0 = __builtin_fma(A[ln + LDA * k], A[i + LDA * k], acc0);
+                acc1 = __builtin_fma(A[ln + LDA * (k + 1)], A[i + LDA * (k + 1)], acc1);
+            }
+            if (k <= l) acc0 = __builtin_fma(A[ln + LDA * k], A[i + LDA * k], acc0);
+        }
+        const double rh = 1.0 / h;
+        const double p = (acc0 + acc1) * rh;
+        const double hh = wave_sum_dpp(p * u) * (0.5 * rh);
         const double qv = p - hh * u;
         if (act) q[ln] = qv;
         __syncthreads();
@@ -522,6 +537,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
     __shared__ double sw[NF], se[NF], sq[NF], scv[NF];
     __shared__ double std_[NF], ste2[NF], sip[NF], smk[NF], sr[NF], sy[NF], sgt2[NF], szc[TRI_MAXC * NF], spa[NF], spb[NF];
     __shared__ int s_flag[2];             // 0: accept, 1: done
+    __shared__ double s_delta;            // trust-region radius after the update
 
     const int li = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int slot = active[li];
@@ -529,6 +545,12 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
     const int t = targets[slot];
     double *Hs = Hstate + (size_t)slot * NF * NF;
     const double *h = ev_h + (size_t)li * CEL_P * CEL_P;
+
+    // scalars of the optimiser state, loaded now so that their latency hides behind the chain rule below
+    const double S_f = S.f, S_m = S.m, S_delta = S.delta;
+    const int S_iter = S.iter, S_interior = S.interior, S_evals = S.evals;
+    const double ft_in = -ev_v[li];
+    const int st_in = ev_status[li];
 
     // ---- chain rule to the free parameters at the evaluated point xt (propagate_derivatives!) ----
     if (tid < CEL_P) sd[tid] = ev_d[(size_t)li * CEL_P + tid];
@@ -617,24 +639,26 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         double dx = dxl, gmax = gl;
         for (int o = 32; o >= 1; o >>= 1) { dx = fmax(dx, __shfl_xor(dx, o, 64)); gmax = fmax(gmax, __shfl_xor(gmax, o, 64)); }
         if (tid == 0) {
-            const double ft = -ev_v[li];
+            const double ft = ft_in;
             int accept = 1, done = 0;
-            S.evals += 1;
-            if (ev_status[li] != CELESTE_OK) { S.status = ev_status[li]; accept = 0; done = 1; }
-            else if (S.iter >= 0) {
-                const double m = S.m;
+            double delta = S_delta;
+            S.evals = S_evals + 1;
+            if (st_in != CELESTE_OK) { S.status = st_in; accept = 0; done = 1; }
+            else if (S_iter >= 0) {
+                const double m = S_m;
                 double rho;
                 if (fabs(m) <= 2.220446049250313e-16) rho = 1.0;
                 else if (m > 0) rho = 0.25 - 1.0;
-                else rho = (S.f - ft) / (0 - m);
-                if (rho < 0.25) S.delta *= 0.25;
-                else if (rho > 0.75 && !S.interior) S.delta = fmin(2 * S.delta, op.delta_hat);
+                else rho = (S_f - ft) / (0 - m);
+                if (rho < 0.25) delta *= 0.25;
+                else if (rho > 0.75 && !S_interior) delta = fmin(2 * delta, op.delta_hat);
                 accept = rho > 0.1;
-                if (accept && (dx <= op.xtol_abs || fabs(ft - S.f) <= op.ftol_rel * fabs(ft) || gmax <= op.gtol)) done = 1;
+                if (accept && (dx <= op.xtol_abs || fabs(ft - S_f) <= op.ftol_rel * fabs(ft) || gmax <= op.gtol)) done = 1;
             }
             if (accept) S.f = ft;
-            S.iter += 1;
-            if (S.iter >= op.max_iters) done = 1;
+            S.delta = delta; s_delta = delta;
+            S.iter = S_iter + 1;
+            if (S_iter + 1 >= op.max_iters) done = 1;
             s_flag[0] = accept; s_flag[1] = done;
         }
     }
@@ -661,7 +685,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
     bool solved = false;
     if (op.solver != 1) {
         const TriLds L = {sA, sw, std_, se, ste2, sip, smk, sr, sy, sgt2, sq, scv, szc, spa, spb};
-        solved = tri_tr_solve(L, fr ? sg[tid] : 0.0, S.delta, tid, step, m, interior);
+        solved = tri_tr_solve(L, fr ? sg[tid] : 0.0, s_delta, tid, step, m, interior);
         if (!solved) {   // hard case: restore H and diagonalise it
             for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hs[k]; }
             __syncthreads();
@@ -681,7 +705,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
             if (om < wmin || (om == wmin && oi < imin)) { wmin = om; imin = oi; }
             wmax = fmax(wmax, __shfl_xor(wmax, o, 64));
         }
-        const double delta = S.delta, d2 = delta * delta;
+        const double delta = s_delta, d2 = delta * delta;
         interior = 0;
         if (wmin >= 1e-8) {
             const double r = fr ? qg / wi : 0.0;
