@@ -27,5 +27,15 @@ for name in gu.CASES:
         if flags:
             out["d%d" % flags] = d; out["h%d" % flags] = h
         out["cnt"] = cnt
+    S = len(f2.catalog)
+    if S >= 2:   # elbo() with all sources active (Sa = S): P x Sa gradient, (P Sa)^2 Hessian
+        full = cabi.Problem(f2.images, f2.patches, [[s for s in range(S) if s != a] for a in range(S)])
+        mv, md, mh, mcnt, mst = oracle.elbo_multi(full, f2.vp, list(range(S)), 7)
+        assert mst == 0
+        out.update(multi_v=np.array(mv), multi_d=md, multi_h=mh, multi_cnt=mcnt)
+    # maximize! of source 0 (neighbours frozen), 12 Newton iterations, KL on
+    ovp, oit, oev, oelbo, ost = oracle.maximize(pb, f2.vp, 0, oracle.OptCfg(max_iters=12))
+    assert ost == 0
+    out.update(opt_vs=ovp[0], opt_elbo=np.array(oelbo), opt_iters=np.array(oit))
     np.savez_compressed(gu.path(name), **arrs, **out)
     print(name, os.path.getsize(gu.path(name)), "bytes", out["v7"][:2])
