@@ -61,7 +61,14 @@ for k in sorted(sq):
     util = c.get("SQ_ACTIVE_INST_VALU", 0) / max(c.get("SQ_BUSY_CYCLES", 1) * 4.0 / 1.0, 1)
     lines.append("%-28s %s" % (k, {n: round(v) for n, v in c.items()}))
 lines += ["```", ""]
-pk = sq.get("pixel_kernel<2, double>", {})
+def find(table, prefix):
+    for k, v in table.items():
+        if k.startswith(prefix):
+            return v
+    return {}
+
+
+pk = find(sq, "pixel_kernel<2, double")
 valu_util = None
 if pk:
     simd_cycles = pk["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
@@ -72,8 +79,8 @@ if pk:
               % (pk["SQ_ACTIVE_INST_VALU"], 100 * valu_util),
               "* SQ_WAVE_CYCLES / SIMD-cycles = %.2f resident waves per SIMD." % (pk["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles), ""]
 open(os.path.join(dst, tag + "_pmc_summary.md"), "w").write("\n".join(lines))
-px = traffic.get("pixel_kernel<2, double>", {})
-rs = traffic.get("record_sum_kernel", {})
+px = find(traffic, "pixel_kernel<2, double")
+rs = find(traffic, "record_sum_kernel")
 json.dump({"pixel_kernel_bytes_per_launch": px.get("fetch_bytes", 0) + px.get("write_bytes", 0),
            "fetch_bytes": px.get("fetch_bytes"), "write_bytes": px.get("write_bytes"),
            "record_sum_bytes_per_launch": (rs.get("fetch_bytes", 0) + rs.get("write_bytes", 0)) or None,
