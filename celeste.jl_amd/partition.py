@@ -96,3 +96,24 @@ def partition_cyclades_dynamic(target_sources: Sequence[int], neighbor_map: Dict
         batches.append(list(comps.values()))
     assert sum(len(c) for b in batches for c in b) == n
     return batches
+
+
+def color_classes(target_sources: Sequence[int], neighbor_map: Dict[int, Sequence[int]]) -> List[List[int]]:
+    """Greedy colouring of the neighbour graph (largest degree first): every class is an independent set, so its
+    sources can be optimised in one launch, and processing the classes in order is one sequential sweep over the
+    sources -- the same serialisability guarantee Cyclades batches give (partition.jl:37-73), with as many launches
+    per sweep as there are colours (max degree + 1 at most) instead of the longest connected component of a batch.
+    Returns lists of *indices into target_sources*."""
+    idx = {s: i for i, s in enumerate(target_sources)}
+    order = sorted(target_sources, key=lambda s: -len(neighbor_map[s]))
+    color: Dict[int, int] = {}
+    for s in order:
+        used = {color[n] for n in neighbor_map[s] if n in color}
+        c = 0
+        while c in used:
+            c += 1
+        color[s] = c
+    classes: List[List[int]] = [[] for _ in range(max(color.values()) + 1)] if color else []
+    for s in target_sources:
+        classes[color[s]].append(idx[s])
+    return classes

@@ -156,6 +156,13 @@ def test_joint_beats_single_on_overlapping_sources():
     s_joint = joint_objective(f.images, f.patches, vs_joint, set(tg))
     print("single", s_single, "joint", s_joint)
     assert s_joint > s_single
+    # the colouring schedule (one launch per colour class) is another conflict-free sweep order; being closer to a
+    # Jacobi sweep it needs more sweeps on a crowded scene, but it climbs monotonically towards the same objective
+    s_col = [joint_objective(f.images, f.patches,
+                             one_node_joint_infer(ctx, f.catalog, tg, f.neighbors, cfg, n_iters=k, schedule="coloring"), set(tg))
+             for k in (1, 3, 6)]
+    print("joint, coloring schedule after 1 / 3 / 6 sweeps", s_col)
+    assert s_col[0] < s_col[1] < s_col[2] and abs(s_col[2] - s_joint) <= 2e-3 * abs(s_joint)
 
 
 def test_single_infer_neighbours_sit_at_catalog_init(oracle):

@@ -175,3 +175,21 @@ def test_cyclades_covers_all_sources_without_conflicts():
                     for i in b[x]:
                         for j in b[y]:
                             assert target_sources[j] not in neighbor_map[target_sources[i]]
+
+
+def test_color_classes_are_independent_sets():
+    from celeste_jl_amd.partition import color_classes
+    rng = np.random.default_rng(3)
+    n = 200
+    nbrs = {s: set() for s in range(n)}
+    for _ in range(500):
+        a, b = rng.integers(n, size=2)
+        if a != b:
+            nbrs[int(a)].add(int(b)); nbrs[int(b)].add(int(a))
+    targets = list(range(n))
+    classes = color_classes(targets, {s: sorted(v) for s, v in nbrs.items()})
+    assert sorted(i for c in classes for i in c) == targets
+    assert len(classes) <= max(len(v) for v in nbrs.values()) + 1
+    for c in classes:
+        cs = set(c)
+        assert all(not (nbrs[s] & cs) for s in c)
