@@ -33,7 +33,6 @@ struct celeste_ctx {
     int device = 0;
     int N = 0, S = 0, K = 0, NC = 0, n_stamps = 0;
     int chunk_px = 256, CH = 1;
-    int ablate = 0;  // debug: CELESTE_ABLATE bit mask, skips parts of pixel_kernel (timing experiments only)
     int max_npx = 0;
     // host mirrors (for work stats / validation)
     std::vector<DevPatch> h_patches;
@@ -375,7 +374,6 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
         if (!c->dense) CTX_TRY(dev_upload(&c->d_link_img, li.data(), li.size()));
     }
 
-    if (const char *env_ab = getenv("CELESTE_ABLATE")) c->ablate = atoi(env_ab);
     const char *env_chunk = getenv("CELESTE_CHUNK_PX");
     if (env_chunk && atoi(env_chunk) >= 64) c->chunk_px = (atoi(env_chunk) + 63) / 64 * 64;
     c->CH = c->max_npx > 0 ? (c->max_npx + c->chunk_px - 1) / c->chunk_px : 1;
@@ -487,7 +485,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     const dim3 grid((unsigned)((size_t)n_targets * c->M * c->CH));
 #define PIXEL_ARGS                                                                                                \
     c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx,       \
-    c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->ablate, c->d_tile_off, c->d_rec, \
+    c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->d_tile_off, c->d_rec, \
     d_active_rank, c->d_items, c->M
 #define LAUNCH_PIXEL_T(MODE, R) hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL_M(MODE) hipLaunchKernelGGL((pixel_kernel<MODE, double, true>), grid, dim3(64), 0, stream, PIXEL_ARGS)

@@ -595,7 +595,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
              const int64_t *__restrict__ val_off, const double2 *__restrict__ val,
              const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px,
-             double *__restrict__ acc, int ablate, const int64_t *__restrict__ tile_off, double *__restrict__ rec,
+             double *__restrict__ acc, const int64_t *__restrict__ tile_off, double *__restrict__ rec,
              const int32_t *__restrict__ active_rank, const int32_t *__restrict__ items, int M) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
     __shared__ double etab[64];
@@ -637,7 +637,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     }
     const CompR<R> *tcr = sizeof(R) == 4 ? tcr_f : reinterpret_cast<const CompR<R> *>(tc);
     const double *__restrict__ tcoef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
-    const int64_t nb0 = nbr_off[t], nb1 = (ablate & 1) ? nb0 : nbr_off[t + 1];
+    const int64_t nb0 = nbr_off[t], nb1 = nbr_off[t + 1];
     // several active sources (celeste_elbo_eval_multi): a pixel of two active patches is visited by the earlier
     // one only (elbo_objective.jl:430-470) -- its value term and inactive-source count are dropped here
     const int my_rank = MULTI ? active_rank[t] : 0;
@@ -721,12 +721,12 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         T.S0d = 0; T.S1x = 0; T.S1y = 0; T.S1xd = 0; T.S1yd = 0;
         T.S2a = 0; T.S2b = 0; T.S2c = 0; T.S2an = 0; T.S2bn = 0; T.S2cn = 0; T.S2ad = 0; T.S2bd = 0; T.S2cd = 0;
         T.S3a = 0; T.S3b = 0; T.S3c = 0; T.S3d = 0; T.S4a = 0; T.S4b = 0; T.S4c = 0; T.S4d = 0; T.S4e = 0;
-        if (own) S0 = galaxy_sums<GM, R>(tcr, (ablate & 2) ? 0 : NC, (R)(hh - si.m1), (R)(ww - si.m2), etab, T);
+        if (own) S0 = galaxy_sums<GM, R>(tcr, NC, (R)(hh - si.m1), (R)(ww - si.m2), etab, T);
         T.f1 = S0;
 
         // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
         T.f0 = 0; T.f0g0 = 0; T.f0g1 = 0; T.f0h0 = 0; T.f0h1 = 0; T.f0h2 = 0;
-        if (own && !(ablate & 4)) {
+        if (own) {
             const double xh = hh + sh0, xw = ww + sw0;
             int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
             int iy = (int)floor(xw); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
@@ -771,7 +771,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             T.cnt_inact = (double)n_inact;
             // derivative weights are zero unless the active source covers the pixel, which zeroes every
             // derivative entry of the record (all lanes take part in the cross-lane exchange below)
-            const double xo = (own && !(ablate & 8)) ? x : 0.0, io = (own && !(ablate & 8)) ? iota : 0.0;
+            const double xo = own ? x : 0.0, io = own ? iota : 0.0;
             const double w1 = xo * (iE + V * iE3) - io;            // dT/dE
             T.w2 = -0.5 * xo * iE2;                                // dT/dVar
             const double w11 = -xo * (iE2 + 3.0 * V * iE2 * iE2);  // d2T/dE2

@@ -10,10 +10,8 @@ S = len(fld.catalog)
 tg = np.arange(S, dtype=np.int32)
 ref = None
 for cfg in os.environ.get("CHUNKS", "1024").split(","):
-    chunk, _, ab = cfg.partition(":")
-    chunk = int(chunk)
+    chunk = int(cfg)
     os.environ["CELESTE_CHUNK_PX"] = str(chunk)
-    os.environ["CELESTE_ABLATE"] = ab or "0"
     ctx = cel.FieldContext(fld.images, fld.patches, fld.neighbors)
     ctx.enable_timing(True)
     ms = []
@@ -24,6 +22,6 @@ for cfg in os.environ.get("CHUNKS", "1024").split(","):
     if ref is None:
         ref = g
     err = max(float(np.abs(g[i] - ref[i]).max() / np.abs(ref[i]).max()) for i in range(3) if g[i] is not None)
-    print("ablate", ab or "0", "chunk %5d: prep %.3f pixel %.3f lift %.3f ms  | visits %d inactive %d | vs first cfg %.1e"
+    print("chunk %5d: prep %.3f pixel %.3f lift %.3f ms  | visits %d inactive %d | vs first cfg %.1e"
           % (chunk, ms[0], ms[1], ms[2], g[3][:, 0].sum(), g[3][:, 1].sum(), err))
     ctx.close()
