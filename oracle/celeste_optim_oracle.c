@@ -7,12 +7,12 @@
  *   ElboMaximize.maximize! (src/deterministic_vi/ElboMaximize.jl:63-108, 161-242) driving a Newton
  *     trust-region iteration.
  * The trust-region method itself lives in the third-party package Optim.jl (REQUIRE: "Optim 0.7.4+", not
- * vendored, unpinned): it is restated here from its published algorithm (Nocedal & Wright, Numerical
- * Optimization, Alg. 4.1 for the radius update with eta = 0.1, shrink below rho = 0.25 by 1/4, grow above 0.75
- * by 2 when the step is on the boundary; the sub-problem is solved exactly in the eigenbasis of the Hessian
- * (N&W section 4.3), including the hard case).  PARITY UNPINNED for iterate-by-iterate agreement with Optim.jl;
- * the reference's own optimiser tests only assert recovery tolerances (test/test_optimization.jl:10-32), which
- * tests/ mirrors.
+ * vendored, unpinned): it is restated here from its published algorithm -- Nocedal & Wright, Numerical
+ * Optimization, Alg. 4.1 for the radius update (eta = 0.1, shrink below rho = 0.25 by 1/4, grow above 0.75 by 2
+ * when the step is not interior), and Optim's solve_tr_subproblem! rules for the sub-problem (see
+ * celeste_oracle_solve_tr below), solved in the eigenbasis of the Hessian (cyclic Jacobi).  PARITY UNPINNED for
+ * iterate-by-iterate agreement with Optim.jl; the reference's own optimiser tests only assert recovery tolerances
+ * (test/test_optimization.jl:10-32), which tests/ mirrors.
  *
  * The ELBO evaluations come from celeste_oracle.c (celeste_oracle_elbo).
  */
