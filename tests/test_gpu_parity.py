@@ -351,6 +351,35 @@ def test_randomised_small_fields(oracle, seed):
     print("fuzz", seed, (H, W, S), "targets", len(tg), "flags", flags, errs)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_multi_active(oracle, seed):
+    """fuzz of celeste_elbo_eval_multi: random crowded scene with NaNs and punched bitmaps, random active subset and
+    order (Sa = 2..4), every other source a value-only neighbour"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    rng = np.random.default_rng(3000 + seed)
+    S = int(rng.integers(3, 8))
+    f = synthetic.make_field(int(rng.integers(50, 80)), int(rng.integers(50, 80)), S, seed=4000 + seed,
+                             nan_fraction=float(rng.choice([0.0, 0.02])), margin=int(rng.integers(8, 20)))
+    for s_ in range(S):
+        if rng.random() < 0.4:
+            p = f.patches[s_][int(rng.integers(5))]
+            p.active_pixel_bitmap &= rng.random(p.active_pixel_bitmap.shape) > 0.15
+    act = rng.permutation(S)[:int(rng.integers(2, min(S, 4) + 1))].tolist()
+    nbrs = [[s for s in range(S) if s != a] for a in range(S)]
+    ctx = cel.FieldContext(f.images, f.patches, nbrs)
+    flags = int(rng.choice([7, 7, 5, 4]))
+    v, d, h, cnt = ctx.eval_multi(f.vp, act, flags)
+    ov, od, oh, ocnt, ost = oracle.elbo_multi(ctx.problem, f.vp, act, flags)
+    assert ost == 0 and np.array_equal(cnt, ocnt), (cnt, ocnt)
+    assert abs(v - ov) <= 1e-8 * abs(ov)
+    if flags & 3:
+        assert max(rel_err(d[:, k], od[k]) for k in range(len(act))) <= 1e-8
+    if flags & 2:
+        assert np.array_equal(h, h.T) and rel_err(h, oh) <= 1e-8
+    print("multi fuzz", seed, "S", S, "active", act, "flags", flags, abs(v - ov) / abs(ov), rel_err(h, oh) if flags & 2 else None)
+
+
 def test_invalid_arguments_are_refused():
     """status codes instead of the reference's assertion failures (include/celeste_mi355x.h)"""
     import ctypes as C
