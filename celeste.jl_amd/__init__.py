@@ -8,5 +8,8 @@ from .params import (ids, CatalogEntry, generic_init_source, catalog_init_source
 from .elbo import (ElboArgs, ElboConfig, SensitiveFloat, FieldContext, elbo, elbo_likelihood,  # noqa: F401
                    maximize)
 
-__all__ = ["ElboArgs", "ElboConfig", "maximize", "SensitiveFloat", "FieldContext", "elbo", "elbo_likelihood", "ids", "CatalogEntry",
+from .infer import (BoundingBox, OptimizedSource, infer_box, one_node_single_infer,  # noqa: F401
+                    one_node_joint_infer)
+
+__all__ = ["BoundingBox", "OptimizedSource", "infer_box", "one_node_single_infer", "one_node_joint_infer", "ElboArgs", "ElboConfig", "maximize", "SensitiveFloat", "FieldContext", "elbo", "elbo_likelihood", "ids", "CatalogEntry",
            "generic_init_source", "catalog_init_source", "init_sources", "perturb_params"]

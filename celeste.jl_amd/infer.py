@@ -4,6 +4,7 @@
   ----------------------------------------------------------  -----------------------------------------
   one_node_single_infer  (:546-607) -> process_source (:468)  one_node_single_infer
   one_node_joint_infer   (:135-196): setup_vecs, Cyclades     one_node_joint_infer
+  infer_box / _infer_box (:610-672), OptimizedSource, bad_sky  infer_box, OptimizedSource, bad_sky
       batches, num_joint_vi_iters sweeps, process_sources_kernel!
       (:372-397) = sequential maximize! inside a connected component
 
@@ -15,6 +16,7 @@ sources of one component are optimised one after another.  On the GPU the j-th s
 batch form one launch ("layer"): no two of them are neighbours, so optimising them simultaneously is exactly
 the reference's schedule.
 """
+from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
@@ -99,3 +101,74 @@ def one_node_joint_infer(ctx: FieldContext, catalog, target_sources: Sequence[in
     vp = joint_infer_sweeps(maximize_layer, vp, targets, neighbors, batch_size, n_iters, rng, rank, world, costs,
                             all_gather, schedule)
     return vp[targets]
+
+
+# ---- box-level driver (ParallelRun.infer_box, ParallelRun.jl:610-672) ------------------------------------------------
+
+@dataclass
+class BoundingBox:
+    """src/dataset.jl:1-13"""
+    ramin: float
+    ramax: float
+    decmin: float
+    decmax: float
+
+    def __post_init__(self):
+        assert self.ramax > self.ramin, "ramax must be greater than ramin"
+        assert self.decmax > self.decmin, "decmax must be greater than decmin"
+
+    def contains(self, pos) -> bool:
+        return self.ramin < pos[0] < self.ramax and self.decmin < pos[1] < self.decmax
+
+
+@dataclass
+class OptimizedSource:
+    """ParallelRun.jl:425-430"""
+    init_ra: float
+    init_dec: float
+    vs: np.ndarray
+    is_sky_bad: bool
+
+
+def bad_sky(ce, images) -> bool:
+    """ParallelRun.jl:437-460: is the claimed sky of the i-band image 5 photons per pixel below the median of the
+    pixels in a 50-pixel box around the object?"""
+    from .model import box_around_point, clamp_box, julia_round
+    img = next((im for im in images if im.b == 4), None)
+    if img is None:
+        return False
+    pc = img.world_to_pix(ce.pos)
+    h = max(1, min(julia_round(pc[0]), img.H))
+    w = max(1, min(julia_round(pc[1]), img.W))
+    claimed_sky = float(img.sky[h - 1, w - 1]) * float(img.nelec_per_nmgy[h - 1])
+    (h0, h1), (w0, w1) = clamp_box(box_around_point(img, ce.pos, 50.0), (img.H, img.W))
+    px = img.pixels[h0 - 1:h1, w0 - 1:w1]
+    px = px[~np.isnan(px)]
+    if px.size == 0:
+        return False
+    return (claimed_sky + 5) < float(np.median(px))
+
+
+def infer_box(images, box: BoundingBox, catalog, method: str = "joint_vi", cfg: Optional[ElboConfig] = None,
+              n_iters: int = NUM_JOINT_VI_ITERS, device: int = 0, schedule: str = "cyclades") -> List[OptimizedSource]:
+    """infer_box / _infer_box (ParallelRun.jl:610-672) for a given catalog: patches for every catalog entry, targets
+    = entries strictly inside the box, neighbours may lie outside it, then joint or single variational inference
+    on the device.  (Source detection and MCMC are out of scope: `catalog` is required, method in {joint_vi, single_vi}.)"""
+    from .model import get_sky_patches, neighbor_map
+    patches = get_sky_patches(images, catalog)
+    neighbors = neighbor_map(patches)
+    targets = [i for i, ce in enumerate(catalog) if box.contains(ce.pos)]
+    if not targets:
+        return []
+    ctx = FieldContext(images, patches, neighbors, device=device)
+    try:
+        if method == "joint_vi":
+            vs = one_node_joint_infer(ctx, catalog, targets, neighbors, cfg, n_iters=n_iters, schedule=schedule)
+        elif method == "single_vi":
+            vs = one_node_single_infer(ctx, catalog, targets, cfg)
+        else:
+            raise ValueError("unknown method: %s" % method)
+    finally:
+        ctx.close()
+    return [OptimizedSource(float(catalog[t].pos[0]), float(catalog[t].pos[1]), vs[k].copy(), bad_sky(catalog[t], images))
+            for k, t in enumerate(targets)]

@@ -194,6 +194,29 @@ def test_joint_beats_single_on_overlapping_sources():
     assert s_col[0] < s_col[1] < s_col[2] and abs(s_col[2] - s_joint) <= 2e-3 * abs(s_joint)
 
 
+def test_infer_box_targets_inside_the_box_only():
+    """ParallelRun.infer_box (:610-672): entries strictly inside the box are optimised, the others only lend light"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.infer import one_node_single_infer
+    f = synthetic.make_field(120, 140, 12, seed=31, margin=12)
+    box = cel.BoundingBox(20.0, 90.0, 15.0, 110.0)
+    inside = [i for i, ce in enumerate(f.catalog) if 20.0 < ce.pos[0] < 90.0 and 15.0 < ce.pos[1] < 110.0]
+    assert 0 < len(inside) < len(f.catalog)
+    for method in ("single_vi", "joint_vi"):
+        res = cel.infer_box(f.images, box, f.catalog, method=method, cfg=cel.ElboConfig(max_iters=10))
+        assert len(res) == len(inside)
+        for r, i in zip(res, inside):
+            assert (r.init_ra, r.init_dec) == (f.catalog[i].pos[0], f.catalog[i].pos[1])
+            assert r.vs.shape == (44,) and np.all(np.isfinite(r.vs)) and r.is_sky_bad is False
+            assert abs(r.vs[0] - r.init_ra) <= 1e-4 + 1e-12      # position box of width loc_width around the catalog position
+    ctx = _ctx(f)
+    ref = one_node_single_infer(ctx, f.catalog, inside, cel.ElboConfig(max_iters=10))
+    got = cel.infer_box(f.images, box, f.catalog, method="single_vi", cfg=cel.ElboConfig(max_iters=10))
+    assert np.array_equal(np.stack([r.vs for r in got]), ref)
+    assert cel.infer_box(f.images, cel.BoundingBox(-10.0, -5.0, 0.0, 1.0), f.catalog) == []
+
+
 def test_single_infer_neighbours_sit_at_catalog_init(oracle):
     """one_node_single_infer == per-target maximize! with init_sources([1], cat_local) (DeterministicVI.jl:94-103)"""
     import celeste_jl_amd as cel

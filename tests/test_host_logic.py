@@ -193,3 +193,21 @@ def test_color_classes_are_independent_sets():
     for c in classes:
         cs = set(c)
         assert all(not (nbrs[s] & cs) for s in c)
+
+
+def test_bounding_box_and_bad_sky():
+    """dataset.jl:1-13; ParallelRun.jl:437-460"""
+    from celeste_jl_amd import BoundingBox, synthetic
+    from celeste_jl_amd.infer import bad_sky
+    with pytest.raises(AssertionError):
+        BoundingBox(1.0, 1.0, 0.0, 2.0)
+    b = BoundingBox(10.0, 20.0, 5.0, 9.0)
+    assert b.contains([15.0, 6.0]) and not b.contains([10.0, 6.0]) and not b.contains([15.0, 9.5])
+    f = synthetic.make_sample_dataset("three_body")
+    assert bad_sky(f.catalog[1], f.images)                 # a bright star fills the 101 x 101 box: median well above the sky
+    ce = synthetic.sample_ce([30.0, 185.0], True)          # an empty corner of the 112 x 238 scene
+    assert not bad_sky(ce, f.images)                       # Poisson noise around the claimed sky: median is not 5 e- above
+    img = next(im for im in f.images if im.b == 4)
+    img.pixels += np.float32(12.0)                          # 12 extra photo-electrons everywhere
+    assert bad_sky(ce, f.images)
+    assert not bad_sky(ce, [im for im in f.images if im.b != 4])
