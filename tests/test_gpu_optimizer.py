@@ -217,6 +217,36 @@ def test_infer_box_targets_inside_the_box_only():
     assert cel.infer_box(f.images, cel.BoundingBox(-10.0, -5.0, 0.0, 1.0), f.catalog) == []
 
 
+def test_end_to_end_recovers_the_synthetic_truth():
+    """images drawn from a catalog -> infer_box (joint VI from generic_init_source) -> catalog rows: the brighter
+    sources come back with the right type, r flux and colours (the idea of AccuracyBenchmark.score_predictions)"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.catalog import celeste_to_rows
+    f = synthetic.make_field(300, 340, 40, seed=77, margin=26)
+    box = cel.BoundingBox(0.0, 300.0, 0.0, 340.0)
+    res = cel.infer_box(f.images, box, f.catalog, method="joint_vi")
+    rows = celeste_to_rows(res)
+    assert len(res) == 40 and len(rows) >= 34
+    truth = {(ce.pos[0], ce.pos[1]): ce for ce in f.catalog}
+    n_bright = n_type = 0
+    flux_err, col_err = [], []
+    for r, row in zip([x for x in res if not x.is_sky_bad], rows):
+        ce = truth[(r.init_ra, r.init_dec)]
+        fl = ce.star_fluxes if ce.is_star else ce.gal_fluxes
+        if fl[2] < 2.0:        # faint: the posterior is broad, nothing to assert
+            continue
+        n_bright += 1
+        n_type += int((row["is_star"] > 0.5) == ce.is_star)
+        flux_err.append(abs(row["flux_r_nmgy"] / fl[2] - 1.0))
+        col_err.append(abs(row["color_gr"] - np.log(fl[2] / fl[1])))
+        assert abs(row["ra"] - ce.pos[0]) <= 1e-4 + 1e-9
+    print("bright sources %d, type right %d, median |flux err| %.3f, median |g-r err| %.3f"
+          % (n_bright, n_type, np.median(flux_err), np.median(col_err)))
+    assert n_bright >= 8 and n_type >= 0.8 * n_bright
+    assert np.median(flux_err) <= 0.10 and np.median(col_err) <= 0.15
+
+
 def test_single_infer_neighbours_sit_at_catalog_init(oracle):
     """one_node_single_infer == per-target maximize! with init_sources([1], cat_local) (DeterministicVI.jl:94-103)"""
     import celeste_jl_amd as cel
