@@ -239,3 +239,34 @@ def test_variational_parameters_to_catalog_row():
     vs = catalog_init_source(synthetic.sample_ce([1.0, 2.0], True))
     res = [OptimizedSource(1.0, 2.0, vs, False), OptimizedSource(1.0, 2.0, vs, True)]
     assert len(celeste_to_rows(res)) == 1
+
+
+def test_scoring_against_truth():
+    """AccuracyBenchmark.jl:140-148 (asinh magnitudes round trip), :801-804, :813-931"""
+    import math
+    from celeste_jl_amd import synthetic, catalog_init_source
+    from celeste_jl_amd.catalog import (flux_to_mag, mag_to_flux, degrees_to_diff, catalog_entry_to_row, get_error_row,
+                                        variational_parameters_to_row, score_predictions, is_good_row)
+    for band in range(1, 6):
+        for flux in (0.05, 1.0, 250.0):
+            assert mag_to_flux(flux_to_mag(flux, band), band) == pytest.approx(flux, rel=1e-9)
+    assert flux_to_mag(1.0, 3) == pytest.approx(22.5, abs=0.02)          # 1 nanomaggy ~ 22.5 mag (asinh softening)
+    assert flux_to_mag(100.0, 3) == pytest.approx(17.5, abs=1e-5)
+    assert degrees_to_diff(10.0, 170.0) == 20.0 and degrees_to_diff(45.0, 225.0) == 0.0
+    truth, pred = [], []
+    for k, is_star in enumerate((True, False, True, False)):
+        ce = synthetic.sample_ce([10.0 + k, 20.0], is_star)
+        if not is_star:
+            ce.gal_frac_dev = 0.99; ce.gal_axis_ratio = 0.4
+        truth.append(catalog_entry_to_row(ce))
+        pred.append(variational_parameters_to_row(catalog_init_source(ce)))
+    e = get_error_row(truth[0], pred[0])
+    assert e["missed_stars"] == 0.0 and e["missed_galaxies"] is None and e["position"] == 0.0 and e["flux_r_mag"] < 1e-9
+    sc = score_predictions(truth, pred)
+    assert sc["flux_r_nmgy"]["N"] == 4 and sc["flux_r_nmgy"]["first"] < 1e-9 and sc["color_gr"]["first"] < 1e-9
+    assert sc["missed_stars"] == {"N": 2, "first": 0.0} and sc["gal_angle_deg"]["N"] == 2   # star rows carry gal_frac_dev = 0.1: filtered
+    wrong = dict(pred[1]); wrong["is_star"] = 0.9; wrong["flux_r_nmgy"] *= 2
+    sc2 = score_predictions(truth, [pred[0], wrong, pred[2], pred[3]])
+    assert sc2["missed_galaxies"]["first"] == 0.5 and sc2["flux_r_mag"]["first"] == pytest.approx(2.5 * math.log10(2) / 4, rel=1e-3)
+    mixed = dict(truth[1]); mixed["gal_frac_dev"] = 0.5
+    assert not is_good_row(mixed, get_error_row(mixed, pred[1]), "gal_radius_px")
