@@ -245,6 +245,14 @@ def test_end_to_end_recovers_the_synthetic_truth():
           % (n_bright, n_type, np.median(flux_err), np.median(col_err)))
     assert n_bright >= 8 and n_type >= 0.8 * n_bright
     assert np.median(flux_err) <= 0.10 and np.median(col_err) <= 0.15
+    # the reference's score table (AccuracyBenchmark.score_predictions) over every source, faint ones included
+    from celeste_jl_amd.catalog import catalog_entry_to_row, score_predictions
+    good = [x for x in res if not x.is_sky_bad]
+    scores = score_predictions([catalog_entry_to_row(truth[(r.init_ra, r.init_dec)]) for r in good], rows)
+    print({k: (v["N"], round(v["first"], 3)) for k, v in scores.items()})
+    assert scores["position"]["first"] <= 1.5e-4        # within the diagonal of the 1e-4 position box
+    assert scores["flux_r_mag"]["first"] <= 0.25
+    assert scores["missed_stars"]["first"] <= 0.35 and scores["missed_galaxies"]["first"] <= 0.35
 
 
 def test_single_infer_neighbours_sit_at_catalog_init(oracle):
