@@ -270,3 +270,20 @@ def test_scoring_against_truth():
     assert sc2["missed_galaxies"]["first"] == 0.5 and sc2["flux_r_mag"]["first"] == pytest.approx(2.5 * math.log10(2) / 4, rel=1e-3)
     mixed = dict(truth[1]); mixed["gal_frac_dev"] = 0.5
     assert not is_good_row(mixed, get_error_row(mixed, pred[1]), "gal_radius_px")
+
+
+def test_fit_raw_psf_recovers_a_two_component_mixture():
+    """PSF.fit_raw_psf_for_celeste (PSF.jl:635-673): fitting the rendered stamp of a known mixture reproduces it"""
+    from celeste_jl_amd.model import make_psf, render_psf
+    from celeste_jl_amd.psf import fit_raw_psf_for_celeste, trim_psf
+    true = make_psf([0.75, 0.25], [[0.05, -0.03], [-0.1, 0.08]],
+                    [np.array([[1.6, 0.15], [0.15, 1.4]]), np.array([[7.5, -0.6], [-0.6, 6.0]])])
+    stamp = render_psf(true, (51, 51))
+    psf, params = fit_raw_psf_for_celeste(stamp, 2)
+    assert np.abs(render_psf(psf, (51, 51)) - stamp).max() <= 1e-7 * stamp.max()
+    order = np.argsort(psf[:, 3])
+    assert np.allclose(psf[order], true[np.argsort(true[:, 3])], rtol=2e-4, atol=2e-4)
+    assert np.all((params[:, 2] >= 0.1) & (params[:, 2] <= 1.0) & (params[:, 5] >= 0.05))
+    t = trim_psf(stamp)
+    assert t.shape[0] == t.shape[1] and t.shape[0] % 2 == 1 and t.shape[0] < 51
+    assert np.abs(t).sum() >= 0.999 * np.abs(stamp).sum() and t[t.shape[0] // 2, t.shape[1] // 2] == stamp[25, 25]
