@@ -8,6 +8,7 @@
   evaluate_psf_fit! (:499-535): sum of squared residuals       _residuals
   fit_raw_psf_for_celeste (:635-673)                           fit_raw_psf_for_celeste
   trim_psf (:676-693)                                          trim_psf
+  get_source_psf (:175-179)                                    get_source_psf
 
 The reference minimises the squared error with its own Newton trust-region code over box-constrained parameters
 (mean, axis ratio, angle, radius, weight per component); here the same objective, parametrisation, bounds and starting
@@ -80,3 +81,9 @@ def trim_psf(raw_psf: np.ndarray, trim_percent: float = 0.999) -> np.ndarray:
     while np.abs(cut()).sum() < trim_percent * tot:
         width += 1
     return cut().copy()
+
+
+def get_source_psf(world_loc, img, psf_K: int = 2) -> np.ndarray:
+    """PSF.get_source_psf (PSF.jl:175-179): the mixture fitted to the PSF map at a world location"""
+    pix = img.world_to_pix(world_loc)
+    return fit_raw_psf_for_celeste(img.psfmap(pix[0], pix[1]), psf_K)[0]
