@@ -89,11 +89,20 @@ def cpu_baseline(problem, vp, targets, seconds_target=15.0):
     _, _, _, _, st = oracle.elbo_batch(problem, vp, sample, FLAGS_ALL, n_threads=cores)
     dt = time.time() - t0
     assert (st == 0).all()
+    # the same sample with the reduced-variable algorithm of the HIP engine on the CPU (oracle/celeste_reduced.c):
+    # separates the algorithmic part of the GPU / CPU ratio from the hardware part
+    oracle.reduced_elbo_batch(problem, vp, sample[: 2 * cores], FLAGS_ALL, n_threads=cores)
+    t0 = time.time()
+    _, _, _, _, st2 = oracle.reduced_elbo_batch(problem, vp, sample, FLAGS_ALL, n_threads=cores)
+    dt2 = time.time() - t0
+    assert (st2 == 0).all()
     return {"value": len(sample) / dt, "unit": "sources/sec", "cores": cores, "kind": "port",
+            "reduced_algorithm_value": len(sample) / dt2,
             "sample": "%d of %d targets (every %d-th), value+grad+Hessian+KL, OpenMP dynamic over sources, %d threads "
-                      "(affinity %d CPUs, cgroup quota respected), %.1f s"
+                      "(affinity %d CPUs, cgroup quota respected), %.1f s; reduced_algorithm_value: same sample, same threads, "
+                      "the engine's reduced-variable algorithm in plain C (%.1f s)"
                       % (len(sample), len(targets), max(1, len(targets) // n), cores,
-                         len(os.sched_getaffinity(0)), dt)}
+                         len(os.sched_getaffinity(0)), dt, dt2)}
 
 
 def main():

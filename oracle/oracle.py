@@ -53,6 +53,7 @@ def lib() -> C.CDLL:
         L.celeste_oracle_elbo.argtypes = [C.POINTER(cabi.ProblemT), dp, C.c_int32, C.c_uint32, dp, dp, dp, lp, lp]
         L.celeste_oracle_elbo_batch.argtypes = [C.POINTER(cabi.ProblemT), dp, C.c_int32, ip, C.c_uint32, dp, dp, dp,
                                                 lp, ip, C.c_int32]
+        L.celeste_reduced_elbo_batch.argtypes = L.celeste_oracle_elbo_batch.argtypes
         L.celeste_oracle_elbo_multi.argtypes = [C.POINTER(cabi.ProblemT), dp, C.c_int32, ip, C.c_uint32,
                                                 C.POINTER(C.c_double), dp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.celeste_oracle_get_bvn_cov.argtypes = [C.c_double, C.c_double, C.c_double, dp]
@@ -105,6 +106,23 @@ def elbo_batch(problem: "cabi.Problem", vp, targets, flags=cabi.FLAG_GRAD | cabi
                                 _dp(d), _dp(h), cnt.ctypes.data_as(cabi.c_int64_p),
                                 status.ctypes.data_as(cabi.c_int32_p), n_threads)
     # h is column-major per target and symmetric (upper triangle mirrored)
+    return v, d, h.transpose(0, 2, 1).copy(), cnt, status
+
+
+def reduced_elbo_batch(problem: "cabi.Problem", vp, targets, flags=cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL,
+                       n_threads: int = 0):
+    """celeste_reduced.c: the reduced-variable algorithm on the CPU (baseline timing); same returns as elbo_batch"""
+    L = lib()
+    vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(problem.n_sources, P))
+    tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32))
+    n = tg.size
+    v = np.zeros(n); d = np.zeros((n, P)); h = np.zeros((n, P, P))
+    cnt = np.zeros((n, 2), dtype=np.int64); status = np.zeros(n, dtype=np.int32)
+    if n_threads <= 0:
+        n_threads = os.cpu_count() or 1
+    L.celeste_reduced_elbo_batch(C.byref(problem.c), _dp(vp), n, tg.ctypes.data_as(cabi.c_int32_p), flags, _dp(v),
+                                 _dp(d), _dp(h), cnt.ctypes.data_as(cabi.c_int64_p),
+                                 status.ctypes.data_as(cabi.c_int32_p), n_threads)
     return v, d, h.transpose(0, 2, 1).copy(), cnt, status
 
 
