@@ -320,7 +320,7 @@ def test_edge_cases(oracle):
     assert_parity(ctx.eval_batch(vp, tg, ALL), oracle.elbo_batch(ctx.problem, vp, tg, ALL), "outside, multi-field")
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(16))
 def test_randomised_small_fields(oracle, seed):
     """fuzz: random image size, source count, NaN fraction, explicit bitmaps, target subset / order, flag set, and
     either evaluation path (fused / split / visit lists forced by giving one source no patch in one image)"""
@@ -340,15 +340,42 @@ def test_randomised_small_fields(oracle, seed):
         (h0, h1), (w0, w1) = p.box
         p.box = ((h0, h0 - 1), (w0, w0 - 1))
         p.active_pixel_bitmap = np.zeros((0, 0), dtype=bool)
-    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    psf_K = 2
+    if rng.random() < 0.35:     # per-patch PSF mixtures with 1 or 3 components, off-centre, anisotropic
+        from celeste_jl_amd.model import render_psf
+        psf_K = int(rng.choice([1, 3]))
+        for row in f.patches:
+            for p in row:
+                w = rng.dirichlet(np.ones(psf_K) * 4)
+                p.psf = np.array([[w[k], 0.2 * rng.normal(), 0.2 * rng.normal(), (1.1 + 0.8 * k) ** 2, 0.15 * rng.normal(),
+                                   (1.2 + 0.8 * k) ** 2] for k in range(psf_K)])
+                p.stamp = render_psf(p.psf)
+    if rng.random() < 0.35:     # affine WCS: every patch of a source maps its world position to the same pixel
+        Jm = np.array([[1.0 + 0.1 * rng.normal(), 0.1 * rng.normal()], [0.1 * rng.normal(), 1.0 + 0.1 * rng.normal()]])
+        Jinv = np.linalg.inv(Jm)
+        for s_, row in enumerate(f.patches):
+            pix = f.vp[s_, 0:2].copy()
+            world = rng.normal(size=2) * 5
+            f.vp[s_, 0:2] = world
+            for p in row:
+                p.wcs_jacobian = Jm.copy()
+                p.world_center = world - Jinv @ (pix - p.pixel_center)
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors, psf_K=psf_K)
     tg = rng.permutation(S)[:int(rng.integers(1, S + 1))].tolist()
     flags = int(rng.choice([0, 4, 1, 5, 3, 7, 7, 7]))
+    if rng.random() < 0.25:
+        flags_dev = flags | cabi.FLAG_FP32
+        g32 = ctx.eval_batch(f.vp, tg, flags_dev)
+        r32 = oracle.elbo_batch(ctx.problem, f.vp, tg, flags)
+        assert np.max(np.abs(g32[0] - r32[0]) / np.abs(r32[0])) <= 1e-4
+        if flags & 3:
+            assert max(np.abs(g32[1][k] - r32[1][k]).max() / np.abs(r32[1][k]).max() for k in range(len(tg))) <= 1e-4
     g = ctx.eval_batch(f.vp, tg, flags)
     r = oracle.elbo_batch(ctx.problem, f.vp, tg, flags)
     errs = assert_parity(g, r, "fuzz %d" % seed)
     if flags & 2:
         assert_parity(ctx.eval_batch(f.vp, tg, flags | cabi.FLAG_SPLIT), r, "fuzz %d split" % seed)
-    print("fuzz", seed, (H, W, S), "targets", len(tg), "flags", flags, errs)
+    print("fuzz", seed, (H, W, S), "targets", len(tg), "flags", flags, "psf_K", psf_K, errs)
 
 
 @pytest.mark.parametrize("seed", range(6))
