@@ -370,8 +370,10 @@ __device__ inline double tri_extreme(const double *__restrict__ td, const double
 // number of secular-equation iterations (celeste_optim_stats)
 __device__ unsigned long long g_optim_stats[5];
 
-#define TRI_MAXC 6   // largest cluster of lowest eigenvalues the hard-case test handles in the tridiagonal basis
-struct TriLds { double *A, *hv, *td, *te, *te2, *ip, *mk, *r, *y, *gt, *q, *gq, *zc, *pa, *pb; };
+#define TRI_MAXC 4   // largest cluster of lowest eigenvalues the hard-case test handles in the tridiagonal basis
+// their eigenvectors live in the spare rows NF .. NF + 3 of the LDA x NF matrix (free once the chain rule is done)
+#define TRI_ZC(L, j, ln) (L).A[(NF + (j)) + LDA * (ln)]
+struct TriLds { double *A, *hv, *td, *te, *te2, *ip, *mk, *r, *y, *gt, *q, *gq, *pa, *pb; };
 
 // Trust-region step in the tridiagonal basis.  In: L.A = H (destroyed), g (lane register), delta.
 // Out: step p (lane register), model decrease m, interior flag.  Returns false in the hard case (caller falls
@@ -437,13 +439,13 @@ __device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int
                     tri_solve(L.te, L.ip, L.mk, L.q, 1.0, L.r, L.gq);
                     z = fr ? L.gq[ln] : 0.0;
                     for (int jj = 0; jj < j; ++jj) {
-                        const double zo = fr ? L.zc[jj * NF + ln] : 0.0;
+                        const double zo = fr ? TRI_ZC(L, jj, ln) : 0.0;
                         z -= wave_sum_dpp(z * zo) * zo;
                     }
                     z *= 1.0 / sqrt(wave_sum_dpp(z * z));
                 }
                 if (fabs(wave_sum_dpp(fr ? z * L.gt[ln] : 0.0)) > 1e-10) orth = false;
-                if (fr) L.zc[j * NF + ln] = z;
+                if (fr) TRI_ZC(L, j, ln) = z;
                 __syncthreads();
             }
             if (orth) {
@@ -451,13 +453,13 @@ __device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int
                 tri_solve(L.te, L.ip, L.mk, L.gt, -1.0, L.r, L.y);
                 y = fr ? L.y[ln] : 0.0;
                 for (int j = 0; j < mc; ++j) {
-                    const double zo = fr ? L.zc[j * NF + ln] : 0.0;
+                    const double zo = fr ? TRI_ZC(L, j, ln) : 0.0;
                     y -= wave_sum_dpp(y * zo) * zo;
                 }
                 const double p2 = wave_sum_dpp(y * y);
                 if (p2 <= d2) {   // N&W (4.45): to the boundary along the lowest eigenvector
                     hard = true;
-                    y += sqrt(d2 - p2) * (fr ? L.zc[ln] : 0.0);
+                    y += sqrt(d2 - p2) * (fr ? TRI_ZC(L, 0, ln) : 0.0);
                     if (fr) L.y[ln] = y;
                     __syncthreads();
                     if (ln == 0) atomicAdd(&g_optim_stats[2], 1ull);
@@ -532,10 +534,18 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
                   const int32_t *__restrict__ ev_status, OptParams op, OptState *__restrict__ st,
                   double *__restrict__ Hstate, int32_t *__restrict__ next_active, int32_t *__restrict__ next_targets,
                   int32_t *__restrict__ next_count) {
-    __shared__ double sA[LDA * CEL_P];    // bound-space Hessian -> trial-point Hessian (negated, free space) -> solver
-    __shared__ double sd[CEL_P], sx[NF], sg[NF], sgt[NF], sJb[26], sHb[26], sp[3][8], sJs[3][8][7];
-    __shared__ double sw[NF], se[NF], sq[NF], scv[NF];
-    __shared__ double std_[NF], ste2[NF], sip[NF], smk[NF], sr[NF], sy[NF], sgt2[NF], szc[TRI_MAXC * NF], spa[NF], spb[NF];
+    // LDS budget: 19.7 KB per workgroup so that 8 workgroups (2 waves per SIMD, the VGPR limit) fit a CU and a batch
+    // of 2000 targets is resident in one round.
+    __shared__ double sA[LDA * NF];       // rows 0..43: H J (44 x 41) -> J'HJ (41 x 41, negated) -> solver; rows 41..44 spare
+    __shared__ double sx[NF], sg[NF], sw[NF], se[NF], scv[NF];
+    __shared__ double sgt_q[NF];          // trial gradient during the chain rule, Householder scratch afterwards
+    __shared__ double sU[9 * NF];         // chain-rule tables, then the solver's vectors (disjoint lifetimes)
+    double *const sgt = sgt_q, *const sq = sgt_q;
+    double *const sd = sU, *const sJb = sU + 44, *const sHb = sU + 70;                   // 44 + 26 + 26
+    double (*const sp)[8] = reinterpret_cast<double (*)[8]>(sU + 96);                    // 3 x 8
+    double (*const sJs)[8][7] = reinterpret_cast<double (*)[8][7]>(sU + 120);            // 3 x 8 x 7 (ends at 288)
+    double *const std_ = sU, *const ste2 = sU + NF, *const sip = sU + 2 * NF, *const smk = sU + 3 * NF, *const sr = sU + 4 * NF,
+           *const sy = sU + 5 * NF, *const sgt2 = sU + 6 * NF, *const spa = sU + 7 * NF, *const spb = sU + 8 * NF;
     __shared__ int s_flag[2];             // 0: accept, 1: done
     __shared__ double s_delta;            // trust-region radius after the update
 
@@ -570,8 +580,6 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         const int n = c_simplex_n[g];
         sJs[g][a][j] = (a < n && j < n - 1) ? (1 - n * c_simplex_lo[g]) * sp[g][a] * ((a == j) - sp[g][j]) : 0.0;
     }
-    // the 44 x 44 bound-space Hessian into LDS
-    for (int k = tid; k < CEL_P * CEL_P; k += nthr) { const int b = k / CEL_P, a = k - b * CEL_P; sA[a + LDA * b] = h[k]; }
     __syncthreads();
     if (tid < NF) {   // gradient: J' d
         double s;
@@ -583,14 +591,14 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         }
         sgt[tid] = -s;  // minimise -elbo
     }
-    // J' H J in place, J block diagonal (26 scalars + simplex blocks 2x1, 8x7, 8x7): rows (lane = row) ...
-    if (tid < CEL_P) {
-        for (int i = 0; i < 26; ++i) sA[tid + LDA * i] *= sJb[i];
+    // J' H J, J block diagonal (26 scalars + simplex blocks 2x1, 8x7, 8x7): rows first (lane = row) ...
+    if (tid < CEL_P) {   // row `tid` of the bound-space Hessian straight from HBM (lanes read consecutive addresses)
+        for (int i = 0; i < 26; ++i) sA[tid + LDA * i] = h[tid + CEL_P * i] * sJb[i];
         for (int g = 0; g < 3; ++g) {
             const int n = c_simplex_n[g], b0 = c_simplex_b0[g], f0 = c_simplex_f0[g];
             double hv[8];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) hv[b] = b < n ? sA[tid + LDA * (b0 + b)] : 0.0;
+            for (int b = 0; b < 8; ++b) hv[b] = b < n ? h[tid + CEL_P * (b0 + b)] : 0.0;
             for (int j = 0; j < n - 1; ++j) {
                 double o = 0;
 #pragma unroll
@@ -684,7 +692,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
     int interior = 0;
     bool solved = false;
     if (op.solver != 1) {
-        const TriLds L = {sA, sw, std_, se, ste2, sip, smk, sr, sy, sgt2, sq, scv, szc, spa, spb};
+        const TriLds L = {sA, sw, std_, se, ste2, sip, smk, sr, sy, sgt2, sq, scv, spa, spb};
         solved = tri_tr_solve(L, fr ? sg[tid] : 0.0, s_delta, tid, step, m, interior);
         if (!solved) {   // hard case: restore H and diagonalise it
             for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hs[k]; }
