@@ -508,3 +508,35 @@ def test_psf_raster(oracle, lib):
     out = out.reshape(51, 51).T
     ref = np.array([[oracle.psf_at_point(psf, r, c) for c in cols] for r in rows])
     assert np.abs(out - ref).max() <= 1e-12 * ref.max()
+
+
+def test_contexts_release_their_memory():
+    """create / use / destroy many contexts (evaluation, split variant, optimiser, renderer, multi-active): device
+    memory returns to where it started"""
+    import gc
+    import torch
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_field(160, 200, 30, seed=11)
+    nbrs_all = [[s for s in range(30) if s != a] for a in range(30)]
+
+    def cycle(i):
+        ctx = cel.FieldContext(f.images, f.patches, f.neighbors if i % 2 else nbrs_all)
+        tg = list(range(30))
+        ctx.eval_batch(f.vp, tg, ALL)
+        ctx.eval_batch(f.vp, tg, ALL | cabi.FLAG_SPLIT)
+        ctx.maximize_batch(f.vp, tg[:10], cel.ElboConfig(max_iters=3))
+        ctx.render_expected(f.vp, 2)
+        if i % 2 == 0:
+            ctx.eval_multi(f.vp, [0, 1, 2], ALL)
+        ctx.close()
+    cycle(0); cycle(1)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(40):
+        cycle(i)
+    gc.collect()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    print("free before / after 40 context cycles: %d / %d MiB" % (free0 >> 20, free1 >> 20))
+    assert free0 - free1 <= 64 << 20
