@@ -540,3 +540,29 @@ def test_contexts_release_their_memory():
     free1, _ = torch.cuda.mem_get_info()
     print("free before / after 40 context cycles: %d / %d MiB" % (free0 >> 20, free1 >> 20))
     assert free0 - free1 <= 64 << 20
+
+
+def test_two_threads_two_contexts(oracle):
+    """the library is thread-compatible: concurrent calls on different contexts (the reference evaluates from many
+    threads, each with its own scratch, ElboMaximize.jl:146-155) give the single-threaded results"""
+    from concurrent.futures import ThreadPoolExecutor
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    fields = [synthetic.make_field(120, 150, 20, seed=50 + k) for k in range(2)]
+    ctxs = [_ctx(f) for f in fields]
+    ref = [c.eval_batch(f.vp, list(range(20)), ALL) for c, f in zip(ctxs, fields)]
+    refm = [c.maximize_batch(f.vp, list(range(20)), cel.ElboConfig(max_iters=6)) for c, f in zip(ctxs, fields)]
+
+    def work(k):
+        out = []
+        for _ in range(10):
+            out.append(ctxs[k].eval_batch(fields[k].vp, list(range(20)), ALL))
+            out.append(ctxs[k].maximize_batch(fields[k].vp, list(range(20)), cel.ElboConfig(max_iters=6)))
+        return out
+    with ThreadPoolExecutor(2) as ex:
+        res = list(ex.map(work, range(2)))
+    for k in range(2):
+        for i, r in enumerate(res[k]):
+            expect = ref[k] if i % 2 == 0 else refm[k]
+            for a, b in zip(r, expect):
+                assert np.array_equal(a, b)
