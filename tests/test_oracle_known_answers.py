@@ -136,3 +136,61 @@ def test_spline_is_the_natural_bicubic_interpolant(oracle):
     # interpolation property on the grid
     for (i, j) in [(1, 1), (26, 26), (51, 51), (7, 40)]:
         assert oracle.spline_value(coef, i, j) == pytest.approx(g[i - 1, j - 1], rel=1e-12, abs=1e-12)
+
+
+def test_kl_closed_forms_against_monte_carlo(oracle):
+    """test_kl.jl:19-28: each closed form agrees with a sample average of log q - log p within 4 standard errors;
+    the whole subtract_kl (with the prior's full 4 x 4 colour covariances) is checked the same way"""
+    from celeste_jl_amd.synthetic import load_prior
+    from celeste_jl_amd import generic_init_source
+    rng = np.random.default_rng(12)
+    n = 400_000
+
+    def check(exact, samples):
+        se = samples.std() / math.sqrt(len(samples))
+        assert abs(samples.mean() - exact) <= 4 * se, (exact, samples.mean(), se)
+
+    # categorical
+    p1, p2 = np.array([1, 2, 3, 4]) / 10, np.array([5, 6, 2, 1]) / 14
+    idx = rng.choice(4, size=n, p=p1)
+    check(oracle.categorical_kl(p1, p2), np.log(p1[idx]) - np.log(p2[idx]))
+    # univariate normal
+    x = rng.normal(0.5, math.sqrt(2.0), size=n)
+    lq = -0.5 * (np.log(2 * np.pi * 2.0) + (x - 0.5) ** 2 / 2.0)
+    lp = -0.5 * (np.log(2 * np.pi * 1.8) + (x - 0.8) ** 2 / 1.8)
+    check(oracle.gaussian_kl(0.5, 2.0, 0.8, 1.8), lq - lp)
+    # subtract_kl of a whole source = -E_q[log q - log p] + log p(radius): sample (a, k, r, c) from q
+    prior = load_prior()
+    vs = generic_init_source([3.0, 4.0])
+    rng2 = np.random.default_rng(13)
+    vs[26:28] = [0.3, 0.7]
+    for i in range(2):
+        vs[28 + 8 * i:36 + 8 * i] = rng2.dirichlet(np.ones(8) * 3)
+        vs[6 + i] = 1.0 + i; vs[8 + i] = 0.4 + 0.2 * i
+        vs[10 + 4 * i:14 + 4 * i] = rng2.normal(size=4) * 0.5
+        vs[18 + 4 * i:22 + 4 * i] = 0.05 + 0.3 * rng2.random(4)
+    exact, _, _ = oracle.subtract_kl(vs, prior)
+    a = rng.choice(2, size=n, p=vs[26:28])
+    total = np.log(vs[26 + a]) - np.log(np.asarray(prior["is_star"])[a])
+    for i in range(2):
+        m = a == i
+        cnt = int(m.sum())
+        kq, kp = vs[28 + 8 * i:36 + 8 * i], np.asarray(prior["k"][i])
+        kd = rng.choice(8, size=cnt, p=kq)
+        t = np.log(kq[kd]) - np.log(kp[kd])
+        r = rng.normal(vs[6 + i], math.sqrt(vs[8 + i]), size=cnt)
+        t += (-0.5 * (np.log(2 * np.pi * vs[8 + i]) + (r - vs[6 + i]) ** 2 / vs[8 + i])
+              + 0.5 * (np.log(2 * np.pi * prior["flux_var"][i]) + (r - prior["flux_mean"][i]) ** 2 / prior["flux_var"][i]))
+        mu, lam = vs[10 + 4 * i:14 + 4 * i], vs[18 + 4 * i:22 + 4 * i]
+        c = mu + rng.normal(size=(cnt, 4)) * np.sqrt(lam)
+        lqc = -0.5 * (np.log(2 * np.pi * lam).sum() + (((c - mu) ** 2) / lam).sum(axis=1))
+        lpc = np.zeros(cnt)
+        for d in range(8):
+            sel = kd == d
+            S = np.asarray(prior["color_cov"][i][d]).reshape(4, 4)
+            dm = c[sel] - np.asarray(prior["color_mean"][i][d])
+            lpc[sel] = -0.5 * (4 * math.log(2 * math.pi) + np.linalg.slogdet(S)[1] + np.einsum("ni,ij,nj->n", dm, np.linalg.inv(S), dm))
+        total[m] += t + lqc - lpc
+    x = vs[5]
+    logp = -0.5 * (math.log(2 * math.pi) + math.log(prior["gal_radius_px_var"]) + (x - prior["gal_radius_px_mean"]) ** 2 / prior["gal_radius_px_var"])
+    check(-(exact - logp), total)
