@@ -23,6 +23,9 @@ import numpy as np  # noqa: E402
 
 FLAGS_ALL = 1 | 2 | 4
 HBM_PEAK_GBS = 8000.0
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X FP64 vector (non-matrix) peak
+FLOPS_PER_PIXEL_VISIT = 4223        # FP64 flops pixel_kernel<2, double> spends per visited pixel, counted in the ISA
+                                    # (tools/count_flops.py: FMA = 2; psf_K = 2)
 
 
 def profiled_traffic_bytes():
@@ -278,6 +281,11 @@ def main():
                          "kernel": "pixel_kernel<2>", "kernel_ms": float(kms[1]),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "valu_utilization": (traffic or {}).get("pixel_kernel_valu_utilization"),
+                         "fp64": {"achieved": FLOPS_PER_PIXEL_VISIT * stats["active_pixel_visits"] / (kms[1] * 1e-3) / 1e12,
+                                  "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": FLOPS_PER_PIXEL_VISIT * stats["active_pixel_visits"] / (kms[1] * 1e-3) / 1e12
+                                  / FP64_VECTOR_PEAK_TFLOPS,
+                                  "flops_per_pixel_visit": FLOPS_PER_PIXEL_VISIT},
                          "note": "the fused kernel is FP64-VALU bound, not HBM- or MFMA-bound (SURVEY.md F8, DESIGN.md 4.3): "
                                  "valu_utilization = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles from the committed PMC pass; "
                                  "the HBM-bound kernel of the path is split_variant.kernel"},
