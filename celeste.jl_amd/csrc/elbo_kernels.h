@@ -576,6 +576,53 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int nc, R dx, 
     return (double)S0;
 }
 
+// Single-precision variant of galaxy_sums (CELESTE_FLAG_FP32) with two components per instruction: the records of
+// components c and c + 1 sit in the two halves of float2 values, so the whole Hermite chain runs on v_pk_fma_f32 /
+// v_pk_mul_f32 (NC = 14 psf_K is even); only the exponential is evaluated per half.  The two halves of every sum are
+// added at the end.  Same arithmetic per component as galaxy_sums<MODE, float>.
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int MODE>
+__device__ __forceinline__ double galaxy_sums_pk(const CompR<float> *tc, int nc, float dx, float dy, PixelTerms &T) {
+    const f2v z = (f2v)(0.0f);
+    f2v S0 = z, S0d = z, S1x = z, S1y = z, S1xd = z, S1yd = z;
+    f2v S2a = z, S2b = z, S2c = z, S2an = z, S2bn = z, S2cn = z, S2ad = z, S2bd = z, S2cd = z;
+    f2v S3a = z, S3b = z, S3c = z, S3d = z, S4a = z, S4b = z, S4c = z, S4d = z, S4e = z;
+    const f2v dxx = (f2v)(dx), dyy = (f2v)(dy);
+    for (int c = 0; c < nc; c += 2) {
+        const CompR<float> a = tc[c], b = tc[c + 1];
+        const f2v p11 = {a.p11, b.p11}, p12 = {a.p12, b.p12}, p22 = {a.p22, b.p22};
+        const f2v xi1 = {a.xi1, b.xi1}, xi2 = {a.xi2, b.xi2}, w0 = {a.w0, b.w0}, wd = {a.wd, b.wd}, nu = {a.nu, b.nu};
+        const f2v d1 = dxx - xi1, d2 = dyy - xi2;
+        const f2v u = p11 * d1 + p12 * d2, v = p12 * d1 + p22 * d2;
+        const f2v q = -0.5f * (d1 * u + d2 * v);
+        const f2v e = {__expf(q.x), __expf(q.y)};
+        const f2v f = w0 * e, fd = wd * e, fn = f * nu;
+        const f2v ha = u * u - p11, hb = u * v - p12, hc = v * v - p22;
+        S0 += f; S0d += fd;
+        S1x += u * f; S1y += v * f;
+        S2an += ha * fn; S2bn += hb * fn; S2cn += hc * fn;
+        if (MODE == 2) {
+            const f2v fdn = fd * nu, fnn = fn * nu;
+            S1xd += u * fd; S1yd += v * fd;
+            S2a += ha * f; S2b += hb * f; S2c += hc * f;
+            S2ad += ha * fdn; S2bd += hb * fdn; S2cd += hc * fdn;
+            const f2v h3a = u * (ha - 2.0f * p11), h3b = v * ha - 2.0f * u * p12, h3c = u * hc - 2.0f * v * p12,
+                      h3d = v * (hc - 2.0f * p22);
+            S3a += h3a * fn; S3b += h3b * fn; S3c += h3c * fn; S3d += h3d * fn;
+            const f2v h4a = u * h3a - 3.0f * ha * p11, h4b = v * h3a - 3.0f * ha * p12,
+                      h4c = u * h3c - 2.0f * hb * p12 - hc * p11, h4d = u * h3d - 3.0f * hc * p12,
+                      h4e = v * h3d - 3.0f * hc * p22;
+            S4a += h4a * fnn; S4b += h4b * fnn; S4c += h4c * fnn; S4d += h4d * fnn; S4e += h4e * fnn;
+        }
+    }
+#define PKSUM(name) T.name = (double)name.x + (double)name.y
+    PKSUM(S0d); PKSUM(S1x); PKSUM(S1y); PKSUM(S1xd); PKSUM(S1yd);
+    PKSUM(S2a); PKSUM(S2b); PKSUM(S2c); PKSUM(S2an); PKSUM(S2bn); PKSUM(S2cn); PKSUM(S2ad); PKSUM(S2bd); PKSUM(S2cd);
+    PKSUM(S3a); PKSUM(S3b); PKSUM(S3c); PKSUM(S3d); PKSUM(S4a); PKSUM(S4b); PKSUM(S4c); PKSUM(S4d); PKSUM(S4e);
+#undef PKSUM
+    return (double)S0.x + (double)S0.y;
+}
+
 #define ACC_Q (ACC_N / 4)  // 17 accumulators per lane: lane l owns record entries e with e % 4 == l % 4
 
 // MODE 0: value only; MODE 1: value + gradient sums; MODE 2: value + gradient + Hessian sums;
@@ -721,7 +768,10 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         T.S0d = 0; T.S1x = 0; T.S1y = 0; T.S1xd = 0; T.S1yd = 0;
         T.S2a = 0; T.S2b = 0; T.S2c = 0; T.S2an = 0; T.S2bn = 0; T.S2cn = 0; T.S2ad = 0; T.S2bd = 0; T.S2cd = 0;
         T.S3a = 0; T.S3b = 0; T.S3c = 0; T.S3d = 0; T.S4a = 0; T.S4b = 0; T.S4c = 0; T.S4d = 0; T.S4e = 0;
-        if (own) S0 = galaxy_sums<GM, R>(tcr, NC, (R)(hh - si.m1), (R)(ww - si.m2), etab, T);
+        if (own) {
+            if constexpr (sizeof(R) == 4) S0 = galaxy_sums_pk<GM>(tcr, NC, (float)(hh - si.m1), (float)(ww - si.m2), T);
+            else S0 = galaxy_sums<GM, R>(tcr, NC, (R)(hh - si.m1), (R)(ww - si.m2), etab, T);
+        }
         T.f1 = S0;
 
         // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
