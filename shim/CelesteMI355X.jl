@@ -1,0 +1,121 @@
+# CelesteMI355X.jl -- ccall shim for libceleste_mi355x.so (include/celeste_mi355x.h), Julia 0.6 syntax.
+#
+# Source only: Julia is not installed in the build container or on the GPU box, so this file has NOT been executed.
+# The tested counterpart is the ctypes binding celeste.jl_amd/cabi.py, which issues the same call sequence
+# (tests/test_gpu_*.py).  To be included next to src/deterministic_vi/elbo_objective.jl inside module DeterministicVI;
+# see INTEGRATION.md for the call-site changes (ElboMaximize.jl:166, ParallelRun.jl:372-397, 468-498).
+
+# Julia 0.6 syntax, to live next to elbo_objective.jl inside module DeterministicVI.
+const libceleste = "libceleste_mi355x"
+
+struct CImage                      # celeste_image_t
+    H::Int32; W::Int32; band::Int32; reserved::Int32
+    pixels::Ptr{Float32}; sky::Ptr{Float32}; nelec_per_nmgy::Ptr{Float32}
+end
+struct CPatch                      # celeste_patch_t
+    off_h::Int32; off_w::Int32; H2::Int32; W2::Int32
+    bitmap::Ptr{UInt8}
+    wcs_jacobian::NTuple{4,Float64}; world_center::NTuple{2,Float64}; pixel_center::NTuple{2,Float64}
+    psf::Ptr{Float64}; stamp::Int32; reserved::Int32
+end
+struct CProblem                    # celeste_problem_t
+    n_images::Int32; n_sources::Int32; psf_K::Int32; n_stamps::Int32
+    images::Ptr{CImage}; patches::Ptr{CPatch}; stamps::Ptr{Float64}
+    nbr_offsets::Ptr{Int64}; nbr_index::Ptr{Int32}; prior::Ptr{Void}
+end
+
+mutable struct MI355XContext
+    handle::Ptr{Void}
+    keep::Vector{Any}              # every buffer the C structs point into
+end
+
+"""
+Build the device context for one ElboArgs (ea.images, ea.patches[S x N], ea.active_sources == [1]):
+the local source list is [target; neighbors] exactly as ParallelRun.process_source builds it.
+"""
+function MI355XContext(ea::ElboArgs; device::Int = 0)
+    keep = Any[]
+    imgs = map(ea.images) do img
+        sky = convert(Matrix{Float32}, img.sky); push!(keep, sky, img.pixels, img.nelec_per_nmgy)
+        CImage(img.H, img.W, img.b, 0, pointer(img.pixels), pointer(sky), pointer(img.nelec_per_nmgy))
+    end
+    stamps = Float64[]; patches = CPatch[]
+    for s in 1:ea.S, n in 1:ea.N
+        p = ea.patches[s, n]
+        psf = vcat([[pc.alphaBar, pc.xiBar[1], pc.xiBar[2], pc.tauBar[1,1], pc.tauBar[1,2], pc.tauBar[2,2]]
+                    for pc in p.psf]...)
+        bm = convert(Matrix{UInt8}, p.active_pixel_bitmap); push!(keep, psf, bm)
+        # raw psfmap stamp at the patch centre; conditioning + prefilter happen inside the library
+        append!(stamps, vec(ea.images[n].psfmap(p.pixel_center[1], p.pixel_center[2])))
+        push!(patches, CPatch(p.bitmap_offset[1], p.bitmap_offset[2], size(bm, 1), size(bm, 2), pointer(bm),
+                              tuple(p.wcs_jacobian...), tuple(p.world_center...), tuple(p.pixel_center...),
+                              pointer(psf), length(patches), 0))
+    end
+    # patches is laid out [s * N + n] (row s = source): transpose of Julia's column-major ea.patches
+    off = Int64[0; fill(ea.S - 1, ea.S)]                 # CSR offsets: only source 1 has neighbours
+    idx = Int32[1:(ea.S - 1);]
+    push!(keep, imgs, patches, stamps, off, idx)
+    prob = CProblem(ea.N, ea.S, ea.psf_K, length(patches), pointer(imgs), pointer(patches), pointer(stamps),
+                    pointer(off), pointer(idx), C_NULL)
+    h = Ref{Ptr{Void}}(C_NULL)
+    st = ccall((:celeste_ctx_create, libceleste), Cint, (Ref{CProblem}, Cint, Ref{Ptr{Void}}), prob, device, h)
+    st == 0 || error(unsafe_string(ccall((:celeste_strerror, libceleste), Cstring, (Cint,), st)))
+    ctx = MI355XContext(h[], keep)
+    finalizer(ctx, c -> ccall((:celeste_ctx_destroy, libceleste), Void, (Ptr{Void},), c.handle))
+    ctx
+end
+
+"""Drop-in for `elbo(ea, vp, elbo_vars, bvn_bundle)` (elbo_objective.jl:482-492), Float64 only."""
+function elbo(ea::ElboArgs, vp::VariationalParams{Float64}, ctx::MI355XContext,
+              elbo_vars::ElboIntermediateVariables{Float64} = ElboIntermediateVariables(Float64, ea.Sa))
+    @assert ea.Sa == 1 && ea.active_sources == [1]
+    @assert(all(all(isfinite, vs) for vs in vp), "vp contains NaNs or Infs")
+    vpm = hcat(vp...)                                   # 44 x S column-major == S rows of 44
+    flags = UInt32(elbo_vars.elbo.has_gradient ? 1 : 0) | UInt32(elbo_vars.elbo.has_hessian ? 2 : 0) |
+            UInt32(ea.include_kl ? 4 : 0)
+    sf = elbo_vars.elbo                                 # the reference returns this scratch object too
+    v = Ref{Float64}(0.0); na = Ref{Int64}(0); ni = Ref{Int64}(0)
+    st = ccall((:celeste_elbo_eval, libceleste), Cint,
+               (Ptr{Void}, Ptr{Float64}, Int32, UInt32, Ref{Float64}, Ptr{Float64}, Ptr{Float64},
+                Ref{Int64}, Ref{Int64}),
+               ctx.handle, vpm, 0, flags, v, sf.d, sf.h, na, ni)
+    @assert st == 0 unsafe_string(ccall((:celeste_strerror, libceleste), Cstring, (Cint,), st))
+    sf.v[] = v[]
+    elbo_vars.active_pixel_counter[] += na[]; elbo_vars.inactive_pixel_counter[] += ni[]
+    sf
+end
+
+
+# ---- whole-box entry points (one context per box; see INTEGRATION.md) ----------------------------------------
+
+"""elbo() for a conflict-free batch of targets; `targets0` are 0-based source ids."""
+function elbo_batch(ctx::MI355XContext, vp_all::Matrix{Float64}, targets0::Vector{Int32}; flags::UInt32 = UInt32(7))
+    n = length(targets0)
+    v = zeros(n); d = zeros(44, n); h = zeros(44, 44, n)
+    counters = zeros(Int64, 2, n); status = zeros(Int32, n); targets = targets0
+    st = ccall((:celeste_elbo_eval_batch, libceleste), Cint,
+               (Ptr{Void}, Ptr{Float64}, Int32, Ptr{Int32}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                Ptr{Int64}, Ptr{Int32}),
+               ctx.handle, vp_all, length(targets), targets0, flags, v, d, h, counters, status)
+    return st, v, d, h, counters, status
+end
+
+struct COptimConfig                # celeste_optim_config_t
+    loc_width::Float64; loc_scale::Float64; max_iters::Int32; include_kl::Int32
+    xtol_abs::Float64; ftol_rel::Float64; gtol::Float64; initial_delta::Float64; delta_hat::Float64
+end
+
+"""ElboMaximize.maximize! for a conflict-free batch; vp_all (44 x S) is updated in place for the targets."""
+function maximize_batch!(ctx::MI355XContext, vp_all::Matrix{Float64}, targets0::Vector{Int32};
+                         vp_frozen_neighbors = C_NULL, box_centres = C_NULL, include_kl::Bool = true)
+    targets = targets0
+    iterations = zeros(Int32, length(targets)); f_calls = zeros(Int32, length(targets))
+    max_values = zeros(length(targets)); status = zeros(Int32, length(targets))
+    cfgc = Ref(COptimConfig(1e-4, 1.0, 50, include_kl, 1e-7, 1e-6, 1e-8, 1.0, 1e9))   # ElboConfig defaults
+    st = ccall((:celeste_maximize_batch, libceleste), Cint,
+               (Ptr{Void}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Int32}, Ref{COptimConfig},
+                Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}),
+               ctx.handle, vp_all, vp_frozen_neighbors #= or C_NULL =#, box_centres #= or C_NULL =#,
+               length(targets), targets0, cfgc, iterations, f_calls, max_values, status)
+    return st, iterations, f_calls, max_values, status
+end
