@@ -24,7 +24,7 @@ import numpy as np  # noqa: E402
 FLAGS_ALL = 1 | 2 | 4
 HBM_PEAK_GBS = 8000.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X FP64 vector (non-matrix) peak
-FLOPS_PER_PIXEL_VISIT = 4223        # FP64 flops pixel_kernel<2, double> spends per visited pixel, counted in the ISA
+FLOPS_PER_PIXEL_VISIT = 4046        # FP64 flops pixel_kernel<2, double> spends per visited pixel, counted in the ISA
                                     # (tools/count_flops.py: FMA = 2; psf_K = 2)
 
 

@@ -367,9 +367,13 @@ struct PixelTerms {
     double vterm, cnt_act, cnt_inact;
     double f0, f1;
     double alpha, beta, w2, w12;
-    double k0, k1, r0, r1;
+    double k0, k1;
     double f0g0, f0g1, f0h0, f0h1, f0h2;
-    double dA0, dA1, dA2, dA3, dA4, dA5, dB0, dB1, dB2, dB3, dB4, dB5;
+    // With dA = c0 ds + c1 dg and dB = 2 q0 f0 ds + 2 q1 f1 dg (ds / dg = gradients of the star / galaxy density) every
+    // derivative entry is a combination of ds, dg and their second derivatives with per-pixel scalar weights:
+    double C0s, C0g, C1s, C1g;   // rows (c0, geo), (c1, geo):  C.s ds + C.g dg
+    double Q0s, Q0g, Q1s, Q1g;   // rows (q0, geo), (q1, geo)
+    double Wgg, Wsg, Wss;        // (geo, geo): Wgg dg dg' + Wsg (ds dg' + dg ds') + Wss ds ds' + k1 d2g + k0 d2s
     // galaxy component sums (see pixel_kernel)
     double S0d, S1x, S1y, S1xd, S1yd, S2a, S2b, S2c, S2an, S2bn, S2cn, S2ad, S2bd, S2cd;
     double S3a, S3b, S3c, S3d, S4a, S4b, S4c, S4d, S4e;
@@ -417,17 +421,6 @@ __device__ __forceinline__ double star_g(const PixelTerms &T) {
     else if constexpr (G == 1) return T.f0g1;
     else return 0.0;
 }
-template <int G>
-__device__ __forceinline__ double dA_g(const PixelTerms &T) {
-    if constexpr (G == 0) return T.dA0; else if constexpr (G == 1) return T.dA1; else if constexpr (G == 2) return T.dA2;
-    else if constexpr (G == 3) return T.dA3; else if constexpr (G == 4) return T.dA4; else return T.dA5;
-}
-template <int G>
-__device__ __forceinline__ double dB_g(const PixelTerms &T) {
-    if constexpr (G == 0) return T.dB0; else if constexpr (G == 1) return T.dB1; else if constexpr (G == 2) return T.dB2;
-    else if constexpr (G == 3) return T.dB3; else if constexpr (G == 4) return T.dB4; else return T.dB5;
-}
-
 constexpr int hess_row(int e) {  // packed upper-triangle index (e - ACC_H0) -> row
     int i = 0, k = e - ACC_H0;
     while (k >= ZV - i) { k -= ZV - i; ++i; }
@@ -451,7 +444,8 @@ __device__ __forceinline__ double record_entry(const PixelTerms &T) {
         else if constexpr (r == 1) return T.alpha * T.f1;
         else if constexpr (r == 2) return T.w2 * T.f0 * T.f0;
         else if constexpr (r == 3) return T.w2 * T.f1 * T.f1;
-        else return T.alpha * dA_g<r - 4>(T) + T.w2 * dB_g<r - 4>(T);
+        else if constexpr (r - 4 < 2) return T.k0 * star_g<r - 4>(T) + T.k1 * gal_g<r - 4>(T);
+        else return T.k1 * gal_g<r - 4>(T);
     } else {
         constexpr int i = hess_row(E), j = hess_col(E);
         if constexpr (j < 2) return T.beta * (i == 0 ? T.f0 : T.f1) * (j == 0 ? T.f0 : T.f1);      // (c, c)
@@ -459,21 +453,20 @@ __device__ __forceinline__ double record_entry(const PixelTerms &T) {
             const double fi = i == 0 ? T.f0 : T.f1, fj = j == 2 ? T.f0 : T.f1;
             return T.w12 * fi * (fj * fj);
         } else if constexpr (j < 4) return 0.0;                                                      // (q, q)
-        else if constexpr (i < 4) {
+        else if constexpr (i < 4) {                                                                   // (c / q, geo)
             constexpr int g2 = j - 4;
-            constexpr bool star = (i & 1) == 0;
-            const double fi = star ? T.f0 : T.f1;
-            double fig;
-            if constexpr (star) fig = star_g<g2>(T); else fig = gal_g<g2>(T);
-            if constexpr (i < 2) return T.alpha * fig + fi * (T.beta * dA_g<g2>(T) + T.w12 * dB_g<g2>(T));  // (c, geo)
-            else return 2.0 * T.w2 * fi * fig + T.w12 * (fi * fi) * dA_g<g2>(T);                              // (q, geo)
+            const double xs = i == 0 ? T.C0s : (i == 1 ? T.C1s : (i == 2 ? T.Q0s : T.Q1s));
+            const double xg = i == 0 ? T.C0g : (i == 1 ? T.C1g : (i == 2 ? T.Q0g : T.Q1g));
+            if constexpr (g2 < 2) return xs * star_g<g2>(T) + xg * gal_g<g2>(T);
+            else return xg * gal_g<g2>(T);
         } else {                                                                                      // (geo, geo)
             constexpr int g = i - 4, g2 = j - 4;
-            double v = T.k1 * gal_h<g, g2>(T) + T.r1 * gal_g<g>(T) * gal_g<g2>(T) + T.beta * dA_g<g>(T) * dA_g<g2>(T) +
-                       T.w12 * (dA_g<g>(T) * dB_g<g2>(T) + dB_g<g>(T) * dA_g<g2>(T));
-            if constexpr (g2 < 2) {
+            double a = T.Wgg * gal_g<g>(T);
+            if constexpr (g < 2) a += T.Wsg * star_g<g>(T);
+            double v = T.k1 * gal_h<g, g2>(T) + a * gal_g<g2>(T);
+            if constexpr (g2 < 2) {   // then g < 2 as well (upper triangle)
                 const double f0h = (g + g2 == 0) ? T.f0h0 : ((g + g2 == 1) ? T.f0h1 : T.f0h2);
-                v += T.k0 * f0h + T.r0 * star_g<g>(T) * star_g<g2>(T);
+                v += T.k0 * f0h + (T.Wsg * gal_g<g>(T) + T.Wss * star_g<g>(T)) * star_g<g2>(T);
             }
             return v;
         }
@@ -830,14 +823,18 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             T.beta = w11 - 2.0 * T.w2 - 4.0 * A * T.w12;
             T.k1 = T.alpha * c1 + 2.0 * T.w2 * q1 * T.f1;          // multiplies d2 f1
             T.k0 = T.alpha * c0 + 2.0 * T.w2 * q0 * T.f0;          // multiplies d2 f0
-            T.r1 = 2.0 * T.w2 * q1; T.r0 = 2.0 * T.w2 * q0;        // multiply df df'
-            const double q0f0 = 2.0 * q0 * T.f0, q1f1 = 2.0 * q1 * T.f1;
-            T.dA0 = c0 * T.f0g0 + c1 * gal_g<0>(T); T.dB0 = q0f0 * T.f0g0 + q1f1 * gal_g<0>(T);
-            T.dA1 = c0 * T.f0g1 + c1 * gal_g<1>(T); T.dB1 = q0f0 * T.f0g1 + q1f1 * gal_g<1>(T);
-            T.dA2 = c1 * gal_g<2>(T); T.dB2 = q1f1 * gal_g<2>(T);
-            T.dA3 = c1 * gal_g<3>(T); T.dB3 = q1f1 * gal_g<3>(T);
-            T.dA4 = c1 * gal_g<4>(T); T.dB4 = q1f1 * gal_g<4>(T);
-            T.dA5 = c1 * gal_g<5>(T); T.dB5 = q1f1 * gal_g<5>(T);
+            {
+                const double t0 = 2.0 * T.w12 * q0 * T.f0, t1 = 2.0 * T.w12 * q1 * T.f1;
+                const double P0 = T.beta * c0 + t0, P1 = T.beta * c1 + t1;      // beta dA + w12 dB = P0 ds + P1 dg
+                T.C0s = T.alpha + T.f0 * P0; T.C0g = T.f0 * P1;
+                T.C1s = T.f1 * P0; T.C1g = T.alpha + T.f1 * P1;
+                const double v0 = T.w12 * (T.f0 * T.f0), v1 = T.w12 * (T.f1 * T.f1), u0 = 2.0 * T.w2 * T.f0, u1 = 2.0 * T.w2 * T.f1;
+                T.Q0s = u0 + v0 * c0; T.Q0g = v0 * c1;                          // 2 w2 f0 ds + w12 f0^2 dA
+                T.Q1s = v1 * c0; T.Q1g = u1 + v1 * c1;
+                T.Wgg = 2.0 * T.w2 * q1 + c1 * (P1 + t1);
+                T.Wss = 2.0 * T.w2 * q0 + c0 * (P0 + t0);
+                T.Wsg = c0 * P1 + c1 * t0;
+            }
         }
         if constexpr (MODE == 3)
             store_entries<0>(T, rec + (size_t)(tile_off[(size_t)t * N + n] + (base >> 6)) * (ACC_N * 64) + lane);
