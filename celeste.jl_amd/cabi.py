@@ -48,7 +48,8 @@ class PriorT(C.Structure):
 class ProblemT(C.Structure):
     _fields_ = [("n_images", C.c_int32), ("n_sources", C.c_int32), ("psf_K", C.c_int32), ("n_stamps", C.c_int32),
                 ("images", C.POINTER(ImageT)), ("patches", C.POINTER(PatchT)), ("stamps", c_double_p),
-                ("nbr_offsets", c_int64_p), ("nbr_index", c_int32_p), ("prior", C.POINTER(PriorT))]
+                ("nbr_offsets", c_int64_p), ("nbr_index", c_int32_p), ("prior", C.POINTER(PriorT)),
+                ("n_patch_entries", C.c_int64), ("patch_source", c_int32_p), ("patch_image", c_int32_p)]
 
 
 class WorkStatsT(C.Structure):
@@ -90,6 +91,15 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         raise ImportError(
             "HIP extension %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    # PyTorch ships its own HIP/HSA runtime libraries.  Whichever HIP runtime is loaded first serves the whole
+    # process, and torch cannot initialise its device after a different one: load torch's first so that tensors,
+    # streams and this library share one runtime whatever the import order of the caller.
+    try:
+        import torch  # noqa: F401
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp = C.c_void_p
     lib.celeste_version.restype = C.c_int
@@ -157,7 +167,7 @@ class Problem:
 
     def __init__(self, images, patches, neighbors: Optional[Sequence[Sequence[int]]] = None, psf_K: int = 2,
                  prior: Optional[dict] = None):
-        from .model import Image, ImagePatch  # noqa: F401
+        from .model import PatchRow
         self.images = images
         self.patches = patches
         N, S = len(images), len(patches)
@@ -174,37 +184,59 @@ class Problem:
             ci.pixels = pix.ctypes.data_as(c_float_p)
             ci.sky = sky.ctypes.data_as(c_float_p)
             ci.nelec_per_nmgy = iota.ctypes.data_as(c_float_p)
-        # shared stamp table: deduplicate by object identity / content of the raw stamp
+        # shared stamp table: deduplicate by content of the raw stamp (object identity first: a constant PSF map hands
+        # the same array to every patch of an image)
         stamps: List[np.ndarray] = []
-        stamp_key = {}
-        self.c_patches = (PatchT * (S * N))()
-        for s in range(S):
-            assert len(patches[s]) == N
-            for n in range(N):
-                p = patches[s][n]
-                st = np.ascontiguousarray(np.asfortranarray(p.stamp, dtype=np.float64).T)  # column-major bytes
+        stamp_key, stamp_obj = {}, {}
+
+        def stamp_index(raw):
+            k = stamp_obj.get(id(raw))
+            if k is None:
+                st = np.ascontiguousarray(np.asfortranarray(raw, dtype=np.float64).T)  # column-major bytes
                 key = st.tobytes()
                 if key not in stamp_key:
                     stamp_key[key] = len(stamps)
                     stamps.append(st.reshape(-1))
-                cp = self.c_patches[s * N + n]
-                cp.off_h, cp.off_w = int(p.bitmap_offset[0]), int(p.bitmap_offset[1])
-                bm = np.asfortranarray(p.active_pixel_bitmap, dtype=np.uint8)
-                cp.H2, cp.W2 = bm.shape[0], bm.shape[1]
-                sub = images[n].pixels[cp.off_h:cp.off_h + cp.H2, cp.off_w:cp.off_w + cp.W2]
-                if bm.size and not np.array_equal(bm.astype(bool), ~np.isnan(sub)):
-                    self._keep.append(bm)
-                    cp.bitmap = bm.ctypes.data_as(c_uint8_p)  # explicit bitmap only when it differs from !isnan
-                J = np.asarray(p.wcs_jacobian, dtype=np.float64)
-                cp.wcs_jacobian[0], cp.wcs_jacobian[1], cp.wcs_jacobian[2], cp.wcs_jacobian[3] = \
-                    J[0, 0], J[1, 0], J[0, 1], J[1, 1]
-                cp.world_center[0], cp.world_center[1] = float(p.world_center[0]), float(p.world_center[1])
-                cp.pixel_center[0], cp.pixel_center[1] = float(p.pixel_center[0]), float(p.pixel_center[1])
-                psf = np.ascontiguousarray(p.psf, dtype=np.float64)
-                assert psf.shape == (psf_K, 6)
-                self._keep.append(psf)
-                cp.psf = _dp(psf)
-                cp.stamp = stamp_key[key]
+                k = stamp_obj[id(raw)] = stamp_key[key]
+                self._keep.append(raw)   # a reference, so that id(raw) stays unique while the table is built
+            return k
+
+        def fill(cp, p, n):
+            cp.off_h, cp.off_w = int(p.bitmap_offset[0]), int(p.bitmap_offset[1])
+            bm = np.asfortranarray(p.active_pixel_bitmap, dtype=np.uint8)
+            cp.H2, cp.W2 = bm.shape[0], bm.shape[1]
+            sub = images[n].pixels[cp.off_h:cp.off_h + cp.H2, cp.off_w:cp.off_w + cp.W2]
+            if bm.size and not np.array_equal(bm.astype(bool), ~np.isnan(sub)):
+                self._keep.append(bm)
+                cp.bitmap = bm.ctypes.data_as(c_uint8_p)  # explicit bitmap only when it differs from !isnan
+            J = np.asarray(p.wcs_jacobian, dtype=np.float64)
+            cp.wcs_jacobian[0], cp.wcs_jacobian[1], cp.wcs_jacobian[2], cp.wcs_jacobian[3] = \
+                J[0, 0], J[1, 0], J[0, 1], J[1, 1]
+            cp.world_center[0], cp.world_center[1] = float(p.world_center[0]), float(p.world_center[1])
+            cp.pixel_center[0], cp.pixel_center[1] = float(p.pixel_center[0]), float(p.pixel_center[1])
+            psf = np.ascontiguousarray(p.psf, dtype=np.float64)
+            assert psf.shape == (psf_K, 6)
+            self._keep.append(psf)
+            cp.psf = _dp(psf)
+            cp.stamp = stamp_index(p.stamp)
+
+        # rows of model.PatchRow (many-image problems) -> the sparse patch list of celeste_problem_t
+        self.sparse = S > 0 and all(isinstance(row, PatchRow) for row in patches)
+        if self.sparse:
+            pairs = [(s, n, p) for s in range(S) for n, p in patches[s].nonempty()]
+            self.c_patches = (PatchT * max(len(pairs), 1))()
+            self.patch_source = np.array([s for s, _, _ in pairs], dtype=np.int32)
+            self.patch_image = np.array([n for _, n, _ in pairs], dtype=np.int32)
+            for k, (s, n, p) in enumerate(pairs):
+                fill(self.c_patches[k], p, n)
+            if not pairs:
+                raise ValueError("no source overlaps any image")
+        else:
+            self.c_patches = (PatchT * (S * N))()
+            for s in range(S):
+                assert len(patches[s]) == N
+                for n in range(N):
+                    fill(self.c_patches[s * N + n], patches[s][n], n)
         self.stamps = np.ascontiguousarray(np.stack(stamps))
         if neighbors is None:
             neighbors = [[] for _ in range(S)]
@@ -225,6 +257,10 @@ class Problem:
         self.c.nbr_offsets = off.ctypes.data_as(c_int64_p)
         self.c.nbr_index = idx.ctypes.data_as(c_int32_p)
         self.c.prior = C.pointer(self.c_prior) if self.c_prior is not None else None
+        if self.sparse:
+            self.c.n_patch_entries = len(self.patch_source)
+            self.c.patch_source = self.patch_source.ctypes.data_as(c_int32_p)
+            self.c.patch_image = self.patch_image.ctypes.data_as(c_int32_p)
         self.n_images, self.n_sources = N, S
 
 

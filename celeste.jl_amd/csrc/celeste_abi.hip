@@ -56,13 +56,18 @@ struct celeste_ctx {
     int32_t *d_needed = nullptr;    // per source: is a target of the current batch
     int32_t *d_link_src = nullptr;  // per neighbour link: the source that owns it (CSR row)
     int64_t n_links = 0;
-    int max_overlap_px = 0;
     // visit lists: the images each source has a non-empty patch in (grids run over these, tables stay S x N)
     std::vector<int32_t> h_vis_off, h_vis_img, h_vis_src;
     int32_t *d_vis_off = nullptr, *d_vis_img = nullptr, *d_vis_src = nullptr;
-    int32_t *d_link_img = nullptr;   // [link * M + j]: image of the j-th visit of the link's target (-1: none)
+    int32_t *d_item_link = nullptr, *d_item_img_chunk = nullptr;   // value_kernel work items: link, image | chunk << 16
+    int64_t n_value_items = 0;
     int32_t *d_items = nullptr;      // [ti * M + j] of the current batch
     size_t items_cap = 0;
+    // work list of pixel_kernel (work_count / work_scan / work_fill kernels), per batch
+    std::vector<int32_t> h_src_chunks;   // per source: chunks of all its patches
+    int max_src_chunks = 0;
+    int32_t *d_work = nullptr, *d_work_blk = nullptr, *d_work_total = nullptr;
+    size_t work_cap = 0, work_blk_cap = 0;
     int M = 1;        // largest number of images one source appears in
     bool dense = false;
     int64_t V = 0;    // visits in total
@@ -99,7 +104,7 @@ struct celeste_ctx {
     int ev_valid = 0;
 };
 
-extern "C" int celeste_version(void) { return 100; }
+extern "C" int celeste_version(void) { return 101; }
 
 extern "C" const char *celeste_strerror(int status) {
     switch (status) {
@@ -252,11 +257,28 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
     CTX_TRY(dev_upload(&c->d_images, c->h_images.data(), c->h_images.size()));
     if (hipDeviceSynchronize() != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
 
-    // patches + explicit bitmaps
-    c->h_patches.resize((size_t)c->S * c->N);
+    // patches + explicit bitmaps (dense [s * N + n] table, or the sparse list sorted by (source, image))
+    {
+        DevPatch empty; memset(&empty, 0, sizeof empty);
+        empty.bitmap_off = -1;
+        c->h_patches.assign((size_t)c->S * c->N, empty);
+    }
     std::vector<uint8_t> pool;
-    for (size_t q = 0; q < c->h_patches.size(); ++q) {
-        const celeste_patch_t &p = pr->patches[q];
+    const bool sparse = pr->n_patch_entries > 0;
+    if (sparse && (!pr->patch_source || !pr->patch_image)) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }
+    const size_t n_entries = sparse ? (size_t)pr->n_patch_entries : c->h_patches.size();
+    int64_t prev = -1;
+    for (size_t k = 0; k < n_entries; ++k) {
+        size_t q = k;
+        if (sparse) {
+            const int32_t s = pr->patch_source[k], n = pr->patch_image[k];
+            if (s < 0 || s >= c->S || n < 0 || n >= c->N || (int64_t)s * c->N + n <= prev) {
+                celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG;
+            }
+            prev = (int64_t)s * c->N + n;
+            q = (size_t)prev;
+        }
+        const celeste_patch_t &p = pr->patches[k];
         const celeste_image_t &im = pr->images[q % c->N];
         DevPatch d; memset(&d, 0, sizeof d);
         d.off_h = p.off_h; d.off_w = p.off_w; d.H2 = p.H2 < 0 ? 0 : p.H2; d.W2 = p.W2 < 0 ? 0 : p.W2;
@@ -329,16 +351,7 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
         CTX_TRY(dev_upload<int32_t>(&c->d_needed, nullptr, (size_t)c->S));
         std::vector<int32_t> lsrc(c->h_nbr_idx.size());
         for (int s = 0; s < c->S; ++s)
-            for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q) {
-                lsrc[q] = s;
-                const int s2 = c->h_nbr_idx[q];
-                for (int n = 0; n < c->N; ++n) {
-                    const DevPatch &a = c->h_patches[(size_t)s * c->N + n], &b = c->h_patches[(size_t)s2 * c->N + n];
-                    const int rh = std::min(a.off_h + a.H2, b.off_h + b.H2) - std::max(a.off_h, b.off_h);
-                    const int rw = std::min(a.off_w + a.W2, b.off_w + b.W2 - 1) - std::max(a.off_w, b.off_w);
-                    if (rh > 0 && rw > 0 && rh * rw > c->max_overlap_px) c->max_overlap_px = rh * rw;
-                }
-            }
+            for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q) lsrc[q] = s;
         c->n_links = (int64_t)lsrc.size();
         CTX_TRY(dev_upload(&c->d_link_src, lsrc.data(), lsrc.size()));
     }
@@ -366,17 +379,42 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
     CTX_TRY(dev_upload(&c->d_vis_off, c->h_vis_off.data(), c->h_vis_off.size()));
     CTX_TRY(dev_upload(&c->d_vis_img, c->h_vis_img.data(), c->h_vis_img.size()));
     CTX_TRY(dev_upload(&c->d_vis_src, c->h_vis_src.data(), c->h_vis_src.size()));
-    {
-        std::vector<int32_t> li((size_t)c->n_links * c->M, -1);
-        for (int s = 0; s < c->S; ++s)
-            for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q)
-                for (int j = 0; j < c->h_vis_off[s + 1] - c->h_vis_off[s]; ++j) li[(size_t)q * c->M + j] = c->h_vis_img[c->h_vis_off[s] + j];
-        if (!c->dense) CTX_TRY(dev_upload(&c->d_link_img, li.data(), li.size()));
-    }
-
     const char *env_chunk = getenv("CELESTE_CHUNK_PX");
     if (env_chunk && atoi(env_chunk) >= 64) c->chunk_px = (atoi(env_chunk) + 63) / 64 * 64;
     c->CH = c->max_npx > 0 ? (c->max_npx + c->chunk_px - 1) / c->chunk_px : 1;
+    c->h_src_chunks.assign((size_t)c->S, 0);
+    for (int s = 0; s < c->S; ++s) {
+        for (int n = 0; n < c->N; ++n) {
+            const DevPatch &q = c->h_patches[(size_t)s * c->N + n];
+            c->h_src_chunks[s] += (q.H2 * q.W2 + c->chunk_px - 1) / c->chunk_px;
+        }
+        c->max_src_chunks = std::max(c->max_src_chunks, c->h_src_chunks[s]);
+    }
+    CTX_TRY(dev_upload<int32_t>(&c->d_work_total, nullptr, 1));
+    {
+        // work items of value_kernel: (link, image, chunk) with a non-empty overlap rectangle, chunk index slowest
+        // (every overlap has a first chunk: those are dispatched first and spread over all XCDs)
+        if (c->N > 0xffff) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> by_chunk;
+        for (int s = 0; s < c->S; ++s)
+            for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q) {
+                const int s2 = c->h_nbr_idx[q];
+                for (int n = 0; n < c->N; ++n) {
+                    const DevPatch &a = c->h_patches[(size_t)s * c->N + n], &b = c->h_patches[(size_t)s2 * c->N + n];
+                    const int rh = std::min(a.off_h + a.H2, b.off_h + b.H2) - std::max(a.off_h, b.off_h);
+                    const int rw = std::min(a.off_w + a.W2, b.off_w + b.W2 - 1) - std::max(a.off_w, b.off_w);
+                    if (rh <= 0 || rw <= 0) continue;
+                    const int nch = (rh * rw + c->chunk_px - 1) / c->chunk_px;
+                    if ((int)by_chunk.size() < nch) by_chunk.resize(nch);
+                    for (int ch = 0; ch < nch; ++ch) by_chunk[ch].push_back({(int32_t)q, (int32_t)(n | (ch << 16))});
+                }
+            }
+        std::vector<int32_t> il, ic;
+        for (auto &v : by_chunk) for (auto &e : v) { il.push_back(e.first); ic.push_back(e.second); }
+        c->n_value_items = (int64_t)il.size();
+        CTX_TRY(dev_upload(&c->d_item_link, il.data(), il.size()));
+        CTX_TRY(dev_upload(&c->d_item_img_chunk, ic.data(), ic.size()));
+    }
     {
         c->h_tile_off.resize(c->h_patches.size());
         int64_t tot = 0;
@@ -400,7 +438,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     (void)hipSetDevice(c->device);
     for (void *p : c->plane_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_link_img, c->d_items, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_item_link, c->d_item_img_chunk, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     {
@@ -415,7 +453,8 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
 
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
-                       void *stream_, bool render_neighbors, const int32_t *d_active_rank = nullptr);
+                       void *stream_, bool render_neighbors, const int32_t *d_active_rank = nullptr,
+                       int64_t n_chunks = -1);
 
 extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_vp, int32_t n_targets,
                                               const int32_t *d_targets, uint32_t flags, double *d_v, double *d_d,
@@ -427,7 +466,7 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
 // during an optimisation, ParallelRun.jl:474-488)
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
-                       void *stream_, bool render_neighbors, const int32_t *d_active_rank) {
+                       void *stream_, bool render_neighbors, const int32_t *d_active_rank, int64_t n_chunks) {
     if (!c || !d_vp || !d_targets || !d_v || !d_status || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
     if ((flags & CELESTE_FLAG_HESS) && !d_h) return CELESTE_ERR_INVALID_ARG;
     if ((flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) && !d_d) return CELESTE_ERR_INVALID_ARG;
@@ -444,6 +483,22 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         if (c->d_items) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_items)); c->d_items = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_items, (size_t)n_targets * c->M * sizeof(int32_t)));
         c->items_cap = (size_t)n_targets * c->M;
+    }
+    // work list: n_chunks = number of chunks of the batch when the caller knows its targets on the host, else bounded
+    // by the largest source (workgroups past the device-side total exit on one scalar load)
+    const int n_visits = n_targets * c->M;
+    const int n_wblk = (n_visits + WORK_NT - 1) / WORK_NT;
+    const size_t work_need = (size_t)(n_chunks >= 0 ? n_chunks : (int64_t)n_targets * c->max_src_chunks);
+    if ((size_t)n_targets * c->M * c->CH > 0x7fffffffull) return CELESTE_ERR_INVALID_ARG;
+    if (work_need > c->work_cap) {
+        if (c->d_work) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_work)); c->d_work = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_work, std::max<size_t>(work_need, 1) * sizeof(int32_t)));
+        c->work_cap = work_need;
+    }
+    if ((size_t)n_wblk * c->CH > c->work_blk_cap) {
+        if (c->d_work_blk) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_work_blk)); c->d_work_blk = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_work_blk, (size_t)n_wblk * c->CH * sizeof(int32_t)));
+        c->work_blk_cap = (size_t)n_wblk * c->CH;
     }
     const bool derivs = (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) != 0;
     const bool split = (flags & CELESTE_FLAG_SPLIT) != 0;
@@ -473,20 +528,23 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
                            render_neighbors ? c->d_needed : nullptr);
     }
+    hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
+                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, (int)c->dense, c->d_work_blk);
+    hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * c->CH, c->d_work_total);
+    hipLaunchKernelGGL(work_fill_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
+                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, (int)c->dense, c->d_work_blk, c->d_work);
     if (render_neighbors) {
-    if (c->n_links > 0 && c->max_overlap_px > 0) {
-        const int chv = (c->max_overlap_px + c->chunk_px - 1) / c->chunk_px;
-        hipLaunchKernelGGL(value_kernel, dim3((unsigned)((size_t)c->n_links * c->M * chv)), dim3(64), 0, stream,
+    if (c->n_value_items > 0)
+        hipLaunchKernelGGL(value_kernel, dim3((unsigned)c->n_value_items), dim3(64), 0, stream,
                            c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->d_link_src, c->d_nbr_idx,
-                           c->d_val_off, c->d_link_img, c->N, c->M, c->NC, chv, c->chunk_px, c->d_val);
-    }
+                           c->d_val_off, c->d_item_link, c->d_item_img_chunk, c->N, c->NC, c->chunk_px, c->d_val);
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
-    const dim3 grid((unsigned)((size_t)n_targets * c->M * c->CH));
+    const dim3 grid((unsigned)std::max<size_t>(work_need, 1));
 #define PIXEL_ARGS                                                                                                \
     c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx,       \
     c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->d_tile_off, c->d_rec, \
-    d_active_rank, c->d_items, c->M
+    d_active_rank, c->d_items, c->M, c->d_work, c->d_work_total
 #define LAUNCH_PIXEL_T(MODE, R) hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL_M(MODE) hipLaunchKernelGGL((pixel_kernel<MODE, double, true>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL(MODE) do { if (flags & CELESTE_FLAG_FP32) LAUNCH_PIXEL_T(MODE, float); else LAUNCH_PIXEL_T(MODE, double); } while (0)
@@ -547,8 +605,10 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
     }
     HIP_TRY(hipMemcpy(c->d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_targets, targets, (size_t)n_targets * sizeof(int32_t), hipMemcpyHostToDevice));
-    int st = celeste_elbo_eval_batch_device(c, c->d_vp, n_targets, c->d_targets, flags, c->d_v, c->d_d, c->d_h,
-                                            c->d_cnt, c->d_status, nullptr);
+    int64_t n_chunks = 0;   // the targets are known here: exact size of the pixel kernel's work list
+    for (int t = 0; t < n_targets; ++t) n_chunks += c->h_src_chunks[targets[t]];
+    int st = launch_eval(c, c->d_vp, n_targets, c->d_targets, flags, c->d_v, c->d_d, c->d_h, c->d_cnt, c->d_status,
+                         nullptr, true, nullptr, n_chunks);
     if (st != CELESTE_OK) return st;
     HIP_TRY(hipDeviceSynchronize());
     std::vector<int32_t> hst(n_targets);
@@ -712,21 +772,29 @@ extern "C" int celeste_ctx_work_stats(celeste_ctx_t *c, int32_t n_targets, const
     for (int q = 0; q < n_targets; ++q) {
         const int t = targets[q];
         if (t < 0 || t >= c->S) return CELESTE_ERR_INVALID_ARG;
-        int64_t A = 0, R = 0;
+        int64_t A = 0, R = 0, PC = 0;   // PC: non-empty (source, image) patches whose constants are read
         for (int n = 0; n < c->N; ++n) {
             const DevPatch &p = c->h_patches[(size_t)t * c->N + n];
-            A += (int64_t)p.H2 * p.W2;  // upper bound of visited pixels (NaN / masked pixels are skipped)
-            R += p.H2;
             if (p.H2 * p.W2 > 0) {
+                A += (int64_t)p.H2 * p.W2;  // upper bound of visited pixels (NaN / masked pixels are skipped)
+                R += p.H2;
+                PC += 1;
                 out->record_bytes += (int64_t)ACC_N * 8 * ((int64_t)p.H2 * p.W2 + 1);
                 out->record_tiles += ((int64_t)p.H2 * p.W2 + 63) / 64;
             }
         }
         const int64_t Kn = c->h_nbr_off[t + 1] - c->h_nbr_off[t];
+        for (int64_t q2 = c->h_nbr_off[t]; q2 < c->h_nbr_off[t + 1]; ++q2)
+            for (int n = 0; n < c->N; ++n) {
+                const DevPatch &p = c->h_patches[(size_t)c->h_nbr_idx[q2] * c->N + n];
+                PC += p.H2 * p.W2 > 0;
+            }
         out->active_pixel_visits += A;
         out->patch_rows += R;
         out->neighbor_links += Kn;
-        out->algorithmic_bytes += 9 * A + 4 * R + 352 * (1 + Kn) + 200 * (int64_t)c->N * (1 + Kn) + 8288;
+        // 9 A + 4 R + 352 (1 + K) + 200 per (source, image) patch of the target and its neighbours
+        // (= 200 N (1 + K) when every source is in every image) + 8288
+        out->algorithmic_bytes += 9 * A + 4 * R + 352 * (1 + Kn) + 200 * PC + 8288;
     }
     return CELESTE_OK;
 }

@@ -300,28 +300,118 @@ __global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__res
     if (is_target && k < n_targets) is_target[targets[k]] = 1;
 }
 
-// One wavefront per (neighbour link t -> s2, image, chunk): renders s2's value-only light on the rectangle
-// where s2's patch (minus its last column, elbo_objective.jl:349) overlaps target t's patch, into s2's own
-// patch buffer.  Links whose source t is not a target of this batch exit immediately.  Two targets that
-// overlap the same part of s2 write identical values to the same addresses (benign).
+// ---------------------------------------------------------------------------------------------
+// Work list of pixel_kernel.  A batch has n_targets x M candidate visits k = ti * M + j (j-th image of target ti) and
+// each is cut into ceil(npx / chunk_px) chunks, 0 for a target that appears in fewer than M images.  Launching the
+// full n_targets x M x CH grid leaves most workgroups with nothing to do (patches of 200 .. 2600 pixels; 5 .. 20
+// images per source in a many-field problem), and an idle workgroup still holds a wave slot with its full register
+// allocation for three dependent loads before it can exit.  The list enumerates exactly the chunks that exist, in
+// the order (chunk index, k): first chunks first (every patch has one), spread over all XCDs.  Three small
+// kernels: per-block counts, one exclusive scan over [chunk][block], fill.  The order is deterministic.
+// ---------------------------------------------------------------------------------------------
+#define WORK_NT 256
+__device__ inline int visit_chunks(int k, const int32_t *__restrict__ targets, const DevPatch *__restrict__ patches,
+                                   const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M,
+                                   int chunk_px, bool dense) {
+    const int ti = k / M, j = k - ti * M;
+    const int t = targets[ti];
+    int n = j;
+    if (!dense) {
+        const int vo = vis_off[t];
+        if (j >= vis_off[t + 1] - vo) return 0;
+        n = vis_img[vo + j];
+    }
+    const DevPatch &P = patches[(size_t)t * N + n];
+    return (P.H2 * P.W2 + chunk_px - 1) / chunk_px;
+}
+
+// rank of this thread among the threads of its block for which pred holds (exclusive), and the block total
+__device__ inline int block_rank(bool pred, int *s_wave /* WORK_NT / 64 + 1 */, int &total) {
+    const unsigned long long m = __ballot(pred);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) s_wave[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WORK_NT / 64; ++w) { const int c = s_wave[w]; off += w < wv ? c : 0; tot += c; }
+    total = tot;
+    return off + r;
+}
+
+__global__ void __launch_bounds__(WORK_NT)
+work_count_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPatch *__restrict__ patches,
+                  const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M, int CH,
+                  int chunk_px, int dense, int32_t *__restrict__ blk_cnt /* [CH][gridDim.x] */) {
+    __shared__ int s_wave[WORK_NT / 64 + 1];
+    const int k = blockIdx.x * WORK_NT + threadIdx.x;
+    const int nch = k < n_visits ? visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, dense != 0) : 0;
+    for (int ch = 0; ch < CH; ++ch) {
+        int tot;
+        block_rank(nch > ch, s_wave, tot);
+        if (threadIdx.x == 0) blk_cnt[(size_t)ch * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+// exclusive scan of cnt[0 .. n) in place, total -> *total (one workgroup)
+__global__ void __launch_bounds__(1024) work_scan_kernel(int32_t *__restrict__ cnt, int n, int32_t *__restrict__ total) {
+    __shared__ int s_part[16];
+    __shared__ int s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? cnt[i] : 0;
+        int x = v;   // inclusive scan within the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+        if (lane == 63) s_part[wv] = x;
+        __syncthreads();
+        int off = s_run;
+        for (int w = 0; w < wv; ++w) off += s_part[w];
+        if (i < n) cnt[i] = off + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_run = off + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_run;
+}
+
+__global__ void __launch_bounds__(WORK_NT)
+work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPatch *__restrict__ patches,
+                 const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M, int CH,
+                 int chunk_px, int dense, const int32_t *__restrict__ blk_base, int32_t *__restrict__ work) {
+    __shared__ int s_wave[WORK_NT / 64 + 1];
+    const int k = blockIdx.x * WORK_NT + threadIdx.x;
+    const int nch = k < n_visits ? visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, dense != 0) : 0;
+    for (int ch = 0; ch < CH; ++ch) {
+        int tot;
+        const int r = block_rank(nch > ch, s_wave, tot);
+        if (nch > ch) work[blk_base[(size_t)ch * gridDim.x + blockIdx.x] + r] = k * CH + ch;
+    }
+}
+
+// One wavefront per work item (neighbour link t -> s2, image, chunk of the overlap): renders s2's value-only
+// light on the rectangle where s2's patch (minus its last column, elbo_objective.jl:349) overlaps target t's
+// patch, into s2's own patch buffer.  The items with a non-empty overlap are listed once per context
+// (geometry only; celeste_ctx_create), first chunks first.  Items whose source t is not a target of this batch
+// exit immediately.  Two targets that overlap the same part of s2 write identical values to the same addresses
+// (benign).
 __global__ void __launch_bounds__(64)
 value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
              const int32_t *__restrict__ is_target, const int32_t *__restrict__ link_src,
              const int32_t *__restrict__ nbr_idx, const int64_t *__restrict__ val_off,
-             const int32_t *__restrict__ link_img, int N, int M, int NC, int CH,
+             const int32_t *__restrict__ item_link, const int32_t *__restrict__ item_img_chunk, int N, int NC,
              int chunk_px, double2 *__restrict__ val) {
     __shared__ double etab[64];
-    // chunk index is the slow grid axis: all first chunks (every overlap has one) are dispatched first and
-    // round-robin over the 8 XCDs, whatever CH is (with ch fastest and CH = 6, half the XCDs sat idle)
-    const int LN = gridDim.x / CH;
-    const int ch = blockIdx.x / LN;
-    const int ln = blockIdx.x - ch * LN;
-    const int q = ln / M;                   // ln = q * M + j: link, j-th image the link's target appears in
-    const int n = link_img ? link_img[ln] : ln - q * M;
-    if (n < 0) return;
+    const int q = item_link[blockIdx.x];
     const int t = link_src[q];
     if (!is_target[t]) return;
+    const int nc = item_img_chunk[blockIdx.x];
+    const int n = nc & 0xffff, ch = nc >> 16;
     const int s = nbr_idx[q];
     const int sn = s * N + n;
     const DevPatch &P = patches[sn];
@@ -636,14 +726,15 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const int64_t *__restrict__ val_off, const double2 *__restrict__ val,
              const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px,
              double *__restrict__ acc, const int64_t *__restrict__ tile_off, double *__restrict__ rec,
-             const int32_t *__restrict__ active_rank, const int32_t *__restrict__ items, int M) {
+             const int32_t *__restrict__ active_rank, const int32_t *__restrict__ items, int M,
+             const int32_t *__restrict__ work, const int32_t *__restrict__ work_total) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
     __shared__ double etab[64];
-    // chunk index is the slow grid axis (see value_kernel): heavy first chunks go first, spread over all XCDs
-    const int TN = gridDim.x / CH;
-    const int ch = blockIdx.x / TN;
-    const int tn = blockIdx.x - ch * TN;
-    const int wg = tn * CH + ch;  // record index, as the lift kernel expects: ((ti * M + j) * CH + ch)
+    // work list (work_fill_kernel): existing chunks only, first chunks first; the grid is an upper bound
+    if ((int)blockIdx.x >= *work_total) return;
+    const int wg = work[blockIdx.x];  // record index, as the lift kernel expects: ((ti * M + j) * CH + ch)
+    const int tn = wg / CH;
+    const int ch = wg - tn * CH;
     const int ti = tn / M;                     // tn = ti * M + j: target, j-th image it appears in (tables stay dense)
     const int n = items ? items[tn] : tn - ti * M;   // items == nullptr: every source is listed in all M = N images
     if (n < 0) return;

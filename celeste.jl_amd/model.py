@@ -10,8 +10,9 @@ never per elbo() call) and mirrors, name for name, the reference's
 Only linear (affine) WCS is supported: the synthetic configurations use the
 identity WCS of test/SampleData.jl:30-34.
 """
+import collections.abc
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 import math
 import numpy as np
 
@@ -63,8 +64,12 @@ class ConstantPSFMap:
     """psf_model.jl:89-92"""
     stamp: np.ndarray
 
+    def __post_init__(self):
+        self.stamp = np.array(self.stamp, dtype=np.float64)
+        self.stamp.setflags(write=False)   # shared by every patch of the image
+
     def __call__(self, x, y):
-        return self.stamp.copy()
+        return self.stamp
 
 
 @dataclass
@@ -210,6 +215,53 @@ class ImagePatch:
                    img.wcs_jacobian.copy(), pixel_center, off, bitmap, stamp_id)
 
 
+def empty_patch(img: Image) -> ImagePatch:
+    """The patch of a source that lies off the image: clamp_box leaves an empty range (imaged_sources.jl:10-14), so
+    it covers no pixel and overlaps nothing.  One shared object per image."""
+    p = getattr(img, "_empty_patch", None)
+    if p is None:
+        p = ImagePatch(((1, 0), (1, 0)), img.pix_to_world(np.array([0.5, 0.5])), img.psf, img.psfmap(0.5, 0.5),
+                       img.wcs_jacobian.copy(), np.array([0.5, 0.5]), (0, 0), np.zeros((0, 0), dtype=bool))
+        img._empty_patch = p
+    return p
+
+
+class PatchRow(collections.abc.Sequence):
+    """patches[s, :] of a many-image problem (overlapping fields): an ImagePatch is stored only for the images the
+    source overlaps; every other index yields the image's `empty_patch`.  Behaves like the dense row (len, index,
+    iteration) so that callers written against patches[s][n] keep working; `cabi.Problem` hands rows of this type
+    to the library as the sparse patch list of celeste_problem_t."""
+    __slots__ = ("images", "entries")
+
+    def __init__(self, images: Sequence[Image], entries: Dict[int, ImagePatch]):
+        self.images = images
+        self.entries = dict(sorted(entries.items()))
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, n):
+        if isinstance(n, slice):
+            return [self[i] for i in range(*n.indices(len(self)))]
+        if n < 0:
+            n += len(self)
+        if not 0 <= n < len(self):
+            raise IndexError(n)
+        p = self.entries.get(n)
+        return p if p is not None else empty_patch(self.images[n])
+
+    def nonempty(self):
+        """(image index, patch) pairs in image order"""
+        return self.entries.items()
+
+
+def row_entries(row):
+    """(image index, patch) for the non-empty patches of a dense or sparse row"""
+    if isinstance(row, PatchRow):
+        return row.nonempty()
+    return [(n, p) for n, p in enumerate(row) if p.active_pixel_bitmap.size > 0]
+
+
 def box_around_point(img: Image, world_center, pixel_radius: float) -> Box:
     """imaged_sources.jl:120-136"""
     pc = img.world_to_pix(world_center)
@@ -240,19 +292,30 @@ def box_from_catalog(img: Image, ce: CatalogEntry, width_scale=1.0, max_radius=2
 
 
 def get_sky_patches(images: Sequence[Image], catalog: Sequence[CatalogEntry],
-                    radius_override_pix: float = math.nan) -> List[List[ImagePatch]]:
-    """imaged_sources.jl:165-182.  Returns patches[s][n]."""
-    out = []
-    for ce in catalog:
-        row = []
-        for img in images:
-            if math.isnan(radius_override_pix):
-                box = box_from_catalog(img, ce, width_scale=1.2)
-            else:
-                box = box_around_point(img, ce.pos, radius_override_pix)
-            row.append(ImagePatch.from_box(img, box))
-        out.append(row)
-    return out
+                    radius_override_pix: float = math.nan, sparse: bool = False):
+    """imaged_sources.jl:165-182.  Returns patches[s][n]; with sparse=True every row is a `PatchRow` that only
+    stores the patches that cover at least one pixel (same boxes: a source is tried against an image whenever it
+    lies within max_radius + 1 pixels of it)."""
+    def patch(img, ce):
+        if math.isnan(radius_override_pix):
+            box = box_from_catalog(img, ce, width_scale=1.2)
+        else:
+            box = box_around_point(img, ce.pos, radius_override_pix)
+        return ImagePatch.from_box(img, box)
+    if not sparse:
+        return [[patch(img, ce) for img in images] for ce in catalog]
+    reach = (25.0 if math.isnan(radius_override_pix) else radius_override_pix) + 1.0
+    pos = np.array([ce.pos for ce in catalog], dtype=float).reshape(-1, 2)
+    entries = [dict() for _ in catalog]
+    for n, img in enumerate(images):
+        pc = (pos - img.wcs_world0) @ img.wcs_jacobian.T + img.wcs_pix0
+        near = np.flatnonzero((pc[:, 0] > -reach) & (pc[:, 0] < img.H + 1 + reach) &
+                              (pc[:, 1] > -reach) & (pc[:, 1] < img.W + 1 + reach))
+        for s in near:
+            p = patch(img, catalog[s])
+            if p.active_pixel_bitmap.size > 0:
+                entries[s][n] = p
+    return [PatchRow(images, e) for e in entries]
 
 
 def find_neighbors(patches: List[List[ImagePatch]], target: int) -> List[int]:
@@ -268,27 +331,34 @@ def find_neighbors(patches: List[List[ImagePatch]], target: int) -> List[int]:
     return out
 
 
-def neighbor_map(patches: List[List[ImagePatch]]) -> List[List[int]]:
-    """find_neighbors for every source, via a sort-based sweep instead of the O(S^2 N) scan
-    (same result, ascending order like the reference's loop)."""
+def neighbor_map(patches) -> List[List[int]]:
+    """find_neighbors for every source, via a sort-based sweep over the non-empty patches of each image instead of
+    the O(S^2 N) scan (same result, ascending order like the reference's loop; empty boxes overlap nothing)."""
     S = len(patches)
     if S == 0:
         return []
     N = len(patches[0])
+    per_image = [[] for _ in range(N)]
+    for s in range(S):
+        for n, p in row_entries(patches[s]):
+            per_image[n].append((s, p.box))
     nbrs = [set() for _ in range(S)]
     for n in range(N):
-        lo_h = np.array([patches[s][n].box[0][0] for s in range(S)])
-        hi_h = np.array([patches[s][n].box[0][1] for s in range(S)])
-        lo_w = np.array([patches[s][n].box[1][0] for s in range(S)])
-        hi_w = np.array([patches[s][n].box[1][1] for s in range(S)])
+        if not per_image[n]:
+            continue
+        src = np.array([s for s, _ in per_image[n]])
+        lo_h = np.array([b[0][0] for _, b in per_image[n]])
+        hi_h = np.array([b[0][1] for _, b in per_image[n]])
+        lo_w = np.array([b[1][0] for _, b in per_image[n]])
+        hi_w = np.array([b[1][1] for _, b in per_image[n]])
         order = np.argsort(lo_h, kind="stable")
         for a_i, a in enumerate(order):
             for b in order[a_i + 1:]:
                 if lo_h[b] > hi_h[a]:
                     break
                 if lo_w[a] <= hi_w[b] and lo_w[b] <= hi_w[a] and lo_h[a] <= hi_h[b]:
-                    nbrs[a].add(int(b))
-                    nbrs[b].add(int(a))
+                    nbrs[src[a]].add(int(src[b]))
+                    nbrs[src[b]].add(int(src[a]))
     return [sorted(x) for x in nbrs]
 
 

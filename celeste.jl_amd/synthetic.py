@@ -108,36 +108,66 @@ def galaxy_density(psf: np.ndarray, m_pos, frac_dev, axis_ratio, angle, radius, 
     return out
 
 
+def render_expected_image(img: Image, catalog: List[CatalogEntry]) -> np.ndarray:
+    """Synthetic.gen_image! with expectation=true for one image, before the nelec scaling: sky + sources, in nmgy."""
+    nm = img.sky.astype(np.float64).copy()
+    coef = cabi.spline_prefilter(img.psfmap(0, 0))
+    pc = (np.array([ce.pos for ce in catalog], dtype=float).reshape(-1, 2) - img.wcs_world0) @ img.wcs_jacobian.T \
+        + img.wcs_pix0
+    near = np.flatnonzero((pc[:, 0] > -27) & (pc[:, 0] < img.H + 28) & (pc[:, 1] > -27) & (pc[:, 1] < img.W + 28))
+    for ce in (catalog[s] for s in near):   # the others' radius-25 boxes miss the image
+        box = box_around_point(img, ce.pos, 25)
+        p = ImagePatch.from_box(img, box)
+        (h0, h1), (w0, w1) = p.box
+        if h1 < h0 or w1 < w0:
+            continue
+        hh = np.arange(h0, h1 + 1, dtype=float)[:, None]
+        ww = np.arange(w0, w1 + 1, dtype=float)[None, :]
+        m = p.wcs_jacobian @ (np.asarray(ce.pos, float) - p.world_center) + p.pixel_center
+        if ce.is_star:
+            dens = star_density(coef, hh - m[0] + 26, ww - m[1] + 26) * ce.star_fluxes[img.b - 1]
+        else:
+            dens = galaxy_density(img.psf, m, ce.gal_frac_dev, ce.gal_axis_ratio, ce.gal_angle,
+                                  ce.gal_radius_px, hh, ww) * ce.gal_fluxes[img.b - 1]
+        nm[h0 - 1:h1, w0 - 1:w1] += dens
+    return nm
+
+
 def render_expected_nmgy(images: List[Image], catalog: List[CatalogEntry]) -> List[np.ndarray]:
-    """Synthetic.gen_image! with expectation=true, before the nelec scaling: sky + sources, in nmgy."""
-    out = []
-    for img in images:
-        nm = img.sky.astype(np.float64).copy()
-        coef = cabi.spline_prefilter(img.psfmap(0, 0))
-        for ce in catalog:
-            box = box_around_point(img, ce.pos, 25)
-            p = ImagePatch.from_box(img, box)
-            (h0, h1), (w0, w1) = p.box
-            if h1 < h0 or w1 < w0:
-                continue
-            hh = np.arange(h0, h1 + 1, dtype=float)[:, None]
-            ww = np.arange(w0, w1 + 1, dtype=float)[None, :]
-            m = p.wcs_jacobian @ (np.asarray(ce.pos, float) - p.world_center) + p.pixel_center
-            if ce.is_star:
-                dens = star_density(coef, hh - m[0] + 26, ww - m[1] + 26) * ce.star_fluxes[img.b - 1]
-            else:
-                dens = galaxy_density(img.psf, m, ce.gal_frac_dev, ce.gal_axis_ratio, ce.gal_angle,
-                                      ce.gal_radius_px, hh, ww) * ce.gal_fluxes[img.b - 1]
-            nm[h0 - 1:h1, w0 - 1:w1] += dens
-        out.append(nm)
-    return out
+    return [render_expected_image(img, catalog) for img in images]
+
+
+def _sample_image(img: Image, catalog, seed) -> np.ndarray:
+    el = render_expected_image(img, catalog) * img.nelec_per_nmgy.astype(np.float64)[:, None]
+    return np.random.Generator(np.random.PCG64(seed)).poisson(el).astype(np.float32)
+
+
+_POOL_ARGS = None
+
+
+def _sample_image_job(n):
+    images, catalog, seed = _POOL_ARGS
+    return _sample_image(images[n], catalog, [seed, n])
 
 
 def gen_images(images: List[Image], catalog: List[CatalogEntry], rng: np.random.Generator,
-               expectation: bool = False) -> None:
-    """Synthetic.gen_images! (Synthetic.jl:30-58)"""
-    for img, nm in zip(images, render_expected_nmgy(images, catalog)):
-        el = nm * img.nelec_per_nmgy.astype(np.float64)[:, None]
+               expectation: bool = False, workers: int = 1, seed: int = 0) -> None:
+    """Synthetic.gen_images! (Synthetic.jl:30-58).  workers > 1 (many-image problems): the images are rendered by
+    forked worker processes and image n is Poisson-sampled from its own generator PCG64([seed, n]) instead of the
+    shared `rng` (the same pixels for any number of workers > 1)."""
+    if workers > 1 and not expectation:
+        import multiprocessing as mp
+        global _POOL_ARGS
+        _POOL_ARGS = (images, catalog, seed)
+        try:
+            with mp.get_context("fork").Pool(workers) as pool:
+                for img, px in zip(images, pool.map(_sample_image_job, range(len(images)), chunksize=1)):
+                    img.pixels = px
+        finally:
+            _POOL_ARGS = None
+        return
+    for img in images:
+        el = render_expected_image(img, catalog) * img.nelec_per_nmgy.astype(np.float64)[:, None]
         if not expectation:
             el = rng.poisson(el).astype(np.float64)
         img.pixels = el.astype(np.float32)
@@ -208,7 +238,8 @@ def make_field(H: int, W: int, n_sources: int, seed: int, stars_only: bool = Fal
 
 
 def make_multifield(grid=(2, 2), H: int = 256, W: int = 256, overlap: float = 0.10, n_sources: int = 120,
-                    seed: int = 5, perturb: bool = True, margin: int = 8) -> Field:
+                    seed: int = 5, perturb: bool = True, margin: int = 8, sparse: bool = False,
+                    workers: int = 1) -> Field:
     """Config 5 of SURVEY.md 8(d) in miniature: a grid of overlapping fields (5 bands each) on one world
     coordinate system (world = global pixel coordinates; each image has its own affine offset).  A source
     has non-empty patches only in the images it overlaps; the others are the reference's empty boxes
@@ -227,8 +258,8 @@ def make_multifield(grid=(2, 2), H: int = 256, W: int = 256, overlap: float = 0.
     for _ in range(n_sources):
         pos = (rng.uniform(margin, tot_h - margin), rng.uniform(margin, tot_w - margin))
         catalog.append(draw_source(prior, rng, pos))
-    gen_images(images, catalog, rng)
-    patches = get_sky_patches(images, catalog)
+    gen_images(images, catalog, rng, workers=workers, seed=seed)
+    patches = get_sky_patches(images, catalog, sparse=sparse)
     nbrs = neighbor_map(patches)
     vp = [catalog_init_source(ce) for ce in catalog]
     if perturb:

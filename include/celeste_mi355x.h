@@ -124,11 +124,19 @@ typedef struct celeste_problem_t {
     int32_t psf_K;                /* ElboArgs.psf_K, default 2 */
     int32_t n_stamps;
     const celeste_image_t *images;      /* n_images */
-    const celeste_patch_t *patches;     /* [s * n_images + n] */
+    const celeste_patch_t *patches;     /* [s * n_images + n], or the sparse list described below */
     const double *stamps;               /* n_stamps x 51 x 51, raw psfmap(...) output */
     const int64_t *nbr_offsets;         /* n_sources + 1 (CSR) */
     const int32_t *nbr_index;           /* 0-based source ids */
     const celeste_prior_t *prior;       /* NULL => built-in cfg/{star,gal}_prior tables */
+    /* Sparse patch table for many-image problems (overlapping fields: a source has a non-empty patch in the few
+     * images that cover it and the reference's empty clamp_box in all others, imaged_sources.jl:10-14).  When
+     * n_patch_entries > 0, `patches` holds only those n_patch_entries entries, sorted by (source, image), entry k
+     * being the patch of source patch_source[k] in image patch_image[k]; every pair not listed has an empty
+     * patch.  n_patch_entries == 0 selects the dense [s * n_images + n] table above. */
+    int64_t n_patch_entries;
+    const int32_t *patch_source;
+    const int32_t *patch_image;
 } celeste_problem_t;
 
 typedef struct celeste_ctx celeste_ctx_t;
@@ -139,7 +147,7 @@ typedef struct celeste_work_stats_t {
     int64_t active_pixel_visits;    /* sum over targets, images of visited pixels */
     int64_t patch_rows;             /* sum of H2 */
     int64_t neighbor_links;         /* sum of K_s */
-    int64_t algorithmic_bytes;      /* 9 A + 4 R + 352 (1+K) + 200 N (1+K) + 8288 per target */
+    int64_t algorithmic_bytes;      /* 9 A + 4 R + 352 (1+K) + 200 per non-empty patch of the target and its neighbours + 8288, per target */
     int64_t record_bytes;           /* split variant: 544 A + 544 per non-empty (target, image) patch */
     int64_t record_tiles;           /* split variant: 64-pixel record tiles actually stored / re-read */
 } celeste_work_stats_t;

@@ -30,6 +30,7 @@
 #include <string.h>
 
 #include "../include/celeste_mi355x.h"
+#include "patch_lookup.h"
 
 #define P 44
 #define NB 5
@@ -869,7 +870,7 @@ static int oracle_elbo_multi(const celeste_problem_t *pr, const double *coefs_al
         const celeste_image_t *img = &pr->images[n];
         const int b = img->band - 1;
         for (int q = 0; q < S; ++q) {
-            const celeste_patch_t *p = &pr->patches[(size_t)src[q] * N + n];
+            const celeste_patch_t *p = oracle_patch_at(pr, src[q], n);
             load_bvn_mixtures_source(mcs + (size_t)q * K * 16, p, K, vp + (size_t)src[q] * P,
                                      has_grad && q < Sa, has_hess);
             coefs[q] = coefs_all + (size_t)p->stamp * 53 * 53;
@@ -877,7 +878,7 @@ static int oracle_elbo_multi(const celeste_problem_t *pr, const double *coefs_al
         /* pixels of several active patches are visited once (elbo_objective.jl:430-470) */
         unsigned char *visited = Sa > 1 ? (unsigned char *)calloc((size_t)img->H * img->W, 1) : NULL;
         for (int sa = 0; sa < Sa; ++sa) {
-        const celeste_patch_t *pa = &pr->patches[(size_t)src[sa] * N + n];
+        const celeste_patch_t *pa = oracle_patch_at(pr, src[sa], n);
         for (int w2 = 1; w2 <= pa->W2; ++w2) for (int h2 = 1; h2 <= pa->H2; ++h2) {
             int hh = pa->off_h + h2, ww = pa->off_w + w2; /* 1-based image coords */
             if (!patch_bitmap(pr, n, pa, h2, w2)) continue;
@@ -891,7 +892,7 @@ static int oracle_elbo_multi(const celeste_problem_t *pr, const double *coefs_al
             /* add_pixel_term! (elbo_objective.jl:330-392) */
             sf_zero(&ev.E_G); sf_zero(&ev.var_G);
             for (int q = 0; q < S; ++q) {
-                const celeste_patch_t *p = &pr->patches[(size_t)src[q] * N + n];
+                const celeste_patch_t *p = oracle_patch_at(pr, src[q], n);
                 int ph2 = hh - p->off_h, pw2 = ww - p->off_w;
                 if (!(1 <= ph2 && ph2 <= p->H2 && 1 <= pw2 && pw2 < p->W2)) continue;
                 if (!patch_bitmap(pr, n, p, ph2, pw2)) continue;

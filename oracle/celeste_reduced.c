@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "../include/celeste_mi355x.h"
+#include "patch_lookup.h"
 
 #define P 44
 #define ZV 10
@@ -205,14 +206,14 @@ static int reduced_elbo_one(const celeste_problem_t *pr, const double *coefs_all
     }
 
     for (int n = 0; n < N; ++n) {
-        const celeste_patch_t *pa = &pr->patches[(size_t)t * N + n];
+        const celeste_patch_t *pa = oracle_patch_at(pr, t, n);
         if (pa->H2 <= 0 || pa->W2 <= 0) continue;
         const celeste_image_t *img = &pr->images[n];
         const int b = img->band - 1;
         r_prep(pa, K, vs, b, eta, nu, tc, &ns[0]);
         for (int q = 0; q < nnb; ++q) {
             const int s2 = pr->nbr_index[nb0 + q];
-            r_prep(&pr->patches[(size_t)s2 * N + n], K, vp + (size_t)s2 * P, b, eta, nu, tc + (size_t)NC * (1 + q), &ns[1 + q]);
+            r_prep(oracle_patch_at(pr, s2, n), K, vp + (size_t)s2 * P, b, eta, nu, tc + (size_t)NC * (1 + q), &ns[1 + q]);
         }
         const double *tcoef = coefs_all + (size_t)pa->stamp * COEF * COEF;
         const RSrc si = ns[0];
@@ -228,7 +229,7 @@ static int reduced_elbo_one(const celeste_problem_t *pr, const double *coefs_all
             double Ebar = (double)img->sky[gi], Vbar = 0;
             for (int q = 0; q < nnb; ++q) {
                 const int s2 = pr->nbr_index[nb0 + q];
-                const celeste_patch_t *Q = &pr->patches[(size_t)s2 * N + n];
+                const celeste_patch_t *Q = oracle_patch_at(pr, s2, n);
                 const int ph2 = hh - Q->off_h, pw2 = ww - Q->off_w;
                 if (!(ph2 >= 1 && ph2 <= Q->H2 && pw2 >= 1 && pw2 < Q->W2)) continue;
                 if (Q->bitmap) { if (!Q->bitmap[(ph2 - 1) + (size_t)Q->H2 * (pw2 - 1)]) continue; }

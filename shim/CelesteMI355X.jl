@@ -22,6 +22,7 @@ struct CProblem                    # celeste_problem_t
     n_images::Int32; n_sources::Int32; psf_K::Int32; n_stamps::Int32
     images::Ptr{CImage}; patches::Ptr{CPatch}; stamps::Ptr{Float64}
     nbr_offsets::Ptr{Int64}; nbr_index::Ptr{Int32}; prior::Ptr{Void}
+    n_patch_entries::Int64; patch_source::Ptr{Int32}; patch_image::Ptr{Int32}   # 0 / NULL: dense patch table
 end
 
 mutable struct MI355XContext
@@ -56,7 +57,7 @@ function MI355XContext(ea::ElboArgs; device::Int = 0)
     idx = Int32[1:(ea.S - 1);]
     push!(keep, imgs, patches, stamps, off, idx)
     prob = CProblem(ea.N, ea.S, ea.psf_K, length(patches), pointer(imgs), pointer(patches), pointer(stamps),
-                    pointer(off), pointer(idx), C_NULL)
+                    pointer(off), pointer(idx), C_NULL, 0, C_NULL, C_NULL)
     h = Ref{Ptr{Void}}(C_NULL)
     st = ccall((:celeste_ctx_create, libceleste), Cint, (Ref{CProblem}, Cint, Ref{Ptr{Void}}), prob, device, h)
     st == 0 || error(unsafe_string(ccall((:celeste_strerror, libceleste), Cstring, (Cint,), st)))

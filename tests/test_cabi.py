@@ -16,7 +16,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(cabi.EXPORTED_SYMBOLS), declared ^ set(cabi.EXPORTED_SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.celeste_version() >= 100
+    assert lib.celeste_version() >= 101
     assert lib.celeste_strerror(0) == b"ok" and b"CPU fallback" in lib.celeste_strerror(cabi.ERR_NO_DEVICE)
 
 
@@ -26,7 +26,7 @@ def test_struct_layout_matches_the_header():
     assert C.sizeof(cabi.ImageT) == 16 + 3 * 8
     assert C.sizeof(cabi.PatchT) == 16 + 8 + 8 * 8 + 8 + 8
     assert C.sizeof(cabi.PriorT) == 8 * (6 + 16 + 64 + 256 + 2)
-    assert C.sizeof(cabi.ProblemT) == 16 + 6 * 8
+    assert C.sizeof(cabi.ProblemT) == 16 + 6 * 8 + 3 * 8
     assert C.sizeof(cabi.WorkStatsT) == 56
 
 

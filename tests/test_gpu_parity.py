@@ -166,6 +166,41 @@ def test_multifield_overlapping_images(oracle):
     assert max(np.abs(d[t] - ref[1][t]).max() / np.abs(ref[1][t]).max() for t in tg) <= 1e-4
 
 
+def test_sparse_patch_list_abi(oracle):
+    """the sparse patch list of celeste_problem_t (many-image problems) gives bit-identical results to the dense
+    table, is checked for order / range, and matches the oracle"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    fd = synthetic.make_multifield((2, 3), 160, 160, 0.10, 70, seed=11)
+    fs = synthetic.make_multifield((2, 3), 160, 160, 0.10, 70, seed=11, sparse=True)
+    cd, cs = _ctx(fd), _ctx(fs)
+    assert cs.problem.sparse and cs.problem.c.n_patch_entries < 0.5 * 70 * 30
+    tg = list(range(70))
+    for flags in (ALL, ALL | cabi.FLAG_SPLIT, 5 | cabi.FLAG_FP32):
+        a, b = cd.eval_batch(fd.vp, tg, flags), cs.eval_batch(fs.vp, tg, flags)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert_parity(cs.eval_batch(fs.vp, tg, ALL), oracle.elbo_batch(cs.problem, fs.vp, tg, ALL), "sparse list")
+    assert cd.work_stats(tg) == cs.work_stats(tg)
+    assert np.array_equal(cd.maximize_batch(fd.vp, tg[:20])[0], cs.maximize_batch(fs.vp, tg[:20])[0])
+    # unsorted / duplicate / out-of-range entries are rejected
+    pr = cs.problem
+    lib = cabi.load_library()
+    import ctypes as C
+    for mutate in ("swap", "dup", "range"):
+        src, img = pr.patch_source.copy(), pr.patch_image.copy()
+        if mutate == "swap":
+            src[[0, -1]] = src[[-1, 0]]; img[[0, -1]] = img[[-1, 0]]
+        elif mutate == "dup":
+            src[1], img[1] = src[0], img[0]
+        else:
+            img[3] = 30
+        c = cabi.ProblemT.from_buffer_copy(pr.c)
+        c.patch_source = src.ctypes.data_as(cabi.c_int32_p); c.patch_image = img.ctypes.data_as(cabi.c_int32_p)
+        h = C.c_void_p()
+        assert lib.celeste_ctx_create(C.byref(c), 0, C.byref(h)) == cabi.ERR_INVALID_ARG
+
+
 def test_expected_image_renderer():
     """celeste_render_expected vs an independent numpy/torch rendering (write_celeste_expectation.jl:112-156)"""
     from celeste_jl_amd import synthetic

@@ -171,3 +171,28 @@ def test_multi_active_swap_invariance_and_single_source_blocks(oracle):
     import torch
     kl = sum(float(neg_kl(torch.tensor(f.vp[t]), load_prior())) for t in (0, 1))
     assert v01 == pytest.approx(joint_objective(f.images, f.patches, f.vp, {0, 1}) + kl, rel=1e-12)
+
+
+def test_sparse_patch_list_equals_dense_table(oracle):
+    """celeste_problem_t's sparse patch list (model.PatchRow rows) describes the same problem as the dense table:
+    same patches, neighbours and, through the CPU restatement, the same numbers"""
+    from celeste_jl_amd import synthetic, cabi
+    from celeste_jl_amd.model import PatchRow
+    fd = synthetic.make_multifield((2, 2), 128, 128, 0.10, 30, seed=5)
+    fs = synthetic.make_multifield((2, 2), 128, 128, 0.10, 30, seed=5, sparse=True)
+    assert all(isinstance(r, PatchRow) for r in fs.patches) and fs.neighbors == fd.neighbors
+    assert np.array_equal(fs.vp, fd.vp)
+    for rd, rs in zip(fd.patches, fs.patches):
+        assert len(rs) == len(rd) == 20
+        for n in range(20):
+            assert rs[n].active_pixel_bitmap.shape == rd[n].active_pixel_bitmap.shape or rd[n].active_pixel_bitmap.size == 0
+            if rd[n].active_pixel_bitmap.size:
+                assert rs[n].box == rd[n].box and rs[n].bitmap_offset == rd[n].bitmap_offset
+    pd, ps = cabi.Problem(fd.images, fd.patches, fd.neighbors), cabi.Problem(fs.images, fs.patches, fs.neighbors)
+    assert ps.sparse and not pd.sparse
+    assert 0 < ps.c.n_patch_entries < 0.6 * 30 * 20 and pd.c.n_patch_entries == 0
+    tg = list(range(30))
+    a, b = oracle.elbo_batch(pd, fd.vp, tg, 7), oracle.elbo_batch(ps, fs.vp, tg, 7)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert np.array_equal(oracle.reduced_elbo_batch(pd, fd.vp, tg, 7)[2], oracle.reduced_elbo_batch(ps, fs.vp, tg, 7)[2])
