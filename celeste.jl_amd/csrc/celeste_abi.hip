@@ -565,9 +565,12 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     c->ev_split = 0;
     if (split) {
         // per-patch sums of the records, then the lift reads one record per (target, image): CH = 1
-        hipLaunchKernelGGL(record_sum_kernel, dim3((unsigned)((size_t)n_targets * c->M * c->RCH)), dim3(RSUM_NT), 0,
+        const bool listed = c->sum_tiles * 64 == c->chunk_px && c->RCH == c->CH;   // parts == the pixel kernel's chunks
+        hipLaunchKernelGGL(record_sum_kernel,
+                           listed ? grid : dim3((unsigned)((size_t)n_targets * c->M * c->RCH)), dim3(RSUM_NT), 0,
                            stream, c->d_patches, d_targets, c->d_tile_off, reinterpret_cast<const double2 *>(c->d_rec),
-                           c->d_items, c->N, c->M, c->RCH, c->sum_tiles, c->d_acc_split);
+                           c->d_items, c->N, c->M, c->RCH, c->sum_tiles, c->d_acc_split,
+                           listed ? c->d_work : nullptr, c->d_work_total);
         if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], stream)); c->ev_split = 1; }
         hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                            c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M,

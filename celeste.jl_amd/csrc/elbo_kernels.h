@@ -963,11 +963,19 @@ __global__ void __launch_bounds__(RSUM_NT)
 record_sum_kernel(const DevPatch *__restrict__ patches, const int32_t *__restrict__ targets,
                   const int64_t *__restrict__ tile_off, const double2 *__restrict__ rec,
                   const int32_t *__restrict__ items, int N, int M, int RCH, int sum_tiles,
-                  double *__restrict__ acc) {
-    // part index is the slow grid axis: every patch's first part is launched before any second part
-    const int TN = gridDim.x / RCH;
-    const int part = blockIdx.x / TN;
-    const int tn = blockIdx.x - part * TN;
+                  double *__restrict__ acc, const int32_t *__restrict__ work, const int32_t *__restrict__ work_total) {
+    // part index is the slow grid axis: every patch's first part is launched before any second part.  When a part
+    // is a chunk of the pixel kernel (sum_tiles * 64 == chunk_px) the grid runs over that kernel's work list.
+    int part, tn;
+    if (work) {
+        if ((int)blockIdx.x >= *work_total) return;
+        const int wg = work[blockIdx.x];
+        tn = wg / RCH; part = wg - tn * RCH;
+    } else {
+        const int TN = gridDim.x / RCH;
+        part = blockIdx.x / TN;
+        tn = blockIdx.x - part * TN;
+    }
     const int ti = tn / M;
     const int n = items ? items[tn] : tn - ti * M;
     if (n < 0) return;
@@ -1050,7 +1058,9 @@ __device__ inline void bright_coef(int q, int b, double &kap, double &lam) {
     }
 }
 
-#define LIFT_NT 8    // images lifted concurrently per pass
+#ifndef LIFT_NT
+#define LIFT_NT 6    // images lifted concurrently per pass (LDS 27 KB: 5 workgroups per CU)
+#endif
 #define LIFT_NP 28   // parameters with likelihood derivatives (the k block, 28..43, only enters the KL)
 
 // Shared state of the analytic KL term (subtract_kl, elbo_kl.jl:94-154)

@@ -137,6 +137,17 @@ def test_config5_overlapping_fields_fp32(oracle):
         assert np.array_equal(vs, v32[shard]) and np.array_equal(ds, d32[shard])
 
 
+def test_config5_full_size(oracle):
+    """BASELINE configs[4] at full size in one context (16 fields = 80 images of 2048 x 1489, 30 k sources, sparse
+    patch list): fp32 component loop within 1e-4 of the fp64 device path on every source and of the CPU oracle on a
+    sample, fp64 within 1e-8 of the oracle, one rank's shard bit-identical to the full sweep (tests/config5_full.py)"""
+    import config5_full
+    out = config5_full.run(log=lambda *a, **k: None)
+    print({k: out[k] for k in ("generate_s", "ctx_create_s", "patch_entries", "pixel_visits", "fp64", "fp32", "fp32_grad",
+                               "shard0_fp32", "fp32_vs_fp64_device", "vs_oracle", "device_memory_GB")})
+    assert out["n_images"] == 80 and out["images_per_source"][2] == 20
+
+
 def test_config3_optimiser_against_cpu_restatement(oracle, field3, ctx3):
     """maximize! to convergence for every source on the device; 24 of them re-optimised by the CPU restatement of the
     same algorithm (different eigen-solver): same optimum"""
