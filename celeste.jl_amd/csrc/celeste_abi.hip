@@ -199,9 +199,8 @@ static void inv4_logdet(const double *S, double *Inv, double *logdet) {
 template <class T>
 static int dev_upload(T **dst, const T *src, size_t n) {
     *dst = nullptr;
-    if (n == 0) n = 1;
-    HIP_TRY(hipMalloc((void **)dst, n * sizeof(T)));
-    if (src) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)));   // never a null table, even when empty
+    if (src && n > 0) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
     return CELESTE_OK;
 }
 

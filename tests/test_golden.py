@@ -1,4 +1,4 @@
-"""Committed golden vectors (tools/make_golden.py): the oracle must keep reproducing them (CPU), and the HIP
+"""Committed golden vectors (tests/golden/make_golden.py): the oracle must keep reproducing them (CPU), and the HIP
 path must reproduce them through the C ABI without the oracle present (-m gpu)."""
 import numpy as np
 import pytest
