@@ -517,9 +517,6 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         }
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
-    if (c->V > 0)
-        hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches,
-                           c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps);
     if (render_neighbors) HIP_TRY(hipMemsetAsync(c->d_needed, 0, (size_t)c->S * sizeof(int32_t), stream));
     {
         const size_t nthreads = std::max<size_t>((size_t)c->S, (size_t)n_targets * (c->dense ? 1 : c->M));
@@ -532,6 +529,19 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * c->CH, c->d_work_total);
     hipLaunchKernelGGL(work_fill_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
                        c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, (int)c->dense, c->d_work_blk, c->d_work);
+    // per-(source, image) constants: of every source when the neighbours are (re)rendered, else of the targets only
+    if (render_neighbors) {
+        if (c->V > 0)
+            hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches,
+                               c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr, nullptr, c->CH,
+                               nullptr, nullptr, c->M);
+    } else {
+        // entries [0, n_first) of the work list are the first chunks = one per visit of a target
+        const int32_t *n_first = c->CH > 1 ? c->d_work_blk + n_wblk : c->d_work_total;
+        hipLaunchKernelGGL(prep_kernel, dim3((unsigned)std::max(n_visits, 1)), dim3(64), 0, stream, d_vp, c->d_images,
+                           c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, c->d_work,
+                           n_first, c->CH, d_targets, c->dense ? nullptr : c->d_items, c->M);
+    }
     if (render_neighbors) {
     if (c->n_value_items > 0)
         hipLaunchKernelGGL(value_kernel, dim3((unsigned)c->n_value_items), dim3(64), 0, stream,
@@ -936,7 +946,8 @@ extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32
     if (rc == CELESTE_OK) {
         if (c->V > 0)
             hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, nullptr, c->d_vp, c->d_images,
-                               c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps);
+                               c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr,
+                               nullptr, c->CH, nullptr, nullptr, c->M);
         hipLaunchKernelGGL(render_kernel, dim3((unsigned)((size_t)c->S * c->CH)), dim3(64), 0, nullptr, c->d_patches,
                            c->d_coefs, c->d_bitmaps, im.pixels, c->d_srcimg, c->d_comps, (int)image, c->N, c->NC,
                            c->CH, c->chunk_px, im.H, d_plane);

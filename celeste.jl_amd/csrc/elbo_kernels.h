@@ -63,10 +63,23 @@ __global__ void __launch_bounds__(64)
 prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const DevPatch *__restrict__ patches, const int32_t *__restrict__ vis_src,
             const int32_t *__restrict__ vis_img, int N, int K,
-            SrcImg *__restrict__ srcimg, Comp *__restrict__ comps) {
+            SrcImg *__restrict__ srcimg, Comp *__restrict__ comps,
+            const int32_t *__restrict__ work, const int32_t *__restrict__ n_first, int CH,
+            const int32_t *__restrict__ targets, const int32_t *__restrict__ items, int M) {
     const int NC = 14 * K;
-    // one workgroup per visit = (source, image) pair with a non-empty patch; the tables stay dense (s * N + n)
-    const int s = vis_src[blockIdx.x], n = vis_img[blockIdx.x];
+    // one workgroup per visit = (source, image) pair with a non-empty patch; the tables stay dense (s * N + n).
+    // work == nullptr: every visit of the context (neighbours are about to be rendered).  Otherwise only the visits
+    // of the batch's targets: they are the first-chunk entries at the head of the pixel kernel's work list.
+    int s, n;
+    if (work) {
+        if ((int)blockIdx.x >= *n_first) return;
+        const int k = work[blockIdx.x] / CH;
+        const int ti = k / M;
+        s = targets[ti];
+        n = items ? items[k] : k - ti * M;
+    } else {
+        s = vis_src[blockIdx.x]; n = vis_img[blockIdx.x];
+    }
     const int sn = s * N + n;
     const int c = threadIdx.x;
     const double *vs = vp + (size_t)s * CEL_P;

@@ -155,7 +155,7 @@ def infer_box(images, box: BoundingBox, catalog, method: str = "joint_vi", cfg: 
     = entries strictly inside the box, neighbours may lie outside it, then joint or single variational inference
     on the device.  (Source detection and MCMC are out of scope: `catalog` is required, method in {joint_vi, single_vi}.)"""
     from .model import get_sky_patches, neighbor_map
-    patches = get_sky_patches(images, catalog)
+    patches = get_sky_patches(images, catalog, sparse=len(images) > 5)   # several fields: sources see a few images each
     neighbors = neighbor_map(patches)
     targets = [i for i, ce in enumerate(catalog) if box.contains(ce.pos)]
     if not targets:

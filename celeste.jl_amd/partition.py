@@ -18,7 +18,8 @@ import numpy as np
 
 def estimate_time(patch_row) -> int:
     """ParallelRun.jl:45-47: sum over images of active pixels of one source's patches."""
-    return int(sum(int(p.active_pixel_bitmap.sum()) for p in patch_row))
+    from .model import row_entries
+    return int(sum(int(p.active_pixel_bitmap.sum()) for _, p in row_entries(patch_row)))
 
 
 def load_balance(n_parts: int, times: Sequence[float]) -> List[float]:

@@ -217,6 +217,32 @@ def test_infer_box_targets_inside_the_box_only():
     assert cel.infer_box(f.images, cel.BoundingBox(-10.0, -5.0, 0.0, 1.0), f.catalog) == []
 
 
+def test_infer_box_over_overlapping_fields():
+    """infer_box on a 2 x 2 grid of overlapping fields (20 images; sparse patch rows): every source is optimised
+    against all the images that cover it; the same numbers as with the dense patch table"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.infer import one_node_joint_infer
+    from celeste_jl_amd.model import get_sky_patches, neighbor_map, PatchRow
+    f = synthetic.make_multifield((2, 2), 150, 150, 0.10, 36, seed=21)
+    box = cel.BoundingBox(0.0, 400.0, 0.0, 400.0)
+    cfg = cel.ElboConfig(max_iters=30)
+    res = cel.infer_box(f.images, box, f.catalog, method="joint_vi", cfg=cfg, n_iters=2)
+    assert len(res) == 36 and all(np.all(np.isfinite(r.vs)) for r in res)
+    dense = get_sky_patches(f.images, f.catalog)
+    assert not isinstance(dense[0], PatchRow)
+    nb = neighbor_map(dense)
+    ctx = cel.FieldContext(f.images, dense, nb)
+    ref = one_node_joint_infer(ctx, f.catalog, list(range(36)), nb, cfg, n_iters=2)
+    assert np.array_equal(np.stack([r.vs for r in res]), ref)
+    # the bright sources come back as the right type
+    from celeste_jl_amd.params import ids
+    flux = [ce.star_fluxes[2] if ce.is_star else ce.gal_fluxes[2] for ce in f.catalog]
+    bright = np.argsort(flux)[-10:]
+    ok = sum((res[i].vs[ids.is_star[0]] > 0.5) == f.catalog[i].is_star for i in bright)
+    assert ok >= 7, ok
+
+
 def test_end_to_end_recovers_the_synthetic_truth():
     """images drawn from a catalog -> infer_box (joint VI from generic_init_source) -> catalog rows: the brighter
     sources come back with the right type, r flux and colours (the idea of AccuracyBenchmark.score_predictions)"""
