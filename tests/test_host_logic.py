@@ -287,3 +287,33 @@ def test_fit_raw_psf_recovers_a_two_component_mixture():
     t = trim_psf(stamp)
     assert t.shape[0] == t.shape[1] and t.shape[0] % 2 == 1 and t.shape[0] < 51
     assert np.abs(t).sum() >= 0.999 * np.abs(stamp).sum() and t[t.shape[0] // 2, t.shape[1] // 2] == stamp[25, 25]
+
+
+def test_reference_known_answers_of_the_catalog_helpers():
+    """the literal known answers of test/test_accuracy_benchmarks.jl:47-97 (flux <-> asinh magnitudes from sdsspy's
+    nmgy2lups, colours, angle canonicalisation, one variational-parameter vector -> catalog row)"""
+    import math
+    from celeste_jl_amd import generic_init_source, ids
+    from celeste_jl_amd.catalog import (flux_to_mag, mag_to_flux, color_from_fluxes, fluxes_from_colors, canonical_angle,
+                                        degrees_to_diff, variational_parameters_to_row)
+    assert flux_to_mag(15.0, 1) == pytest.approx(19.559677, abs=1e-5)
+    assert flux_to_mag(15.0, 3) == pytest.approx(19.559702, abs=1e-5)
+    assert mag_to_flux(19.559677, 1) == pytest.approx(15.0, abs=1e-5)
+    assert mag_to_flux(19.559702, 3) == pytest.approx(15.0, abs=1e-5)
+    assert color_from_fluxes(15.0, 20.0) == pytest.approx(math.log(20 / 15))
+    assert color_from_fluxes(15.0, 0.0) is None
+    fl = fluxes_from_colors(10.0, [-1.0, 0.0, 1.0, 2.0])
+    assert np.allclose(fl, [math.e * 10, 10.0, 10.0, math.e * 10, math.exp(3.0) * 10], rtol=1e-12)
+    assert canonical_angle(95.0) == 95.0 and canonical_angle(195.0) == 15.0 and canonical_angle(-20.0) == 160.0
+    assert degrees_to_diff(20.0, -30.0) == pytest.approx(50.0) and degrees_to_diff(-10.0, 190.0) == pytest.approx(20.0)
+    vs = generic_init_source([1.0, 2.0])
+    vs[ids.gal_axis_ratio] = 0.5
+    vs[ids.gal_radius_px] = 10.0
+    vs[ids.gal_angle] = -math.pi / 4
+    vs[ids.flux_loc[1]] = math.log(20.0)
+    vs[ids.is_star[0]] = 0.01
+    vs[ids.is_star[1]] = 0.99
+    row = variational_parameters_to_row(vs)
+    assert row["gal_radius_px"] == pytest.approx(10 * math.sqrt(0.5))
+    assert row["gal_angle_deg"] == pytest.approx(135.0)
+    assert row["flux_r_nmgy"] == pytest.approx(20.0)
