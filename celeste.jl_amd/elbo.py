@@ -14,7 +14,7 @@ Sa = 1 is the production configuration (batched, tuned); Sa > 1 goes through cel
 """
 import ctypes as C
 from dataclasses import dataclass
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 

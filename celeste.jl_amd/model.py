@@ -12,7 +12,7 @@ identity WCS of test/SampleData.jl:30-34.
 """
 import collections.abc
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple
 import math
 import numpy as np
 

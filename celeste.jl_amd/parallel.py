@@ -5,7 +5,7 @@ its cost-balanced shard of targets, and the per-source results (value + 44-gradi
 Hessian) are all-gathered once per sweep -- the "catalog gather".  No other exchange exists on this
 path, mirroring the reference's thread-level independence (ParallelRun.jl:546-607).
 """
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Callable, Optional, Sequence, Tuple
 
 import numpy as np
 

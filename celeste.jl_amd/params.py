@@ -4,7 +4,7 @@ Mirrors src/model/param_set.jl:76-107 (CanonicalParams, 0-based here),
 src/model/light_source_model.jl:11-20 (CatalogEntry) and
 src/DeterministicVI.jl:39-91 (generic_init_source / catalog_init_source).
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List
 import math
 import numpy as np
