@@ -307,6 +307,20 @@ def test_psf_K_other_than_two(oracle, K):
     print("psf_K", K, errs)
 
 
+def test_duplicate_and_unordered_targets():
+    """the batch's work list is built per target *slot*: a source listed twice, or in any order, gets the same numbers"""
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_field(200, 260, 70, seed=19, margin=20)
+    ctx = _ctx(f)
+    base = ctx.eval_batch(f.vp, list(range(70)), ALL)
+    tg = [5, 5, 69, 0, 33, 5, 12, 69] + list(range(69, -1, -1)) * 5      # 358 slots: several count / fill blocks
+    for flags in (ALL, 5, ALL | cabi.FLAG_FP32):
+        ref = base if flags == ALL else ctx.eval_batch(f.vp, list(range(70)), flags)
+        got = ctx.eval_batch(f.vp, tg, flags)
+        for x, y in zip(got, ref):
+            assert (x is None and y is None) or np.array_equal(x, y[tg])
+
+
 def test_edge_cases(oracle):
     """empty target list; a target without a single active pixel (ELBO = -KL, derivatives of the KL only); a source
     whose box misses every image (clamp_box, imaged_sources.jl:10-14); the last-column rule on a 1-column patch"""
