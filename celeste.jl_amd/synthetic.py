@@ -160,9 +160,13 @@ def gen_images(images: List[Image], catalog: List[CatalogEntry], rng: np.random.
         global _POOL_ARGS
         _POOL_ARGS = (images, catalog, seed)
         try:
-            with mp.get_context("fork").Pool(workers) as pool:
+            pool = mp.get_context("fork").Pool(workers)
+            try:
                 for img, px in zip(images, pool.map(_sample_image_job, range(len(images)), chunksize=1)):
                     img.pixels = px
+            finally:
+                pool.close()    # let the workers run out and exit by themselves (no SIGTERM: tools that wrap the
+                pool.join()     # process, e.g. profilers, may intercept it)
         finally:
             _POOL_ARGS = None
         return

@@ -317,3 +317,14 @@ def test_reference_known_answers_of_the_catalog_helpers():
     assert row["gal_radius_px"] == pytest.approx(10 * math.sqrt(0.5))
     assert row["gal_angle_deg"] == pytest.approx(135.0)
     assert row["flux_r_nmgy"] == pytest.approx(20.0)
+
+
+def test_parallel_image_generation_is_deterministic():
+    """gen_images with worker processes (many-image problems): image n is sampled from PCG64([seed, n]), so the pixels
+    do not depend on the number of workers"""
+    from celeste_jl_amd import synthetic
+    a = synthetic.make_multifield((1, 2), 90, 90, 0.10, 12, seed=8, sparse=True, workers=2)
+    b = synthetic.make_multifield((1, 2), 90, 90, 0.10, 12, seed=8, sparse=True, workers=3)
+    assert all(np.array_equal(x.pixels, y.pixels) for x, y in zip(a.images, b.images))
+    assert all(x.pixels.dtype == np.float32 and np.isfinite(x.pixels).all() for x in a.images)
+    assert np.array_equal(a.vp, b.vp) and a.neighbors == b.neighbors
