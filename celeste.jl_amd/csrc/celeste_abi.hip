@@ -494,10 +494,11 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         HIP_TRY(hipMalloc((void **)&c->d_work, std::max<size_t>(work_need, 1) * sizeof(int32_t)));
         c->work_cap = work_need;
     }
-    if ((size_t)n_wblk * c->CH > c->work_blk_cap) {
+    const int n_classes = c->chunk_px / 64;   // work-list classes: pixel-loop iterations a chunk is short of a full one
+    if ((size_t)n_wblk * n_classes > c->work_blk_cap) {
         if (c->d_work_blk) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_work_blk)); c->d_work_blk = nullptr; }
-        HIP_TRY(hipMalloc((void **)&c->d_work_blk, (size_t)n_wblk * c->CH * sizeof(int32_t)));
-        c->work_blk_cap = (size_t)n_wblk * c->CH;
+        HIP_TRY(hipMalloc((void **)&c->d_work_blk, (size_t)n_wblk * n_classes * sizeof(int32_t)));
+        c->work_blk_cap = (size_t)n_wblk * n_classes;
     }
     const bool derivs = (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) != 0;
     const bool split = (flags & CELESTE_FLAG_SPLIT) != 0;
@@ -525,22 +526,20 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            render_neighbors ? c->d_needed : nullptr);
     }
     hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
-                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, (int)c->dense, c->d_work_blk);
-    hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * c->CH, c->d_work_total);
+                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, (int)c->dense, c->d_work_blk);
+    hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * n_classes, c->d_work_total);
     hipLaunchKernelGGL(work_fill_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
                        c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, (int)c->dense, c->d_work_blk, c->d_work);
     // per-(source, image) constants: of every source when the neighbours are (re)rendered, else of the targets only
     if (render_neighbors) {
         if (c->V > 0)
             hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches,
-                               c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr, nullptr, c->CH,
-                               nullptr, nullptr, c->M);
+                               c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr, c->d_vis_off, c->M,
+                               (int)c->dense);
     } else {
-        // entries [0, n_first) of the work list are the first chunks = one per visit of a target
-        const int32_t *n_first = c->CH > 1 ? c->d_work_blk + n_wblk : c->d_work_total;
         hipLaunchKernelGGL(prep_kernel, dim3((unsigned)std::max(n_visits, 1)), dim3(64), 0, stream, d_vp, c->d_images,
-                           c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, c->d_work,
-                           n_first, c->CH, d_targets, c->dense ? nullptr : c->d_items, c->M);
+                           c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, d_targets,
+                           c->d_vis_off, c->M, (int)c->dense);
     }
     if (render_neighbors) {
     if (c->n_value_items > 0)
@@ -574,12 +573,11 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     c->ev_split = 0;
     if (split) {
         // per-patch sums of the records, then the lift reads one record per (target, image): CH = 1
-        const bool listed = c->sum_tiles * 64 == c->chunk_px && c->RCH == c->CH;   // parts == the pixel kernel's chunks
-        hipLaunchKernelGGL(record_sum_kernel,
-                           listed ? grid : dim3((unsigned)((size_t)n_targets * c->M * c->RCH)), dim3(RSUM_NT), 0,
+        // its own (part, patch) grid, part index slowest: streaming order matters more to this kernel than the idle
+        // workgroups do (run over the pixel kernel's longest-first work list it lost 5 %)
+        hipLaunchKernelGGL(record_sum_kernel, dim3((unsigned)((size_t)n_targets * c->M * c->RCH)), dim3(RSUM_NT), 0,
                            stream, c->d_patches, d_targets, c->d_tile_off, reinterpret_cast<const double2 *>(c->d_rec),
-                           c->d_items, c->N, c->M, c->RCH, c->sum_tiles, c->d_acc_split,
-                           listed ? c->d_work : nullptr, c->d_work_total);
+                           c->d_items, c->N, c->M, c->RCH, c->sum_tiles, c->d_acc_split, nullptr, c->d_work_total);
         if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], stream)); c->ev_split = 1; }
         hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                            c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M,
@@ -947,7 +945,7 @@ extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32
         if (c->V > 0)
             hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, nullptr, c->d_vp, c->d_images,
                                c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr,
-                               nullptr, c->CH, nullptr, nullptr, c->M);
+                               c->d_vis_off, c->M, (int)c->dense);
         hipLaunchKernelGGL(render_kernel, dim3((unsigned)((size_t)c->S * c->CH)), dim3(64), 0, nullptr, c->d_patches,
                            c->d_coefs, c->d_bitmaps, im.pixels, c->d_srcimg, c->d_comps, (int)image, c->N, c->NC,
                            c->CH, c->chunk_px, im.H, d_plane);

@@ -64,19 +64,23 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const DevPatch *__restrict__ patches, const int32_t *__restrict__ vis_src,
             const int32_t *__restrict__ vis_img, int N, int K,
             SrcImg *__restrict__ srcimg, Comp *__restrict__ comps,
-            const int32_t *__restrict__ work, const int32_t *__restrict__ n_first, int CH,
-            const int32_t *__restrict__ targets, const int32_t *__restrict__ items, int M) {
+            const int32_t *__restrict__ targets, const int32_t *__restrict__ vis_off, int M, int dense) {
     const int NC = 14 * K;
     // one workgroup per visit = (source, image) pair with a non-empty patch; the tables stay dense (s * N + n).
-    // work == nullptr: every visit of the context (neighbours are about to be rendered).  Otherwise only the visits
-    // of the batch's targets: they are the first-chunk entries at the head of the pixel kernel's work list.
+    // targets == nullptr: every visit of the context (neighbours are about to be rendered).  Otherwise one workgroup
+    // per candidate visit k = ti * M + j of the batch's targets only (neighbours frozen).
     int s, n;
-    if (work) {
-        if ((int)blockIdx.x >= *n_first) return;
-        const int k = work[blockIdx.x] / CH;
-        const int ti = k / M;
+    if (targets) {
+        const int k = blockIdx.x, ti = k / M, j = k - ti * M;
         s = targets[ti];
-        n = items ? items[k] : k - ti * M;
+        n = j;
+        if (!dense) {
+            const int vo = vis_off[s];
+            if (j >= vis_off[s + 1] - vo) return;
+            n = vis_img[vo + j];
+        }
+        const DevPatch &q = patches[(size_t)s * N + n];
+        if (q.H2 * q.W2 <= 0) return;
     } else {
         s = vis_src[blockIdx.x]; n = vis_img[blockIdx.x];
     }
@@ -318,28 +322,37 @@ __global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__res
 // each is cut into ceil(npx / chunk_px) chunks, 0 for a target that appears in fewer than M images.  Launching the
 // full n_targets x M x CH grid leaves most workgroups with nothing to do (patches of 200 .. 2600 pixels; 5 .. 20
 // images per source in a many-field problem), and an idle workgroup still holds a wave slot with its full register
-// allocation for three dependent loads before it can exit.  The list enumerates exactly the chunks that exist, in
-// the order (chunk index, k): first chunks first (every patch has one), spread over all XCDs.  Three small
-// kernels: per-block counts, one exclusive scan over [chunk][block], fill.  The order is deterministic.
+// allocation for three dependent loads before it can exit.  The list enumerates exactly the chunks that exist,
+// longest first: class 0 = full chunks (chunk_px / 64 iterations of the pixel loop), class c = the last, partial
+// chunk of a patch that needs c iterations fewer -- so the kernel's tail is made of its shortest workgroups.
+// Three small kernels: per-block counts, one exclusive scan over [class][block], fill.  The order is deterministic.
 // ---------------------------------------------------------------------------------------------
 #define WORK_NT 256
-__device__ inline int visit_chunks(int k, const int32_t *__restrict__ targets, const DevPatch *__restrict__ patches,
-                                   const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M,
-                                   int chunk_px, bool dense) {
+// chunks of candidate visit k: n_full of class 0 (chunk indices 0 .. n_full - 1) and, if last_class > 0, one of that
+// class (chunk index n_full)
+__device__ inline void visit_chunks(int k, const int32_t *__restrict__ targets, const DevPatch *__restrict__ patches,
+                                    const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M,
+                                    int chunk_px, bool dense, int &n_full, int &last_class) {
+    n_full = 0; last_class = 0;
     const int ti = k / M, j = k - ti * M;
     const int t = targets[ti];
     int n = j;
     if (!dense) {
         const int vo = vis_off[t];
-        if (j >= vis_off[t + 1] - vo) return 0;
+        if (j >= vis_off[t + 1] - vo) return;
         n = vis_img[vo + j];
     }
     const DevPatch &P = patches[(size_t)t * N + n];
-    return (P.H2 * P.W2 + chunk_px - 1) / chunk_px;
+    const int npx = P.H2 * P.W2;
+    if (npx <= 0) return;
+    const int nch = (npx + chunk_px - 1) / chunk_px;
+    const int last_px = npx - (nch - 1) * chunk_px;
+    last_class = (chunk_px >> 6) - ((last_px + 63) >> 6);
+    n_full = last_class == 0 ? nch : nch - 1;
 }
 
 // rank of this thread among the threads of its block for which pred holds (exclusive), and the block total
-__device__ inline int block_rank(bool pred, int *s_wave /* WORK_NT / 64 + 1 */, int &total) {
+__device__ inline int block_rank(bool pred, int *s_wave /* WORK_NT / 64 */, int &total) {
     const unsigned long long m = __ballot(pred);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = __popcll(m & ((1ull << lane) - 1ull));
@@ -352,18 +365,36 @@ __device__ inline int block_rank(bool pred, int *s_wave /* WORK_NT / 64 + 1 */, 
     total = tot;
     return off + r;
 }
+// exclusive prefix sum of v over the threads of the block, and the block total
+__device__ inline int block_prefix(int v, int *s_wave /* WORK_NT / 64 */, int &total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+    __syncthreads();
+    if (lane == 63) s_wave[wv] = x;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WORK_NT / 64; ++w) { const int c = s_wave[w]; off += w < wv ? c : 0; tot += c; }
+    total = tot;
+    return off + x - v;
+}
 
 __global__ void __launch_bounds__(WORK_NT)
 work_count_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPatch *__restrict__ patches,
-                  const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M, int CH,
-                  int chunk_px, int dense, int32_t *__restrict__ blk_cnt /* [CH][gridDim.x] */) {
-    __shared__ int s_wave[WORK_NT / 64 + 1];
+                  const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M,
+                  int chunk_px, int dense, int32_t *__restrict__ blk_cnt /* [chunk_px / 64][gridDim.x] */) {
+    __shared__ int s_wave[WORK_NT / 64];
     const int k = blockIdx.x * WORK_NT + threadIdx.x;
-    const int nch = k < n_visits ? visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, dense != 0) : 0;
-    for (int ch = 0; ch < CH; ++ch) {
-        int tot;
-        block_rank(nch > ch, s_wave, tot);
-        if (threadIdx.x == 0) blk_cnt[(size_t)ch * gridDim.x + blockIdx.x] = tot;
+    int n_full = 0, lc = 0;
+    if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, dense != 0, n_full, lc);
+    int tot;
+    block_prefix(n_full, s_wave, tot);
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
+    for (int c = 1; c < (chunk_px >> 6); ++c) {
+        block_rank(lc == c, s_wave, tot);
+        if (threadIdx.x == 0) blk_cnt[(size_t)c * gridDim.x + blockIdx.x] = tot;
     }
 }
 
@@ -396,13 +427,16 @@ __global__ void __launch_bounds__(WORK_NT)
 work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPatch *__restrict__ patches,
                  const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M, int CH,
                  int chunk_px, int dense, const int32_t *__restrict__ blk_base, int32_t *__restrict__ work) {
-    __shared__ int s_wave[WORK_NT / 64 + 1];
+    __shared__ int s_wave[WORK_NT / 64];
     const int k = blockIdx.x * WORK_NT + threadIdx.x;
-    const int nch = k < n_visits ? visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, dense != 0) : 0;
-    for (int ch = 0; ch < CH; ++ch) {
-        int tot;
-        const int r = block_rank(nch > ch, s_wave, tot);
-        if (nch > ch) work[blk_base[(size_t)ch * gridDim.x + blockIdx.x] + r] = k * CH + ch;
+    int n_full = 0, lc = 0;
+    if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, dense != 0, n_full, lc);
+    int tot;
+    const int p0 = blk_base[blockIdx.x] + block_prefix(n_full, s_wave, tot);
+    for (int ch = 0; ch < n_full; ++ch) work[p0 + ch] = k * CH + ch;
+    for (int c = 1; c < (chunk_px >> 6); ++c) {
+        const int r = block_rank(lc == c, s_wave, tot);
+        if (lc == c) work[blk_base[(size_t)c * gridDim.x + blockIdx.x] + r] = k * CH + n_full;
     }
 }
 
