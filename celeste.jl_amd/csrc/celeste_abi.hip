@@ -391,10 +391,11 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
     }
     CTX_TRY(dev_upload<int32_t>(&c->d_work_total, nullptr, 1));
     {
-        // work items of value_kernel: (link, image, chunk) with a non-empty overlap rectangle, chunk index slowest
-        // (every overlap has a first chunk: those are dispatched first and spread over all XCDs)
+        // work items of value_kernel: (link, image, chunk) with a non-empty overlap rectangle, longest first (by the
+        // number of 64-pixel iterations the chunk takes) so that the kernel's tail is made of its shortest workgroups
         if (c->N > 0xffff) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }
-        std::vector<std::vector<std::pair<int32_t, int32_t>>> by_chunk;
+        const int n_cls = c->chunk_px / 64;
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> by_len(n_cls);   // [n_cls - iterations]
         for (int s = 0; s < c->S; ++s)
             for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q) {
                 const int s2 = c->h_nbr_idx[q];
@@ -403,13 +404,15 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
                     const int rh = std::min(a.off_h + a.H2, b.off_h + b.H2) - std::max(a.off_h, b.off_h);
                     const int rw = std::min(a.off_w + a.W2, b.off_w + b.W2 - 1) - std::max(a.off_w, b.off_w);
                     if (rh <= 0 || rw <= 0) continue;
-                    const int nch = (rh * rw + c->chunk_px - 1) / c->chunk_px;
-                    if ((int)by_chunk.size() < nch) by_chunk.resize(nch);
-                    for (int ch = 0; ch < nch; ++ch) by_chunk[ch].push_back({(int32_t)q, (int32_t)(n | (ch << 16))});
+                    const int npx = rh * rw, nch = (npx + c->chunk_px - 1) / c->chunk_px;
+                    for (int ch = 0; ch < nch; ++ch) {
+                        const int px = std::min(c->chunk_px, npx - ch * c->chunk_px);
+                        by_len[n_cls - (px + 63) / 64].push_back({(int32_t)q, (int32_t)(n | (ch << 16))});
+                    }
                 }
             }
         std::vector<int32_t> il, ic;
-        for (auto &v : by_chunk) for (auto &e : v) { il.push_back(e.first); ic.push_back(e.second); }
+        for (auto &v : by_len) for (auto &e : v) { il.push_back(e.first); ic.push_back(e.second); }
         c->n_value_items = (int64_t)il.size();
         CTX_TRY(dev_upload(&c->d_item_link, il.data(), il.size()));
         CTX_TRY(dev_upload(&c->d_item_img_chunk, ic.data(), ic.size()));
