@@ -1079,6 +1079,17 @@ __device__ inline void param_rows(int p, int &start, int &cnt, int &stride, int 
     } else { start = 0; cnt = 0; stride = 1; cls = 5; }
 }
 
+// The 10 x 28 Jacobian of the reduced variables is sparse: parameter p only moves the rows param_rows(p) lists (2, 1,
+// 3 or 2 of them).  It is stored compactly, entry a of parameter p at jz_off(p) + a: LIFT_JZ = 58 doubles per image.
+#define LIFT_JZ 58
+__device__ __forceinline__ int jz_off(int p) { return p < 2 ? 2 * p : (p == 2 ? 4 : (p < 6 ? 5 + 3 * (p - 3) : 14 + 2 * (p - 6))); }
+__device__ __forceinline__ void jz_unrank(int slot, int &p, int &a) {
+    if (slot < 4) { p = slot >> 1; a = slot & 1; }
+    else if (slot == 4) { p = 2; a = 0; }
+    else if (slot < 14) { const int q = slot - 5; p = 3 + q / 3; a = q - 3 * (p - 3); }
+    else { const int q = slot - 14; p = 6 + (q >> 1); a = q & 1; }
+}
+
 // index of canonical parameter p inside its type's brightness vector (bids order), -1 for is_star
 __device__ inline int bright_slot(int p) {
     if (p < 8) return 0;
@@ -1106,7 +1117,7 @@ __device__ inline void bright_coef(int q, int b, double &kap, double &lam) {
 }
 
 #ifndef LIFT_NT
-#define LIFT_NT 6    // images lifted concurrently per pass (LDS 27 KB: 5 workgroups per CU)
+#define LIFT_NT 8    // images lifted concurrently per pass
 #endif
 #define LIFT_NP 28   // parameters with likelihood derivatives (the k block, 28..43, only enters the KL)
 
@@ -1180,7 +1191,9 @@ __device__ inline double kl_grad(const KLShared &K, const PriorDev *prior, const
     return -a * (K.t[8 * i + d] + 1.0 + K.m[8 * i + d]);
 }
 
-__global__ void __launch_bounds__(256)
+// 8 waves per SIMD (64 VGPRs, a 52-byte spill) and 17.7 KB of LDS: 8 workgroups per CU, so that a 2000-target batch is
+// resident in one round (with 5 per CU it ran in two: 76 -> 65 us)
+__global__ void __launch_bounds__(256, 8)
 lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
             const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
@@ -1193,7 +1206,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
     __shared__ double sh_d[LIFT_NP];
     __shared__ double s_vs[CEL_P], s_jsh[9], s_tsh[27];
     __shared__ double s_rec[LIFT_NT][ACC_N];
-    __shared__ double s_jz[LIFT_NT][ZV * LIFT_NP];
+    __shared__ double s_jz[LIFT_NT][LIFT_JZ];          // compact Jacobians of the reduced variables (jz_off)
     __shared__ double s_kap[LIFT_NT][10], s_lam[LIFT_NT][10], s_El[LIFT_NT][2], s_Ell[LIFT_NT][2];
     __shared__ KLShared K;
     __shared__ double sh_v, sh_cnt[2];
@@ -1277,10 +1290,13 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         __syncthreads();
         if (tid == 0) for (int i = 0; i < nt; ++i) { sh_v += s_rec[i][0]; sh_cnt[0] += s_rec[i][ACC_CNT]; sh_cnt[1] += s_rec[i][ACC_CNT + 1]; }
         if (want_grad) {
-            // pass 2: 10 x 28 Jacobians of the reduced variables
-            for (int k = tid; k < nt * ZV * LIFT_NP; k += nthr) {
-                const int i = k / (ZV * LIFT_NP), rp = k - i * (ZV * LIFT_NP);
-                const int r = rp / LIFT_NP, p = rp - r * LIFT_NP;
+            // pass 2: the non-zero entries of the 10 x 28 Jacobians of the reduced variables
+            for (int k = tid; k < nt * LIFT_JZ; k += nthr) {
+                const int i = k / LIFT_JZ, slot = k - i * LIFT_JZ;
+                int p, a, st0, cn0, sd0, cls0;
+                jz_unrank(slot, p, a);
+                param_rows(p, st0, cn0, sd0, cls0);
+                const int r = st0 + a * sd0;
                 double v = 0.0;
                 if (r >= 4 && r < 6) { if (p < 2) v = patches[(size_t)t * N + vis_img[vo + n0 + i]].J[(r - 4) + 2 * p]; }
                 else if (r == 6) { if (p == 2) v = 1.0; }
@@ -1297,7 +1313,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
                         else v = vs[26 + ty] * Ev * (isq ? s_lam[i][slot] : s_kap[i][slot]);
                     }
                 }
-                s_jz[i][rp] = v;
+                s_jz[i][slot] = v;
             }
             __syncthreads();
             // pass 3: gradient and upper-triangle Hessian; every entry is owned by one thread
@@ -1309,7 +1325,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
                     param_rows(p, st, cn, sd, cls);
                     double s = 0.0;
                     for (int i = 0; i < nt; ++i)
-                        for (int a = 0; a < cn; ++a) { const int r = st + a * sd; s += s_jz[i][r * LIFT_NP + p] * s_rec[i][1 + r]; }
+                        for (int a = 0; a < cn; ++a) { const int r = st + a * sd; s += s_jz[i][jz_off(p) + a] * s_rec[i][1 + r]; }
                     sh_d[p] += s;
                     continue;
                 }
@@ -1323,17 +1339,18 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
                 param_rows(p1, st1, cn1, sd1, cls1);
                 param_rows(p2, st2, cn2, sd2, cls2);
                 double s = 0.0;
+                const int o1 = jz_off(p1), o2 = jz_off(p2);
                 for (int i = 0; i < nt; ++i) {
                     const double *rec = s_rec[i];
                     const double *jz = s_jz[i];
                     for (int a = 0; a < cn1; ++a) {
                         const int r1 = st1 + a * sd1;
-                        const double j1 = jz[r1 * LIFT_NP + p1];
+                        const double j1 = jz[o1 + a];
                         double inner = 0.0;
                         for (int c = 0; c < cn2; ++c) {
                             const int r2 = st2 + c * sd2;
                             const int lo = r1 < r2 ? r1 : r2, hi = r1 < r2 ? r2 : r1;
-                            inner += rec[hidx(lo, hi)] * jz[r2 * LIFT_NP + p2];
+                            inner += rec[hidx(lo, hi)] * jz[o2 + c];
                         }
                         s += j1 * inner;
                     }
