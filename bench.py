@@ -1,11 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- sources/sec of the ELBO hot path (value + gradient + Hessian + KL) on MI355X.
 
-One "step" = one sweep of elbo() over every source of one synthetic 2048x1489x5 SDSS-size field
-(~2000 star+galaxy sources, BASELINE.json configs[2]), inputs resident in HBM.  With --gpus N each rank
-owns one such field (sources shard with no data-path collective; weak scaling) and the per-source results
-(value + 44-gradient) are all-gathered over RCCL after every sweep (the "catalog gather"), on a second stream
-so that the gather of sweep k overlaps the kernels of sweep k + 1; every gather is complete before the clock stops.
+One "step" = one sweep of elbo() over every source of the workload, inputs resident in HBM:
+
+  --config 3 (default)  BASELINE.json configs[2] / configs[3]: ONE synthetic 2048x1489x5 SDSS-size field, ~2000
+                        star+galaxy sources, fp64.
+  --config 5            BASELINE.json configs[4]: 16 overlapping SDSS-size fields (80 images, ~30k sources, sparse
+                        patch list), fp32 component loop (--dtype f32, the default for this config), checked inside the
+                        run against the fp64 device path at 1e-4.
+
+With --gpus N the SAME workload is sharded by source across the N ranks ("strong" scaling, the default: this is
+BASELINE configs[3], the reference's one-field source list drained by N workers, ParallelRun.jl:546-607): every rank
+holds the replicated images, evaluates its cost-balanced shard of the targets (estimate_time, ParallelRun.jl:45-56)
+and the per-source results (value + 44-gradient) are all-gathered over RCCL after every sweep (the "catalog gather",
+the only exchange of the path) on a second stream, overlapping the kernels of the next sweep; every gather is complete
+before the clock stops.  --scaling weak gives every rank its own field instead (round-1 behaviour).
+--backend gloo stages the gather through the host (lets two ranks share one GPU; used by the tests).
 
 Prints ONE JSON line on rank 0 (contract in the task description).
 """
@@ -24,13 +34,13 @@ import numpy as np  # noqa: E402
 FLAGS_ALL = 1 | 2 | 4
 HBM_PEAK_GBS = 8000.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X FP64 vector (non-matrix) peak
-FLOPS_PER_PIXEL_VISIT = 4046        # FP64 flops pixel_kernel<2, double> spends per visited pixel, counted in the ISA
-                                    # (tools/count_flops.py: FMA = 2; psf_K = 2)
+FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X FP32 vector peak (packed)
 
 
-def profiled_traffic_bytes():
-    """HBM bytes per pixel_kernel<2> launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    separate passes, KiB -> bytes, uncorrected: see DESIGN.md 4.3).  None when no profile is present."""
+def profile_facts():
+    """Figures that only a rocprofv3 / ISA pass can give (HBM bytes per launch from the PMC passes, VALU issue
+    utilisation, FP64 flops per visited pixel counted in the compiled ISA), committed under profiles/ by
+    tools/profile_round.sh for the kernels as they are in this tree.  None when no profile is present."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
@@ -39,25 +49,39 @@ def profiled_traffic_bytes():
         return None
 
 
-def build_field(H, W, n_sources, seed, cache=True):
+def _cached(path, make, cache=True):
     import pickle
-    from celeste_jl_amd import synthetic
-    path = "/tmp/celeste_field_%d_%d_%d_%d.pkl" % (H, W, n_sources, seed)
     if cache and os.path.exists(path):
         try:
             with open(path, "rb") as f:
                 return pickle.load(f)
         except Exception:
             pass
-    fld = synthetic.make_field(H, W, n_sources, seed=seed, name="synthetic_%dx%dx5_%dsrc" % (H, W, n_sources))
+    obj = make()
     if cache:
         try:
-            with open(path + ".tmp%d" % os.getpid(), "wb") as f:
-                pickle.dump(fld, f)
-            os.replace(path + ".tmp%d" % os.getpid(), path)
+            tmp = path + ".tmp%d" % os.getpid()
+            with open(tmp, "wb") as f:
+                pickle.dump(obj, f, protocol=4)
+            os.replace(tmp, path)
         except Exception:
             pass
-    return fld
+    return obj
+
+
+def build_field(H, W, n_sources, seed, cache=True):
+    from celeste_jl_amd import synthetic
+    return _cached("/tmp/celeste_field_%d_%d_%d_%d.pkl" % (H, W, n_sources, seed),
+                   lambda: synthetic.make_field(H, W, n_sources, seed=seed,
+                                                name="synthetic_%dx%dx5_%dsrc" % (H, W, n_sources)), cache)
+
+
+def build_multifield(grid, H, W, n_sources, seed, cache=True):
+    from celeste_jl_amd import synthetic
+    workers = max(1, min(16, usable_cores()))
+    # (not pickled: 80 planes of 12 MB; generation takes ~15 s with 16 workers)
+    return synthetic.make_multifield(grid=grid, H=H, W=W, overlap=0.10, n_sources=n_sources, seed=seed, sparse=True,
+                                     workers=workers)
 
 
 def usable_cores():
@@ -111,19 +135,37 @@ def cpu_baseline(problem, vp, targets, seconds_target=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, choices=(3, 5))
+    ap.add_argument("--dtype", default=None, choices=("f64", "f32"))
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--width", type=int, default=1489)
-    ap.add_argument("--sources", type=int, default=2000)
-    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--sources", type=int, default=None)
+    ap.add_argument("--grid", default="4,4", help="config 5: grid of overlapping fields")
+    ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed sweep and the roofline")
+    ap.add_argument("--check-dir", default=None,
+                    help="every rank writes its gathered (v, d) of the last sweep to <dir>/rank<r>.npz (tests)")
     args = ap.parse_args()
+    if args.dtype is None:
+        args.dtype = "f32" if args.config == 5 else "f64"
+    if args.steps is None:
+        args.steps = 50 if args.config == 3 else 10
+    if args.sources is None:
+        args.sources = 2000 if args.config == 3 else 30000
+    if args.seed is None:
+        args.seed = 3 if args.config == 3 else 5
 
     import torch
     import torch.distributed as dist
     import celeste_jl_amd as cel
     from celeste_jl_amd import cabi
+    from celeste_jl_amd.parallel import DeviceShardedSweep
+    from celeste_jl_amd.partition import estimate_time
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
@@ -131,111 +173,135 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = args.gpus > 1 or world > 1 or "RANK" in os.environ   # launched by torch.distributed.run
+    n_dev = torch.cuda.device_count()
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if args.backend == "nccl" and local_rank >= n_dev:
+            raise SystemExit("rank %d has no GPU of its own (%d visible): RCCL needs one device per rank; "
+                             "use --backend gloo to share a device" % (local_rank, n_dev))
+        dev_index = local_rank % n_dev
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if use_dist else 0)
+    dev = torch.device("cuda", dev_index)
+    strong = args.scaling == "strong"
+    flags = FLAGS_ALL | (cabi.FLAG_FP32 if args.dtype == "f32" else 0)
 
-    # one field per rank (weak scaling): same shape, rank-dependent seed
-    fld = build_field(args.height, args.width, args.sources, args.seed + rank)
+    # ---- the workload: the same field(s) on every rank (strong), or one per rank (weak) ----
+    seed = args.seed if strong else args.seed + rank
+
+    def make():
+        if args.config == 3:
+            return build_field(args.height, args.width, args.sources, seed)
+        grid = tuple(int(x) for x in args.grid.split(","))
+        return build_multifield(grid, args.height, args.width, args.sources, seed)
+    if use_dist and strong and args.config == 3:
+        if rank == 0:      # one rank renders the field and caches it; the others load the cache
+            fld = make()
+        dist.barrier()
+        if rank != 0:
+            fld = make()
+    else:
+        fld = make()
     S = len(fld.catalog)
     ctx = cel.FieldContext(fld.images, fld.patches, fld.neighbors, device=dev.index)
     targets = np.arange(S, dtype=np.int32)
-    stats = ctx.work_stats(targets)
-
+    costs = [estimate_time(row) for row in fld.patches]
+    sweep = DeviceShardedSweep(ctx, targets, costs, rank, world, flags, backend=args.backend if use_dist else None,
+                               shards=None if strong else [list(range(S))] * world)
+    mine = sweep.mine
+    stats = ctx.work_stats(mine)
     d_vp = torch.tensor(fld.vp, dtype=torch.float64, device=dev)
-    d_tg = torch.tensor(targets, dtype=torch.int32, device=dev)
-    # value / gradient outputs are double-buffered so that the catalog gather of sweep k (RCCL, on its own stream)
-    # overlaps the kernels of sweep k + 1
-    d_vs = [torch.zeros(S, dtype=torch.float64, device=dev) for _ in range(2)]
-    d_ds = [torch.zeros(S, 44, dtype=torch.float64, device=dev) for _ in range(2)]
-    d_v, d_d = d_vs[0], d_ds[0]
-    d_h = torch.zeros(S, 44, 44, dtype=torch.float64, device=dev)
-    d_cnt = torch.zeros(S, 2, dtype=torch.int64, device=dev)
-    d_st = torch.zeros(S, dtype=torch.int32, device=dev)
-    compute_stream = torch.cuda.current_stream(dev)
-    stream = compute_stream.cuda_stream
-    if use_dist:
-        comm_stream = torch.cuda.Stream(dev)
-        gather_in = [torch.zeros(S, 45, dtype=torch.float64, device=dev) for _ in range(2)]
-        gather_out = torch.zeros(world * S, 45, dtype=torch.float64, device=dev)
-        buf_free = [torch.cuda.Event(), torch.cuda.Event()]
-        for e in buf_free:
-            e.record(compute_stream)
-    step_no = [0]
-
-    def step():
-        k = step_no[0] % 2
-        step_no[0] += 1
-        if use_dist:
-            compute_stream.wait_event(buf_free[k])      # the gather that last read this buffer pair is through
-        ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_ALL, d_vs[k].data_ptr(), d_ds[k].data_ptr(),
-                              d_h.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), stream)
-        if use_dist:  # the catalog gather: value + 44-gradient of every source, RCCL over xGMI
-            done = torch.cuda.Event()
-            done.record(compute_stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(done)
-                gather_in[k][:, 0] = d_vs[k]
-                gather_in[k][:, 1:] = d_ds[k]
-                dist.all_gather_into_tensor(gather_out, gather_in[k])
-                buf_free[k].record(comm_stream)
 
     def sync():
+        sweep.wait()
         if use_dist:
-            comm_stream.synchronize()
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step()
+        sweep.step(d_vp.data_ptr())
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        sweep.step(d_vp.data_ptr())
     sync()
     dt = time.perf_counter() - t0
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    assert int((d_st != 0).sum().item()) == 0, "non-zero per-target status"
-    pixel_visits = int(d_cnt[:, 0].sum().item())
+    g_v, g_d, st_loc, cnt_loc = sweep.results()
+    assert int((st_loc != 0).sum()) == 0, "non-zero per-target status"
+    if strong:
+        assert np.isfinite(g_v).all() and np.isfinite(g_d).all()
+    if args.check_dir:
+        os.makedirs(args.check_dir, exist_ok=True)
+        np.savez(os.path.join(args.check_dir, "rank%d.npz" % rank), v=g_v, d=g_d, mine=mine, h=sweep.hessians())
+    pixel_visits_local = int(cnt_loc[:, 0].sum())
 
-    # secondary figure: value + gradient only (first-order mode; the headline includes the Hessian)
-    FLAGS_GRAD = 1 | 4
-
-    def step_grad():
-        ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_GRAD, d_v.data_ptr(), d_d.data_ptr(),
-                              0, d_cnt.data_ptr(), d_st.data_ptr(), stream)
-    for _ in range(3):
-        step_grad()
-    sync()
-    tg0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_grad()
-    sync()
-    dt_grad = time.perf_counter() - tg0
-
-    # dominant-kernel duration: HIP events recorded by the library on the launch stream, averaged
+    # ---- dominant-kernel duration: HIP events recorded by the library on the launch stream, averaged ----
     ctx.enable_timing(True)
     kms = []
     for _ in range(min(20, max(3, args.steps))):
-        step()
-        torch.cuda.synchronize(dev)
+        sweep.step(d_vp.data_ptr())
+        sweep.wait()
         kms.append(ctx.last_kernel_ms())
     ctx.enable_timing(False)
     kms = np.array(kms).mean(axis=0)
+    sync()
+
+    extras = world == 1 and not args.no_extras
+    d_tg = sweep.d_tg
+    d_v = torch.zeros(S, dtype=torch.float64, device=dev)
+    d_d = torch.zeros(S, 44, dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(S, 2, dtype=torch.int64, device=dev)
+    d_st = torch.zeros(S, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    out_extra = {}
+    if extras:
+        # secondary figure: value + gradient only (first-order mode; the headline includes the Hessian)
+        fl_grad = (flags & ~2)
+
+        def step_grad():
+            ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), fl_grad, d_v.data_ptr(), d_d.data_ptr(),
+                                  0, d_cnt.data_ptr(), d_st.data_ptr(), stream)
+        for _ in range(3):
+            step_grad()
+        torch.cuda.synchronize(dev)
+        tg0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_grad()
+        torch.cuda.synchronize(dev)
+        out_extra["grad_only_sources_per_sec_rank0"] = S / ((time.perf_counter() - tg0) / args.steps)
+
+    if args.config == 5 and world == 1 and args.dtype == "f32":
+        # the configuration's stated tolerance: fp32 component loop within 1e-4 of the fp64 device path, every source
+        d_h64 = torch.zeros(S, 44, 44, dtype=torch.float64, device=dev)
+        ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_ALL, d_v.data_ptr(), d_d.data_ptr(),
+                              d_h64.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), stream)
+        torch.cuda.synchronize(dev)
+        v64, d64 = d_v.cpu().numpy(), d_d.cpu().numpy()
+        ev = float(np.max(np.abs(g_v - v64) / np.abs(v64)))
+        ed = float(np.max(np.abs(g_d - d64).max(axis=1) / np.abs(d64).max(axis=1)))
+        h32 = sweep.d_h
+        eh = float(((h32 - d_h64).abs().amax(dim=(1, 2)) / d_h64.abs().amax(dim=(1, 2))).max().item())
+        assert max(ev, ed, eh) <= 1e-4, (ev, ed, eh)
+        out_extra["fp32_vs_fp64_device"] = {"v": ev, "d": ed, "h": eh, "tolerance": 1e-4, "sources_checked": S}
+        del d_h64
 
     # split variant: per-pixel records to HBM, then the streaming per-patch sum -- the one
     # HBM-bound kernel of the path; a measurement aid next to the fused throughput configuration
     split = None
-    if world == 1:
+    facts = profile_facts() or {}
+    if extras and args.config == 3:
+        d_h = sweep.d_h
+
         def step_split():
             ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_ALL | cabi.FLAG_SPLIT, d_v.data_ptr(),
                                   d_d.data_ptr(), d_h.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), stream)
@@ -253,65 +319,116 @@ def main():
                  "algorithmic_bytes_per_launch": rb, "achieved": rb / (sm[3] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": rb / (sm[3] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "stored_record_bytes": stats["record_tiles"] * 68 * 64 * 8,
-                 "traffic": (profiled_traffic_bytes() or {}).get("record_sum_bytes_per_launch"),
+                 "traffic": facts.get("record_sum_bytes_per_launch"),
                  "record_write_kernel_ms": float(sm[1]), "lift_ms": float(sm[2]),
                  "note": "544 B (68 f64) per visited pixel + one 544 B result per patch; fused kernel stays the "
                          "throughput configuration"}
 
+    # whole-job figures need every rank's share
+    if use_dist:
+        tot = torch.tensor([float(len(mine)), float(pixel_visits_local), float(stats["algorithmic_bytes"])],
+                           dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        per_rank = [torch.zeros_like(tot) for _ in range(world)]
+        dist.all_gather(per_rank, tot)
+        per_rank = [[float(x) for x in t.cpu()] for t in per_rank]
+    else:
+        per_rank = [[float(len(mine)), float(pixel_visits_local), float(stats["algorithmic_bytes"])]]
+
     if rank == 0:
+        n_total = int(sum(p[0] for p in per_rank))           # sources evaluated per step by the whole job
         ms_per_step = dt / args.steps * 1e3
-        value = world * S / (dt / args.steps)
-        alg_bytes = stats["algorithmic_bytes"]
-        traffic = profiled_traffic_bytes()
+        value = n_total / (dt / args.steps)
+        alg_bytes = stats["algorithmic_bytes"]                # of rank 0's launch
         achieved = alg_bytes / (kms[1] * 1e-3) / 1e9
+        fpp = facts.get("flops_per_pixel_visit_f32" if args.dtype == "f32" else "flops_per_pixel_visit")
+        peak_fl = FP32_VECTOR_PEAK_TFLOPS if args.dtype == "f32" else FP64_VECTOR_PEAK_TFLOPS
+        kname = "pixel_kernel<2, %s>" % ("float" if args.dtype == "f32" else "double")
+        if args.config == 3:
+            workload = ("BASELINE.json configs[%d]: synthetic %dx%dx5 SDSS-size field, %d star+galaxy sources%s, fp64, "
+                        "Sa=1 with value-only neighbours, psf_K=2"
+                        % (2 if world == 1 else 3, args.height, args.width, S,
+                           "" if world == 1 else (" sharded by source across %d GPUs" % world if strong
+                                                  else " per GPU (one field per rank)")))
+        else:
+            workload = ("BASELINE.json configs[4]: %s grid of overlapping %dx%dx5 fields (%d images), %d sources in the "
+                        "sparse patch list, %s component loop%s, tolerance 1e-4 vs fp64"
+                        % (args.grid.replace(",", "x"), args.height, args.width, len(fld.images), S,
+                           "fp32" if args.dtype == "f32" else "fp64",
+                           "" if world == 1 else ", sharded by source across %d GPUs" % world))
         out = {
             "metric": "sources/sec (ELBO value+gradient+Hessian+KL per target source)",
             "value": value, "unit": "sources/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: synthetic %dx%dx5 SDSS-size field, %d star+galaxy "
-                                   "sources per GPU, fp64, Sa=1 with value-only neighbours, psf_K=2"
-                                   % (args.height, args.width, S),
-                       "sources_per_gpu": S, "pixel_visits_per_sweep": pixel_visits,
-                       "neighbor_links": stats["neighbor_links"], "parallelism": "sources sharded, 1 field per GPU"},
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": workload, "sources_per_step": n_total,
+                       "shard_sizes": [int(p[0]) for p in per_rank],
+                       "shard_pixel_visits": [int(p[1]) for p in per_rank],
+                       "catalog_gather_bytes_per_step": sweep.gather_bytes, "gather_backend": sweep.backend,
+                       "pixel_visits_per_sweep": int(sum(p[1] for p in per_rank)),
+                       "neighbor_links_rank0": stats["neighbor_links"],
+                       "parallelism": ("one field, targets sharded by estimated cost, images replicated, one all-gather of "
+                                       "(v, d) per sweep" if strong else "one field per GPU, all-gather of (v, d) per sweep")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (traffic or {}).get("pixel_kernel_bytes_per_launch"),
-                         "traffic_source": (traffic or {}).get("source"),
-                         "kernel": "pixel_kernel<2>", "kernel_ms": float(kms[1]),
+                         "traffic": facts.get("pixel_kernel_bytes_per_launch") if (world == 1 and args.config == 3 and
+                                                                                     args.dtype == "f64") else None,
+                         "traffic_source": facts.get("source"),
+                         "kernel": kname, "kernel_ms": float(kms[1]),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu_utilization": (traffic or {}).get("pixel_kernel_valu_utilization"),
-                         "fp64": {"achieved": FLOPS_PER_PIXEL_VISIT * stats["active_pixel_visits"] / (kms[1] * 1e-3) / 1e12,
-                                  "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": FLOPS_PER_PIXEL_VISIT * stats["active_pixel_visits"] / (kms[1] * 1e-3) / 1e12
-                                  / FP64_VECTOR_PEAK_TFLOPS,
-                                  "flops_per_pixel_visit": FLOPS_PER_PIXEL_VISIT},
+                         "valu_utilization": facts.get("pixel_kernel_valu_utilization") if args.dtype == "f64" else None,
                          "note": "the fused kernel is FP64-VALU bound, not HBM- or MFMA-bound (SURVEY.md F8, DESIGN.md 4.3): "
                                  "valu_utilization = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles from the committed PMC pass; "
-                                 "the HBM-bound kernel of the path is split_variant.kernel"},
+                                 "the HBM-bound kernel of the path is split_variant.kernel; figures are rank 0's launch"},
             "kernels_ms": {"prep": float(kms[0]), "pixel": float(kms[1]), "lift": float(kms[2])},
-            "pixel_visits_per_sec": pixel_visits / (kms[1] * 1e-3),
-            "grad_only_sources_per_sec_rank0": S / (dt_grad / args.steps),
+            "pixel_visits_per_sec_rank0": pixel_visits_local / (kms[1] * 1e-3),
         }
+        if fpp:
+            fl = fpp * stats["active_pixel_visits"] / (kms[1] * 1e-3) / 1e12
+            out["roofline"]["valu"] = {"achieved": fl, "peak": peak_fl, "unit": "TFLOP/s", "frac": fl / peak_fl,
+                                       "flops_per_pixel_visit": fpp, "dtype": args.dtype}
+            if args.dtype == "f64":
+                out["roofline"]["fp64"] = out["roofline"]["valu"]
+        out.update(out_extra)
         if split is not None:
             out["split_variant"] = split
-        if world == 1:
-            # secondary, end-to-end figure: ElboMaximize.maximize! (Newton trust region, <= 50 iterations, KL on)
-            # for every source of the field, neighbours frozen; wall time includes H2D/D2H and allocations
-            import celeste_jl_amd as _cel
-            ctx.maximize_batch(fld.vp, targets[:64], _cel.ElboConfig(max_iters=3))  # warm-up
-            t1 = time.perf_counter()
-            _, its, evals, _, ost = ctx.maximize_batch(fld.vp, targets, _cel.ElboConfig())
-            dt_opt = time.perf_counter() - t1
-            out["optimizer"] = {"optimized_sources_per_sec": S / dt_opt, "seconds": dt_opt,
-                                "mean_newton_iterations": float(its.mean()), "elbo_evaluations": int(evals.sum()),
-                                "failed": int((ost != 0).sum())}
+        if extras:
+            out.update(secondary_figures(ctx, fld, targets, args))
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ctx.problem, fld.vp, targets)
+            tg_cpu = targets if args.config == 3 else targets[:: max(1, S // 2000)]
+            out["cpu_baseline"] = cpu_baseline(ctx.problem, fld.vp, tg_cpu)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary_figures(ctx, fld, targets, args):
+    """End-to-end figures next to the headline (rank 0, one GPU): the host-pointer API the Julia shim calls, and
+    ElboMaximize.maximize! for every source."""
+    import celeste_jl_amd as cel
+    out = {}
+    S = len(targets)
+    # host-pointer API (celeste_elbo_eval_batch): vp H2D, kernels, D2H of v / d / h / counters / status
+    for packed in (False, True):
+        fl = FLAGS_ALL | (cel.cabi.FLAG_PACKED_HESS if packed else 0)
+        ctx.eval_batch(fld.vp, targets, fl)
+        t1 = time.perf_counter()
+        reps = 5 if S <= 4000 else 2
+        for _ in range(reps):
+            ctx.eval_batch(fld.vp, targets, fl)
+        out["host_api_sources_per_sec" + ("_packed_hessian" if packed else "")] = S * reps / (time.perf_counter() - t1)
+    if args.config == 3:
+        # ElboMaximize.maximize! (Newton trust region, <= 50 iterations, KL on) for every source of the field,
+        # neighbours frozen; wall time includes H2D/D2H
+        ctx.maximize_batch(fld.vp, targets[:64], cel.ElboConfig(max_iters=3))  # warm-up
+        t1 = time.perf_counter()
+        _, its, evals, _, ost = ctx.maximize_batch(fld.vp, targets, cel.ElboConfig())
+        dt_opt = time.perf_counter() - t1
+        out["optimizer"] = {"optimized_sources_per_sec": S / dt_opt, "seconds": dt_opt,
+                            "mean_newton_iterations": float(its.mean()), "elbo_evaluations": int(evals.sum()),
+                            "failed": int((ost != 0).sum())}
+    return out
 
 
 if __name__ == "__main__":

@@ -14,7 +14,8 @@ STAMP = 51
 COEF = 53
 
 OK, ERR_INVALID_ARG, ERR_NONFINITE_INPUT, ERR_NONFINITE_RESULT, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = range(7)
-FLAG_GRAD, FLAG_HESS, FLAG_KL, FLAG_FP32, FLAG_SPLIT = 1, 2, 4, 8, 16
+FLAG_GRAD, FLAG_HESS, FLAG_KL, FLAG_FP32, FLAG_SPLIT, FLAG_PACKED_HESS = 1, 2, 4, 8, 16, 32
+HP = 990   # doubles of a packed Hessian (upper triangle by columns)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libceleste_mi355x.so")
@@ -62,7 +63,8 @@ class OptimConfigT(C.Structure):
     """celeste_optim_config_t: ElboConfig defaults (ElboMaximize.jl:43-49, 95-108)"""
     _fields_ = [("loc_width", C.c_double), ("loc_scale", C.c_double), ("max_iters", C.c_int32),
                 ("include_kl", C.c_int32), ("xtol_abs", C.c_double), ("ftol_rel", C.c_double), ("gtol", C.c_double),
-                ("initial_delta", C.c_double), ("delta_hat", C.c_double)]
+                ("initial_delta", C.c_double), ("delta_hat", C.c_double), ("tr_secular_iters", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class CelesteError(RuntimeError):
@@ -77,6 +79,8 @@ EXPORTED_SYMBOLS = [
     "celeste_elbo_eval_batch", "celeste_elbo_eval_multi", "celeste_elbo_eval_batch_device", "celeste_ctx_enable_timing",
     "celeste_ctx_last_kernel_ms", "celeste_ctx_last_record_sum_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter", "celeste_psf_raster",
     "celeste_maximize_batch", "celeste_render_expected", "celeste_optim_stats",
+    "celeste_images_create", "celeste_images_destroy", "celeste_ctx_create_on",
+    "celeste_host_alloc", "celeste_host_free", "celeste_host_register", "celeste_host_unregister",
 ]
 
 _lib = None
@@ -126,6 +130,16 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                            C.POINTER(OptimConfigT), c_int32_p, c_int32_p, c_double_p, c_int32_p]
     lib.celeste_optim_stats.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.celeste_render_expected.argtypes = [vp, c_double_p, C.c_int32, c_double_p]
+    lib.celeste_images_create.argtypes = [C.c_int32, C.POINTER(ImageT), C.c_int, C.POINTER(vp)]
+    lib.celeste_images_destroy.argtypes = [vp]
+    lib.celeste_images_destroy.restype = None
+    lib.celeste_ctx_create_on.argtypes = [vp, C.POINTER(ProblemT), C.POINTER(vp)]
+    lib.celeste_host_alloc.argtypes = [C.c_size_t]
+    lib.celeste_host_alloc.restype = vp
+    lib.celeste_host_free.argtypes = [vp]
+    lib.celeste_host_free.restype = None
+    lib.celeste_host_register.argtypes = [vp, C.c_size_t]
+    lib.celeste_host_unregister.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -138,6 +152,115 @@ def check(status: int, lib=None):
 
 def _dp(a: np.ndarray):
     return a.ctypes.data_as(c_double_p)
+
+
+def marshal_image_structs(images, keep: list):
+    """Model.Image list -> celeste_image_t array (column-major float32 planes; `keep` holds the buffers alive)."""
+    c_images = (ImageT * len(images))()
+    for n, im in enumerate(images):
+        pix = np.asfortranarray(im.pixels, dtype=np.float32)
+        sky = np.asfortranarray(im.sky, dtype=np.float32)
+        iota = np.ascontiguousarray(im.nelec_per_nmgy, dtype=np.float32)
+        assert sky.shape == pix.shape and iota.shape == (pix.shape[0],)
+        keep += [pix, sky, iota]
+        ci = c_images[n]
+        ci.H, ci.W, ci.band = pix.shape[0], pix.shape[1], int(im.b)
+        ci.pixels = pix.ctypes.data_as(c_float_p)
+        ci.sky = sky.ctypes.data_as(c_float_p)
+        ci.nelec_per_nmgy = iota.ctypes.data_as(c_float_p)
+    return c_images
+
+
+class ImageSet:
+    """celeste_images_t: the image planes of a box in HBM, shared by every context created on it -- the reference's
+    per-source `ElboArgs(images, patches[[t; neighbors], :], [1])` all borrow the same `images`
+    (process_source, ParallelRun.jl:468-488).  Reference counted by the library: `close()` drops this object's
+    reference; the planes are released when the last context on the set is closed too."""
+
+    def __init__(self, images, device: int = 0):
+        self.lib = load_library()
+        self.images = images
+        self.device = device
+        keep: List[object] = []
+        c_images = marshal_image_structs(images, keep)
+        h = C.c_void_p()
+        check(self.lib.celeste_images_create(len(images), c_images, device, C.byref(h)), self.lib)
+        self.handle = h   # the host planes are not needed after the upload
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.celeste_images_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- page-locked host arrays for the host-pointer entry points ----------------------------------------------
+class _PinnedBlock:
+    """One celeste_host_alloc block; returns to the pool (or is freed) when the last array on it dies."""
+    __slots__ = ("ptr", "nbytes", "__weakref__")
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+
+    def __del__(self):
+        try:
+            _pinned_release(self.ptr, self.nbytes)
+        except Exception:
+            pass
+
+
+_pinned_pool = {}          # nbytes -> [ptr, ...]
+_pinned_pool_bytes = [0]
+PINNED_POOL_LIMIT = 1 << 30
+
+
+def _pinned_release(ptr, nbytes):
+    if _lib is None:
+        return
+    if _pinned_pool_bytes[0] + nbytes <= PINNED_POOL_LIMIT:
+        _pinned_pool.setdefault(nbytes, []).append(ptr)
+        _pinned_pool_bytes[0] += nbytes
+    else:
+        _lib.celeste_host_free(ptr)
+
+
+def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
+    """np.empty in page-locked memory (celeste_host_alloc): the library DMAs results straight into such arrays.
+    Blocks are recycled through a size-keyed pool, because page-locking is slow (the array may be kept as long as
+    needed: its block goes back to the pool when the array is garbage collected)."""
+    lib = load_library()
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    dt = np.dtype(dtype)
+    nbytes = max(int(np.prod(shape)) * dt.itemsize, 1)
+    nbytes = (nbytes + 4095) // 4096 * 4096
+    free = _pinned_pool.get(nbytes)
+    if free:
+        ptr = free.pop()
+        _pinned_pool_bytes[0] -= nbytes
+    else:
+        ptr = lib.celeste_host_alloc(nbytes)
+        if not ptr:   # no device / out of lockable memory: plain pageable memory works too (staged by the library)
+            return np.empty(shape, dtype=dt)
+    block = _PinnedBlock(ptr, nbytes)
+    buf = (C.c_char * nbytes).from_address(ptr)
+    buf._celeste_block = block   # ties the block's lifetime to the ctypes buffer numpy keeps as its base
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
+def unpack_hessian(hp: np.ndarray) -> np.ndarray:
+    """[..., 990] packed upper triangles (CELESTE_FLAG_PACKED_HESS) -> [..., 44, 44] symmetric matrices."""
+    hp = np.asarray(hp)
+    iu = np.triu_indices(P)            # row-major (i <= j) pairs ...
+    order = np.argsort(iu[1] * (iu[1] + 1) // 2 + iu[0], kind="stable")   # ... -> position j (j + 1) / 2 + i
+    out = np.zeros(hp.shape[:-1] + (P, P))
+    out[..., iu[0][order], iu[1][order]] = hp
+    out[..., iu[1][order], iu[0][order]] = hp
+    return out
 
 
 def prior_struct(prior: dict) -> PriorT:
@@ -166,24 +289,15 @@ class Problem:
     """
 
     def __init__(self, images, patches, neighbors: Optional[Sequence[Sequence[int]]] = None, psf_K: int = 2,
-                 prior: Optional[dict] = None):
+                 prior: Optional[dict] = None, marshal_images: bool = True):
+        """marshal_images=False: the planes already live on the device behind a shared image handle (`ImageSet`);
+        the struct's `images` stays NULL and only patches / stamps / neighbours are marshalled."""
         from .model import PatchRow
         self.images = images
         self.patches = patches
         N, S = len(images), len(patches)
         self._keep: List[object] = []
-        self.c_images = (ImageT * N)()
-        for n, im in enumerate(images):
-            pix = np.asfortranarray(im.pixels, dtype=np.float32)
-            sky = np.asfortranarray(im.sky, dtype=np.float32)
-            iota = np.ascontiguousarray(im.nelec_per_nmgy, dtype=np.float32)
-            assert sky.shape == pix.shape and iota.shape == (pix.shape[0],)
-            self._keep += [pix, sky, iota]
-            ci = self.c_images[n]
-            ci.H, ci.W, ci.band = pix.shape[0], pix.shape[1], int(im.b)
-            ci.pixels = pix.ctypes.data_as(c_float_p)
-            ci.sky = sky.ctypes.data_as(c_float_p)
-            ci.nelec_per_nmgy = iota.ctypes.data_as(c_float_p)
+        self.c_images = marshal_image_structs(images, self._keep) if marshal_images else None
         # shared stamp table: deduplicate by content of the raw stamp (object identity first: a constant PSF map hands
         # the same array to every patch of an image)
         stamps: List[np.ndarray] = []
@@ -251,7 +365,8 @@ class Problem:
         self.c_prior = prior_struct(prior) if prior is not None else None
         self.c = ProblemT()
         self.c.n_images, self.c.n_sources, self.c.psf_K, self.c.n_stamps = N, S, psf_K, len(stamps)
-        self.c.images = self.c_images
+        if self.c_images is not None:
+            self.c.images = self.c_images
         self.c.patches = self.c_patches
         self.c.stamps = _dp(self.stamps)
         self.c.nbr_offsets = off.ctypes.data_as(c_int64_p)

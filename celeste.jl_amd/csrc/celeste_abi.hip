@@ -6,6 +6,7 @@
 // that computes returns CELESTE_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,8 +30,29 @@ static const celeste_prior_t DEFAULT_PRIOR =
 #include "prior_tables.inc"
     ;
 
+// image planes in HBM, shared by every context created on the handle (reference counted)
+struct celeste_images {
+    int device = 0;
+    int N = 0;
+    std::vector<DevImage> h_images;
+    std::vector<void *> plane_allocs;
+    DevImage *d_images = nullptr;
+    std::atomic<int> refs{1};
+};
+
+static void images_release(celeste_images *im) {
+    if (!im || im->refs.fetch_sub(1) != 1) return;
+    (void)hipSetDevice(im->device);
+    for (void *p : im->plane_allocs) (void)hipFree(p);
+    if (im->d_images) (void)hipFree(im->d_images);
+    delete im;
+}
+
 struct celeste_ctx {
     int device = 0;
+    celeste_images *imgs = nullptr;
+    hipStream_t stream = nullptr;        // private non-blocking stream of the host-pointer entry points
+    hipStream_t copy_stream = nullptr;   // device-to-host copies of finished parts of a batch
     int N = 0, S = 0, K = 0, NC = 0, n_stamps = 0;
     int chunk_px = 256, CH = 1;
     int max_npx = 0;
@@ -38,10 +60,8 @@ struct celeste_ctx {
     std::vector<DevPatch> h_patches;
     std::vector<int64_t> h_nbr_off;
     std::vector<int32_t> h_nbr_idx;
-    std::vector<DevImage> h_images;
     // device
-    std::vector<void *> plane_allocs;
-    DevImage *d_images = nullptr;
+    DevImage *d_images = nullptr;        // = imgs->d_images
     DevPatch *d_patches = nullptr;
     double *d_coefs = nullptr;
     uint8_t *d_bitmaps = nullptr;
@@ -82,13 +102,20 @@ struct celeste_ctx {
     // per-batch scratch (grown on demand)
     double *d_acc = nullptr;
     size_t acc_cap = 0;
-    // staging for the host-pointer API
+    // staging for the host-pointer API: device side, and page-locked host side
     double *d_vp = nullptr;
     int32_t *d_targets = nullptr;
     double *d_v = nullptr, *d_d = nullptr, *d_h = nullptr;
     int64_t *d_cnt = nullptr;
     int32_t *d_status = nullptr;
     size_t stage_cap = 0;
+    double *p_vp = nullptr;              // pinned: S x 44
+    int32_t *p_targets = nullptr, *p_status = nullptr;
+    double *p_v = nullptr, *p_d = nullptr, *p_h = nullptr;
+    int64_t *p_cnt = nullptr;
+    size_t pin_cap = 0;
+    static const int MAX_PARTS = 8;
+    hipEvent_t part_done[MAX_PARTS] = {}, part_copied[MAX_PARTS] = {};
     // buffers of celeste_maximize_batch, kept between calls (grown on demand)
     struct OptBuffers {
         size_t cap = 0;
@@ -96,6 +123,12 @@ struct celeste_ctx {
         int32_t *d_targets = nullptr, *d_act[2] = {nullptr, nullptr}, *d_evt[2] = {nullptr, nullptr}, *d_count = nullptr,
                 *d_st = nullptr;
         void *d_state = nullptr;
+        // page-locked: the parameter table (in / out), the final optimiser states, a ring of live-target counts
+        static const int RING = 4;
+        double *h_vp = nullptr;
+        void *h_state = nullptr;
+        int32_t *h_count = nullptr;
+        hipEvent_t ev[RING] = {};
     } opt;
     // timing
     int timing = 0;
@@ -213,38 +246,31 @@ static int select_device(int device) {
     return CELESTE_OK;
 }
 
-extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celeste_ctx_t **out) {
-    if (!pr || !out) return CELESTE_ERR_INVALID_ARG;
+extern "C" int celeste_images_create(int32_t n_images, const celeste_image_t *images, int device,
+                                     celeste_images_t **out) {
+    if (!images || !out || n_images <= 0) return CELESTE_ERR_INVALID_ARG;
     *out = nullptr;
-    if (pr->n_images <= 0 || pr->n_sources <= 0 || pr->psf_K <= 0 || pr->psf_K > CEL_MAXK ||
-        !pr->images || !pr->patches || pr->n_stamps <= 0 || !pr->stamps || 14 * pr->psf_K > 62)
-        return CELESTE_ERR_INVALID_ARG;
     int st = select_device(device);
     if (st != CELESTE_OK) return st;
-
-    celeste_ctx *c = new (std::nothrow) celeste_ctx();
+    celeste_images *c = new (std::nothrow) celeste_images();
     if (!c) return CELESTE_ERR_ALLOC;
-    c->device = device;
-    c->N = pr->n_images; c->S = pr->n_sources; c->K = pr->psf_K; c->NC = 14 * pr->psf_K;
-    c->n_stamps = pr->n_stamps;
-#define CTX_TRY(expr) do { int s__ = (expr); if (s__ != CELESTE_OK) { celeste_ctx_destroy(c); return s__; } } while (0)
-
-    // images
+    c->device = device; c->N = n_images;
+#define IMG_TRY(expr) do { int s__ = (expr); if (s__ != CELESTE_OK) { images_release(c); return s__; } } while (0)
     c->h_images.resize(c->N);
     for (int n = 0; n < c->N; ++n) {
-        const celeste_image_t &im = pr->images[n];
+        const celeste_image_t &im = images[n];
         if (im.H <= 0 || im.W <= 0 || im.band < 1 || im.band > 5 || !im.pixels || !im.sky || !im.nelec_per_nmgy) {
-            celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG;
+            images_release(c); return CELESTE_ERR_INVALID_ARG;
         }
         DevImage d; d.H = im.H; d.W = im.W; d.band = im.band; d.pad = 0;
         float *dp = nullptr, *ds = nullptr, *di = nullptr;
-        CTX_TRY(dev_upload(&dp, im.pixels, (size_t)im.H * im.W)); c->plane_allocs.push_back(dp);
-        CTX_TRY(dev_upload(&ds, im.sky, (size_t)im.H * im.W)); c->plane_allocs.push_back(ds);
-        CTX_TRY(dev_upload(&di, im.nelec_per_nmgy, (size_t)im.H)); c->plane_allocs.push_back(di);
+        IMG_TRY(dev_upload(&dp, im.pixels, (size_t)im.H * im.W)); c->plane_allocs.push_back(dp);
+        IMG_TRY(dev_upload(&ds, im.sky, (size_t)im.H * im.W)); c->plane_allocs.push_back(ds);
+        IMG_TRY(dev_upload(&di, im.nelec_per_nmgy, (size_t)im.H)); c->plane_allocs.push_back(di);
         d.pixels = dp; d.sky = ds; d.iota = di;
         double *dl = nullptr, *dli = nullptr;
-        CTX_TRY(dev_upload<double>(&dl, nullptr, (size_t)im.H * im.W)); c->plane_allocs.push_back(dl);
-        CTX_TRY(dev_upload<double>(&dli, nullptr, (size_t)im.H)); c->plane_allocs.push_back(dli);
+        IMG_TRY(dev_upload<double>(&dl, nullptr, (size_t)im.H * im.W)); c->plane_allocs.push_back(dl);
+        IMG_TRY(dev_upload<double>(&dli, nullptr, (size_t)im.H)); c->plane_allocs.push_back(dli);
         {
             const size_t npix = (size_t)im.H * im.W;
             hipLaunchKernelGGL(plane_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, nullptr, dp, di, im.H,
@@ -253,8 +279,49 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
         d.lgx = dl; d.log_iota = dli;
         c->h_images[n] = d;
     }
-    CTX_TRY(dev_upload(&c->d_images, c->h_images.data(), c->h_images.size()));
-    if (hipDeviceSynchronize() != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
+    IMG_TRY(dev_upload(&c->d_images, c->h_images.data(), c->h_images.size()));
+#undef IMG_TRY
+    if (hipDeviceSynchronize() != hipSuccess) { images_release(c); return CELESTE_ERR_HIP; }
+    *out = c;
+    return CELESTE_OK;
+}
+
+extern "C" void celeste_images_destroy(celeste_images_t *images) { images_release(images); }
+
+extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celeste_ctx_t **out) {
+    if (!pr || !out) return CELESTE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (pr->n_images <= 0 || !pr->images) return CELESTE_ERR_INVALID_ARG;
+    celeste_images_t *im = nullptr;
+    int st = celeste_images_create(pr->n_images, pr->images, device, &im);
+    if (st != CELESTE_OK) return st;
+    st = celeste_ctx_create_on(im, pr, out);
+    images_release(im);   // the context holds its own reference
+    return st;
+}
+
+extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_problem_t *pr, celeste_ctx_t **out) {
+    if (!imgs || !pr || !out) return CELESTE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (pr->n_images != imgs->N || pr->n_sources <= 0 || pr->psf_K <= 0 || pr->psf_K > CEL_MAXK ||
+        !pr->patches || pr->n_stamps <= 0 || !pr->stamps || 14 * pr->psf_K > 62)
+        return CELESTE_ERR_INVALID_ARG;
+    const int device = imgs->device;
+    int st = select_device(device);
+    if (st != CELESTE_OK) return st;
+
+    celeste_ctx *c = new (std::nothrow) celeste_ctx();
+    if (!c) return CELESTE_ERR_ALLOC;
+    c->device = device;
+    c->imgs = imgs; imgs->refs.fetch_add(1);
+    c->d_images = imgs->d_images;
+    c->N = pr->n_images; c->S = pr->n_sources; c->K = pr->psf_K; c->NC = 14 * pr->psf_K;
+    c->n_stamps = pr->n_stamps;
+#define CTX_TRY(expr) do { int s__ = (expr); if (s__ != CELESTE_OK) { celeste_ctx_destroy(c); return s__; } } while (0)
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        celeste_ctx_destroy(c); return CELESTE_ERR_HIP;
+    }
 
     // patches + explicit bitmaps (dense [s * N + n] table, or the sparse list sorted by (source, image))
     {
@@ -278,7 +345,7 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
             q = (size_t)prev;
         }
         const celeste_patch_t &p = pr->patches[k];
-        const celeste_image_t &im = pr->images[q % c->N];
+        const DevImage &im = imgs->h_images[q % c->N];
         DevPatch d; memset(&d, 0, sizeof d);
         d.off_h = p.off_h; d.off_w = p.off_w; d.H2 = p.H2 < 0 ? 0 : p.H2; d.W2 = p.W2 < 0 ? 0 : p.W2;
         if (d.H2 > 0 && d.W2 > 0 &&
@@ -430,6 +497,13 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
     }
     for (int i = 0; i < 5; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
+    for (int i = 0; i < celeste_ctx::MAX_PARTS; ++i)
+        if (hipEventCreateWithFlags(&c->part_done[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->part_copied[i], hipEventDisableTiming) != hipSuccess) {
+            celeste_ctx_destroy(c); return CELESTE_ERR_HIP;
+        }
+    // the constant tables above were written on the NULL stream; the context's own streams do not wait for it
+    if (hipStreamSynchronize(nullptr) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
 #undef CTX_TRY
     *out = c;
     return CELESTE_OK;
@@ -438,8 +512,9 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
 extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (void *p : c->plane_allocs) (void)hipFree(p);
-    void *ptrs[] = {c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    void *ptrs[] = {c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
                     c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_item_link, c->d_item_img_chunk, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -448,15 +523,27 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
         void *optr[] = {o.d_vp, o.d_v, o.d_d, o.d_h, o.d_H, o.d_pos, o.d_targets, o.d_act[0], o.d_act[1], o.d_evt[0], o.d_evt[1],
                         o.d_count, o.d_st, o.d_state};
         for (void *q : optr) if (q) (void)hipFree(q);
+        void *hptr[] = {o.h_vp, o.h_state, o.h_count};
+        for (void *q : hptr) if (q) (void)hipHostFree(q);
+        for (int k = 0; k < celeste_ctx::OptBuffers::RING; ++k) if (o.ev[k]) (void)hipEventDestroy(o.ev[k]);
     }
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < celeste_ctx::MAX_PARTS; ++i) {
+        if (c->part_done[i]) (void)hipEventDestroy(c->part_done[i]);
+        if (c->part_copied[i]) (void)hipEventDestroy(c->part_copied[i]);
+    }
+    void *pins[] = {c->p_vp, c->p_targets, c->p_status, c->p_v, c->p_d, c->p_h, c->p_cnt};
+    for (void *q : pins) if (q) (void)hipHostFree(q);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    images_release(c->imgs);
     delete c;
 }
 
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
                        void *stream_, bool render_neighbors, const int32_t *d_active_rank = nullptr,
-                       int64_t n_chunks = -1);
+                       int64_t n_chunks = -1, bool tables_current = false, const int32_t *d_live = nullptr);
 
 extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_vp, int32_t n_targets,
                                               const int32_t *d_targets, uint32_t flags, double *d_v, double *d_d,
@@ -468,7 +555,12 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
 // during an optimisation, ParallelRun.jl:474-488)
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
-                       void *stream_, bool render_neighbors, const int32_t *d_active_rank, int64_t n_chunks) {
+                       void *stream_, bool render_neighbors, const int32_t *d_active_rank, int64_t n_chunks,
+                       bool tables_current, const int32_t *d_live) {
+    // d_live (device, optional): the number of leading entries of d_targets that are live; n_targets is then an upper
+    // bound known to the host (the optimiser loop runs ahead of the device)
+    // tables_current: the per-(source, image) tables were filled from this very vp by an earlier launch of the same
+    // call (parts of one host batch): only the neighbours of this part's targets are rendered
     if (!c || !d_vp || !d_targets || !d_v || !d_status || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
     if ((flags & CELESTE_FLAG_HESS) && !d_h) return CELESTE_ERR_INVALID_ARG;
     if ((flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) && !d_d) return CELESTE_ERR_INVALID_ARG;
@@ -529,20 +621,20 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            render_neighbors ? c->d_needed : nullptr);
     }
     hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
-                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, (int)c->dense, c->d_work_blk);
+                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, (int)c->dense, c->d_work_blk, d_live);
     hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * n_classes, c->d_work_total);
     hipLaunchKernelGGL(work_fill_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
-                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, (int)c->dense, c->d_work_blk, c->d_work);
+                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, (int)c->dense, c->d_work_blk, c->d_work, d_live);
     // per-(source, image) constants: of every source when the neighbours are (re)rendered, else of the targets only
     if (render_neighbors) {
-        if (c->V > 0)
+        if (c->V > 0 && !tables_current)
             hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches,
                                c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr, c->d_vis_off, c->M,
-                               (int)c->dense);
+                               (int)c->dense, nullptr);
     } else {
         hipLaunchKernelGGL(prep_kernel, dim3((unsigned)std::max(n_visits, 1)), dim3(64), 0, stream, d_vp, c->d_images,
                            c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, d_targets,
-                           c->d_vis_off, c->M, (int)c->dense);
+                           c->d_vis_off, c->M, (int)c->dense, d_live);
     }
     if (render_neighbors) {
     if (c->n_value_items > 0)
@@ -585,17 +677,57 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                            c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M,
                            c->RCH, c->sum_tiles * 64, flags,
-                           d_v, d_d, d_h, d_counters, d_status);
+                           d_v, d_d, d_h, d_counters, d_status, d_live);
     } else
     hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                        c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH,
                        c->chunk_px, flags,
-                       d_v, d_d, d_h, d_counters, d_status);
+                       d_v, d_d, d_h, d_counters, d_status, d_live);
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[3], stream)); c->ev_valid = 1; }
     HIP_TRY(hipGetLastError());
     return CELESTE_OK;
 }
 
+// ---- page-locked host memory ---------------------------------------------------------------------------------
+extern "C" void *celeste_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void celeste_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
+extern "C" int celeste_host_register(void *ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return CELESTE_ERR_INVALID_ARG;
+    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return CELESTE_ERR_HIP; }
+    return CELESTE_OK;
+}
+extern "C" int celeste_host_unregister(void *ptr) {
+    if (!ptr) return CELESTE_ERR_INVALID_ARG;
+    if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return CELESTE_ERR_HIP; }
+    return CELESTE_OK;
+}
+// is [ptr, ptr + bytes) page-locked memory the DMA engines can write directly?
+static bool is_pinned(const void *ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a.type != hipMemoryTypeHost) return false;
+    if (hipPointerGetAttributes(&a, (const char *)ptr + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+template <class T>
+static int pinned_grow(T **p, size_t n) {
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; }
+    HIP_TRY(hipHostMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault));
+    return CELESTE_OK;
+}
+
+// The host-pointer sweep (what the Julia shim calls).  vp and the target list go up through page-locked staging;
+// the batch is cut into up to MAX_PARTS parts that are evaluated back to back on the context's stream, and each
+// part's results are copied down on the copy stream while the next part computes -- straight into the caller's
+// buffers when those are page-locked (celeste_host_alloc / celeste_host_register), else into page-locked staging
+// followed by a host copy of that part (which again overlaps the device work of the following parts).  Only the
+// context's own streams are waited for.
 extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32_t n_targets, const int32_t *targets,
                                        uint32_t flags, double *v, double *d, double *h, int64_t *counters,
                                        int32_t *status) {
@@ -603,11 +735,18 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
     if (n_targets == 0) return CELESTE_OK;
     for (int t = 0; t < n_targets; ++t) if (targets[t] < 0 || targets[t] >= c->S) return CELESTE_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    if (!c->d_vp) HIP_TRY(hipMalloc((void **)&c->d_vp, (size_t)c->S * CEL_P * sizeof(double)));
-    if ((size_t)n_targets > c->stage_cap) {
+    const bool want_h = h && (flags & CELESTE_FLAG_HESS);
+    const bool want_d = d && (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS));
+    const size_t HS = (flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;   // doubles per Hessian
+    const size_t n = (size_t)n_targets;
+    const size_t vp_bytes = (size_t)c->S * CEL_P * sizeof(double);
+    if (!c->d_vp) HIP_TRY(hipMalloc((void **)&c->d_vp, vp_bytes));
+    if (!c->p_vp) { int st = pinned_grow(&c->p_vp, (size_t)c->S * CEL_P); if (st != CELESTE_OK) return st; }
+    if (n > c->stage_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
         void **ps[] = {(void **)&c->d_targets, (void **)&c->d_v, (void **)&c->d_d, (void **)&c->d_h, (void **)&c->d_cnt, (void **)&c->d_status};
         for (void **p : ps) if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; }
-        const size_t n = (size_t)n_targets;
+        c->stage_cap = 0;
         HIP_TRY(hipMalloc((void **)&c->d_targets, n * sizeof(int32_t)));
         HIP_TRY(hipMalloc((void **)&c->d_v, n * sizeof(double)));
         HIP_TRY(hipMalloc((void **)&c->d_d, n * CEL_P * sizeof(double)));
@@ -616,26 +755,73 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
         HIP_TRY(hipMalloc((void **)&c->d_status, n * sizeof(int32_t)));
         c->stage_cap = n;
     }
-    HIP_TRY(hipMemcpy(c->d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_targets, targets, (size_t)n_targets * sizeof(int32_t), hipMemcpyHostToDevice));
-    int64_t n_chunks = 0;   // the targets are known here: exact size of the pixel kernel's work list
-    for (int t = 0; t < n_targets; ++t) n_chunks += c->h_src_chunks[targets[t]];
-    int st = launch_eval(c, c->d_vp, n_targets, c->d_targets, flags, c->d_v, c->d_d, c->d_h, c->d_cnt, c->d_status,
-                         nullptr, true, nullptr, n_chunks);
-    if (st != CELESTE_OK) return st;
-    HIP_TRY(hipDeviceSynchronize());
-    std::vector<int32_t> hst(n_targets);
-    HIP_TRY(hipMemcpy(hst.data(), c->d_status, (size_t)n_targets * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (v) HIP_TRY(hipMemcpy(v, c->d_v, (size_t)n_targets * sizeof(double), hipMemcpyDeviceToHost));
-    if (d && (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)))
-        HIP_TRY(hipMemcpy(d, c->d_d, (size_t)n_targets * CEL_P * sizeof(double), hipMemcpyDeviceToHost));
-    if (h && (flags & CELESTE_FLAG_HESS))
-        HIP_TRY(hipMemcpy(h, c->d_h, (size_t)n_targets * CEL_P * CEL_P * sizeof(double), hipMemcpyDeviceToHost));
-    if (counters) HIP_TRY(hipMemcpy(counters, c->d_cnt, (size_t)n_targets * 2 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    // which outputs need staging on the host
+    const bool pin_v = is_pinned(v, n * sizeof(double)), pin_d = !want_d || is_pinned(d, n * CEL_P * sizeof(double));
+    const bool pin_h = !want_h || is_pinned(h, n * HS * sizeof(double));
+    const bool pin_c = !counters || is_pinned(counters, n * 2 * sizeof(int64_t));
+    if (n > c->pin_cap) {
+        c->pin_cap = 0;
+        int st = pinned_grow(&c->p_targets, n);
+        if (st == CELESTE_OK) st = pinned_grow(&c->p_status, n);
+        if (st == CELESTE_OK) st = pinned_grow(&c->p_v, n);
+        if (st == CELESTE_OK) st = pinned_grow(&c->p_d, n * CEL_P);
+        if (st == CELESTE_OK) st = pinned_grow(&c->p_cnt, n * 2);
+        if (st == CELESTE_OK) st = pinned_grow(&c->p_h, n * CEL_P * CEL_P);
+        if (st != CELESTE_OK) return st;
+        c->pin_cap = n;
+    }
+    // inputs: through page-locked staging unless the caller's vp already is page-locked
+    const double *vp_src = vp;
+    if (!is_pinned(vp, vp_bytes)) { memcpy(c->p_vp, vp, vp_bytes); vp_src = c->p_vp; }
+    memcpy(c->p_targets, targets, n * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(c->d_vp, vp_src, vp_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_targets, c->p_targets, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+
+    // parts: at least 192 targets each so that a part still fills the chip; one part when nothing large comes back
+    int n_parts = 1;
+    if (want_h) n_parts = (int)std::min<size_t>(celeste_ctx::MAX_PARTS, std::max<size_t>(1, n / 192));
+    if (c->timing) n_parts = 1;   // the kernel timers describe one launch
+    double *const o_v = pin_v ? v : c->p_v;
+    double *const o_d = want_d ? (pin_d ? d : c->p_d) : nullptr;
+    double *const o_h = want_h ? (pin_h ? h : c->p_h) : nullptr;
+    int64_t *const o_c = counters ? (pin_c ? counters : c->p_cnt) : nullptr;
+    int part_lo[celeste_ctx::MAX_PARTS + 1];
+    for (int k = 0; k <= n_parts; ++k) part_lo[k] = (int)((int64_t)n_targets * k / n_parts);
+    for (int k = 0; k < n_parts; ++k) {
+        const int lo = part_lo[k], cnt = part_lo[k + 1] - lo;
+        int64_t n_chunks = 0;   // the targets are known here: exact size of the pixel kernel's work list
+        for (int t = lo; t < lo + cnt; ++t) n_chunks += c->h_src_chunks[targets[t]];
+        int st = launch_eval(c, c->d_vp, cnt, c->d_targets + lo, flags, c->d_v + lo, c->d_d + (size_t)lo * CEL_P,
+                             c->d_h + (size_t)lo * HS, c->d_cnt + 2 * (size_t)lo, c->d_status + lo, c->stream, true,
+                             nullptr, n_chunks, k > 0);
+        if (st != CELESTE_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy_stream); return st; }
+        HIP_TRY(hipEventRecord(c->part_done[k], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->part_done[k], 0));
+        if (o_h) HIP_TRY(hipMemcpyAsync(o_h + (size_t)lo * HS, c->d_h + (size_t)lo * HS, (size_t)cnt * HS * sizeof(double),
+                                        hipMemcpyDeviceToHost, c->copy_stream));
+        if (o_d) HIP_TRY(hipMemcpyAsync(o_d + (size_t)lo * CEL_P, c->d_d + (size_t)lo * CEL_P,
+                                        (size_t)cnt * CEL_P * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(o_v + lo, c->d_v + lo, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
+        if (o_c) HIP_TRY(hipMemcpyAsync(o_c + 2 * (size_t)lo, c->d_cnt + 2 * (size_t)lo, (size_t)cnt * 2 * sizeof(int64_t),
+                                        hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(c->p_status + lo, c->d_status + lo, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost,
+                               c->copy_stream));
+        HIP_TRY(hipEventRecord(c->part_copied[k], c->copy_stream));
+    }
+    for (int k = 0; k < n_parts; ++k) {   // staged outputs: host copy of part k while later parts are still in flight
+        const int lo = part_lo[k], cnt = part_lo[k + 1] - lo;
+        HIP_TRY(hipEventSynchronize(c->part_copied[k]));
+        if (v && !pin_v) memcpy(v + lo, c->p_v + lo, (size_t)cnt * sizeof(double));
+        if (want_d && !pin_d) memcpy(d + (size_t)lo * CEL_P, c->p_d + (size_t)lo * CEL_P, (size_t)cnt * CEL_P * sizeof(double));
+        if (want_h && !pin_h) memcpy(h + (size_t)lo * HS, c->p_h + (size_t)lo * HS, (size_t)cnt * HS * sizeof(double));
+        if (counters && !pin_c) memcpy(counters + 2 * (size_t)lo, c->p_cnt + 2 * (size_t)lo, (size_t)cnt * 2 * sizeof(int64_t));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     int worst = CELESTE_OK;
     for (int t = 0; t < n_targets; ++t) {
-        if (status) status[t] = hst[t];
-        if (hst[t] != CELESTE_OK && worst == CELESTE_OK) worst = hst[t];
+        const int32_t s1 = c->p_status[t];
+        if (status) status[t] = s1;
+        if (s1 != CELESTE_OK && worst == CELESTE_OK) worst = s1;
     }
     return worst;
 }
@@ -656,7 +842,7 @@ extern "C" int celeste_elbo_eval(celeste_ctx_t *c, const double *vp, int32_t tar
 extern "C" int celeste_elbo_eval_multi(celeste_ctx_t *c, const double *vp, int32_t n_active, const int32_t *active,
                                        uint32_t flags, double *v, double *d, double *h, int64_t *n_active_px,
                                        int64_t *n_inactive_px) {
-    if (!c || !vp || !active || n_active < 1 || (flags & CELESTE_FLAG_SPLIT)) return CELESTE_ERR_INVALID_ARG;
+    if (!c || !vp || !active || n_active < 1 || (flags & (CELESTE_FLAG_SPLIT | CELESTE_FLAG_PACKED_HESS))) return CELESTE_ERR_INVALID_ARG;
     const int Sa = n_active;
     for (int a = 0; a < Sa; ++a) {
         if (active[a] < 0 || active[a] >= c->S) return CELESTE_ERR_INVALID_ARG;
@@ -697,31 +883,31 @@ extern "C" int celeste_elbo_eval_multi(celeste_ctx_t *c, const double *vp, int32
     MU_TRY(hipMalloc((void **)&d_st, Sa * sizeof(int32_t)));
     MU_TRY(hipMalloc((void **)&d_cnt, (size_t)Sa * 2 * sizeof(int64_t)));
     MU_TRY(hipMalloc((void **)&d_rank, (size_t)c->S * sizeof(int32_t)));
-    MU_TRY(hipMemcpy(d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
-    MU_TRY(hipMemcpy(d_t, active, Sa * sizeof(int32_t), hipMemcpyHostToDevice));
-    MU_TRY(hipMemcpy(d_rank, rank.data(), (size_t)c->S * sizeof(int32_t), hipMemcpyHostToDevice));
-    rc = launch_eval(c, d_vp, Sa, d_t, flags, d_v, d_d, d_h, d_cnt, d_st, nullptr, true, d_rank);
+    MU_TRY(hipMemcpyAsync(d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    MU_TRY(hipMemcpyAsync(d_t, active, Sa * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    MU_TRY(hipMemcpyAsync(d_rank, rank.data(), (size_t)c->S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    rc = launch_eval(c, d_vp, Sa, d_t, flags, d_v, d_d, d_h, d_cnt, d_st, c->stream, true, d_rank);
     if (rc != CELESTE_OK) goto done;
     if (np > 0) {
         MU_TRY(hipMalloc((void **)&d_pa, np * sizeof(int32_t)));
         MU_TRY(hipMalloc((void **)&d_pb, np * sizeof(int32_t)));
         MU_TRY(hipMalloc((void **)&d_rec, np * c->N * ZV * ZV * sizeof(double)));
         MU_TRY(hipMalloc((void **)&d_x, np * LIFT_NP * LIFT_NP * sizeof(double)));
-        MU_TRY(hipMemcpy(d_pa, pa.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
-        MU_TRY(hipMemcpy(d_pb, pb.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(cross_kernel, dim3((unsigned)(np * c->N)), dim3(64), 0, nullptr, c->d_images, c->d_patches,
+        MU_TRY(hipMemcpyAsync(d_pa, pa.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        MU_TRY(hipMemcpyAsync(d_pb, pb.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(cross_kernel, dim3((unsigned)(np * c->N)), dim3(64), 0, c->stream, c->d_images, c->d_patches,
                            c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off,
                            c->d_val, d_pa, d_pb, c->N, c->NC, d_rec);
-        hipLaunchKernelGGL(cross_lift_kernel, dim3((unsigned)np), dim3(256), 0, nullptr, d_vp, c->d_images, c->d_patches,
+        hipLaunchKernelGGL(cross_lift_kernel, dim3((unsigned)np), dim3(256), 0, c->stream, d_vp, c->d_images, c->d_patches,
                            c->d_geo, d_pa, d_pb, d_rec, c->N, d_x);
-        MU_TRY(hipMemcpy(hx.data(), d_x, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
+        MU_TRY(hipMemcpyAsync(hx.data(), d_x, hx.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    MU_TRY(hipDeviceSynchronize());
-    MU_TRY(hipMemcpy(hv.data(), d_v, Sa * sizeof(double), hipMemcpyDeviceToHost));
-    MU_TRY(hipMemcpy(hst.data(), d_st, Sa * sizeof(int32_t), hipMemcpyDeviceToHost));
-    MU_TRY(hipMemcpy(hcnt.data(), d_cnt, hcnt.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    if (want_grad) MU_TRY(hipMemcpy(hd.data(), d_d, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
-    if (want_hess) MU_TRY(hipMemcpy(hh.data(), d_h, hh.size() * sizeof(double), hipMemcpyDeviceToHost));
+    MU_TRY(hipMemcpyAsync(hv.data(), d_v, Sa * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MU_TRY(hipMemcpyAsync(hst.data(), d_st, Sa * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    MU_TRY(hipMemcpyAsync(hcnt.data(), d_cnt, hcnt.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (want_grad) MU_TRY(hipMemcpyAsync(hd.data(), d_d, hd.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (want_hess) MU_TRY(hipMemcpyAsync(hh.data(), d_h, hh.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MU_TRY(hipStreamSynchronize(c->stream));
     {
         double vs = 0; int64_t na = 0, ni = 0;
         for (int a = 0; a < Sa; ++a) {
@@ -748,6 +934,7 @@ extern "C" int celeste_elbo_eval_multi(celeste_ctx_t *c, const double *vp, int32
     }
 done:
 #undef MU_TRY
+    (void)hipStreamSynchronize(c->stream);   // nothing of this call is in flight when its buffers are released
     {
         void *ptrs[] = {d_vp, d_v, d_d, d_h, d_rec, d_x, d_t, d_st, d_rank, d_pa, d_pb, d_cnt};
         for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -834,27 +1021,41 @@ extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, cons
 
 
 // ---- maximize! for a batch of targets (ElboMaximize.jl:228-242; neighbours frozen at the input vp) ----------
+// The Newton loop is device resident: the host enqueues iteration `it` while the device is still two iterations
+// behind, sizing the grids by the number of unconverged targets two iterations ago (an upper bound: the count never
+// grows); the true count lives in device memory and the kernels that depend on it read it there.  The counts come
+// back through page-locked slots with an event each, so the host never waits for the iteration it just enqueued.
 extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double *vp_neighbors,
                                       const double *pos_centers, int32_t n_targets, const int32_t *targets,
                                       const celeste_optim_config_t *cfg_in, int32_t *iterations, int32_t *f_evals,
                                       double *elbo, int32_t *status) {
     if (!c || !vp || !targets || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
     if (n_targets == 0) return CELESTE_OK;
-    for (int t = 0; t < n_targets; ++t) if (targets[t] < 0 || targets[t] >= c->S) return CELESTE_ERR_INVALID_ARG;
-    celeste_optim_config_t cfg = {1e-4, 1.0, 50, 1, 1e-7, 1e-6, 1e-8, 1.0, 1e9};
+    {
+        std::vector<uint8_t> seen((size_t)c->S, 0);   // two optimisations of one source would share its row of vp
+        for (int t = 0; t < n_targets; ++t) {
+            if (targets[t] < 0 || targets[t] >= c->S || seen[targets[t]]) return CELESTE_ERR_INVALID_ARG;
+            seen[targets[t]] = 1;
+        }
+    }
+    celeste_optim_config_t cfg = {1e-4, 1.0, 50, 1, 1e-7, 1e-6, 1e-8, 1.0, 1e9, 0, 0};
     if (cfg_in) cfg = *cfg_in;
-    if (!(cfg.loc_width > 0) || !(cfg.loc_scale > 0) || cfg.max_iters < 0) return CELESTE_ERR_INVALID_ARG;
+    if (!(cfg.loc_width > 0) || !(cfg.loc_scale > 0) || cfg.max_iters < 0 || cfg.tr_secular_iters < 0)
+        return CELESTE_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
     OptParams op;
     op.loc_width = cfg.loc_width; op.loc_scale = cfg.loc_scale; op.xtol_abs = cfg.xtol_abs; op.ftol_rel = cfg.ftol_rel;
     op.gtol = cfg.gtol; op.initial_delta = cfg.initial_delta; op.delta_hat = cfg.delta_hat; op.max_iters = cfg.max_iters;
+    op.secular_iters = cfg.tr_secular_iters > 0 ? cfg.tr_secular_iters : 20;
     // CELESTE_TR_SOLVER=eig: full eigen-decomposition for every sub-problem (cross-check of the default
     // tridiagonal-space solve)
     const char *env_solver = getenv("CELESTE_TR_SOLVER");
     op.solver = (env_solver && strcmp(env_solver, "eig") == 0) ? 1 : 0;
     const uint32_t flags = CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS | (cfg.include_kl ? CELESTE_FLAG_KL : 0);
     const size_t n = (size_t)n_targets;
+    const size_t vp_bytes = (size_t)c->S * CEL_P * sizeof(double);
     auto &ob = c->opt;
+    hipStream_t stream = c->stream;
     int rc = CELESTE_OK;
 #define MX_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto cleanup; } } while (0)
     if (n > ob.cap) {   // (re)allocate every per-target buffer at the new capacity
@@ -864,50 +1065,74 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double
         const size_t bytes[] = {sizeof(double), CEL_P * sizeof(double), CEL_P * CEL_P * sizeof(double), NF * NF * sizeof(double),
                                 2 * sizeof(double), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t),
                                 sizeof(int32_t), sizeof(int32_t), sizeof(OptState)};
+        MX_TRY(hipStreamSynchronize(stream));
         ob.cap = 0;
         for (int k = 0; k < 12; ++k) {
             if (*grow[k]) { (void)hipFree(*grow[k]); *grow[k] = nullptr; }
             MX_TRY(hipMalloc(grow[k], n * bytes[k]));
         }
+        if (ob.h_state) { (void)hipHostFree(ob.h_state); ob.h_state = nullptr; }
+        MX_TRY(hipHostMalloc(&ob.h_state, n * sizeof(OptState), hipHostMallocDefault));
         ob.cap = n;
     }
-    if (!ob.d_vp) MX_TRY(hipMalloc((void **)&ob.d_vp, (size_t)c->S * CEL_P * sizeof(double)));
-    if (!ob.d_count) MX_TRY(hipMalloc((void **)&ob.d_count, sizeof(int32_t)));
+    if (!ob.d_vp) MX_TRY(hipMalloc((void **)&ob.d_vp, vp_bytes));
+    if (!ob.d_count) MX_TRY(hipMalloc((void **)&ob.d_count, 2 * sizeof(int32_t)));
+    if (!ob.h_vp) MX_TRY(hipHostMalloc((void **)&ob.h_vp, 2 * vp_bytes, hipHostMallocDefault));
+    if (!ob.h_count) {
+        MX_TRY(hipHostMalloc((void **)&ob.h_count, celeste_ctx::OptBuffers::RING * sizeof(int32_t), hipHostMallocDefault));
+        for (int k = 0; k < celeste_ctx::OptBuffers::RING; ++k) MX_TRY(hipEventCreateWithFlags(&ob.ev[k], hipEventDisableTiming));
+    }
     {
     double *const d_vp = ob.d_vp, *const d_v = ob.d_v, *const d_d = ob.d_d, *const d_h = ob.d_h, *const d_H = ob.d_H;
     double *const d_pos = pos_centers ? ob.d_pos : nullptr;
-    int32_t *const d_targets = ob.d_targets, *const d_count = ob.d_count, *const d_st = ob.d_st;
+    int32_t *const d_targets = ob.d_targets, *const d_st = ob.d_st;
+    int32_t *const d_cnt[2] = {ob.d_count, ob.d_count + 1};
     int32_t *const *d_act = ob.d_act, *const *d_evt = ob.d_evt;
     OptState *const d_state = (OptState *)ob.d_state;
-    MX_TRY(hipMemcpy(d_targets, targets, n * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (pos_centers) MX_TRY(hipMemcpy(d_pos, pos_centers, n * 2 * sizeof(double), hipMemcpyHostToDevice));
+    double *const h_vp0 = ob.h_vp, *const h_vp1 = ob.h_vp + (size_t)c->S * CEL_P;
+    constexpr int RING = celeste_ctx::OptBuffers::RING;
+    MX_TRY(hipMemcpyAsync(d_targets, targets, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    if (pos_centers) MX_TRY(hipMemcpyAsync(d_pos, pos_centers, n * 2 * sizeof(double), hipMemcpyHostToDevice, stream));
     {
         // neighbours are rendered once, from their frozen parameters, before any target moves
-        MX_TRY(hipMemcpy(d_vp, vp_neighbors ? vp_neighbors : vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
-        int st0 = launch_eval(c, d_vp, n_targets, d_targets, 0, d_v, nullptr, nullptr, nullptr, d_st, nullptr, true);
+        memcpy(h_vp0, vp_neighbors ? vp_neighbors : vp, vp_bytes);
+        MX_TRY(hipMemcpyAsync(d_vp, h_vp0, vp_bytes, hipMemcpyHostToDevice, stream));
+        int st0 = launch_eval(c, d_vp, n_targets, d_targets, 0, d_v, nullptr, nullptr, nullptr, d_st, stream, true);
         if (st0 != CELESTE_OK) { rc = st0; goto cleanup; }
-        if (vp_neighbors) MX_TRY(hipMemcpy(d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(optim_init_kernel, dim3((n_targets + 63) / 64), dim3(64), 0, nullptr, d_vp, d_targets,
+        if (vp_neighbors) {
+            memcpy(h_vp1, vp, vp_bytes);
+            MX_TRY(hipMemcpyAsync(d_vp, h_vp1, vp_bytes, hipMemcpyHostToDevice, stream));
+        }
+        hipLaunchKernelGGL(optim_init_kernel, dim3((n_targets + 63) / 64), dim3(64), 0, stream, d_vp, d_targets,
                            n_targets, op, d_state, d_act[0], d_pos);
-        MX_TRY(hipMemcpy(d_evt[0], d_targets, n * sizeof(int32_t), hipMemcpyDeviceToDevice));
-        int32_t n_active = n_targets;
+        MX_TRY(hipMemcpyAsync(d_evt[0], d_targets, n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        int32_t n_upper = n_targets;
         int cur = 0;
-        for (int it = 0; it <= cfg.max_iters + 1 && n_active > 0; ++it) {
-            int st1 = launch_eval(c, d_vp, n_active, d_evt[cur], flags, d_v, d_d, d_h, nullptr, d_st, nullptr, false);
+        for (int it = 0; it <= cfg.max_iters + 1; ++it) {
+            if (it >= 2) {   // the count two iterations back: an upper bound of the live targets, 0 = all converged
+                MX_TRY(hipEventSynchronize(ob.ev[(it - 2) % RING]));
+                n_upper = ob.h_count[(it - 2) % RING];
+                if (n_upper <= 0) break;
+            }
+            const int32_t *d_live = it == 0 ? nullptr : d_cnt[cur];
+            int st1 = launch_eval(c, d_vp, n_upper, d_evt[cur], flags, d_v, d_d, d_h, nullptr, d_st, stream, false, nullptr,
+                                  -1, false, d_live);
             if (st1 != CELESTE_OK) { rc = st1; goto cleanup; }
-            MX_TRY(hipMemsetAsync(d_count, 0, sizeof(int32_t), nullptr));
-            hipLaunchKernelGGL(optim_step_kernel, dim3(n_active), dim3(64), 0, nullptr, d_vp, d_targets, d_act[cur],
-                               d_v, d_d, d_h, d_st, op, d_state, d_H, d_act[1 - cur], d_evt[1 - cur], d_count);
-            MX_TRY(hipMemcpy(&n_active, d_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+            MX_TRY(hipMemsetAsync(d_cnt[1 - cur], 0, sizeof(int32_t), stream));
+            hipLaunchKernelGGL(optim_step_kernel, dim3(n_upper), dim3(64), 0, stream, d_vp, d_targets, d_act[cur],
+                               d_v, d_d, d_h, d_st, op, d_state, d_H, d_act[1 - cur], d_evt[1 - cur], d_cnt[1 - cur], d_live);
+            MX_TRY(hipMemcpyAsync(&ob.h_count[it % RING], d_cnt[1 - cur], sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            MX_TRY(hipEventRecord(ob.ev[it % RING], stream));
             cur = 1 - cur;
         }
-        MX_TRY(hipDeviceSynchronize());
-        std::vector<OptState> hs(n);
-        MX_TRY(hipMemcpy(hs.data(), d_state, n * sizeof(OptState), hipMemcpyDeviceToHost));
-        std::vector<double> hvp((size_t)c->S * CEL_P);
-        MX_TRY(hipMemcpy(hvp.data(), d_vp, hvp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        OptState *const hs = (OptState *)ob.h_state;
+        MX_TRY(hipMemcpyAsync(hs, d_state, n * sizeof(OptState), hipMemcpyDeviceToHost, stream));
+        MX_TRY(hipMemcpyAsync(h_vp0, d_vp, vp_bytes, hipMemcpyDeviceToHost, stream));
+        MX_TRY(hipStreamSynchronize(stream));
         for (int t = 0; t < n_targets; ++t) {
-            memcpy(vp + (size_t)targets[t] * CEL_P, hvp.data() + (size_t)targets[t] * CEL_P, CEL_P * sizeof(double));
+            // a target that failed keeps its input row; the others are unaffected (ParallelRun.jl:582-597)
+            if (hs[t].status == CELESTE_OK)
+                memcpy(vp + (size_t)targets[t] * CEL_P, h_vp0 + (size_t)targets[t] * CEL_P, CEL_P * sizeof(double));
             if (iterations) iterations[t] = hs[t].iter;
             if (f_evals) f_evals[t] = hs[t].evals;
             if (elbo) elbo[t] = -hs[t].f;
@@ -918,6 +1143,7 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double
     }
 cleanup:
 #undef MX_TRY
+    if (rc == CELESTE_ERR_HIP) (void)hipStreamSynchronize(stream);
     return rc;
 }
 
@@ -936,24 +1162,25 @@ extern "C" int celeste_optim_stats(int reset, uint64_t out[5]) {
 extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32_t image, double *out_plane) {
     if (!c || !vp || !out_plane || image < 0 || image >= c->N) return CELESTE_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    const DevImage &im = c->h_images[image];
+    const DevImage &im = c->imgs->h_images[image];
     const size_t npix = (size_t)im.H * im.W;
     double *d_plane = nullptr;
     if (!c->d_vp) HIP_TRY(hipMalloc((void **)&c->d_vp, (size_t)c->S * CEL_P * sizeof(double)));
-    HIP_TRY(hipMemcpy(c->d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMalloc((void **)&d_plane, npix * sizeof(double)));
     int rc = CELESTE_OK;
-    if (hipMemset(d_plane, 0, npix * sizeof(double)) != hipSuccess) rc = CELESTE_ERR_HIP;
+    if (hipMemsetAsync(d_plane, 0, npix * sizeof(double), c->stream) != hipSuccess) rc = CELESTE_ERR_HIP;
     if (rc == CELESTE_OK) {
         if (c->V > 0)
-            hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, nullptr, c->d_vp, c->d_images,
+            hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, c->stream, c->d_vp, c->d_images,
                                c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr,
-                               c->d_vis_off, c->M, (int)c->dense);
-        hipLaunchKernelGGL(render_kernel, dim3((unsigned)((size_t)c->S * c->CH)), dim3(64), 0, nullptr, c->d_patches,
+                               c->d_vis_off, c->M, (int)c->dense, nullptr);
+        hipLaunchKernelGGL(render_kernel, dim3((unsigned)((size_t)c->S * c->CH)), dim3(64), 0, c->stream, c->d_patches,
                            c->d_coefs, c->d_bitmaps, im.pixels, c->d_srcimg, c->d_comps, (int)image, c->N, c->NC,
                            c->CH, c->chunk_px, im.H, d_plane);
-        if (hipMemcpy(out_plane, d_plane, npix * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = CELESTE_ERR_HIP;
+        if (hipMemcpyAsync(out_plane, d_plane, npix * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = CELESTE_ERR_HIP;
     }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = CELESTE_ERR_HIP;
     (void)hipFree(d_plane);
     return rc;
 }

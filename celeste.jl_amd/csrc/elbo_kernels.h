@@ -64,7 +64,8 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const DevPatch *__restrict__ patches, const int32_t *__restrict__ vis_src,
             const int32_t *__restrict__ vis_img, int N, int K,
             SrcImg *__restrict__ srcimg, Comp *__restrict__ comps,
-            const int32_t *__restrict__ targets, const int32_t *__restrict__ vis_off, int M, int dense) {
+            const int32_t *__restrict__ targets, const int32_t *__restrict__ vis_off, int M, int dense,
+            const int32_t *__restrict__ live) {
     const int NC = 14 * K;
     // one workgroup per visit = (source, image) pair with a non-empty patch; the tables stay dense (s * N + n).
     // targets == nullptr: every visit of the context (neighbours are about to be rendered).  Otherwise one workgroup
@@ -72,6 +73,7 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
     int s, n;
     if (targets) {
         const int k = blockIdx.x, ti = k / M, j = k - ti * M;
+        if (live && ti >= *live) return;
         s = targets[ti];
         n = j;
         if (!dense) {
@@ -384,9 +386,11 @@ __device__ inline int block_prefix(int v, int *s_wave /* WORK_NT / 64 */, int &t
 __global__ void __launch_bounds__(WORK_NT)
 work_count_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPatch *__restrict__ patches,
                   const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M,
-                  int chunk_px, int dense, int32_t *__restrict__ blk_cnt /* [chunk_px / 64][gridDim.x] */) {
+                  int chunk_px, int dense, int32_t *__restrict__ blk_cnt /* [chunk_px / 64][gridDim.x] */,
+                  const int32_t *__restrict__ live) {
     __shared__ int s_wave[WORK_NT / 64];
     const int k = blockIdx.x * WORK_NT + threadIdx.x;
+    if (live) n_visits = min(n_visits, *live * M);   // the host's target count is an upper bound (device-resident loops)
     int n_full = 0, lc = 0;
     if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, dense != 0, n_full, lc);
     int tot;
@@ -426,9 +430,11 @@ __global__ void __launch_bounds__(1024) work_scan_kernel(int32_t *__restrict__ c
 __global__ void __launch_bounds__(WORK_NT)
 work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPatch *__restrict__ patches,
                  const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M, int CH,
-                 int chunk_px, int dense, const int32_t *__restrict__ blk_base, int32_t *__restrict__ work) {
+                 int chunk_px, int dense, const int32_t *__restrict__ blk_base, int32_t *__restrict__ work,
+                 const int32_t *__restrict__ live) {
     __shared__ int s_wave[WORK_NT / 64];
     const int k = blockIdx.x * WORK_NT + threadIdx.x;
+    if (live) n_visits = min(n_visits, *live * M);
     int n_full = 0, lc = 0;
     if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, dense != 0, n_full, lc);
     int tot;
@@ -1201,7 +1207,8 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const PriorDev *__restrict__ prior, const int32_t *__restrict__ vis_off,
             const int32_t *__restrict__ vis_img, int N, int M, int CH, int chunk_px, uint32_t flags,
             double *__restrict__ out_v, double *__restrict__ out_d, double *__restrict__ out_h,
-            int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status) {
+            int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status, const int32_t *__restrict__ live) {
+    if (live && (int)blockIdx.x >= *live) return;
     __shared__ double sh_h[LIFT_NP * LIFT_NP];         // likelihood Hessian, upper triangle, params < 28
     __shared__ double sh_d[LIFT_NP];
     __shared__ double s_vs[CEL_P], s_jsh[9], s_tsh[27];
@@ -1408,7 +1415,8 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             double v = (p2 < LIFT_NP) ? sh_h[p1 + LIFT_NP * p2] : 0.0;
             if (want_kl) v += kl_hess(K, prior, vs, p1, p2);
             if (!isfinite(v)) bad = 1;
-            out_h[(size_t)ti * CEL_P * CEL_P + k] = v;
+            if (!(flags & CELESTE_FLAG_PACKED_HESS)) out_h[(size_t)ti * CEL_P * CEL_P + k] = v;
+            else if (c1 <= c2) out_h[(size_t)ti * CELESTE_HP + c2 * (c2 + 1) / 2 + c1] = v;   // upper triangle, by columns
         }
     }
     if (bad) atomicOr(&sh_bad, 1);

@@ -42,6 +42,7 @@ struct OptState {                 // per target slot
 struct OptParams {
     double loc_width, loc_scale, xtol_abs, ftol_rel, gtol, initial_delta, delta_hat;
     int32_t max_iters, solver;    // 0: tridiagonal-space solve (default), 1: eigen-decomposition always
+    int32_t secular_iters, pad;   // cap of the Newton iterations on lambda (20: to convergence; Optim.jl stops after 5)
 };
 
 __device__ __forceinline__ void box_bounds(int i, const double *pos0, const OptParams &op, double &lo, double &hi,
@@ -378,8 +379,8 @@ struct TriLds { double *A, *hv, *td, *te, *te2, *ip, *mk, *r, *y, *gt, *q, *gq, 
 // Trust-region step in the tridiagonal basis.  In: L.A = H (destroyed), g (lane register), delta.
 // Out: step p (lane register), model decrease m, interior flag.  Returns false in the hard case (caller falls
 // back to the eigen-decomposition).
-__device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int ln, double &p_out, double &m_out,
-                                    int &interior_out) {
+__device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int ln, int secular_iters, double &p_out,
+                                    double &m_out, int &interior_out) {
     const bool fr = ln < NF;
     tred_wave(L.A, L.hv, L.te, L.q, ln);
     if (fr) { const double ek = L.te[ln]; L.td[ln] = L.A[ln + LDA * ln]; L.te2[ln] = ek * ek; }
@@ -468,7 +469,7 @@ __device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int
         }
         if (!hard) {
         int it = 0;
-        for (; it < 20; ++it) {
+        for (; it < secular_iters; ++it) {
             tri_factor(L.td, L.te, L.te2, lambda, L.ip, L.mk, L.pa, L.pb, ln);
             tri_solve(L.te, L.ip, L.mk, L.gt, -1.0, L.r, L.y);
             y = fr ? L.y[ln] : 0.0;
@@ -533,7 +534,8 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
                   const double *__restrict__ ev_v, const double *__restrict__ ev_d, const double *__restrict__ ev_h,
                   const int32_t *__restrict__ ev_status, OptParams op, OptState *__restrict__ st,
                   double *__restrict__ Hstate, int32_t *__restrict__ next_active, int32_t *__restrict__ next_targets,
-                  int32_t *__restrict__ next_count) {
+                  int32_t *__restrict__ next_count, const int32_t *__restrict__ live) {
+    if (live && (int)blockIdx.x >= *live) return;   // the grid is sized by an older, larger count
     // LDS budget: 19.7 KB per workgroup so that 8 workgroups (2 waves per SIMD, the VGPR limit) fit a CU and a batch
     // of 2000 targets is resident in one round.
     __shared__ double sA[LDA * NF];       // rows 0..43: H J (44 x 41) -> J'HJ (41 x 41, negated) -> solver; rows 41..44 spare
@@ -662,7 +664,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
                 else if (rho > 0.75 && !S_interior) delta = fmin(2 * delta, op.delta_hat);
                 accept = rho > 0.1;
                 if (accept && (dx <= op.xtol_abs || fabs(ft - S_f) <= op.ftol_rel * fabs(ft) || gmax <= op.gtol)) done = 1;
-            }
+            } else if (gmax <= op.gtol) done = 1;   // already stationary at the starting point: no iteration at all
             if (accept) S.f = ft;
             S.delta = delta; s_delta = delta;
             S.iter = S_iter + 1;
@@ -693,7 +695,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
     bool solved = false;
     if (op.solver != 1) {
         const TriLds L = {sA, sw, std_, se, ste2, sip, smk, sr, sy, sgt2, sq, scv, spa, spb};
-        solved = tri_tr_solve(L, fr ? sg[tid] : 0.0, s_delta, tid, step, m, interior);
+        solved = tri_tr_solve(L, fr ? sg[tid] : 0.0, s_delta, tid, op.secular_iters, step, m, interior);
         if (!solved) {   // hard case: restore H and diagonalise it
             for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hs[k]; }
             __syncthreads();
@@ -738,7 +740,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
                 }
             }
             if (!hard) {
-                for (int it = 0; it < 20; ++it) {
+                for (int it = 0; it < op.secular_iters; ++it) {
                     cv = fr ? -qg / (wi + lambda) : 0.0;
                     const double q2 = wave_sum(cv * cv), q3 = wave_sum(fr ? cv * cv / (wi + lambda) : 0.0);
                     const double prev = lambda;

@@ -44,13 +44,21 @@ class FieldContext:
     """Device-resident problem: images, all patches, neighbour graph (celeste_ctx_t)."""
 
     def __init__(self, images, patches, neighbors=None, psf_K: int = 2, prior: Optional[dict] = None,
-                 device: int = 0):
+                 device: int = 0, image_set: Optional["cabi.ImageSet"] = None):
+        """image_set: a shared image handle (cabi.ImageSet over the same `images`); the context then costs a patch-table
+        upload instead of a copy of every plane -- the per-source ElboArgs of ParallelRun.jl:468-488."""
         self.lib = cabi.load_library()
-        self.problem = cabi.Problem(images, patches, neighbors, psf_K=psf_K, prior=prior)
+        self.problem = cabi.Problem(images, patches, neighbors, psf_K=psf_K, prior=prior,
+                                    marshal_images=image_set is None)
         self.S, self.N = self.problem.n_sources, self.problem.n_images
-        self.device = device
         h = C.c_void_p()
-        cabi.check(self.lib.celeste_ctx_create(C.byref(self.problem.c), device, C.byref(h)), self.lib)
+        if image_set is None:
+            self.device = device
+            cabi.check(self.lib.celeste_ctx_create(C.byref(self.problem.c), device, C.byref(h)), self.lib)
+        else:
+            assert len(image_set.images) == self.N
+            self.device = image_set.device
+            cabi.check(self.lib.celeste_ctx_create_on(image_set.handle, C.byref(self.problem.c), C.byref(h)), self.lib)
         self.handle = h
 
     def close(self):
@@ -66,14 +74,20 @@ class FieldContext:
 
     # -- host-pointer API ---------------------------------------------------------------
     def eval_batch(self, vp, targets: Sequence[int], flags: int = FLAG_GRAD | FLAG_HESS | FLAG_KL,
-                   raise_on_error: bool = True):
-        """vp: S x 44 array (row s = source s).  Returns (v[n], d[n,44], h[n,44,44], counters[n,2], status[n])."""
+                   raise_on_error: bool = True, pinned: bool = True):
+        """vp: S x 44 array (row s = source s).  Returns (v[n], d[n,44], h[n,44,44], counters[n,2], status[n]);
+        with FLAG_PACKED_HESS h is [n, 990] (cabi.unpack_hessian).  pinned: large outputs are allocated in page-locked
+        memory (cabi.pinned_empty), which the library fills by DMA while later parts of the batch still compute."""
         vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(self.S, P))
         tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32))
         n = tg.size
+        big = pinned and n >= 64
         v = np.zeros(n)
         d = np.zeros((n, P)) if flags & (FLAG_GRAD | FLAG_HESS) else None
-        h = np.zeros((n, P, P)) if flags & FLAG_HESS else None
+        h = None
+        if flags & FLAG_HESS:
+            hshape = (n, cabi.HP) if flags & cabi.FLAG_PACKED_HESS else (n, P, P)
+            h = cabi.pinned_empty(hshape) if big else np.zeros(hshape)
         cnt = np.zeros((n, 2), dtype=np.int64)
         status = np.zeros(n, dtype=np.int32)
         dp = cabi.c_double_p
@@ -118,10 +132,14 @@ class FieldContext:
                                                            d_h, d_counters, d_status, stream), self.lib)
 
     def maximize_batch(self, vp, targets: Sequence[int], cfg: Optional["ElboConfig"] = None, include_kl: bool = True,
-                       vp_neighbors=None, pos_centers=None):
+                       vp_neighbors=None, pos_centers=None, raise_on_error: bool = True):
         """maximize! for every target (ElboMaximize.jl:228-242), neighbours frozen at `vp_neighbors` (default: the
         input vp); `pos_centers` [n,2] pins the position boxes (default: the current positions).
-        Returns (vp_new[S,44], iterations[n], f_evals[n], elbo[n], status[n]); vp is not modified."""
+        Returns (vp_new[S,44], iterations[n], f_evals[n], elbo[n], status[n]); vp is not modified.
+        A target whose ELBO turns non-finite keeps its input row and gets a non-zero status; the other targets are
+        optimised normally.  raise_on_error=True turns such a status into the reference's AssertionError (as a direct
+        maximize! call would raise); the node-level loops pass False and skip the source like the reference's
+        try/catch does (ParallelRun.jl:389-396, 582-597)."""
         cfg = cfg or ElboConfig()
         vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(self.S, P)).copy()
         tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32))
@@ -139,8 +157,10 @@ class FieldContext:
                                              its.ctypes.data_as(cabi.c_int32_p), evals.ctypes.data_as(cabi.c_int32_p),
                                              el.ctypes.data_as(cabi.c_double_p), status.ctypes.data_as(cabi.c_int32_p))
         if st in (cabi.ERR_NONFINITE_INPUT, cabi.ERR_NONFINITE_RESULT):
-            raise AssertionError(self.lib.celeste_strerror(st).decode())
-        cabi.check(st, self.lib)
+            if raise_on_error:
+                raise AssertionError(self.lib.celeste_strerror(st).decode())
+        else:
+            cabi.check(st, self.lib)
         return vp, its, evals, el, status
 
     def render_expected(self, vp, image: int) -> np.ndarray:
@@ -186,10 +206,11 @@ class ElboConfig:
     gtol: float = 1e-8
     initial_delta: float = 1.0
     delta_hat: float = 1e9
+    tr_secular_iters: int = 0   # 0: multiplier iterations run to convergence; 5: Optim.jl's cap (celeste_optim_config_t)
 
     def to_c(self, include_kl: bool) -> "cabi.OptimConfigT":
         return cabi.OptimConfigT(self.loc_width, self.loc_scale, self.max_iters, int(include_kl), self.xtol_abs,
-                                 self.ftol_rel, self.gtol, self.initial_delta, self.delta_hat)
+                                 self.ftol_rel, self.gtol, self.initial_delta, self.delta_hat, self.tr_secular_iters, 0)
 
 
 class ElboArgs:

@@ -16,6 +16,7 @@ sources of one component are optimised one after another.  On the GPU the j-th s
 batch form one launch ("layer"): no two of them are neighbours, so optimising them simultaneously is exactly
 the reference's schedule.
 """
+import logging
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -27,16 +28,30 @@ from .parallel import sharded_maximize
 from .partition import color_classes, partition_cyclades_dynamic
 
 NUM_JOINT_VI_ITERS = 3   # Config.num_joint_vi_iters (src/config.jl:17-25)
+log = logging.getLogger("celeste_jl_amd.infer")
+
+
+def _report_failures(targets, status, where: str, failed: Optional[set]):
+    """A source whose ELBO turned non-finite is logged and skipped -- the reference's production / multi-thread
+    behaviour (Log.exception in process_sources_kernel! and one_node_single_infer, ParallelRun.jl:389-396, 582-597):
+    its row stays where it was, every other source of the batch keeps its result."""
+    for t, st in zip(targets, status):
+        if st != 0:
+            log.warning("%s: source %d skipped (status %d)", where, int(t), int(st))
+            if failed is not None:
+                failed.add(int(t))
 
 
 def one_node_single_infer(ctx: FieldContext, catalog, target_sources: Sequence[int],
-                          cfg: Optional[ElboConfig] = None) -> np.ndarray:
-    """Returns the optimised parameters, one row per target (OptimizedSource.vs)."""
+                          cfg: Optional[ElboConfig] = None, failed: Optional[set] = None) -> np.ndarray:
+    """Returns the optimised parameters, one row per target (OptimizedSource.vs).  Targets that failed are logged,
+    keep their initial row and are added to `failed` (the reference drops them from its result list)."""
     vp_nbr = np.stack([catalog_init_source(ce) for ce in catalog])
     vp = vp_nbr.copy()
     for t in target_sources:
         vp[t] = generic_init_source(catalog[t].pos)
-    new, _, _, _, st = ctx.maximize_batch(vp, list(target_sources), cfg, vp_neighbors=vp_nbr)
+    new, _, _, _, st = ctx.maximize_batch(vp, list(target_sources), cfg, vp_neighbors=vp_nbr, raise_on_error=False)
+    _report_failures(target_sources, st, "one_node_single_infer", failed)
     return new[list(target_sources)]
 
 
@@ -44,7 +59,7 @@ def joint_infer_sweeps(maximize_layer: Callable, vp: np.ndarray, targets: Sequen
                        batch_size: int = 400, n_iters: int = NUM_JOINT_VI_ITERS,
                        rng: Optional[np.random.Generator] = None, rank: int = 0, world: int = 1,
                        costs: Optional[Sequence[float]] = None, all_gather: Optional[Callable] = None,
-                       schedule: str = "cyclades") -> np.ndarray:
+                       schedule: str = "cyclades", device: Optional[int] = None) -> np.ndarray:
     """The joint-inference schedule, independent of who optimises a layer.
 
     schedule = "cyclades": the reference's randomly drawn batches, connected components processed source by source
@@ -80,7 +95,7 @@ def joint_infer_sweeps(maximize_layer: Callable, vp: np.ndarray, targets: Sequen
                     vp[layer] = run(layer)
                 else:
                     lc = [1.0 if costs is None else costs[t] for t in layer]
-                    vp[layer] = sharded_maximize(run, layer, lc, rank, world, all_gather)
+                    vp[layer] = sharded_maximize(run, layer, lc, rank, world, all_gather, device)
     return vp
 
 
@@ -88,18 +103,21 @@ def one_node_joint_infer(ctx: FieldContext, catalog, target_sources: Sequence[in
                          cfg: Optional[ElboConfig] = None, batch_size: int = 400, n_iters: int = NUM_JOINT_VI_ITERS,
                          rng: Optional[np.random.Generator] = None, rank: int = 0, world: int = 1,
                          costs: Optional[Sequence[float]] = None, all_gather: Optional[Callable] = None,
-                         schedule: str = "cyclades") -> np.ndarray:
+                         schedule: str = "cyclades", failed: Optional[set] = None) -> np.ndarray:
     """Cyclades-batched joint inference; returns the optimised parameters, one row per target.  rank / world > 1:
-    one process per GPU, images replicated (every rank builds the same FieldContext), layers sharded."""
+    one process per GPU, images replicated (every rank builds the same FieldContext), layers sharded.
+    A source that fails in some layer keeps the row it had before that layer (logged, added to `failed`)."""
     targets = list(target_sources)
     vp = np.stack([catalog_init_source(ce) for ce in catalog])
     for t in targets:
         vp[t] = generic_init_source(catalog[t].pos)
 
     def maximize_layer(table, layer, pc):
-        return ctx.maximize_batch(table, layer, cfg, pos_centers=pc)[0][layer]
+        new, _, _, _, st = ctx.maximize_batch(table, layer, cfg, pos_centers=pc, raise_on_error=False)
+        _report_failures(layer, st, "one_node_joint_infer", failed)
+        return new[layer]
     vp = joint_infer_sweeps(maximize_layer, vp, targets, neighbors, batch_size, n_iters, rng, rank, world, costs,
-                            all_gather, schedule)
+                            all_gather, schedule, device=ctx.device)
     return vp[targets]
 
 
@@ -128,6 +146,7 @@ class OptimizedSource:
     init_dec: float
     vs: np.ndarray
     is_sky_bad: bool
+    failed: bool = False   # the optimiser reported a non-finite ELBO for this source; vs is its last good row
 
 
 def bad_sky(ce, images) -> bool:
@@ -161,14 +180,17 @@ def infer_box(images, box: BoundingBox, catalog, method: str = "joint_vi", cfg: 
     if not targets:
         return []
     ctx = FieldContext(images, patches, neighbors, device=device)
+    failed: set = set()
     try:
         if method == "joint_vi":
-            vs = one_node_joint_infer(ctx, catalog, targets, neighbors, cfg, n_iters=n_iters, schedule=schedule)
+            vs = one_node_joint_infer(ctx, catalog, targets, neighbors, cfg, n_iters=n_iters, schedule=schedule,
+                                      failed=failed)
         elif method == "single_vi":
-            vs = one_node_single_infer(ctx, catalog, targets, cfg)
+            vs = one_node_single_infer(ctx, catalog, targets, cfg, failed=failed)
         else:
             raise ValueError("unknown method: %s" % method)
     finally:
         ctx.close()
-    return [OptimizedSource(float(catalog[t].pos[0]), float(catalog[t].pos[1]), vs[k].copy(), bad_sky(catalog[t], images))
+    return [OptimizedSource(float(catalog[t].pos[0]), float(catalog[t].pos[1]), vs[k].copy(), bad_sky(catalog[t], images),
+                            t in failed)
             for k, t in enumerate(targets)]

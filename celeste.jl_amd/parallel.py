@@ -14,13 +14,32 @@ from .partition import shard_targets
 P = 44
 
 
+def _default_all_gather(block: np.ndarray, world: int, device: Optional[int]):
+    """torch.distributed.all_gather of one equally-shaped block per rank.  With the nccl (= RCCL) backend the block is
+    staged on `device` -- the HIP device of this rank's FieldContext, which must be given: the library only calls
+    hipSetDevice internally, so torch's current device says nothing about where the rank computes."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        if device is None:
+            raise ValueError("the nccl backend needs the device index of this rank's FieldContext (device=...)")
+        t = torch.from_numpy(block).to("cuda:%d" % device)
+    else:
+        t = torch.from_numpy(block)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return [o.cpu().numpy() for o in outs]
+
+
 def sharded_sweep(evaluate: Callable[[Sequence[int]], Tuple[np.ndarray, np.ndarray]], targets: Sequence[int],
-                  costs: Sequence[float], rank: int, world: int, all_gather: Optional[Callable] = None):
+                  costs: Sequence[float], rank: int, world: int, all_gather: Optional[Callable] = None,
+                  device: Optional[int] = None):
     """Evaluate `targets` sharded over `world` ranks and return (v[n], d[n,44]) for all targets, in order.
 
     evaluate(local_targets) -> (v, d) runs on this rank's device (FieldContext.eval_batch in production).
     all_gather(local_block: np.ndarray [max_shard, 45]) -> list of `world` blocks; defaults to
-    torch.distributed.all_gather on the current default group.
+    torch.distributed.all_gather on the current default group (`device` = the HIP device of this rank's
+    FieldContext, required with the nccl backend).
     """
     targets = list(targets)
     shards = shard_targets(costs, world)
@@ -35,13 +54,7 @@ def sharded_sweep(evaluate: Callable[[Sequence[int]], Tuple[np.ndarray, np.ndarr
     elif all_gather is not None:
         blocks = all_gather(block)
     else:
-        import torch
-        import torch.distributed as dist
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.from_numpy(block).to(dev)
-        outs = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(outs, t)
-        blocks = [o.cpu().numpy() for o in outs]
+        blocks = _default_all_gather(block, world, device)
     out_v = np.zeros(len(targets))
     out_d = np.zeros((len(targets), P))
     for r in range(world):
@@ -52,7 +65,8 @@ def sharded_sweep(evaluate: Callable[[Sequence[int]], Tuple[np.ndarray, np.ndarr
 
 
 def sharded_maximize(maximize: Callable[[Sequence[int]], np.ndarray], targets: Sequence[int], costs: Sequence[float],
-                     rank: int, world: int, all_gather: Optional[Callable] = None) -> np.ndarray:
+                     rank: int, world: int, all_gather: Optional[Callable] = None,
+                     device: Optional[int] = None) -> np.ndarray:
     """one_node_single_infer across ranks (ParallelRun.jl:546-607): every rank optimises its cost-balanced shard
     of targets against replicated images (neighbours frozen, so shards are independent) and the optimised
     44-vectors are all-gathered.  maximize(local_targets) -> [n_local, 44].  Returns [len(targets), 44]."""
@@ -68,14 +82,122 @@ def sharded_maximize(maximize: Callable[[Sequence[int]], np.ndarray], targets: S
     elif all_gather is not None:
         blocks = all_gather(block)
     else:
-        import torch
-        import torch.distributed as dist
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.from_numpy(block).to(dev)
-        outs = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(outs, t)
-        blocks = [o.cpu().numpy() for o in outs]
+        blocks = _default_all_gather(block, world, device)
     out = np.zeros((len(targets), P))
     for r in range(world):
         out[shards[r]] = blocks[r][:len(shards[r])]
     return out
+
+
+class DeviceShardedSweep:
+    """BASELINE.json configs[3]: ONE field, its targets sharded by source across `world` ranks, on the device.
+
+    The reference drains one field's source list with N workers (ParallelRun.jl:546-607); here every rank holds the
+    replicated images (its own FieldContext over the whole field), evaluates its cost-balanced shard of the targets
+    (`estimate_time`, ParallelRun.jl:45-56 -> partition.shard_targets) with one `celeste_elbo_eval_batch_device` launch,
+    and the per-source results (value + 44-gradient, 360 B per target) are all-gathered -- the "catalog gather", the
+    only exchange of the path.  Every shard is padded to the widest one so that one `all_gather_into_tensor` serves:
+    the library writes the values and gradients of a rank straight into its gather block ([width] values followed by
+    [width x 44] gradients), no packing kernel.  The gather of sweep k runs on its own stream and overlaps the kernels
+    of sweep k + 1 (two blocks, alternating).
+
+    backend "nccl" (= RCCL): device-side gather over xGMI.  backend "gloo": the block is staged through the host --
+    this is how two ranks share ONE GPU in the tests (RCCL refuses two ranks on a device).
+    Hessians stay on the rank that owns the target (`hessians()`), as the optimiser consumes them locally.
+    """
+
+    def __init__(self, ctx, targets: Sequence[int], costs: Sequence[float], rank: int, world: int, flags: int,
+                 backend: Optional[str] = None, shards=None):
+        """`shards` (index lists into `targets`, one per rank) overrides the cost-balanced partition -- bench.py's
+        weak-scaling mode, where every rank sweeps all targets of its own field, uses it."""
+        import torch
+        self.torch = torch
+        self.ctx, self.rank, self.world, self.flags = ctx, rank, world, flags
+        self.targets = np.asarray(targets, dtype=np.int32)
+        assert len(costs) == len(self.targets)
+        self.shards = shards if shards is not None else shard_targets(costs, world)
+        self.mine = self.targets[self.shards[rank]]
+        self.n = int(self.mine.size)
+        self.width = max(1, max(len(s) for s in self.shards))
+        self.dev = torch.device("cuda", ctx.device)
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            self.backend = backend or dist.get_backend()
+        else:
+            self.backend = backend or "none"
+        W = self.width
+        with torch.cuda.device(self.dev):
+            self.d_tg = torch.tensor(self.mine, dtype=torch.int32, device=self.dev)
+            self.blocks = [torch.zeros(W * (1 + P), dtype=torch.float64, device=self.dev) for _ in range(2)]
+            want_h = bool(flags & 2)
+            self.d_h = torch.zeros(max(self.n, 1), P, P, dtype=torch.float64, device=self.dev) if want_h else None
+            self.d_cnt = torch.zeros(max(self.n, 1), 2, dtype=torch.int64, device=self.dev)
+            self.d_st = torch.zeros(max(self.n, 1), dtype=torch.int32, device=self.dev)
+            self.compute_stream = torch.cuda.current_stream(self.dev)
+            if world > 1 and self.backend == "nccl":
+                self.comm_stream = torch.cuda.Stream(self.dev)
+                self.gathered = torch.zeros(world * W * (1 + P), dtype=torch.float64, device=self.dev)
+                self.buf_free = [torch.cuda.Event(), torch.cuda.Event()]
+                for e in self.buf_free:
+                    e.record(self.compute_stream)
+            elif world > 1:
+                self.h_block = torch.zeros(W * (1 + P), dtype=torch.float64).pin_memory()
+                self.gathered = torch.zeros(world * W * (1 + P), dtype=torch.float64)
+        self.k = 0
+        self.last = 0
+        self.gather_bytes = world * W * (1 + P) * 8 if world > 1 else 0
+
+    def step(self, d_vp_ptr: int):
+        """One sweep: evaluate this rank's shard against the parameter table at device pointer `d_vp_ptr`
+        (n_sources x 44 doubles), then start the catalog gather.  Asynchronous with the nccl backend."""
+        torch = self.torch
+        k = self.k & 1
+        self.k += 1
+        self.last = k
+        blk = self.blocks[k]
+        nccl = self.world > 1 and self.backend == "nccl"
+        if nccl:
+            self.compute_stream.wait_event(self.buf_free[k])   # the gather that last read this block is through
+        if self.n > 0:
+            base = blk.data_ptr()
+            self.ctx.eval_batch_device(d_vp_ptr, self.n, self.d_tg.data_ptr(), self.flags, base, base + 8 * self.width,
+                                       self.d_h.data_ptr() if self.d_h is not None else 0, self.d_cnt.data_ptr(),
+                                       self.d_st.data_ptr(), self.compute_stream.cuda_stream)
+        if nccl:
+            done = torch.cuda.Event()
+            done.record(self.compute_stream)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(done)
+                self.dist.all_gather_into_tensor(self.gathered, blk)
+                self.buf_free[k].record(self.comm_stream)
+        elif self.world > 1:   # gloo: stage through the host (two ranks on one GPU in the tests)
+            self.h_block.copy_(blk, non_blocking=True)
+            self.compute_stream.synchronize()
+            outs = list(self.gathered.view(self.world, -1).unbind(0))
+            self.dist.all_gather(outs, self.h_block)
+
+    def wait(self):
+        """Every launched sweep and every gather is complete when this returns."""
+        if self.world > 1 and self.backend == "nccl":
+            self.comm_stream.synchronize()
+        self.torch.cuda.synchronize(self.dev)
+
+    def results(self):
+        """(v[len(targets)], d[len(targets), 44]) of the last sweep for ALL targets, in the order of `targets`
+        (identical on every rank), plus the status codes and pixel counters of this rank's shard."""
+        self.wait()
+        W = self.width
+        g = (self.gathered if self.world > 1 else self.blocks[self.last]).cpu().numpy().reshape(self.world, W * (1 + P))
+        v = np.zeros(len(self.targets))
+        d = np.zeros((len(self.targets), P))
+        for r in range(self.world):
+            idx = self.shards[r]
+            v[idx] = g[r, :len(idx)]
+            d[idx] = g[r, W:].reshape(W, P)[:len(idx)]
+        return v, d, self.d_st[:self.n].cpu().numpy(), self.d_cnt[:self.n].cpu().numpy()
+
+    def hessians(self):
+        """[n_local, 44, 44] Hessians of this rank's shard (targets `self.mine`)."""
+        self.wait()
+        return None if self.d_h is None else self.d_h[:self.n].cpu().numpy()

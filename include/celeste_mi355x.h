@@ -20,6 +20,8 @@
  *       src/PSF.jl:150-161, src/model/psf_model.jl:61-75
  *   estimate_time (sum of active pixels)                     celeste_ctx_work_stats
  *       src/ParallelRun.jl:45-47
+ *   images shared by the per-source ElboArgs of a box        celeste_images_create + celeste_ctx_create_on
+ *       src/ParallelRun.jl:468-488 (process_source)
  *
  * Conventions (all taken from the reference):
  *   - matrices are column-major with the first index (h, image row) fastest;
@@ -33,6 +35,7 @@
 #ifndef CELESTE_MI355X_H
 #define CELESTE_MI355X_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -70,8 +73,14 @@ enum {
      * 68-double record per visited pixel to HBM and a separate streaming kernel forms the per-patch sums
      * (the accumulation of add_pixel_term! into elbo_vars.elbo, elbo_objective.jl:330-392,452-466).
      * Requires CELESTE_FLAG_HESS; distinct targets in the batch.  Same results up to summation order. */
-    CELESTE_FLAG_SPLIT = 16u
+    CELESTE_FLAG_SPLIT = 16u,
+    /* Packed Hessian output: h holds CELESTE_HP = 990 doubles per target instead of 44 x 44 -- the upper triangle,
+     * column by column: element (i, j), i <= j, at j (j + 1) / 2 + i.  Halves the D2H traffic of the host-pointer
+     * entry points; the consumer (propagate_derivatives!, ConstraintTransforms.jl:379-393) symmetrises anyway
+     * (:452-457).  Not valid with celeste_elbo_eval_multi. */
+    CELESTE_FLAG_PACKED_HESS = 32u
 };
+#define CELESTE_HP 990          /* 44 * 45 / 2 */
 
 /* Model.Image (src/model/image_model.jl:6-38).  Borrowed for the duration of
  * celeste_ctx_create only. */
@@ -140,6 +149,7 @@ typedef struct celeste_problem_t {
 } celeste_problem_t;
 
 typedef struct celeste_ctx celeste_ctx_t;
+typedef struct celeste_images celeste_images_t;
 
 /* Per-sweep work statistics. */
 typedef struct celeste_work_stats_t {
@@ -161,6 +171,34 @@ const char *celeste_strerror(int status);
 int celeste_ctx_create(const celeste_problem_t *problem, int device, celeste_ctx_t **out);
 void celeste_ctx_destroy(celeste_ctx_t *ctx);
 
+/* Shared image handle.  The reference builds one ElboArgs per source over the SAME images
+ * (process_source, ParallelRun.jl:468-488: `ElboArgs(images, patches[[t; neighbors], :], [1])`); uploading the
+ * planes (and computing their lgamma / log-iota planes) once and creating every per-source context on the handle
+ * makes such a context cost a patch-table upload.  celeste_images_create copies the pixel / sky / calibration
+ * planes of `images` to HBM of `device`; celeste_ctx_create_on is celeste_ctx_create with problem->images ignored
+ * (problem->n_images must equal the handle's; patch boxes are validated against the handle's image sizes).  The
+ * handle is reference counted: celeste_images_destroy drops the creator's reference, device memory is released
+ * when the last context created on it is destroyed as well.  celeste_ctx_create is the two calls in sequence. */
+int celeste_images_create(int32_t n_images, const celeste_image_t *images, int device, celeste_images_t **out);
+void celeste_images_destroy(celeste_images_t *images);
+int celeste_ctx_create_on(celeste_images_t *images, const celeste_problem_t *problem, celeste_ctx_t **out);
+
+/* Concurrency contract (all entry points that take a ctx): a context owns its scratch tables (per-source constants,
+ * pre-rendered neighbour light, work lists, pixel-sum records), so AT MOST ONE call per context may be in flight at
+ * any time -- including asynchronous celeste_elbo_eval_batch_device launches that have not completed on their
+ * stream.  Callers that want concurrency use one context per thread / stream (cheap on a shared image handle);
+ * contexts never synchronise each other: the host-pointer entry points run on a private non-blocking stream of the
+ * context and wait for that stream only. */
+
+/* Page-locked host memory for the host-pointer entry points.  Outputs (and vp) that live in memory obtained from
+ * celeste_host_alloc, or registered with celeste_host_register, are copied straight from / to HBM by DMA,
+ * overlapped with the kernels of the next part of the batch; pageable buffers work too but go through a staging
+ * copy on the host.  (hipHostMalloc / hipHostRegister; no reference counterpart.) */
+void *celeste_host_alloc(size_t bytes);
+void celeste_host_free(void *ptr);
+int celeste_host_register(void *ptr, size_t bytes);
+int celeste_host_unregister(void *ptr);
+
 /* elbo(ea, vp) for one target (Sa = 1, neighbours value-only).
  * vp: n_sources x 44 host doubles (row s = source s).  Outputs may be NULL when
  * the corresponding flag is off.  Counters: elbo_args.jl:62-63. */
@@ -170,7 +208,10 @@ int celeste_elbo_eval(celeste_ctx_t *ctx, const double *vp, int32_t target, uint
 
 /* One launch for a whole batch of targets that may be evaluated together
  * (a Cyclades batch, or every source of the field for an evaluate-only sweep).
- * Host pointers; v[n], d[n*44], h[n*44*44], counters[n*2], status[n]. */
+ * Host pointers; v[n], d[n*44], h[n*44*44] (n*990 with CELESTE_FLAG_PACKED_HESS), counters[n*2], status[n].
+ * Large batches are cut into parts whose device-to-host copies overlap the kernels of the next part (results do not
+ * depend on the cut).  Targets may repeat.  Returns the first non-OK per-target status, if any; the outputs of
+ * the other targets are valid. */
 int celeste_elbo_eval_batch(celeste_ctx_t *ctx, const double *vp, int32_t n_targets,
                             const int32_t *targets, uint32_t flags,
                             double *v, double *d, double *h,
@@ -229,6 +270,10 @@ typedef struct celeste_optim_config_t {
     double gtol;           /* 1e-8 */
     double initial_delta;  /* 1.0 */
     double delta_hat;      /* 1e9 */
+    int32_t tr_secular_iters;  /* cap of the Newton iterations on the trust-region multiplier: 0 = run to convergence
+                                * (<= 20); 5 = Optim.jl's solve_tr_subproblem! default (third-party, stops after 5
+                                * whether or not converged) for comparisons with a real Optim.jl run */
+    int32_t reserved;
 } celeste_optim_config_t;
 
 /* ElboMaximize.maximize!(ea, vp, cfg) (ElboMaximize.jl:228-242) for a batch of targets, entirely on the device:
@@ -242,7 +287,11 @@ typedef struct celeste_optim_config_t {
  * generic_init_source while their neighbours sit at catalog_init_source, DeterministicVI.jl:94-103).
  * pos_centers (n_targets x 2, may be NULL = current position) are the centres of the position boxes, which the
  * reference keeps fixed across repeated maximize! calls (ParallelRun.jl:96-100).  cfg == NULL selects the
- * defaults above.  Per-target outputs may be NULL. */
+ * defaults above.  Per-target outputs may be NULL.  Targets must be distinct (CELESTE_ERR_INVALID_ARG otherwise: two
+ * optimisations of one source would share its row of vp).  A target whose ELBO becomes non-finite stops with its
+ * status set (CELESTE_ERR_NONFINITE_*), its row of vp is left as it was on entry, and every other target is optimised
+ * normally -- the reference catches per source and keeps the rest (ParallelRun.jl:582-597, 389-396); the return
+ * value is the first such status. */
 int celeste_maximize_batch(celeste_ctx_t *ctx, double *vp, const double *vp_neighbors, const double *pos_centers,
                            int32_t n_targets, const int32_t *targets, const celeste_optim_config_t *cfg,
                            int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status);

@@ -187,7 +187,14 @@ void celeste_oracle_jacobi_eig(int n, const double *A_in, double *w, double *V) 
  * the root, so a non-increasing update means the rounding floor is reached).  parity unpinned: Optim's source is
  * not available here; pinned only through the reference's recovery tolerances (test/test_optimization.jl). */
 /* returns model value m; interior flag; s */
+double celeste_oracle_solve_tr_capped(int n, const double *g, const double *H, double delta, int secular_iters, double *s,
+                                      int *interior_out);
 double celeste_oracle_solve_tr(int n, const double *g, const double *H, double delta, double *s, int *interior_out) {
+    return celeste_oracle_solve_tr_capped(n, g, H, delta, 20, s, interior_out);
+}
+/* secular_iters: cap of the Newton iterations on lambda (20 = to convergence; 5 = Optim.jl's default) */
+double celeste_oracle_solve_tr_capped(int n, const double *g, const double *H, double delta, int secular_iters, double *s,
+                                      int *interior_out) {
     double *w = (double *)malloc(sizeof(double) * n), *V = (double *)malloc(sizeof(double) * n * n);
     double *qg = (double *)malloc(sizeof(double) * n), *c = (double *)malloc(sizeof(double) * n);
     celeste_oracle_jacobi_eig(n, H, w, V);
@@ -218,7 +225,7 @@ double celeste_oracle_solve_tr(int n, const double *g, const double *H, double d
             }
         }
         if (!hard) {
-            for (int it = 0; it < 20; ++it) {
+            for (int it = 0; it < secular_iters; ++it) {
                 double q2 = 0, q3 = 0;
                 for (int i = 0; i < n; ++i) { c[i] = -qg[i] / (w[i] + lambda); q2 += c[i] * c[i]; q3 += c[i] * c[i] / (w[i] + lambda); }
                 const double prev = lambda;
@@ -240,6 +247,7 @@ double celeste_oracle_solve_tr(int n, const double *g, const double *H, double d
 typedef struct celeste_optim_config_oracle {
     double loc_width, loc_scale; int32_t max_iters; int32_t include_kl;
     double xtol_abs, ftol_rel, gtol, initial_delta, delta_hat;
+    int32_t tr_secular_iters, reserved;   /* 0 = to convergence (<= 20); 5 = Optim.jl's cap */
 } OptCfg;
 
 static int eval_free(const celeste_problem_t *pr, double *vp, int target, uint32_t flags, const double *x, const Boxes *b,
@@ -270,10 +278,16 @@ int celeste_oracle_maximize(const celeste_problem_t *pr, double *vp, int32_t tar
     double f, ft, delta = cfg->initial_delta;
     int evals = 1, it = 0;
     int st = eval_free(pr, vp, target, flags, x, &b, &f, g, H);
+    const int sec = cfg->tr_secular_iters > 0 ? cfg->tr_secular_iters : 20;
+    if (st == 0) {   /* Optim.optimize tests the gradient at the starting point before its first iteration */
+        double gmax0 = 0;
+        for (int i = 0; i < NF; ++i) gmax0 = fmax(gmax0, fabs(g[i]));
+        if (gmax0 <= cfg->gtol) st = -1;   /* stationary already: skip the loop (st is reset below) */
+    }
     while (st == 0 && it < cfg->max_iters) {
         ++it;
         int interior;
-        const double m = celeste_oracle_solve_tr(NF, g, H, delta, s, &interior);
+        const double m = celeste_oracle_solve_tr_capped(NF, g, H, delta, sec, s, &interior);
         for (int i = 0; i < NF; ++i) xt[i] = x[i] + s[i];
         st = eval_free(pr, vp, target, flags, xt, &b, &ft, gt, Ht); ++evals;
         if (st != 0) break;
@@ -292,6 +306,7 @@ int celeste_oracle_maximize(const celeste_problem_t *pr, double *vp, int32_t tar
             if (dx <= cfg->xtol_abs || df <= cfg->ftol_rel * fabs(f) || gmax <= cfg->gtol) break;
         }
     }
+    if (st == -1) st = 0;
     celeste_oracle_to_bound(x, &b, vs, NULL, NULL, NULL);
     if (stats) { stats[0] = it; stats[1] = evals; stats[2] = -f; }
     free(H); free(Ht);

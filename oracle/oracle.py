@@ -26,12 +26,13 @@ class OptCfg(C.Structure):
     """ElboConfig defaults (ElboMaximize.jl:43-49, 95-108)"""
     _fields_ = [("loc_width", C.c_double), ("loc_scale", C.c_double), ("max_iters", C.c_int32),
                 ("include_kl", C.c_int32), ("xtol_abs", C.c_double), ("ftol_rel", C.c_double), ("gtol", C.c_double),
-                ("initial_delta", C.c_double), ("delta_hat", C.c_double)]
+                ("initial_delta", C.c_double), ("delta_hat", C.c_double), ("tr_secular_iters", C.c_int32),
+                ("reserved", C.c_int32)]
 
     def __init__(self, loc_width=1e-4, loc_scale=1.0, max_iters=50, include_kl=True, xtol_abs=1e-7, ftol_rel=1e-6,
-                 gtol=1e-8, initial_delta=1.0, delta_hat=1e9):
+                 gtol=1e-8, initial_delta=1.0, delta_hat=1e9, tr_secular_iters=0):
         super().__init__(loc_width, loc_scale, max_iters, int(include_kl), xtol_abs, ftol_rel, gtol, initial_delta,
-                         delta_hat)
+                         delta_hat, tr_secular_iters, 0)
 P = 44
 _lib = None
 

@@ -28,6 +28,23 @@ def test_struct_layout_matches_the_header():
     assert C.sizeof(cabi.PriorT) == 8 * (6 + 16 + 64 + 256 + 2)
     assert C.sizeof(cabi.ProblemT) == 16 + 6 * 8 + 3 * 8
     assert C.sizeof(cabi.WorkStatsT) == 56
+    assert C.sizeof(cabi.OptimConfigT) == 2 * 8 + 2 * 4 + 5 * 8 + 2 * 4
+    hdr = open(os.path.join(ROOT, "include", "celeste_mi355x.h")).read()
+    for name, value in (("GRAD", cabi.FLAG_GRAD), ("HESS", cabi.FLAG_HESS), ("KL", cabi.FLAG_KL), ("FP32", cabi.FLAG_FP32),
+                        ("SPLIT", cabi.FLAG_SPLIT), ("PACKED_HESS", cabi.FLAG_PACKED_HESS)):
+        assert re.search(r"CELESTE_FLAG_%s = %du" % (name, value), hdr), name
+    assert cabi.HP == 44 * 45 // 2 and "#define CELESTE_HP 990" in hdr
+
+
+def test_unpack_hessian_layout():
+    """CELESTE_FLAG_PACKED_HESS: element (i, j), i <= j, at j (j + 1) / 2 + i"""
+    from celeste_jl_amd import cabi
+    full = np.random.default_rng(0).normal(size=(3, 44, 44)); full = full + full.transpose(0, 2, 1)
+    packed = np.zeros((3, cabi.HP))
+    for j in range(44):
+        for i in range(j + 1):
+            packed[:, j * (j + 1) // 2 + i] = full[:, i, j]
+    assert np.array_equal(cabi.unpack_hessian(packed), full)
 
 
 def test_no_cpu_fallback(lib):

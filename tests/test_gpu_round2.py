@@ -1,0 +1,249 @@
+"""-m gpu: round-2 boundary features, all through the C ABI.
+
+* BASELINE configs[3]: one field sharded by source across 2 ranks (two processes on the one GPU, gloo staging) equals
+  the single-rank sweep bit for bit -- through bench.py itself, and through parallel.DeviceShardedSweep;
+* shared image handle (celeste_images_create / celeste_ctx_create_on): 100 per-source contexts on one handle,
+  device memory flat, results identical to the whole-field context (ParallelRun.jl:468-488);
+* host-pointer sweep: page-locked and pageable outputs, packed Hessians, parts -- all bit-identical;
+* optimiser: duplicate targets refused; a failing target does not take the batch down (ParallelRun.jl:582-597).
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALL = 7
+
+
+def _free_device_bytes():
+    free, total = C.c_size_t(), C.c_size_t()
+    assert C.CDLL("libamdhip64.so").hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def _launch_bench(tmp_path, nproc, extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(nproc)] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_two_ranks_on_one_gpu_equals_single_rank(tmp_path):
+    """bench.py --gpus 2 --backend gloo: the SAME field on both ranks, targets sharded by estimate_time, (v, d)
+    all-gathered; every rank ends up with the single-rank sweep's numbers, bit for bit"""
+    import celeste_jl_amd as cel
+    sys.path.insert(0, ROOT)
+    import bench
+    shape = ["--height", "420", "--width", "380", "--sources", "180", "--seed", "7"]
+    d = _launch_bench(tmp_path, 2, shape + ["--backend", "gloo", "--steps", "3", "--warmup", "1", "--no-extras",
+                                            "--check-dir", str(tmp_path)])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gather_backend"] == "gloo"
+    sizes = d["config"]["shard_sizes"]
+    assert sum(sizes) == 180 == d["config"]["sources_per_step"] and len(sizes) == 2 and min(sizes) > 0
+    assert d["config"]["catalog_gather_bytes_per_step"] == 2 * max(sizes) * 45 * 8
+    pv = d["config"]["shard_pixel_visits"]
+    assert abs(pv[0] - pv[1]) <= 0.1 * max(pv), "cost-balanced shards"
+    fld = bench.build_field(420, 380, 180, 7)
+    ctx = cel.FieldContext(fld.images, fld.patches, fld.neighbors)
+    v, dd, h, cnt, st = ctx.eval_batch(fld.vp, np.arange(180), ALL)
+    assert (st == 0).all()
+    seen = np.zeros(180, dtype=bool)
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert np.array_equal(z["v"], v) and np.array_equal(z["d"], dd), "rank %d gathered catalog" % r
+        assert np.array_equal(z["h"], h[z["mine"]]), "Hessians stay with the owner"
+        seen[z["mine"]] = True
+    assert seen.all()
+
+
+def test_bench_single_rank_under_the_launcher(tmp_path):
+    """N = 1 launched the way the driver launches N > 1 (torch.distributed.run, RCCL group of one)"""
+    d = _launch_bench(tmp_path, 1, ["--height", "300", "--width", "260", "--sources", "60", "--steps", "3", "--warmup", "1",
+                                    "--no-extras"])
+    assert d["n_gpus"] == 1 and d["config"]["shard_sizes"] == [60] and d["value"] > 0
+    assert d["config"]["catalog_gather_bytes_per_step"] == 0
+
+
+def test_device_sharded_sweep_single_process_matches_host_api():
+    import torch
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.parallel import DeviceShardedSweep
+    from celeste_jl_amd.partition import estimate_time
+    f = synthetic.make_field(200, 240, 40, seed=12)
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    tg = np.arange(40)
+    sweep = DeviceShardedSweep(ctx, tg, [estimate_time(r) for r in f.patches], 0, 1, ALL)
+    d_vp = torch.tensor(f.vp, dtype=torch.float64, device="cuda:0")
+    for _ in range(3):     # alternating output blocks
+        sweep.step(d_vp.data_ptr())
+    v, d, st, cnt = sweep.results()
+    rv, rd, rh, rcnt, rst = ctx.eval_batch(f.vp, tg, ALL)
+    assert np.array_equal(v, rv) and np.array_equal(d, rd) and np.array_equal(sweep.hessians(), rh)
+    assert np.array_equal(cnt, rcnt) and (st == 0).all()
+
+
+def test_hundred_contexts_on_one_image_handle(oracle):
+    """the reference's per-source ElboArgs over shared images (process_source, ParallelRun.jl:468-488): every context
+    holds only its patch table; the planes are uploaded once"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_field(1024, 900, 100, seed=31)
+    whole = cel.FieldContext(f.images, f.patches, f.neighbors)
+    rv, rd, rh, rcnt, _ = whole.eval_batch(f.vp, np.arange(100), ALL)
+    iset = cabi.ImageSet(f.images)
+    plane_bytes = sum(im.pixels.size for im in f.images) * (4 + 4 + 8)
+    base = _free_device_bytes()
+    ctxs = []
+    for t in range(100):
+        loc = [t] + list(f.neighbors[t])           # patches[[t; neighbors], :], active source first
+        patches = [f.patches[s] for s in loc]
+        nbrs = [list(range(1, len(loc)))] + [[] for _ in loc[1:]]
+        ctxs.append((cel.FieldContext(f.images, patches, nbrs, image_set=iset), loc))
+    used = base - _free_device_bytes()
+    # a context costs its patch tables and scratch (a few MB), not a copy of the planes (74 MB here, 244 MB for an
+    # SDSS-size field)
+    assert used < 100 * 0.06 * plane_bytes, (used, plane_bytes)
+    for t, (ctx, loc) in enumerate(ctxs):
+        v, d, h, cnt, st = ctx.eval_batch(f.vp[loc], [0], ALL)
+        assert st[0] == 0 and np.array_equal(cnt[0], rcnt[t])
+        assert v[0] == rv[t] and np.array_equal(d[0], rd[t]) and np.array_equal(h[0], rh[t])
+    # one of them against the oracle as well (the local problem is a complete problem of its own)
+    ctx, loc = ctxs[17]
+    iset_free_before = _free_device_bytes()
+    iset.close()                                    # contexts keep the planes alive
+    assert abs(_free_device_bytes() - iset_free_before) < (1 << 20)
+    v, d, h, cnt, st = ctx.eval_batch(f.vp[loc], [0], ALL)
+    pb = cabi.Problem(f.images, [f.patches[s] for s in loc], [list(range(1, len(loc)))] + [[] for _ in loc[1:]])
+    ov, od, oh, ocnt, ost = oracle.elbo_batch(pb, f.vp[loc], [0], ALL)
+    from parity_util import assert_parity
+    assert_parity((v, d, h, cnt, st), (ov, od, oh, ocnt, ost), "context on a shared handle")
+    for ctx, _ in ctxs:
+        ctx.close()
+    assert _free_device_bytes() >= base + int(0.9 * plane_bytes), "planes released with the last context"
+
+
+def test_image_handle_argument_checks(lib):
+    from celeste_jl_amd import synthetic, cabi
+    import celeste_jl_amd as cel
+    f = synthetic.make_sample_dataset("two_body")
+    h = C.c_void_p()
+    assert lib.celeste_images_create(0, None, 0, C.byref(h)) == cabi.ERR_INVALID_ARG
+    assert lib.celeste_ctx_create_on(None, None, C.byref(h)) == cabi.ERR_INVALID_ARG
+    iset = cabi.ImageSet(f.images)
+    pb = cabi.Problem(f.images[:3], [row[:3] for row in f.patches], f.neighbors, marshal_images=False)
+    assert lib.celeste_ctx_create_on(iset.handle, C.byref(pb.c), C.byref(h)) == cabi.ERR_INVALID_ARG   # 3 images != 5
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors, image_set=iset)
+    ref = cel.FieldContext(f.images, f.patches, f.neighbors)
+    a, b = ctx.eval_batch(f.vp, [0, 1], ALL), ref.eval_batch(f.vp, [0, 1], ALL)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_host_api_pinned_pageable_packed_and_parts():
+    """celeste_elbo_eval_batch: outputs in page-locked or pageable memory, full or packed Hessians, one part or
+    several -- the same bits; the packed layout is the column-wise upper triangle"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_field(512, 512, 420, seed=77)      # > 2 x 192 targets: the batch is cut into parts
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    tg = np.random.default_rng(3).permutation(420)
+    a = ctx.eval_batch(f.vp, tg, ALL, pinned=True)
+    b = ctx.eval_batch(f.vp, tg, ALL, pinned=False)
+    assert (a[4] == 0).all()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    singles = [ctx.eval_batch(f.vp, [int(t)], ALL) for t in tg[[0, 5, 200, 419]]]
+    for k, t in enumerate([0, 5, 200, 419]):
+        assert singles[k][0][0] == a[0][t] and np.array_equal(singles[k][2][0], a[2][t])
+    for pinned in (True, False):
+        p = ctx.eval_batch(f.vp, tg, ALL | cabi.FLAG_PACKED_HESS, pinned=pinned)
+        assert p[2].shape == (420, cabi.HP)
+        assert np.array_equal(p[0], a[0]) and np.array_equal(p[1], a[1]) and np.array_equal(p[3], a[3])
+        assert np.array_equal(cabi.unpack_hessian(p[2]), a[2])
+    assert a[2][3][2, 7] == p[2][3][7 * 8 // 2 + 2]       # element (i, j), i <= j, at j (j + 1) / 2 + i
+    # caller-registered memory (celeste_host_register) behaves like celeste_host_alloc memory
+    h = np.zeros((420, 44, 44))
+    assert ctx.lib.celeste_host_register(h.ctypes.data_as(C.c_void_p), h.nbytes) == 0
+    v = np.zeros(420); d = np.zeros((420, 44)); cnt = np.zeros((420, 2), dtype=np.int64); st = np.zeros(420, dtype=np.int32)
+    vp = np.ascontiguousarray(f.vp); t32 = np.ascontiguousarray(tg, dtype=np.int32)
+    dp = cabi.c_double_p
+    rc = ctx.lib.celeste_elbo_eval_batch(ctx.handle, vp.ctypes.data_as(dp), 420, t32.ctypes.data_as(cabi.c_int32_p), ALL,
+                                         v.ctypes.data_as(dp), d.ctypes.data_as(dp), h.ctypes.data_as(dp),
+                                         cnt.ctypes.data_as(cabi.c_int64_p), st.ctypes.data_as(cabi.c_int32_p))
+    assert rc == 0 and np.array_equal(h, a[2]) and np.array_equal(v, a[0])
+    assert ctx.lib.celeste_host_unregister(h.ctypes.data_as(C.c_void_p)) == 0
+    # pinned arrays are recycled through the pool without aliasing live results
+    keep = a[2].copy()
+    del p
+    c = ctx.eval_batch(f.vp, tg[::-1].copy(), ALL)
+    assert np.array_equal(a[2], keep) and np.array_equal(c[2][::-1], a[2])
+
+
+def test_optimiser_refuses_duplicate_targets_and_survives_a_failing_target():
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    f = synthetic.make_field(160, 200, 24, seed=11)
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    with pytest.raises(cabi.CelesteError) as e:
+        ctx.maximize_batch(f.vp, [3, 5, 3], cel.ElboConfig(max_iters=2))
+    assert e.value.status == cabi.ERR_INVALID_ARG
+    # a neighbour with a non-finite parameter: every target that lists it fails (non-finite result), keeps its row,
+    # and the rest of the batch is optimised exactly as it would be alone
+    bad = int(np.argmax([len(n) for n in f.neighbors]))
+    hit = set(f.neighbors[bad])
+    targets = [t for t in range(24) if t != bad]
+    nb = f.vp.copy(); nb[bad, 7] = np.nan
+    cfg = cel.ElboConfig(max_iters=4)
+    with pytest.raises(AssertionError):
+        ctx.maximize_batch(f.vp, targets, cfg, vp_neighbors=nb)
+    vp, its, evals, el, st = ctx.maximize_batch(f.vp, targets, cfg, vp_neighbors=nb, raise_on_error=False)
+    ok = [k for k, t in enumerate(targets) if t not in hit]
+    ko = [k for k, t in enumerate(targets) if t in hit]
+    assert len(ko) > 0 and len(ok) > 0
+    assert np.isin(st[ko], (cabi.ERR_NONFINITE_INPUT, cabi.ERR_NONFINITE_RESULT)).all() and (st[ok] == 0).all()
+    for k in ko:
+        assert np.array_equal(vp[targets[k]], f.vp[targets[k]]), "a failed target keeps its input row"
+    good_targets = [targets[k] for k in ok]
+    vp2, its2, _, el2, st2 = ctx.maximize_batch(f.vp, good_targets, cfg)
+    assert (st2 == 0).all() and np.array_equal(vp2[good_targets], vp[good_targets]) and np.array_equal(el2, el[ok])
+    # the node-level loop logs and skips instead of raising
+    from celeste_jl_amd.infer import one_node_single_infer
+    failed = set()
+    cat = list(f.catalog)
+    import copy
+    cat[bad] = copy.deepcopy(cat[bad]); cat[bad].gal_fluxes = cat[bad].gal_fluxes.copy(); cat[bad].star_fluxes = cat[bad].star_fluxes.copy()
+    cat[bad].star_fluxes[:] = np.nan; cat[bad].gal_fluxes[:] = np.nan      # catalog_init_source -> NaN brightness
+    vs = one_node_single_infer(ctx, cat, targets, cfg, failed=failed)
+    assert failed == hit & set(targets) and np.isfinite(vs).all()
+
+
+def test_optimiser_initial_gradient_check_and_secular_cap(oracle):
+    """the two Optim.jl details ADVICE r1 asked for: the g_tol test at the starting point, and the cap of the
+    multiplier iterations (tr_secular_iters = 5 is Optim's); device and CPU restatement agree in both modes"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_sample_dataset("galaxy")
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    # a gradient tolerance larger than any gradient: converged before the first iteration, one evaluation
+    vp, its, evals, el, st = ctx.maximize_batch(f.vp, [0], cel.ElboConfig(gtol=1e30))
+    assert its[0] == 0 and evals[0] == 1 and st[0] == 0
+    o = oracle.maximize(ctx.problem, f.vp, 0, oracle.OptCfg(gtol=1e30))
+    assert o[1] == 0 and o[2] == 1 and abs(o[3] - el[0]) <= 1e-9 * abs(el[0])
+    for cap in (5, 0):
+        vp, its, evals, el, st = ctx.maximize_batch(f.vp, [0], cel.ElboConfig(max_iters=8, tr_secular_iters=cap))
+        o = oracle.maximize(ctx.problem, f.vp, 0, oracle.OptCfg(max_iters=8, tr_secular_iters=cap))
+        assert st[0] == 0 and its[0] == o[1] and evals[0] == o[2]
+        assert np.max(np.abs(vp[0] - o[0][0]) / np.maximum(np.abs(o[0][0]), 1e-3)) <= 1e-6, cap
