@@ -21,6 +21,13 @@
 #include "elbo_device.h"
 #include "../../include/celeste_mi355x.h"
 
+// Mutation testing (tests/test_mutants.py builds the library with -DCELESTE_MUTANT=k and checks that the parity
+// tests notice): 0 = the product; 1 = iota indexed by column instead of row; 2 = sky plane read transposed;
+// 3 = every patch uses stamp 0.  Never defined in the shipped build.
+#ifndef CELESTE_MUTANT
+#define CELESTE_MUTANT 0
+#endif
+
 // galaxy prototypes, normalised (light_source_model.jl:45-75), filled at context creation
 __constant__ double c_eta[16];
 __constant__ double c_nu[16];
@@ -249,29 +256,7 @@ __device__ inline double galaxy_value(const Comp *tc, int NC, double dx, double 
     return v;
 }
 
-// ---- cross-lane helpers (wave64; DPP quad permutes move data without touching LDS) ----------
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double x) {
-    const long long b = __builtin_bit_cast(long long, x);
-    int lo = (int)b, hi = (int)(b >> 32);
-    // old == src: every lane of the quad is active here, so the "old" value is never selected (and no
-    // zero-initialising v_mov is needed in front of each v_mov_b32_dpp)
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-#define DPP_XOR1 0xB1  // quad_perm [1,0,3,2]
-#define DPP_XOR2 0x4E  // quad_perm [2,3,0,1]
-
-// sum over the 16 lanes l, l^4, l^8, ... (same lane & 3): butterfly on xor 4, 8, 16, 32
-__device__ __forceinline__ double quad_class_sum(double x) {
-    x += __shfl_xor(x, 4, 64);
-    x += __shfl_xor(x, 8, 64);
-    x += __shfl_xor(x, 16, 64);
-    x += __shfl_xor(x, 32, 64);
-    return x;
-}
-
+// ---- cross-lane helpers (wave64) ----------------------------------------------------------------
 __device__ inline double wave_sum(double x) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -487,7 +472,7 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
         for (int i = threadIdx.x; i < NC * 8; i += 64) dst[i] = src[i];
         __syncthreads();
     }
-    const double *__restrict__ coef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
+    const double *__restrict__ coef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
     double2 *__restrict__ out = val + val_off[sn];
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
     for (int idx = p0 + (int)threadIdx.x; idx < p1; idx += 64) {
@@ -616,25 +601,25 @@ __device__ __forceinline__ double record_entry(const PixelTerms &T) {
     }
 }
 
-// Fold the 68 entries across each lane quad so that a lane only accumulates 17 of them: after the
-// xor-1 and xor-2 exchanges lane l holds, for its quad, the entries e = 4 j + (l & 3).
-template <int MODE, int E>
-__device__ __forceinline__ double mode_entry(const PixelTerms &T) {
-    // MODE 1 (gradient only): Hessian entries are not formed
-    if constexpr (MODE == 1 && E > ZV && E < ACC_CNT) return 0.0;
-    else return record_entry<E>(T);
+// Accumulation of the per-pixel record into the chunk's record: every lane adds its 68 entries into LDS with
+// ds_add_f64, 16 slots per entry (slot = lane & 15, so the lanes l, l + 16, l + 32, l + 48 of one instruction meet in
+// one slot; the LDS unit serialises them in a fixed order -- results are bitwise reproducible).  The first version
+// folded the entries across lane quads with DPP exchanges and kept 17 accumulators per lane: 374 VALU instructions per
+// 64 pixels (12 v_cndmask + 6 DPP moves + 4 adds per group of four entries) and 34 VGPRs; the LDS adder does the same
+// work off the VALU (68 LDS instructions, ~11 cycles each per CU, a quarter of the LDS pipe's time at 8 waves per
+// CU) and needs no accumulator registers.  Identically zero entries (the (q, q) block) are never touched.
+#define ACC_SLOTS 16
+template <int E>
+constexpr bool entry_is_zero() {
+    if (E > ZV && E < ACC_CNT) { const int i = hess_row(E), j = hess_col(E); return i >= 2 && i < 4 && j < 4; }
+    return false;
 }
-template <int MODE, int J>
-__device__ __forceinline__ void fold_entries(const PixelTerms &T, bool b0, bool b1, double *a) {
-    constexpr bool skip = (MODE == 1) && (4 * J > ZV) && (4 * J + 3 < ACC_CNT);  // group of Hessian entries only
-    if constexpr (!skip) {
-        const double e0 = mode_entry<MODE, 4 * J>(T), e1 = mode_entry<MODE, 4 * J + 1>(T);
-        const double e2 = mode_entry<MODE, 4 * J + 2>(T), e3 = mode_entry<MODE, 4 * J + 3>(T);
-        const double t0 = (b0 ? e1 : e0) + dpp_f64<DPP_XOR1>(b0 ? e0 : e1);  // entry 4J + b0
-        const double t1 = (b0 ? e3 : e2) + dpp_f64<DPP_XOR1>(b0 ? e2 : e3);  // entry 4J + 2 + b0
-        a[J] += (b1 ? t1 : t0) + dpp_f64<DPP_XOR2>(b1 ? t0 : t1);
-    }
-    if constexpr (J + 1 < ACC_N / 4) fold_entries<MODE, J + 1>(T, b0, b1, a);
+template <int MODE, int E>
+__device__ __forceinline__ void accum_entries(const PixelTerms &T, double *__restrict__ slot) {
+    constexpr bool hess_only = E > ZV && E < ACC_CNT;
+    if constexpr (!(MODE == 1 && hess_only) && !entry_is_zero<E>())
+        __hip_atomic_fetch_add(slot + ACC_SLOTS * E, record_entry<E>(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if constexpr (E + 1 < ACC_N) accum_entries<MODE, E + 1>(T, slot);
 }
 
 // Split variant (CELESTE_FLAG_SPLIT): instead of folding, every pixel's 68-entry record goes to HBM, entry-major
@@ -759,7 +744,6 @@ __device__ __forceinline__ double galaxy_sums_pk(const CompR<float> *tc, int nc,
     return (double)S0.x + (double)S0.y;
 }
 
-#define ACC_Q (ACC_N / 4)  // 17 accumulators per lane: lane l owns record entries e with e % 4 == l % 4
 
 // MODE 0: value only; MODE 1: value + gradient sums; MODE 2: value + gradient + Hessian sums;
 // MODE 3: as MODE 2 but the per-pixel records are written to HBM for record_sum_kernel (split variant)
@@ -820,7 +804,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         __syncthreads();
     }
     const CompR<R> *tcr = sizeof(R) == 4 ? tcr_f : reinterpret_cast<const CompR<R> *>(tc);
-    const double *__restrict__ tcoef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
+    const double *__restrict__ tcoef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
     const int64_t nb0 = nbr_off[t], nb1 = nbr_off[t + 1];
     // several active sources (celeste_elbo_eval_multi): a pixel of two active patches is visited by the earlier
     // one only (elbo_objective.jl:430-470) -- its value term and inactive-source count are dropped here
@@ -828,11 +812,15 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const double c0 = si.c0, c1 = si.c1, q0 = si.q0, q1 = si.q1;
     // index offsets of the star spline: itp[h - m1 + 26, w - m2 + 26]
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
-    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
-
-    double a[ACC_Q];
+    // the chunk's record, 16 slots per entry (accum_entries); MODE 0 keeps its three sums in registers
+    __shared__ double sacc[MODE == 0 || MODE == 3 ? 1 : ACC_N * ACC_SLOTS];
+    if constexpr (MODE == 1 || MODE == 2) {
 #pragma unroll
-    for (int i = 0; i < ACC_Q; ++i) a[i] = 0.0;
+        for (int i = 0; i < ACC_N * ACC_SLOTS / 64; ++i) sacc[lane + 64 * i] = 0.0;   // (visible after the barrier below)
+    }
+    double *const slot = sacc + (lane & (ACC_SLOTS - 1));
+    double a[3] = {0.0, 0.0, 0.0};
+    if constexpr (MODE == 1 || MODE == 2) __syncthreads();
 
     for (int base = p0; base < p1; base += 64) {
         const int idx = min(base + lane, p1 - 1);           // clamped: every lane stays in the loop body
@@ -842,10 +830,19 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         const size_t gi = (size_t)(h - 1) + (size_t)img.H * (w - 1);
         // coalesced (along h) loads of every per-pixel input, issued together
         const float xf = img.pixels[gi];
+#if CELESTE_MUTANT == 2
+        const float skyf = img.sky[(size_t)(w - 1) + (size_t)img.W * (h - 1)];
+#else
         const float skyf = img.sky[gi];
+#endif
         const double lgx = img.lgx[gi];
-        const double iota = (double)img.iota[h - 1];
-        const double log_iota = img.log_iota[h - 1];
+#if CELESTE_MUTANT == 1
+        const int irow = min(w, img.H);
+#else
+        const int irow = h;   // iota is per ROW: img.nelec_per_nmgy[h] (elbo_objective.jl:374-385)
+#endif
+        const double iota = (double)img.iota[irow - 1];
+        const double log_iota = img.log_iota[irow - 1];
         bool valid = in_range && !isnan(xf);                // elbo_objective.jl:459
         if (P.bitmap_off >= 0) valid = valid && bitmaps[P.bitmap_off + h2 + (int64_t)H2 * w2] != 0;  // :445
         const double hh = (double)h, ww = (double)w;
@@ -983,7 +980,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         if constexpr (MODE == 3)
             store_entries<0>(T, rec + (size_t)(tile_off[(size_t)t * N + n] + (base >> 6)) * (ACC_N * 64) + lane);
         else
-            fold_entries<MODE, 0>(T, b0, b1, a);
+            accum_entries<MODE, 0>(T, slot);
     }
     if (MODE == 3) return;
 
@@ -994,11 +991,15 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         if (lane == 0) { out[0] = s0; out[ACC_CNT] = s1; out[ACC_CNT + 1] = s2; }
         return;
     }
+    // lane e sums the 16 slots of entry e (rotated start: 4-way instead of 64-way bank conflicts; the order of the
+    // additions is fixed per entry, so the record is reproducible)
+    __syncthreads();
+    for (int e = lane; e < ACC_N; e += 64) {
+        if (MODE == 1 && e > ZV && e < ACC_CNT) continue;   // Hessian entries are not produced
+        double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < ACC_Q; ++j) {
-        if (MODE == 1 && (4 * j > ZV) && (4 * j + 3 < ACC_CNT)) continue;  // Hessian-only groups are not produced
-        const double s = quad_class_sum(a[j]);
-        if (lane < 4) out[4 * j + lane] = s;
+        for (int k = 0; k < ACC_SLOTS; ++k) s += sacc[e * ACC_SLOTS + ((k + e) & (ACC_SLOTS - 1))];
+        out[e] = s;
     }
 }
 
@@ -1650,7 +1651,7 @@ render_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ c
         for (int i = threadIdx.x; i < NC * 8; i += 64) dst[i] = src[i];
         __syncthreads();
     }
-    const double *__restrict__ coef = coefs + (size_t)P.stamp * (CEL_COEF * CEL_COEF);
+    const double *__restrict__ coef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
     for (int idx = p0 + (int)threadIdx.x; idx < p1; idx += 64) {
         const int w2 = idx / H2, h2 = idx - w2 * H2;
         const size_t gi = (size_t)(P.off_h + h2) + (size_t)imgH * (P.off_w + w2);

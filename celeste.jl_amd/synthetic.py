@@ -20,8 +20,8 @@ from typing import List, Optional
 import numpy as np
 
 from . import cabi
-from .model import (ConstantPSFMap, Image, ImagePatch, box_around_point, get_sky_patches, make_psf, neighbor_map,
-                    render_psf)
+from .model import (ConstantPSFMap, Image, ImagePatch, SDSSBackground, SDSSPSFMap, box_around_point, get_sky_patches,
+                    make_psf, neighbor_map, render_psf)
 from .params import CatalogEntry, catalog_init_source, perturb_params
 
 SKY_NMGY = (0.20, 0.35, 0.60, 0.95, 1.40)
@@ -69,6 +69,62 @@ def blank_images(H: int, W: int) -> List[Image]:
     return images
 
 
+SDSS_GAIN = (1.62, 3.32, 4.71, 5.165, 4.745)   # electrons per DN (camcol 1 of the SDSS gain table, SDSSIO.jl:680-690)
+
+
+def variable_images(H: int, W: int, seed: int = 0) -> List[Image]:
+    """Images shaped like a real SDSS frame instead of the constant template: the three per-image inputs of the
+    pixel term all vary (elbo_objective.jl:374-385: iota = img.nelec_per_nmgy[h] per ROW, img.sky[h, w] per PIXEL,
+    and a per-patch star stamp, imaged_sources.jl:97-107):
+      * sky = SDSSBackground.materialize(): bilinear interpolation of a small sky image (+-20 %, smooth) at per-row /
+        per-column coordinates, times the per-row calibration (SDSSIO.jl:56-99);
+      * nelec_per_nmgy[h] = gain / calibration[h] with a calibration drifting +-10 % along the rows (SDSSIO.jl:773);
+      * psfmap = SDSSPSFMap with 3 eigen-images and first-order weight polynomials (SDSSIO.jl:239-299): eigen-image 0
+        is the raster of the image-centre mixture `img.psf`, 1 and 2 widen / skew it away from the centre -- every patch
+        gets its own stamp, hence its own spline, while `patch.psf` stays the image-centre fit (SURVEY.md trap A4).
+    The objects are kept on the image (`background`, `psfmap`) so that fixtures can store their small defining arrays."""
+    rng = np.random.Generator(np.random.PCG64([seed, 977]))
+    images = []
+    for b in range(5):
+        psf = band_psf(b)
+        # --- sky: a (9 x 7) sky image in DN, smooth, +-20 %
+        nx, ny = 9, 7
+        gx, gy = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny), indexing="ij")
+        ph = rng.uniform(0, 2 * np.pi, 3)
+        rel = 1.0 + 0.2 * (0.6 * np.sin(2.1 * gx + ph[0]) * np.cos(1.7 * gy + ph[1]) + 0.4 * np.sin(3.0 * (gx + gy) + ph[2]))
+        hh = np.arange(H) / max(H - 1, 1)
+        drift = 1.0 + 0.1 * np.sin(2.6 * hh + rng.uniform(0, 2 * np.pi)) * np.cos(1.3 * hh + 0.4)
+        calib0 = SDSS_GAIN[b] / NELEC_PER_NMGY[b]                      # nMgy per DN at drift = 1
+        calibration = (calib0 * drift).astype(np.float32)
+        sky_small = (SKY_NMGY[b] / calib0 * rel).astype(np.float32)    # DN
+        # interpolation coordinates (1-based, with some constant extrapolation at both ends like real frames)
+        sky_x = (np.linspace(0.6, nx + 0.4, H)).astype(np.float32)
+        sky_y = (np.linspace(0.7, ny + 0.3, W)).astype(np.float32)
+        bkg = SDSSBackground(sky_small, sky_x, sky_y, calibration)
+        nelec = (np.float32(SDSS_GAIN[b]) / calibration).astype(np.float32)
+        # --- PSF map: base raster + "wider" and "skewed" difference images, weights linear in (x, y), zero at the centre
+        base = render_psf(psf, (51, 51))
+        wide = render_psf(make_psf(PSF_ALPHA, [(0.0, 0.0)] * 2,
+                                   [np.eye(2) * (1.25 * sig * PSF_BAND_SCALE[b]) ** 2 for sig in PSF_SIGMA]), (51, 51))
+        skew = render_psf(make_psf(PSF_ALPHA, [(0.35, -0.25), (0.6, 0.4)],
+                                   [np.array([[1.2, 0.3], [0.3, 0.9]]) * (sig * PSF_BAND_SCALE[b]) ** 2 for sig in PSF_SIGMA]),
+                          (51, 51))
+        rrows = np.stack([base.T.reshape(-1), (wide - base).T.reshape(-1), (skew - base).T.reshape(-1)], axis=1)
+        RCS = 0.001
+        cx, cy = RCS * (H / 2.0 - 1.0), RCS * (W / 2.0 - 1.0)
+        a1, a2 = 0.45 / max(cx, 1e-9), 0.45 / max(cy, 1e-9)            # weights reach +-0.45 at the image edges
+        cmat = np.zeros((2, 2, 3))
+        cmat[0, 0, 0] = 1.0                                            # w0 = 1
+        cmat[0, 0, 1], cmat[1, 0, 1] = -a1 * cx, a1                    # w1 = a1 (RCS (x - 1) - cx): 0 at the centre row
+        cmat[0, 0, 2], cmat[0, 1, 2] = -a2 * cy, a2                    # w2 = a2 (RCS (y - 1) - cy): 0 at the centre column
+        psfmap = SDSSPSFMap(rrows, 51, 51, cmat)
+        img = Image(pixels=np.zeros((H, W), dtype=np.float32), b=b + 1, psf=psf, sky=bkg.materialize(),
+                    nelec_per_nmgy=nelec, psfmap=psfmap)
+        img.background = bkg
+        images.append(img)
+    return images
+
+
 # ---- value-only light densities (numpy; used only to paint synthetic pixels) ----------------------
 def _bspline_w(f):
     o = 1.0 - f
@@ -111,7 +167,8 @@ def galaxy_density(psf: np.ndarray, m_pos, frac_dev, axis_ratio, angle, radius, 
 def render_expected_image(img: Image, catalog: List[CatalogEntry]) -> np.ndarray:
     """Synthetic.gen_image! with expectation=true for one image, before the nelec scaling: sky + sources, in nmgy."""
     nm = img.sky.astype(np.float64).copy()
-    coef = cabi.spline_prefilter(img.psfmap(0, 0))
+    constant_map = isinstance(img.psfmap, ConstantPSFMap)
+    coef = cabi.spline_prefilter(img.psfmap(0, 0)) if constant_map else None
     pc = (np.array([ce.pos for ce in catalog], dtype=float).reshape(-1, 2) - img.wcs_world0) @ img.wcs_jacobian.T \
         + img.wcs_pix0
     near = np.flatnonzero((pc[:, 0] > -27) & (pc[:, 0] < img.H + 28) & (pc[:, 1] > -27) & (pc[:, 1] < img.W + 28))
@@ -125,6 +182,8 @@ def render_expected_image(img: Image, catalog: List[CatalogEntry]) -> np.ndarray
         ww = np.arange(w0, w1 + 1, dtype=float)[None, :]
         m = p.wcs_jacobian @ (np.asarray(ce.pos, float) - p.world_center) + p.pixel_center
         if ce.is_star:
+            if not constant_map:   # the stamp of the source's own patch (its box centre), as the model will see it
+                coef = cabi.spline_prefilter(img.psfmap(p.pixel_center[0], p.pixel_center[1]))
             dens = star_density(coef, hh - m[0] + 26, ww - m[1] + 26) * ce.star_fluxes[img.b - 1]
         else:
             dens = galaxy_density(img.psf, m, ce.gal_frac_dev, ce.gal_axis_ratio, ce.gal_angle,
@@ -219,11 +278,13 @@ class Field:
 
 
 def make_field(H: int, W: int, n_sources: int, seed: int, stars_only: bool = False, perturb: bool = True,
-               nan_fraction: float = 0.0, margin: int = 26, name: str = "") -> Field:
-    """Configs 2 / 3 of SURVEY.md 8(d): uniform positions with a margin, prior-drawn sources."""
+               nan_fraction: float = 0.0, margin: int = 26, name: str = "", variable: bool = False) -> Field:
+    """Configs 2 / 3 of SURVEY.md 8(d): uniform positions with a margin, prior-drawn sources.
+    variable=True: SDSS-like varying sky plane, per-row calibration and per-patch PSF stamps (`variable_images`)
+    instead of the constant template of AccuracyBenchmark.make_image."""
     rng = np.random.Generator(np.random.PCG64(seed))
     prior = load_prior()
-    images = blank_images(H, W)
+    images = variable_images(H, W, seed) if variable else blank_images(H, W)
     catalog = []
     for _ in range(n_sources):
         pos = (rng.uniform(margin, H - margin), rng.uniform(margin, W - margin))

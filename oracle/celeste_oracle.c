@@ -1005,3 +1005,92 @@ int celeste_oracle_elbo_batch(const celeste_problem_t *pr, const double *vp, int
     free(coefs_all);
     return worst;
 }
+
+/* ---- per-function hooks for the micro-goldens (tests/golden/micro/, tests/test_oracle_micro.py) ----------------
+ * They expose the intermediate results of the restated functions so that each can be compared with an independent
+ * 50-digit evaluation (mpmath; values and numerically differentiated derivatives).  Test infrastructure only. */
+
+/* eval_bvn_pdf! + get_bvn_derivs! + GalaxySigmaDerivs + transform_bvn_derivs! for ONE component
+ * (BivariateNormals.jl:143-572) with mean = `mean`, covariance = tau + nuBar XiXi(ratio, angle, radius), evaluated at x.
+ * out[87]: f_pre, py1, py2 | bvn_x_d[2] bvn_sig_d[3] bvn_xx_h[4] bvn_xsig_h[6] bvn_sigsig_h[9] | j[9] t[27] |
+ *          bvn_u_d[2] bvn_uu_h[4] bvn_s_d[3] bvn_ss_h[9] bvn_us_h[6] */
+void celeste_oracle_micro_bvn(const double mean[2], const double tau[3], double weight, const double x[2],
+                              const double J[4], double ratio, double angle, double radius, double nuBar, double *out) {
+    double XiXi[4];
+    celeste_oracle_get_bvn_cov(ratio, angle, radius, XiXi);
+    double cov[4] = {tau[0] + nuBar * XiXi[0], tau[1] + nuBar * XiXi[1], tau[1] + nuBar * XiXi[2], tau[2] + nuBar * XiXi[3]};
+    Bvn b; bvn_make(&b, mean, cov, weight, 1);
+    SigSF s; sigsf_make(&s, angle, ratio, radius, XiXi, nuBar, 1);
+    BvnDerivs bd; memset(&bd, 0, sizeof bd);
+    eval_bvn_pdf(&bd, &b, x);
+    get_bvn_derivs(&bd, &b, 1, 1);
+    transform_bvn_derivs(&bd, &s, J, 1);
+    int k = 0;
+    out[k++] = bd.f_pre; out[k++] = bd.py1; out[k++] = bd.py2;
+    for (int q = 0; q < 2; ++q) out[k++] = bd.bvn_x_d[q];
+    for (int q = 0; q < 3; ++q) out[k++] = bd.bvn_sig_d[q];
+    for (int q = 0; q < 4; ++q) out[k++] = bd.bvn_xx_h[q];
+    for (int q = 0; q < 6; ++q) out[k++] = bd.bvn_xsig_h[q];
+    for (int q = 0; q < 9; ++q) out[k++] = bd.bvn_sigsig_h[q];
+    for (int q = 0; q < 9; ++q) out[k++] = s.j[q];
+    for (int q = 0; q < 27; ++q) out[k++] = s.t[q];
+    for (int q = 0; q < 2; ++q) out[k++] = bd.bvn_u_d[q];
+    for (int q = 0; q < 4; ++q) out[k++] = bd.bvn_uu_h[q];
+    for (int q = 0; q < 3; ++q) out[k++] = bd.bvn_s_d[q];
+    for (int q = 0; q < 9; ++q) out[k++] = bd.bvn_ss_h[q];
+    for (int q = 0; q < 6; ++q) out[k++] = bd.bvn_us_h[q];
+}
+
+/* SourceBrightness (source_brightness.jl:27-202): out[(b + 5 i) * 111 + ...] = v, d[10], h[100] of E_l_a[b, i], then the
+ * same block again for E_ll_a */
+void celeste_oracle_micro_brightness(const double *vs, double *out) {
+    SourceBrightness sb; sb_load(&sb, vs, 1);
+    for (int w = 0; w < 2; ++w) for (int i = 0; i < 2; ++i) for (int b = 0; b < NB; ++b) {
+        const SF *E = w == 0 ? &sb.E_l_a[b][i] : &sb.E_ll_a[b][i];
+        double *o = out + (size_t)((w * 2 + i) * NB + b) * 111;
+        o[0] = E->v; memcpy(o + 1, E->d, sizeof(double) * 10); memcpy(o + 11, E->h, sizeof(double) * 100);
+    }
+    sb_free(&sb);
+}
+
+/* One pixel (h, w; 1-based) of image n for source s as the ACTIVE source, nothing else on the pixel:
+ * star_light_density!, populate_gal_fsm!, calculate_G_s!, then E_G = sky + E_G_s, var_G = var_G_s and
+ * add_elbo_log_term! (elbo_objective.jl:17-327; fsm_util.jl:194-248).
+ * out: fs0m (1 + 2 + 4) | fs1m (1 + 6 + 36) | E_G_s (1 + 44 + 1936) | var_G_s (same) | elbo_log_term (same) */
+int celeste_oracle_micro_pixel(const celeste_problem_t *pr, const double *vp, int32_t s, int32_t n, int32_t h, int32_t w,
+                               double *out) {
+    if (!pr || !vp || s < 0 || s >= pr->n_sources || n < 0 || n >= pr->n_images) return CELESTE_ERR_INVALID_ARG;
+    const celeste_image_t *img = &pr->images[n];
+    const celeste_patch_t *p = oracle_patch_at(pr, s, n);
+    const int K = pr->psf_K;
+    const double *vs = vp + (size_t)s * P;
+    double *coef = (double *)malloc(sizeof(double) * 53 * 53);
+    celeste_oracle_spline_coefs(pr->stamps + (size_t)p->stamp * 51 * 51, coef);
+    ElboVars ev; memset(&ev, 0, sizeof ev);
+    ev.has_grad = 1; ev.has_hess = 1;
+    ev.fs0m = sf_new(2); ev.fs1m = sf_new(6);
+    ev.E_G_s = sf_new(P); ev.E_G2_s = sf_new(P); ev.var_G_s = sf_new(P);
+    ev.E_G = sf_new(P); ev.var_G = sf_new(P); ev.elbo_log_term = sf_new(P); ev.elbo = sf_new(P);
+    SourceBrightness sb; sb_load(&sb, vs, 1);
+    GalComp *mcs = (GalComp *)malloc(sizeof(GalComp) * K * 16);
+    BvnDerivs bd; memset(&bd, 0, sizeof bd);
+    load_bvn_mixtures_source(mcs, p, K, vs, 1, 1);
+    star_light_density(&ev.fs0m, p, coef, h, w, vs + ID_POS, 1, 1, 1);
+    populate_gal_fsm(&ev.fs1m, &bd, mcs, K, h, w, 1, p->wcs_jacobian, 1, 1);
+    calculate_G_s(vs, &ev, &sb, img->band - 1, 1);
+    add_sources_sf(&ev.E_G, &ev.E_G_s, 0, 1, 1);
+    add_sources_sf(&ev.var_G, &ev.var_G_s, 0, 1, 1);
+    ev.E_G.v += (double)img->sky[(h - 1) + (size_t)img->H * (w - 1)];
+    add_elbo_log_term(&ev, 1.0f, img->nelec_per_nmgy[h - 1]);
+    double *o = out;
+    *o++ = ev.fs0m.v; memcpy(o, ev.fs0m.d, sizeof(double) * 2); o += 2; memcpy(o, ev.fs0m.h, sizeof(double) * 4); o += 4;
+    *o++ = ev.fs1m.v; memcpy(o, ev.fs1m.d, sizeof(double) * 6); o += 6; memcpy(o, ev.fs1m.h, sizeof(double) * 36); o += 36;
+    const SF *big[3] = {&ev.E_G_s, &ev.var_G_s, &ev.elbo_log_term};
+    for (int q = 0; q < 3; ++q) {
+        *o++ = big[q]->v; memcpy(o, big[q]->d, sizeof(double) * P); o += P; memcpy(o, big[q]->h, sizeof(double) * P * P); o += P * P;
+    }
+    sb_free(&sb); free(mcs); free(coef);
+    sf_free(&ev.fs0m); sf_free(&ev.fs1m); sf_free(&ev.E_G_s); sf_free(&ev.E_G2_s); sf_free(&ev.var_G_s);
+    sf_free(&ev.E_G); sf_free(&ev.var_G); sf_free(&ev.elbo_log_term); sf_free(&ev.elbo);
+    return CELESTE_OK;
+}

@@ -235,3 +235,57 @@ def maximize(problem, vp, target, cfg=None):
     stats = np.zeros(3)
     st = lib().celeste_oracle_maximize(C.byref(problem.c), _dp(vp), int(target), C.byref(cfg), _dp(stats))
     return vp, int(stats[0]), int(stats[1]), float(stats[2]), int(st)
+
+
+# ---- per-function hooks (tests/test_oracle_micro.py) -----------------------------------------------------------------
+def micro_bvn(mean, tau, weight, x, J, ratio, angle, radius, nu_bar):
+    """One BVN component through eval_bvn_pdf! / get_bvn_derivs! / GalaxySigmaDerivs / transform_bvn_derivs!.
+    Returns a dict of the intermediate arrays (column-major reshaped to the reference's index order)."""
+    L = lib()
+    L.celeste_oracle_micro_bvn.restype = None
+    out = np.zeros(87)
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (mean, tau, x, np.asarray(J, dtype=np.float64).T)]
+    L.celeste_oracle_micro_bvn(_dp(a[0]), _dp(a[1]), C.c_double(weight), _dp(a[2]), _dp(a[3]), C.c_double(ratio),
+                               C.c_double(angle), C.c_double(radius), C.c_double(nu_bar), _dp(out))
+    k = [0]
+
+    def take(n, shape=None):
+        v = out[k[0]:k[0] + n].copy(); k[0] += n
+        return v if shape is None else v.reshape(shape, order="F")
+    return dict(f_pre=take(1)[0], py=take(2), x_d=take(2), sig_d=take(3), xx_h=take(4, (2, 2)), xsig_h=take(6, (2, 3)),
+                sigsig_h=take(9, (3, 3)), j=take(9, (3, 3)), t=take(27, (3, 3, 3)), u_d=take(2), uu_h=take(4, (2, 2)),
+                s_d=take(3), ss_h=take(9, (3, 3)), us_h=take(6, (2, 3)))
+
+
+def micro_brightness(vs):
+    """SourceBrightness SensitiveFloats: {("E_l_a" | "E_ll_a", b, i): (v, d[10], h[10, 10])}, b = 0..4, i = 0..1"""
+    L = lib()
+    L.celeste_oracle_micro_brightness.restype = None
+    out = np.zeros(2 * 2 * 5 * 111)
+    L.celeste_oracle_micro_brightness(_dp(np.ascontiguousarray(vs, dtype=np.float64)), _dp(out))
+    res = {}
+    for w, name in enumerate(("E_l_a", "E_ll_a")):
+        for i in range(2):
+            for b in range(5):
+                o = out[((w * 2 + i) * 5 + b) * 111:][:111]
+                res[(name, b, i)] = (o[0], o[1:11].copy(), o[11:].reshape(10, 10).T.copy())
+    return res
+
+
+def micro_pixel(problem, vp, s, n, h, w):
+    """One pixel (1-based h, w) of image n with source s active and alone: the SensitiveFloats fs0m, fs1m, E_G_s,
+    var_G_s and elbo_log_term as (v, d, h) triples."""
+    L = lib()
+    vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(problem.n_sources, P))
+    out = np.zeros(7 + 43 + 3 * (1 + P + P * P))
+    L.celeste_oracle_micro_pixel.argtypes = [C.POINTER(cabi.ProblemT), C.POINTER(C.c_double), C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    st = L.celeste_oracle_micro_pixel(C.byref(problem.c), _dp(vp), s, n, h, w, _dp(out))
+    assert st == 0
+    k = [0]
+
+    def sf(p):
+        v = out[k[0]]; d = out[k[0] + 1:k[0] + 1 + p].copy(); hh = out[k[0] + 1 + p:k[0] + 1 + p + p * p].reshape(p, p).T.copy()
+        k[0] += 1 + p + p * p
+        return v, d, hh
+    return dict(fs0m=sf(2), fs1m=sf(6), E_G_s=sf(P), var_G_s=sf(P), elbo_log_term=sf(P))

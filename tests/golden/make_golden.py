@@ -13,7 +13,8 @@ import golden_util as gu
 from celeste_jl_amd import cabi
 from oracle import oracle
 
-for name in gu.CASES:
+# usage: make_golden.py [case ...]   (default: every case of golden_util.CASES)
+for name in (sys.argv[1:] or gu.CASES):
     f = gu.build_case(name)
     arrs = gu.field_to_arrays(f)
     f2 = gu.arrays_to_field(arrs)  # the fixture must be self-contained

@@ -11,6 +11,9 @@ CASES = {
     "sample_galaxy": ("sample", "galaxy"),
     "sample_two_body": ("sample", "two_body"),
     "field_64x80_8src_nan": ("field", (64, 80, 8, 21, 0.01)),
+    # SDSS-like varying sky plane (SDSSBackground), per-row nelec_per_nmgy and per-patch PSF stamps (SDSSPSFMap):
+    # the inputs elbo_objective.jl:374-385 indexes per row / per pixel, and imaged_sources.jl:97-107 per patch
+    "field_72x88_9src_variable": ("variable", (72, 88, 9, 33, 0.01)),
 }
 
 
@@ -20,19 +23,34 @@ def build_case(name):
     if kind == "sample":
         return synthetic.make_sample_dataset(arg)
     H, W, S, seed, nanf = arg
-    return synthetic.make_field(H, W, S, seed=seed, nan_fraction=nanf)
+    return synthetic.make_field(H, W, S, seed=seed, nan_fraction=nanf, variable=kind == "variable")
 
 
 def field_to_arrays(f):
     cat = f.catalog
-    return dict(
+    out = dict(
         pixels=np.stack([im.pixels for im in f.images]),
-        sky=np.array([im.sky[0, 0] for im in f.images], dtype=np.float32),
-        iota=np.array([im.nelec_per_nmgy[0] for im in f.images], dtype=np.float32),
         pos=np.array([c.pos for c in cat]), is_star=np.array([c.is_star for c in cat]),
         star_fluxes=np.array([c.star_fluxes for c in cat]), gal_fluxes=np.array([c.gal_fluxes for c in cat]),
         shape=np.array([[c.gal_frac_dev, c.gal_axis_ratio, c.gal_angle, c.gal_radius_px] for c in cat]),
         vp=f.vp)
+    if hasattr(f.images[0], "background"):
+        # variable images: the small defining arrays of SDSSBackground and SDSSPSFMap (SDSSIO.jl:56-99, 239-299);
+        # the planes and the per-patch stamps are rebuilt from them by the package's host classes
+        out.update(
+            sky_small=np.stack([im.background.sky_small for im in f.images]),
+            sky_x=np.stack([im.background.sky_x for im in f.images]),
+            sky_y=np.stack([im.background.sky_y for im in f.images]),
+            calibration=np.stack([im.background.calibration for im in f.images]),
+            iota_rows=np.stack([im.nelec_per_nmgy for im in f.images]),
+            psf_rrows=np.stack([im.psfmap.rrows for im in f.images]),
+            psf_cmat=np.stack([im.psfmap.cmat for im in f.images]))
+    else:
+        for im in f.images:   # the constant template (AccuracyBenchmark.make_image): one sky, one calibration per band
+            assert (im.sky == im.sky[0, 0]).all() and (im.nelec_per_nmgy == im.nelec_per_nmgy[0]).all()
+        out.update(sky=np.array([im.sky[0, 0] for im in f.images], dtype=np.float32),
+                   iota=np.array([im.nelec_per_nmgy[0] for im in f.images], dtype=np.float32))
+    return out
 
 
 def arrays_to_field(z):
@@ -40,10 +58,18 @@ def arrays_to_field(z):
     from celeste_jl_amd import synthetic
     from celeste_jl_amd.model import get_sky_patches, neighbor_map
     from celeste_jl_amd.params import CatalogEntry
+    from celeste_jl_amd.model import SDSSBackground, SDSSPSFMap
     _, H, W = z["pixels"].shape
     images = synthetic.blank_images(H, W)
     for n, im in enumerate(images):
-        assert im.sky[0, 0] == z["sky"][n] and im.nelec_per_nmgy[0] == z["iota"][n]
+        if "sky_small" in z:
+            bkg = SDSSBackground(z["sky_small"][n], z["sky_x"][n], z["sky_y"][n], z["calibration"][n])
+            im.sky = bkg.materialize()
+            im.nelec_per_nmgy = z["iota_rows"][n].astype(np.float32)
+            im.psfmap = SDSSPSFMap(z["psf_rrows"][n], 51, 51, z["psf_cmat"][n])
+            im.background = bkg
+        else:
+            assert im.sky[0, 0] == z["sky"][n] and im.nelec_per_nmgy[0] == z["iota"][n]
         im.pixels = z["pixels"][n].copy()
     cat = [CatalogEntry(z["pos"][s], bool(z["is_star"][s]), z["star_fluxes"][s], z["gal_fluxes"][s],
                         *[float(x) for x in z["shape"][s]]) for s in range(len(z["pos"]))]

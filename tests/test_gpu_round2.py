@@ -247,3 +247,39 @@ def test_optimiser_initial_gradient_check_and_secular_cap(oracle):
         o = oracle.maximize(ctx.problem, f.vp, 0, oracle.OptCfg(max_iters=8, tr_secular_iters=cap))
         assert st[0] == 0 and its[0] == o[1] and evals[0] == o[2]
         assert np.max(np.abs(vp[0] - o[0][0]) / np.maximum(np.abs(o[0][0]), 1e-3)) <= 1e-6, cap
+
+
+def test_variable_sky_calibration_and_psf_map_on_the_device(oracle):
+    """SURVEY.md 8(f) row 3 on the device, trap A2 / A4: an SDSSBackground sky plane, a per-row calibration and an
+    SDSSPSFMap with 3 eigen-images (every patch its own spline) through the fused, split, fp32, gradient-only and
+    multi-active paths against the oracle (SDSSIO.jl:56-99, 239-299; elbo_objective.jl:374-385)"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    from parity_util import assert_parity, rel_err
+    f = synthetic.make_field(300, 340, 60, seed=41, variable=True, nan_fraction=0.005)
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    assert ctx.problem.c.n_stamps > 200
+    tg = list(range(60))
+    ref = oracle.elbo_batch(ctx.problem, f.vp, tg, ALL)
+    print("fused", assert_parity(ctx.eval_batch(f.vp, tg, ALL), ref, "variable field"))
+    print("split", assert_parity(ctx.eval_batch(f.vp, tg, ALL | cabi.FLAG_SPLIT), ref, "variable field, split"))
+    v32, d32, h32, c32, s32 = ctx.eval_batch(f.vp, tg, ALL | cabi.FLAG_FP32)
+    assert np.array_equal(c32, ref[3]) and np.max(np.abs(v32 - ref[0]) / np.abs(ref[0])) <= 1e-4
+    assert max(rel_err(d32[t], ref[1][t]) for t in tg) <= 1e-4 and max(rel_err(h32[t], ref[2][t]) for t in tg) <= 1e-4
+    g = ctx.eval_batch(f.vp, tg, 1 | 4)
+    assert np.max(np.abs(g[0] - ref[0]) / np.abs(ref[0])) <= 1e-8 and max(rel_err(g[1][t], ref[1][t]) for t in tg) <= 1e-8
+    # two overlapping active sources (Sa = 2) on the same planes
+    a = int(np.argmax([len(n) for n in f.neighbors])); b = f.neighbors[a][0]
+    loc = sorted(set([a, b] + list(f.neighbors[a]) + list(f.neighbors[b])))
+    ia, ib = loc.index(a), loc.index(b)
+    patches = [f.patches[s] for s in loc]
+    nbrs = [[j for j in range(len(loc)) if j != i] if i in (ia, ib) else [] for i in range(len(loc))]
+    mctx = cel.FieldContext(f.images, patches, nbrs)
+    mv, md, mh, mcnt = mctx.eval_multi(f.vp[loc], [ia, ib], ALL)
+    ov, od, oh, ocnt, ost = oracle.elbo_multi(mctx.problem, f.vp[loc], [ia, ib], ALL)
+    assert ost == 0 and np.array_equal(mcnt, ocnt) and abs(mv - ov) <= 1e-8 * abs(ov)
+    assert rel_err(md.T, od) <= 1e-8 and rel_err(mh, oh) <= 1e-8
+    # the optimiser runs on these planes as well (a few iterations against the CPU restatement)
+    vp, its, _, el, st = ctx.maximize_batch(f.vp, [a], cel.ElboConfig(max_iters=6))
+    o = oracle.maximize(ctx.problem, f.vp, a, oracle.OptCfg(max_iters=6))
+    assert st[0] == 0 and its[0] == o[1] and abs(el[0] - o[3]) <= 1e-9 * abs(o[3])

@@ -1,0 +1,76 @@
+"""-m gpu: mutation tests of the parity suite (trap A2 / A4).
+
+The HIP library is rebuilt with one deliberate indexing bug at a time (tests/mutants/build_mutants.py,
+-DCELESTE_MUTANT=k in csrc/elbo_kernels.h): iota read by column instead of by row, the sky plane read transposed,
+one star stamp for every patch.  On the variable-field golden (varying sky plane, per-row calibration, per-patch
+stamps: tests/golden/field_72x88_9src_variable.npz) every mutant must break parity with the committed oracle
+outputs; on a constant-template golden the first two cannot be seen at all -- which is exactly why round 1's
+fixtures, all constant, did not cover the trap."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHECK = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import golden_util as gu
+from parity_util import RTOL, rel_err
+import celeste_jl_amd as cel
+z = np.load(gu.path(sys.argv[1]))
+f = gu.arrays_to_field(z)
+ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+tg = list(range(len(f.catalog)))
+worst = 0.0
+for flags in ((7, 7 | 16, 7 | 8) if len(sys.argv) < 3 else (7,)):
+    v, d, h, cnt, st = ctx.eval_batch(f.vp, tg, flags)
+    tol = 1e-4 if flags & 8 else RTOL
+    e = max(float(np.max(np.abs(v - z["v7"]) / np.abs(z["v7"]))),
+            max(rel_err(d[t], z["d7"][t]) for t in tg), max(rel_err(h[t], z["h7"][t]) for t in tg))
+    worst = max(worst, e / tol)
+print("worst error / tolerance: %%.3g" %% worst)
+sys.exit(0 if worst <= 1.0 else 3)
+"""
+
+
+def _parity(lib_path, case):
+    env = dict(os.environ)
+    if lib_path:
+        env["CELESTE_MI355X_LIB"] = lib_path
+    out = subprocess.run([sys.executable, "-c", CHECK % {"root": ROOT}, case], capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode in (0, 3), out.stderr[-2000:]
+    return out.returncode == 0, out.stdout.strip()
+
+
+@pytest.fixture(scope="module")
+def mutants():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "mutants"))
+    import build_mutants
+    return build_mutants.build()
+
+
+def test_product_library_holds_parity_on_both_goldens():
+    for case in ("field_72x88_9src_variable", "field_64x80_8src_nan"):
+        ok, msg = _parity(None, case)
+        assert ok, (case, msg)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_mutant_is_caught_by_the_variable_field(mutants, k):
+    ok, msg = _parity(mutants[k], "field_72x88_9src_variable")
+    print(os.path.basename(mutants[k]), "on the variable field:", msg)
+    assert not ok, "the mutated kernel still passes parity: the fixture has no power against this bug"
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_constant_template_fixtures_cannot_see_plane_indexing_bugs(mutants, k):
+    """documentation of the round-1 hole: with one sky and one calibration per band, iota[w] == iota[h] and
+    sky[w, h] == sky[h, w]"""
+    ok, msg = _parity(mutants[k], "field_64x80_8src_nan")
+    print(os.path.basename(mutants[k]), "on the constant template:", msg)
+    assert ok

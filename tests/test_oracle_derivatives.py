@@ -38,6 +38,20 @@ def test_affine_wcs_and_variable_psf_target(oracle):
     _check(oracle, f, int(np.argmax([len(n) for n in f.neighbors])))
 
 
+def test_variable_sky_calibration_and_psf_map_target(oracle):
+    """trap A2 / A4 with inputs that can tell: sky varies per pixel (SDSSBackground), nelec_per_nmgy per row, the
+    star stamp per patch (SDSSPSFMap) -- elbo_objective.jl:374-385, imaged_sources.jl:97-107.  The oracle (C, 1-based
+    loops following the Julia) and the torch model (vectorised slices) index the planes independently."""
+    import golden_util as gu
+    f = gu.arrays_to_field(np.load(gu.path("field_72x88_9src_variable")))
+    for im in f.images:   # the fixture really varies
+        assert im.sky.std() > 0.02 * im.sky.mean() and im.nelec_per_nmgy.std() > 0.01 * im.nelec_per_nmgy.mean()
+    stamps = {id(p.stamp): p.stamp for row in f.patches for p in row}
+    assert len({s.tobytes() for s in stamps.values()}) >= 4 * len(f.catalog)   # (patches with the same box centre share one)
+    for t in (int(np.argmax([len(n) for n in f.neighbors])), 0):
+        _check(oracle, f, t)
+
+
 def test_kl_derivatives(oracle):
     """subtract_kl: analytic gradient / Hessian vs autograd (the reference uses ReverseDiff / ForwardDiff)"""
     import torch
