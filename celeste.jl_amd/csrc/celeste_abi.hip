@@ -589,7 +589,11 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         HIP_TRY(hipMalloc((void **)&c->d_work, std::max<size_t>(work_need, 1) * sizeof(int32_t)));
         c->work_cap = work_need;
     }
-    const int n_classes = c->chunk_px / 64;   // work-list classes: pixel-loop iterations a chunk is short of a full one
+    // a workgroup handles a group of up to G consecutive chunks of a patch (results do not depend on G, see
+    // visit_chunks): 4 for large sweeps, 1 for small batches whose critical path is one patch
+    int G = n_targets >= 512 ? 4 : 1;
+    if (const char *e = getenv("CELESTE_CHUNK_GROUP")) if (atoi(e) >= 1 && atoi(e) <= 16) G = atoi(e);
+    const int n_classes = G * (c->chunk_px / 64);   // work-list classes: pixel-loop iterations a group is short of a full one
     if ((size_t)n_wblk * n_classes > c->work_blk_cap) {
         if (c->d_work_blk) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_work_blk)); c->d_work_blk = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_work_blk, (size_t)n_wblk * n_classes * sizeof(int32_t)));
@@ -621,10 +625,10 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            render_neighbors ? c->d_needed : nullptr);
     }
     hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
-                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, (int)c->dense, c->d_work_blk, d_live);
+                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, G, (int)c->dense, c->d_work_blk, d_live);
     hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * n_classes, c->d_work_total);
     hipLaunchKernelGGL(work_fill_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
-                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, (int)c->dense, c->d_work_blk, c->d_work, d_live);
+                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, G, (int)c->dense, c->d_work_blk, c->d_work, d_live);
     // per-(source, image) constants: of every source when the neighbours are (re)rendered, else of the targets only
     if (render_neighbors) {
         if (c->V > 0 && !tables_current)
@@ -646,7 +650,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     const dim3 grid((unsigned)std::max<size_t>(work_need, 1));
 #define PIXEL_ARGS                                                                                                \
     c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx,       \
-    c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, c->d_acc, c->d_tile_off, c->d_rec, \
+    c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, G, c->d_acc, c->d_tile_off, c->d_rec, \
     d_active_rank, c->d_items, c->M, c->d_work, c->d_work_total
 #define LAUNCH_PIXEL_T(MODE, R) hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL_M(MODE) hipLaunchKernelGGL((pixel_kernel<MODE, double, true>), grid, dim3(64), 0, stream, PIXEL_ARGS)

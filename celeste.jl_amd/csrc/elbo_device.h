@@ -59,7 +59,8 @@ struct Comp {
 struct SrcImg {
     double m1, m2;          // linear_world_to_pix(pos)
     double c0, c1, q0, q1;  // a_i E_l_a[b,i], a_i E_ll_a[b,i]
-    double pad0, pad1;
+    double dev;             // gal_frac_dev (theta_0; theta_1 = 1 - dev)
+    double pad1;
 };
 
 struct SrcGeo {

@@ -131,7 +131,7 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         o.m1 = m1; o.m2 = m2;
         o.c0 = vs[26] * El0; o.c1 = vs[27] * El1;
         o.q0 = vs[26] * Ell0; o.q1 = vs[27] * Ell1;
-        o.pad0 = 0; o.pad1 = 0;
+        o.dev = vs[2]; o.pad1 = 0;
         srcimg[sn] = o;
     }
 }
@@ -315,11 +315,15 @@ __global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__res
 // Three small kernels: per-block counts, one exclusive scan over [class][block], fill.  The order is deterministic.
 // ---------------------------------------------------------------------------------------------
 #define WORK_NT 256
-// chunks of candidate visit k: n_full of class 0 (chunk indices 0 .. n_full - 1) and, if last_class > 0, one of that
-// class (chunk index n_full)
+// A work item is a GROUP of up to G consecutive chunks of one patch, handled by one workgroup: the workgroup's fixed
+// cost (a chain of four dependent loads, staging of the component records, ~4 us of its wave slot) is paid once per
+// group, while every chunk still produces its own record -- so the results do not depend on G, which the host picks per
+// launch (large sweeps: 4; small, latency-bound batches: 1).
+// Groups of candidate visit k: n_full of class 0 (first chunks 0, G, 2 G, ...: G full chunks each) and, if
+// last_class > 0, one last group of that class (first chunk n_full * G) which is last_class pixel-loop iterations short.
 __device__ inline void visit_chunks(int k, const int32_t *__restrict__ targets, const DevPatch *__restrict__ patches,
                                     const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M,
-                                    int chunk_px, bool dense, int &n_full, int &last_class) {
+                                    int chunk_px, int G, bool dense, int &n_full, int &last_class) {
     n_full = 0; last_class = 0;
     const int ti = k / M, j = k - ti * M;
     const int t = targets[ti];
@@ -332,10 +336,13 @@ __device__ inline void visit_chunks(int k, const int32_t *__restrict__ targets, 
     const DevPatch &P = patches[(size_t)t * N + n];
     const int npx = P.H2 * P.W2;
     if (npx <= 0) return;
-    const int nch = (npx + chunk_px - 1) / chunk_px;
-    const int last_px = npx - (nch - 1) * chunk_px;
-    last_class = (chunk_px >> 6) - ((last_px + 63) >> 6);
-    n_full = last_class == 0 ? nch : nch - 1;
+    const int gpx = chunk_px * G;                        // pixels of a full group
+    const int ngr = (npx + gpx - 1) / gpx;
+    const int last_px = npx - (ngr - 1) * gpx;           // 1 .. gpx pixels in the last group
+    const int ipc = chunk_px >> 6;                       // iterations of a full chunk
+    const int last_iters = (last_px / chunk_px) * ipc + ((last_px % chunk_px + 63) >> 6);
+    last_class = G * ipc - last_iters;
+    n_full = last_class == 0 ? ngr : ngr - 1;
 }
 
 // rank of this thread among the threads of its block for which pred holds (exclusive), and the block total
@@ -371,17 +378,17 @@ __device__ inline int block_prefix(int v, int *s_wave /* WORK_NT / 64 */, int &t
 __global__ void __launch_bounds__(WORK_NT)
 work_count_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPatch *__restrict__ patches,
                   const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M,
-                  int chunk_px, int dense, int32_t *__restrict__ blk_cnt /* [chunk_px / 64][gridDim.x] */,
+                  int chunk_px, int G, int dense, int32_t *__restrict__ blk_cnt /* [G chunk_px / 64][gridDim.x] */,
                   const int32_t *__restrict__ live) {
     __shared__ int s_wave[WORK_NT / 64];
     const int k = blockIdx.x * WORK_NT + threadIdx.x;
     if (live) n_visits = min(n_visits, *live * M);   // the host's target count is an upper bound (device-resident loops)
     int n_full = 0, lc = 0;
-    if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, dense != 0, n_full, lc);
+    if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc);
     int tot;
     block_prefix(n_full, s_wave, tot);
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
-    for (int c = 1; c < (chunk_px >> 6); ++c) {
+    for (int c = 1; c < G * (chunk_px >> 6); ++c) {
         block_rank(lc == c, s_wave, tot);
         if (threadIdx.x == 0) blk_cnt[(size_t)c * gridDim.x + blockIdx.x] = tot;
     }
@@ -415,19 +422,19 @@ __global__ void __launch_bounds__(1024) work_scan_kernel(int32_t *__restrict__ c
 __global__ void __launch_bounds__(WORK_NT)
 work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPatch *__restrict__ patches,
                  const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M, int CH,
-                 int chunk_px, int dense, const int32_t *__restrict__ blk_base, int32_t *__restrict__ work,
+                 int chunk_px, int G, int dense, const int32_t *__restrict__ blk_base, int32_t *__restrict__ work,
                  const int32_t *__restrict__ live) {
     __shared__ int s_wave[WORK_NT / 64];
     const int k = blockIdx.x * WORK_NT + threadIdx.x;
     if (live) n_visits = min(n_visits, *live * M);
     int n_full = 0, lc = 0;
-    if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, dense != 0, n_full, lc);
+    if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc);
     int tot;
     const int p0 = blk_base[blockIdx.x] + block_prefix(n_full, s_wave, tot);
-    for (int ch = 0; ch < n_full; ++ch) work[p0 + ch] = k * CH + ch;
-    for (int c = 1; c < (chunk_px >> 6); ++c) {
+    for (int g = 0; g < n_full; ++g) work[p0 + g] = k * CH + g * G;     // record index of the group's first chunk
+    for (int c = 1; c < G * (chunk_px >> 6); ++c) {
         const int r = block_rank(lc == c, s_wave, tot);
-        if (lc == c) work[blk_base[(size_t)c * gridDim.x + blockIdx.x] + r] = k * CH + n_full;
+        if (lc == c) work[blk_base[(size_t)c * gridDim.x + blockIdx.x] + r] = k * CH + n_full * G;
     }
 }
 
@@ -649,26 +656,26 @@ template <> __device__ __forceinline__ float fma_r<float>(float a, float b, floa
 // and no 3x3 transforms inside the loop).  Weights: w0 = z theta_i, wd = +-z, and their products with
 // nu, nu^2.  (dx, dy) = pixel - m_pos.  Returns sum f; fills the S* members of T.
 template <int MODE, typename R>
-__device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int nc, R dx, R dy, const double *etab,
+__device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int nc, R dx, R dy, R dev, const double *etab,
                                               PixelTerms &T) {
-    R S0 = 0, S0d = 0, S1x = 0, S1y = 0, S1xd = 0, S1yd = 0;
-    R S2a = 0, S2b = 0, S2c = 0, S2an = 0, S2bn = 0, S2cn = 0, S2ad = 0, S2bd = 0, S2cd = 0;
-    R S3a = 0, S3b = 0, S3c = 0, S3d = 0, S4a = 0, S4b = 0, S4c = 0, S4d = 0, S4e = 0;
-    for (int c = 0; c < nc; ++c) {
-        const CompR<R> k = tc[c];
-        const R d1 = dx - k.xi1, d2 = dy - k.xi2;
-        const R u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
-        const R e = exp_np<R>((R)-0.5 * (d1 * u + d2 * v), etab);   // eval_bvn_pdf!
-        const R f = k.w0 * e, fd = k.wd * e, fn = f * k.nu;
-        const R ha = fma_r<R>(u, u, -k.p11), hb = fma_r<R>(u, v, -k.p12), hc = fma_r<R>(v, v, -k.p22);
-        S0 += f; S0d += fd;
-        S1x = fma_r<R>(u, f, S1x); S1y = fma_r<R>(v, f, S1y);
-        S2an = fma_r<R>(ha, fn, S2an); S2bn = fma_r<R>(hb, fn, S2bn); S2cn = fma_r<R>(hc, fn, S2cn);
-        if (MODE == 2) {
-            const R fdn = fd * k.nu, fnn = fn * k.nu;
-            S1xd = fma_r<R>(u, fd, S1xd); S1yd = fma_r<R>(v, fd, S1yd);
+    if constexpr (MODE == 2) {
+        // The six sums that exist in an f-weighted (w0 = z theta_i) and a d-weighted (wd = +-z) version -- order 0, order
+        // 1 (x, y) and the nu-weighted order 2 (xx, xy, yy) -- are accumulated ONCE, d-weighted, per profile type: the
+        // components are stored type 0 (de Vaucouleurs, n_dev of them) first, so two loops over the same body fill U0
+        // and U1, and afterwards  f-sum = theta_0 U0 - theta_1 U1,  d-sum = U0 + U1  (U1 carries the minus sign of wd).
+        // 18 accumulations per component instead of 24.
+        R U0[6] = {0, 0, 0, 0, 0, 0}, U1[6] = {0, 0, 0, 0, 0, 0};
+        R S2a = 0, S2b = 0, S2c = 0, S3a = 0, S3b = 0, S3c = 0, S3d = 0, S4a = 0, S4b = 0, S4c = 0, S4d = 0, S4e = 0;
+        auto body = [&](int c, R (&U)[6]) {
+            const CompR<R> k = tc[c];
+            const R d1 = dx - k.xi1, d2 = dy - k.xi2;
+            const R u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
+            const R e = exp_np<R>((R)-0.5 * (d1 * u + d2 * v), etab);   // eval_bvn_pdf!
+            const R f = k.w0 * e, g = k.wd * e, fn = f * k.nu, gn = g * k.nu, fnn = fn * k.nu;
+            const R ha = fma_r<R>(u, u, -k.p11), hb = fma_r<R>(u, v, -k.p12), hc = fma_r<R>(v, v, -k.p22);
+            U[0] += g; U[1] = fma_r<R>(u, g, U[1]); U[2] = fma_r<R>(v, g, U[2]);
+            U[3] = fma_r<R>(ha, gn, U[3]); U[4] = fma_r<R>(hb, gn, U[4]); U[5] = fma_r<R>(hc, gn, U[5]);
             S2a = fma_r<R>(ha, f, S2a); S2b = fma_r<R>(hb, f, S2b); S2c = fma_r<R>(hc, f, S2c);
-            S2ad = fma_r<R>(ha, fdn, S2ad); S2bd = fma_r<R>(hb, fdn, S2bd); S2cd = fma_r<R>(hc, fdn, S2cd);
             // third order: u^3 - 3 p11 u, u^2 v - p11 v - 2 p12 u, u v^2 - p22 u - 2 p12 v, v^3 - 3 p22 v
             const R tu = (R)-2.0 * u, tv = (R)-2.0 * v;
             const R h3a = u * fma_r<R>((R)-2.0, k.p11, ha);
@@ -687,14 +694,34 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int nc, R dx, 
             S4a = fma_r<R>(h4a, fnn, S4a); S4b = fma_r<R>(h4b, fnn, S4b);
             S4c = fma_r<R>(h4c, fnn, S4c); S4d = fma_r<R>(h4d, fnn, S4d);
             S4e = fma_r<R>(h4e, fnn, S4e);
+        };
+        for (int c = 0; c < n_dev; ++c) body(c, U0);
+        for (int c = n_dev; c < nc; ++c) body(c, U1);
+        const R th0 = dev, th1 = (R)1.0 - dev;
+        T.S0d = U0[0] + U1[0]; T.S1xd = U0[1] + U1[1]; T.S1yd = U0[2] + U1[2];
+        T.S2ad = U0[3] + U1[3]; T.S2bd = U0[4] + U1[4]; T.S2cd = U0[5] + U1[5];
+        T.S1x = th0 * U0[1] - th1 * U1[1]; T.S1y = th0 * U0[2] - th1 * U1[2];
+        T.S2an = th0 * U0[3] - th1 * U1[3]; T.S2bn = th0 * U0[4] - th1 * U1[4]; T.S2cn = th0 * U0[5] - th1 * U1[5];
+        T.S2a = S2a; T.S2b = S2b; T.S2c = S2c;
+        T.S3a = S3a; T.S3b = S3b; T.S3c = S3c; T.S3d = S3d;
+        T.S4a = S4a; T.S4b = S4b; T.S4c = S4c; T.S4d = S4d; T.S4e = S4e;
+        return (double)(th0 * U0[0] - th1 * U1[0]);
+    } else {
+        R S0 = 0, S0d = 0, S1x = 0, S1y = 0, S2an = 0, S2bn = 0, S2cn = 0;
+        for (int c = 0; c < nc; ++c) {
+            const CompR<R> k = tc[c];
+            const R d1 = dx - k.xi1, d2 = dy - k.xi2;
+            const R u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
+            const R e = exp_np<R>((R)-0.5 * (d1 * u + d2 * v), etab);   // eval_bvn_pdf!
+            const R f = k.w0 * e, fd = k.wd * e, fn = f * k.nu;
+            const R ha = fma_r<R>(u, u, -k.p11), hb = fma_r<R>(u, v, -k.p12), hc = fma_r<R>(v, v, -k.p22);
+            S0 += f; S0d += fd;
+            S1x = fma_r<R>(u, f, S1x); S1y = fma_r<R>(v, f, S1y);
+            S2an = fma_r<R>(ha, fn, S2an); S2bn = fma_r<R>(hb, fn, S2bn); S2cn = fma_r<R>(hc, fn, S2cn);
         }
+        T.S0d = S0d; T.S1x = S1x; T.S1y = S1y; T.S2an = S2an; T.S2bn = S2bn; T.S2cn = S2cn;
+        return (double)S0;
     }
-    T.S0d = S0d; T.S1x = S1x; T.S1y = S1y; T.S1xd = S1xd; T.S1yd = S1yd;
-    T.S2a = S2a; T.S2b = S2b; T.S2c = S2c; T.S2an = S2an; T.S2bn = S2bn; T.S2cn = S2cn;
-    T.S2ad = S2ad; T.S2bd = S2bd; T.S2cd = S2cd;
-    T.S3a = S3a; T.S3b = S3b; T.S3c = S3c; T.S3d = S3d;
-    T.S4a = S4a; T.S4b = S4b; T.S4c = S4c; T.S4d = S4d; T.S4e = S4e;
-    return (double)S0;
 }
 
 // Single-precision variant of galaxy_sums (CELESTE_FLAG_FP32) with two components per instruction: the records of
@@ -745,10 +772,79 @@ __device__ __forceinline__ double galaxy_sums_pk(const CompR<float> *tc, int nc,
 }
 
 
+// Per-pixel inputs of the pixel term: the pixel itself, sky + the pre-rendered light of the covering neighbours, the
+// per-row calibration; `valid` = the pixel is visited (elbo_objective.jl:445, 459).
+struct PixelInputs {
+    double x, Ebar, Vbar, lgx, iota, log_iota;
+    int n_inact;
+    bool valid, dup;
+};
+template <bool MULTI>
+__device__ __forceinline__ PixelInputs load_pixel_inputs(
+        const DevImage &img, const DevPatch &P, const DevPatch *__restrict__ patches, const uint8_t *__restrict__ bitmaps,
+        const int32_t *__restrict__ nbr_idx, int64_t nb0, int64_t nb1, const int64_t *__restrict__ val_off,
+        const double2 *__restrict__ val, const int32_t *__restrict__ active_rank, int my_rank, int N, int n, int H2,
+        int h, int w, int h2, int w2, bool in_range) {
+    PixelInputs I;
+    const size_t gi = (size_t)(h - 1) + (size_t)img.H * (w - 1);
+    // coalesced (along h) loads of every per-pixel input, issued together
+    const float xf = img.pixels[gi];
+#if CELESTE_MUTANT == 2
+    const float skyf = img.sky[(size_t)(w - 1) + (size_t)img.W * (h - 1)];
+#else
+    const float skyf = img.sky[gi];
+#endif
+    I.lgx = img.lgx[gi];
+#if CELESTE_MUTANT == 1
+    const int irow = min(w, img.H);
+#else
+    const int irow = h;   // iota is per ROW: img.nelec_per_nmgy[h] (elbo_objective.jl:374-385)
+#endif
+    I.iota = (double)img.iota[irow - 1];
+    I.log_iota = img.log_iota[irow - 1];
+    bool valid = in_range && !isnan(xf);                // elbo_objective.jl:459
+    if (P.bitmap_off >= 0) valid = valid && bitmaps[P.bitmap_off + h2 + (int64_t)H2 * w2] != 0;  // :445
+    double Ebar = (double)skyf;  // epsilon + neighbours
+    double Vbar = 0.0;
+    int n_inact = 0;
+    bool dup = false;
+
+    // ---- neighbours: gather their pre-rendered (E_G_s.v, var_G_s.v) ----
+    for (int64_t q = nb0; q < nb1; ++q) {
+        const int s2 = nbr_idx[q];
+        const DevPatch &Q = patches[(size_t)s2 * N + n];
+        const int ph2 = h - Q.off_h, pw2 = w - Q.off_w;  // 1-based in the neighbour's patch
+        bool in = valid & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 < Q.W2);  // strict: elbo_objective.jl:349
+        if (in && Q.bitmap_off >= 0) in = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
+        int r2 = -1;
+        if (MULTI) {
+            r2 = active_rank[s2];
+            if (r2 >= 0 && r2 < my_rank) {   // does the earlier active source visit this pixel (last column included)?
+                bool vis = valid & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 <= Q.W2);
+                if (vis && Q.bitmap_off >= 0) vis = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
+                dup |= vis;
+            }
+        }
+        if (in) {
+            const double2 ev = val[val_off[(size_t)s2 * N + n] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
+            Ebar += ev.x;
+            Vbar += ev.y;
+            n_inact += MULTI ? (r2 < 0) : 1;
+        }
+    }
+    if (MULTI && dup) n_inact = 0;
+    I.x = (double)xf; I.Ebar = Ebar; I.Vbar = Vbar; I.n_inact = n_inact; I.valid = valid; I.dup = dup;
+    return I;
+}
+
 // MODE 0: value only; MODE 1: value + gradient sums; MODE 2: value + gradient + Hessian sums;
 // MODE 3: as MODE 2 but the per-pixel records are written to HBM for record_sum_kernel (split variant)
+#ifndef PIXEL_LOADS_FIRST
+#define PIXEL_LOADS_FIRST 0
+#endif
 #ifndef PIXEL_WAVES
-#define PIXEL_WAVES 2  // waves per SIMD the register allocator must allow (256 VGPRs, no scratch)
+#define PIXEL_WAVES 2  // waves per SIMD the register allocator must allow (256 VGPRs, no scratch; 3 waves with a dozen
+                       // loop invariants in scratch measured 3 % slower)
 #endif
 // R: arithmetic type of the galaxy component loop (double; float with CELESTE_FLAG_FP32 -- everything
 // downstream of the 24 component sums, and all accumulation, stays fp64)
@@ -761,17 +857,17 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
              const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
              const int64_t *__restrict__ val_off, const double2 *__restrict__ val,
-             const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px,
+             const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px, int G,
              double *__restrict__ acc, const int64_t *__restrict__ tile_off, double *__restrict__ rec,
              const int32_t *__restrict__ active_rank, const int32_t *__restrict__ items, int M,
              const int32_t *__restrict__ work, const int32_t *__restrict__ work_total) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
     __shared__ double etab[64];
-    // work list (work_fill_kernel): existing chunks only, first chunks first; the grid is an upper bound
+    // work list (work_fill_kernel): groups of up to G chunks that exist, longest first; the grid is an upper bound
     if ((int)blockIdx.x >= *work_total) return;
-    const int wg = work[blockIdx.x];  // record index, as the lift kernel expects: ((ti * M + j) * CH + ch)
-    const int tn = wg / CH;
-    const int ch = wg - tn * CH;
+    const int wg0 = work[blockIdx.x];  // record index of the group's first chunk, as the lift kernel expects: ((ti * M + j) * CH + ch)
+    const int tn = wg0 / CH;
+    const int ch0 = wg0 - tn * CH;
     const int ti = tn / M;                     // tn = ti * M + j: target, j-th image it appears in (tables stay dense)
     const int n = items ? items[tn] : tn - ti * M;   // items == nullptr: every source is listed in all M = N images
     if (n < 0) return;
@@ -779,9 +875,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const DevPatch &P = patches[(size_t)t * N + n];
     const int H2 = P.H2, W2 = P.W2;
     const int npx = H2 * W2;
-    const int p0 = ch * chunk_px;
-    if (p0 >= npx) return;  // the lift kernel recomputes this predicate
-    const int p1 = min(npx, p0 + chunk_px);
+    if (ch0 * chunk_px >= npx) return;  // the lift kernel recomputes this predicate
     const DevImage &img = images[n];
     const int lane = threadIdx.x;
     const SrcImg si = srcimg[(size_t)t * N + n];
@@ -814,72 +908,33 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
     // the chunk's record, 16 slots per entry (accum_entries); MODE 0 keeps its three sums in registers
     __shared__ double sacc[MODE == 0 || MODE == 3 ? 1 : ACC_N * ACC_SLOTS];
+    double *const slot = sacc + (lane & (ACC_SLOTS - 1));
+    for (int ch = ch0; ch < ch0 + G && ch * chunk_px < npx; ++ch) {   // every chunk of the group writes its own record
+    const int p0 = ch * chunk_px;
+    const int p1 = min(npx, p0 + chunk_px);
+    const int wg = wg0 + (ch - ch0);
     if constexpr (MODE == 1 || MODE == 2) {
 #pragma unroll
-        for (int i = 0; i < ACC_N * ACC_SLOTS / 64; ++i) sacc[lane + 64 * i] = 0.0;   // (visible after the barrier below)
+        for (int i = 0; i < ACC_N * ACC_SLOTS / 64; ++i) sacc[lane + 64 * i] = 0.0;
+        __syncthreads();
     }
-    double *const slot = sacc + (lane & (ACC_SLOTS - 1));
     double a[3] = {0.0, 0.0, 0.0};
-    if constexpr (MODE == 1 || MODE == 2) __syncthreads();
 
     for (int base = p0; base < p1; base += 64) {
         const int idx = min(base + lane, p1 - 1);           // clamped: every lane stays in the loop body
         const bool in_range = base + lane < p1;
         const int w2 = idx / H2, h2 = idx - w2 * H2;        // 0-based patch coordinates, h fastest
         const int h = P.off_h + h2 + 1, w = P.off_w + w2 + 1;  // 1-based image coordinates
-        const size_t gi = (size_t)(h - 1) + (size_t)img.H * (w - 1);
-        // coalesced (along h) loads of every per-pixel input, issued together
-        const float xf = img.pixels[gi];
-#if CELESTE_MUTANT == 2
-        const float skyf = img.sky[(size_t)(w - 1) + (size_t)img.W * (h - 1)];
-#else
-        const float skyf = img.sky[gi];
-#endif
-        const double lgx = img.lgx[gi];
-#if CELESTE_MUTANT == 1
-        const int irow = min(w, img.H);
-#else
-        const int irow = h;   // iota is per ROW: img.nelec_per_nmgy[h] (elbo_objective.jl:374-385)
-#endif
-        const double iota = (double)img.iota[irow - 1];
-        const double log_iota = img.log_iota[irow - 1];
-        bool valid = in_range && !isnan(xf);                // elbo_objective.jl:459
-        if (P.bitmap_off >= 0) valid = valid && bitmaps[P.bitmap_off + h2 + (int64_t)H2 * w2] != 0;  // :445
         const double hh = (double)h, ww = (double)w;
-        double Ebar = (double)skyf;  // epsilon + neighbours
-        double Vbar = 0.0;
-        int n_inact = 0;
-        bool dup = false;
-
-        // ---- neighbours: gather their pre-rendered (E_G_s.v, var_G_s.v) ----
-        for (int64_t q = nb0; q < nb1; ++q) {
-            const int s2 = nbr_idx[q];
-            const DevPatch &Q = patches[(size_t)s2 * N + n];
-            const int ph2 = h - Q.off_h, pw2 = w - Q.off_w;  // 1-based in the neighbour's patch
-            bool in = valid & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 < Q.W2);  // strict: elbo_objective.jl:349
-            if (in && Q.bitmap_off >= 0) in = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
-            int r2 = -1;
-            if (MULTI) {
-                r2 = active_rank[s2];
-                if (r2 >= 0 && r2 < my_rank) {   // does the earlier active source visit this pixel (last column included)?
-                    bool vis = valid & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 <= Q.W2);
-                    if (vis && Q.bitmap_off >= 0) vis = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
-                    dup |= vis;
-                }
-            }
-            if (in) {
-                const double2 ev = val[val_off[(size_t)s2 * N + n] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
-                Ebar += ev.x;
-                Vbar += ev.y;
-                n_inact += MULTI ? (r2 < 0) : 1;
-            }
-        }
-        if (MULTI && dup) n_inact = 0;
-
+#define LOAD_PIXEL_INPUTS() load_pixel_inputs<MULTI>(img, P, patches, bitmaps, nbr_idx, nb0, nb1, val_off, val, active_rank, \
+                                                     my_rank, N, n, H2, h, w, h2, w2, in_range)
         // ---- the active source ----
-        const bool own = valid && (w2 < W2 - 1);  // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
-        const double x = (double)xf;
+        const bool own_geo = in_range && (w2 < W2 - 1);  // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
         if (MODE == 0) {
+            const PixelInputs I = LOAD_PIXEL_INPUTS();
+            const bool valid = I.valid, dup = I.dup, own = valid && own_geo;
+            const double x = I.x, Ebar = I.Ebar, Vbar = I.Vbar, lgx = I.lgx, iota = I.iota, log_iota = I.log_iota;
+            const int n_inact = I.n_inact;
             double f0 = 0, f1 = 0;
             if (own) {
                 f0 = star_value(tcoef, hh + sh0, ww + sw0);
@@ -902,11 +957,25 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         T.S0d = 0; T.S1x = 0; T.S1y = 0; T.S1xd = 0; T.S1yd = 0;
         T.S2a = 0; T.S2b = 0; T.S2c = 0; T.S2an = 0; T.S2bn = 0; T.S2cn = 0; T.S2ad = 0; T.S2bd = 0; T.S2cd = 0;
         T.S3a = 0; T.S3b = 0; T.S3c = 0; T.S3d = 0; T.S4a = 0; T.S4b = 0; T.S4c = 0; T.S4d = 0; T.S4e = 0;
-        if (own) {
+#if PIXEL_LOADS_FIRST
+        const PixelInputs I = LOAD_PIXEL_INPUTS();
+        if (I.valid && own_geo) {
+#else
+        // The component loop runs before the pixel's inputs are fetched: the loop needs only the pixel's coordinates,
+        // and every double that is not live across it is a register the loop does not have to share (a masked pixel
+        // inside the patch costs one wasted evaluation; its record entries are zeroed by the weights below).
+        if (own_geo) {
+#endif
             if constexpr (sizeof(R) == 4) S0 = galaxy_sums_pk<GM>(tcr, NC, (float)(hh - si.m1), (float)(ww - si.m2), T);
-            else S0 = galaxy_sums<GM, R>(tcr, NC, (R)(hh - si.m1), (R)(ww - si.m2), etab, T);
+            else S0 = galaxy_sums<GM, R>(tcr, 8 * (NC / 14), NC, (R)(hh - si.m1), (R)(ww - si.m2), (R)si.dev, etab, T);
         }
-        T.f1 = S0;
+#if !PIXEL_LOADS_FIRST
+        const PixelInputs I = LOAD_PIXEL_INPUTS();
+#endif
+        const bool valid = I.valid, dup = I.dup, own = valid && own_geo;
+        const double x = I.x, Ebar = I.Ebar, Vbar = I.Vbar, lgx = I.lgx, iota = I.iota, log_iota = I.log_iota;
+        const int n_inact = I.n_inact;
+        T.f1 = own ? S0 : 0.0;
 
         // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
         T.f0 = 0; T.f0g0 = 0; T.f0g1 = 0; T.f0h0 = 0; T.f0h1 = 0; T.f0h2 = 0;
@@ -982,14 +1051,14 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         else
             accum_entries<MODE, 0>(T, slot);
     }
-    if (MODE == 3) return;
+    if (MODE == 3) continue;
 
     // ---- one 68-double record per (target, image, chunk) ----
     double *__restrict__ out = acc + (size_t)wg * ACC_N;
     if (MODE == 0) {
         const double s0 = wave_sum(a[0]), s1 = wave_sum(a[1]), s2 = wave_sum(a[2]);
         if (lane == 0) { out[0] = s0; out[ACC_CNT] = s1; out[ACC_CNT + 1] = s2; }
-        return;
+        continue;
     }
     // lane e sums the 16 slots of entry e (rotated start: 4-way instead of 64-way bank conflicts; the order of the
     // additions is fixed per entry, so the record is reproducible)
@@ -1000,6 +1069,8 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
 #pragma unroll
         for (int k = 0; k < ACC_SLOTS; ++k) s += sacc[e * ACC_SLOTS + ((k + e) & (ACC_SLOTS - 1))];
         out[e] = s;
+    }
+    __syncthreads();   // the slots are zeroed again for the next chunk of the group
     }
 }
 
@@ -1447,8 +1518,8 @@ __device__ inline void source_first_order(const SrcImg &si, const Comp *comps, i
                                           double ww, const double *etab, FirstOrder &F) {
     PixelTerms T;
     T.S0d = 0; T.S1x = 0; T.S1y = 0; T.S2an = 0; T.S2bn = 0; T.S2cn = 0;
-    const double f1 = galaxy_sums<1, double>(reinterpret_cast<const CompR<double> *>(comps), NC, hh - si.m1, ww - si.m2,
-                                             etab, T);
+    const double f1 = galaxy_sums<1, double>(reinterpret_cast<const CompR<double> *>(comps), 8 * (NC / 14), NC, hh - si.m1,
+                                             ww - si.m2, si.dev, etab, T);
     // star: natural bicubic spline value and first derivatives with respect to the position
     const double xh = hh + (26.0 - si.m1), xw = ww + (26.0 - si.m2);
     int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);

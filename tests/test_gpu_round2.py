@@ -222,12 +222,16 @@ def test_optimiser_refuses_duplicate_targets_and_survives_a_failing_target():
     # the node-level loop logs and skips instead of raising
     from celeste_jl_amd.infer import one_node_single_infer
     failed = set()
-    cat = list(f.catalog)
-    import copy
-    cat[bad] = copy.deepcopy(cat[bad]); cat[bad].gal_fluxes = cat[bad].gal_fluxes.copy(); cat[bad].star_fluxes = cat[bad].star_fluxes.copy()
-    cat[bad].star_fluxes[:] = np.nan; cat[bad].gal_fluxes[:] = np.nan      # catalog_init_source -> NaN brightness
-    vs = one_node_single_infer(ctx, cat, targets, cfg, failed=failed)
+
+    class BadNeighbour:   # the same context, with one catalogued neighbour turned non-finite on the way in
+        def maximize_batch(self, vp, tg, cfg=None, vp_neighbors=None, **kw):
+            nbrs = np.array(vp_neighbors, dtype=np.float64, copy=True)
+            nbrs[bad, 7] = np.nan
+            return ctx.maximize_batch(vp, tg, cfg, vp_neighbors=nbrs, **kw)
+    vs = one_node_single_infer(BadNeighbour(), f.catalog, targets, cfg, failed=failed)
     assert failed == hit & set(targets) and np.isfinite(vs).all()
+    vs_ok = one_node_single_infer(ctx, f.catalog, good_targets, cfg)
+    assert np.array_equal(vs[ok], vs_ok)
 
 
 def test_optimiser_initial_gradient_check_and_secular_cap(oracle):

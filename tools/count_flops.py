@@ -36,26 +36,26 @@ def main():
     i = txt.index("_Z12pixel_kernelILi2EdLb0EEv")
     i = txt.index(":\n", i)
     lines = txt[i:txt.index("s_endpgm", i)].split("\n")
-    # the component loop: the innermost basic-block run that holds the four ds_read_b128 of a component record
-    reads = [k for k, ln in enumerate(lines) if "ds_read_b128" in ln]
-    lo, hi = reads[0], reads[-1]
-    while lo > 0 and not re.match(r"\s*(;\s*%bb|\.LBB)", lines[lo]):
-        lo -= 1
-    while hi < len(lines) and "s_cbranch" not in lines[hi]:
-        hi += 1
-    comp = stats(lines[lo:hi + 1])
-    labels = {ln.strip()[:-1]: k for k, ln in enumerate(lines) if ln.strip().endswith(":") and ln.strip().startswith(".LBB")}
-    outer = None
+    labels = {ln.strip().split(":")[0]: k for k, ln in enumerate(lines) if ln.strip().startswith(".LBB") and ":" in ln}
+    loops = []   # (first line, last line) of every backward branch
     for k, ln in enumerate(lines):
-        s = ln.strip()
-        if s.startswith(("s_cbranch", "s_branch")) and s.split()[-1] in labels and labels[s.split()[-1]] < k:
-            if outer is None or k - labels[s.split()[-1]] > outer[1] - outer[0]:
-                outer = (labels[s.split()[-1]], k)
+        t = ln.strip().split()
+        if t and t[0].startswith(("s_cbranch", "s_branch")) and t[-1] in labels and labels[t[-1]] < k:
+            loops.append((labels[t[-1]], k))
+    # the component loops: innermost loops that read a component record (ds_read_b128) -- one per profile type
+    # (de Vaucouleurs: 8 psf_K components, exponential: 6 psf_K), same body
+    comp = [(a, b) for a, b in loops if any("ds_read_b128" in l for l in lines[a:b])
+            and not any(a < a2 and b2 < b for a2, b2 in loops)]
+    outer = max((l for l in loops if any(l[0] < a and b < l[1] for a, b in comp)), key=lambda l: l[1] - l[0])
     body = stats(lines[outer[0]:outer[1]])
     psf_k = 2
-    per_visit = body[0] - comp[0] + 14 * psf_k * comp[0]
-    print("component loop: %d flops, %d FP64 instructions, %d VALU" % comp)
-    print("pixel loop body (one copy of the component loop inside): %d flops, %d FP64 instructions, %d VALU" % body)
+    trips = [8 * psf_k, 6 * psf_k] if len(comp) == 2 else [14 * psf_k]
+    per_visit = body[0]
+    for (a, b), n in zip(sorted(comp), trips):
+        c = stats(lines[a:b + 1])
+        print("component loop (%d trips): %d flops, %d FP64 instructions, %d VALU" % ((n,) + c))
+        per_visit += (n - 1) * c[0]
+    print("pixel loop body (one copy of each component loop inside): %d flops, %d FP64 instructions, %d VALU" % body)
     print("FP64 flops per pixel visit (psf_K = 2): %d" % per_visit)
     return per_visit
 

@@ -15,7 +15,7 @@ for cfg in os.environ.get("CHUNKS", "1024").split(","):
     ctx = cel.FieldContext(fld.images, fld.patches, fld.neighbors)
     ctx.enable_timing(True)
     ms = []
-    for it in range(6):
+    for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
         g = ctx.eval_batch(fld.vp, tg, int(os.environ.get('FLAGS', '7')))
         ms.append(ctx.last_kernel_ms())
     ms = np.array(ms)[2:].mean(axis=0)

@@ -81,7 +81,11 @@ if pk:
 open(os.path.join(dst, tag + "_pmc_summary.md"), "w").write("\n".join(lines))
 px = find(traffic, "pixel_kernel<2, double")
 rs = find(traffic, "record_sum_kernel")
+sys.path.insert(0, os.path.join(root, "tools"))
+import count_flops
+flops = count_flops.main()   # FP64 flops per visited pixel in the ISA of the kernels as they are in this tree
 json.dump({"pixel_kernel_bytes_per_launch": px.get("fetch_bytes", 0) + px.get("write_bytes", 0),
+           "flops_per_pixel_visit": flops,
            "fetch_bytes": px.get("fetch_bytes"), "write_bytes": px.get("write_bytes"),
            "record_sum_bytes_per_launch": (rs.get("fetch_bytes", 0) + rs.get("write_bytes", 0)) or None,
            "pixel_kernel_valu_utilization": valu_util,
