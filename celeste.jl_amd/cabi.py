@@ -104,6 +104,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
             torch.cuda.init()
     except ImportError:
         pass
+    except RuntimeError:
+        # a forked worker of a process that already initialised its device (synthetic.gen_images with workers > 1):
+        # only the host-side entry points (celeste_spline_prefilter) are used there
+        pass
     lib = C.CDLL(path)
     vp = C.c_void_p
     lib.celeste_version.restype = C.c_int

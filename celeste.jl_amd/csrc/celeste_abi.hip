@@ -593,7 +593,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     // visit_chunks): 4 for large sweeps, 1 for small batches whose critical path is one patch
     int G = n_targets >= 512 ? 4 : 1;
     if (const char *e = getenv("CELESTE_CHUNK_GROUP")) if (atoi(e) >= 1 && atoi(e) <= 16) G = atoi(e);
-    const int n_classes = G * (c->chunk_px / 64);   // work-list classes: pixel-loop iterations a group is short of a full one
+    const int n_classes = WORK_CLASSES;   // work-list classes: full groups, then the patches' last groups by length
     if ((size_t)n_wblk * n_classes > c->work_blk_cap) {
         if (c->d_work_blk) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_work_blk)); c->d_work_blk = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_work_blk, (size_t)n_wblk * n_classes * sizeof(int32_t)));

@@ -315,6 +315,7 @@ __global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__res
 // Three small kernels: per-block counts, one exclusive scan over [class][block], fill.  The order is deterministic.
 // ---------------------------------------------------------------------------------------------
 #define WORK_NT 256
+#define WORK_CLASSES 4
 // A work item is a GROUP of up to G consecutive chunks of one patch, handled by one workgroup: the workgroup's fixed
 // cost (a chain of four dependent loads, staging of the component records, ~4 us of its wave slot) is paid once per
 // group, while every chunk still produces its own record -- so the results do not depend on G, which the host picks per
@@ -341,7 +342,10 @@ __device__ inline void visit_chunks(int k, const int32_t *__restrict__ targets, 
     const int last_px = npx - (ngr - 1) * gpx;           // 1 .. gpx pixels in the last group
     const int ipc = chunk_px >> 6;                       // iterations of a full chunk
     const int last_iters = (last_px / chunk_px) * ipc + ((last_px % chunk_px + 63) >> 6);
-    last_class = G * ipc - last_iters;
+    const int shortfall = G * ipc - last_iters;          // 0 .. G ipc - 1 iterations short of a full group
+    // WORK_CLASSES - 1 length classes for the last groups (quantised shortfall): the order only has to be roughly
+    // longest first, and every class costs the list kernels a ballot pass
+    last_class = shortfall == 0 ? 0 : 1 + ((shortfall - 1) * (WORK_CLASSES - 1)) / (G * ipc - 1);
     n_full = last_class == 0 ? ngr : ngr - 1;
 }
 
@@ -378,7 +382,7 @@ __device__ inline int block_prefix(int v, int *s_wave /* WORK_NT / 64 */, int &t
 __global__ void __launch_bounds__(WORK_NT)
 work_count_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPatch *__restrict__ patches,
                   const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M,
-                  int chunk_px, int G, int dense, int32_t *__restrict__ blk_cnt /* [G chunk_px / 64][gridDim.x] */,
+                  int chunk_px, int G, int dense, int32_t *__restrict__ blk_cnt /* [WORK_CLASSES][gridDim.x] */,
                   const int32_t *__restrict__ live) {
     __shared__ int s_wave[WORK_NT / 64];
     const int k = blockIdx.x * WORK_NT + threadIdx.x;
@@ -388,7 +392,7 @@ work_count_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPa
     int tot;
     block_prefix(n_full, s_wave, tot);
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
-    for (int c = 1; c < G * (chunk_px >> 6); ++c) {
+    for (int c = 1; c < WORK_CLASSES; ++c) {
         block_rank(lc == c, s_wave, tot);
         if (threadIdx.x == 0) blk_cnt[(size_t)c * gridDim.x + blockIdx.x] = tot;
     }
@@ -432,7 +436,7 @@ work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPat
     int tot;
     const int p0 = blk_base[blockIdx.x] + block_prefix(n_full, s_wave, tot);
     for (int g = 0; g < n_full; ++g) work[p0 + g] = k * CH + g * G;     // record index of the group's first chunk
-    for (int c = 1; c < G * (chunk_px >> 6); ++c) {
+    for (int c = 1; c < WORK_CLASSES; ++c) {
         const int r = block_rank(lc == c, s_wave, tot);
         if (lc == c) work[blk_base[(size_t)c * gridDim.x + blockIdx.x] + r] = k * CH + n_full * G;
     }

@@ -266,11 +266,21 @@ static int eval_free(const celeste_problem_t *pr, double *vp, int target, uint32
     return st;
 }
 
-/* vp (S x 44) is updated in place for `target`; returns status; stats: [iterations, f_evals, final elbo] */
+/* vp (S x 44) is updated in place for `target`; returns status; stats: [iterations, f_evals, final elbo].
+ * pos_center (may be NULL = the current position): centre of the position box, which the reference keeps where the
+ * first ElboConfig of the source put it across the sweeps of joint inference (ParallelRun.jl:96-100). */
+int celeste_oracle_maximize_at(const celeste_problem_t *pr, double *vp, int32_t target, const OptCfg *cfg,
+                               const double *pos_center, double *stats);
 int celeste_oracle_maximize(const celeste_problem_t *pr, double *vp, int32_t target, const OptCfg *cfg, double *stats) {
+    return celeste_oracle_maximize_at(pr, vp, target, cfg, NULL, stats);
+}
+int celeste_oracle_maximize_at(const celeste_problem_t *pr, double *vp, int32_t target, const OptCfg *cfg,
+                               const double *pos_center, double *stats) {
     const uint32_t flags = CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS | (cfg->include_kl ? CELESTE_FLAG_KL : 0);
     double *vs = vp + (size_t)target * P;
-    Boxes b; make_boxes(&b, vs, cfg->loc_width, cfg->loc_scale);
+    double centre[P]; memcpy(centre, vs, sizeof centre);
+    if (pos_center) { centre[0] = pos_center[0]; centre[1] = pos_center[1]; }
+    Boxes b; make_boxes(&b, centre, cfg->loc_width, cfg->loc_scale);
     enforce(vs, &b);
     double x[NF], xt[NF], s[NF], g[NF], gt[NF];
     double *H = (double *)malloc(sizeof(double) * NF * NF), *Ht = (double *)malloc(sizeof(double) * NF * NF);

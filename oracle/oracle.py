@@ -228,12 +228,18 @@ def propagate(x, vs0, d, h, loc_width=1e-4, loc_scale=1.0):
     return gf, Hf.reshape(41, 41).T.copy()
 
 
-def maximize(problem, vp, target, cfg=None):
-    """maximize! for one target (neighbours frozen); returns (vp_new, iterations, f_evals, elbo, status)"""
+def maximize(problem, vp, target, cfg=None, pos_center=None):
+    """maximize! for one target (neighbours frozen); returns (vp_new, iterations, f_evals, elbo, status).
+    pos_center: centre of the position box (default: the current position)"""
     cfg = cfg or OptCfg()
     vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(problem.n_sources, P)).copy()
     stats = np.zeros(3)
-    st = lib().celeste_oracle_maximize(C.byref(problem.c), _dp(vp), int(target), C.byref(cfg), _dp(stats))
+    L = lib()
+    L.celeste_oracle_maximize_at.argtypes = [C.POINTER(cabi.ProblemT), C.POINTER(C.c_double), C.c_int32, C.POINTER(OptCfg),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    pc = None if pos_center is None else np.ascontiguousarray(pos_center, dtype=np.float64)
+    st = L.celeste_oracle_maximize_at(C.byref(problem.c), _dp(vp), int(target), C.byref(cfg),
+                                      _dp(pc) if pc is not None else None, _dp(stats))
     return vp, int(stats[0]), int(stats[1]), float(stats[2]), int(st)
 
 

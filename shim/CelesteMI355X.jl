@@ -5,7 +5,6 @@
 # (tests/test_gpu_*.py).  To be included next to src/deterministic_vi/elbo_objective.jl inside module DeterministicVI;
 # see INTEGRATION.md for the call-site changes (ElboMaximize.jl:166, ParallelRun.jl:372-397, 468-498).
 
-# Julia 0.6 syntax, to live next to elbo_objective.jl inside module DeterministicVI.
 const libceleste = "libceleste_mi355x"
 
 struct CImage                      # celeste_image_t
@@ -25,43 +24,66 @@ struct CProblem                    # celeste_problem_t
     n_patch_entries::Int64; patch_source::Ptr{Int32}; patch_image::Ptr{Int32}   # 0 / NULL: dense patch table
 end
 
+check(st) = st == 0 || error(unsafe_string(ccall((:celeste_strerror, libceleste), Cstring, (Cint,), st)))
+
+# ---- the images of a box, uploaded ONCE (celeste_images_create) ------------------------------------------------
+# process_source builds one ElboArgs per source over the same `images` (ParallelRun.jl:468-488); every per-source
+# context below is created on this handle and costs a patch-table upload, not a copy of the planes.
+mutable struct MI355XImages
+    handle::Ptr{Void}
+    images::Vector{Image}
+end
+function MI355XImages(images::Vector{Image}; device::Int = 0)
+    keep = Any[]
+    cimgs = map(images) do img
+        sky = convert(Matrix{Float32}, img.sky)          # SDSSBackground / Fill materialised: img.sky[h, w]
+        push!(keep, sky)
+        CImage(img.H, img.W, img.b, 0, pointer(img.pixels), pointer(sky), pointer(img.nelec_per_nmgy))
+    end
+    h = Ref{Ptr{Void}}(C_NULL)
+    check(ccall((:celeste_images_create, libceleste), Cint, (Int32, Ptr{CImage}, Cint, Ref{Ptr{Void}}),
+                length(cimgs), cimgs, device, h))       # the planes are copied: `keep` may go after the call
+    imgs = MI355XImages(h[], images)
+    finalizer(imgs, x -> ccall((:celeste_images_destroy, libceleste), Void, (Ptr{Void},), x.handle))
+    imgs
+end
+
 mutable struct MI355XContext
     handle::Ptr{Void}
-    keep::Vector{Any}              # every buffer the C structs point into
+    images::MI355XImages
 end
 
 """
-Build the device context for one ElboArgs (ea.images, ea.patches[S x N], ea.active_sources == [1]):
-the local source list is [target; neighbors] exactly as ParallelRun.process_source builds it.
+Device context for one ElboArgs (ea.images, ea.patches[S x N], ea.active_sources == [1]): the local source list is
+[target; neighbors] exactly as ParallelRun.process_source builds it.  `imgs` is the box's image handle.
 """
-function MI355XContext(ea::ElboArgs; device::Int = 0)
+function MI355XContext(ea::ElboArgs, imgs::MI355XImages)
     keep = Any[]
-    imgs = map(ea.images) do img
-        sky = convert(Matrix{Float32}, img.sky); push!(keep, sky, img.pixels, img.nelec_per_nmgy)
-        CImage(img.H, img.W, img.b, 0, pointer(img.pixels), pointer(sky), pointer(img.nelec_per_nmgy))
-    end
-    stamps = Float64[]; patches = CPatch[]
+    stamps = Float64[]; stamp_id = Dict{Tuple{Int,UInt64},Int32}(); patches = CPatch[]
     for s in 1:ea.S, n in 1:ea.N
         p = ea.patches[s, n]
         psf = vcat([[pc.alphaBar, pc.xiBar[1], pc.xiBar[2], pc.tauBar[1,1], pc.tauBar[1,2], pc.tauBar[2,2]]
                     for pc in p.psf]...)
         bm = convert(Matrix{UInt8}, p.active_pixel_bitmap); push!(keep, psf, bm)
-        # raw psfmap stamp at the patch centre; conditioning + prefilter happen inside the library
-        append!(stamps, vec(ea.images[n].psfmap(p.pixel_center[1], p.pixel_center[2])))
+        # raw psfmap stamp at the patch centre (conditioning + prefilter happen inside the library); patches that share
+        # a stamp -- every patch of an image with a ConstantPSFMap -- share one entry of the table
+        raw = ea.images[n].psfmap(p.pixel_center[1], p.pixel_center[2])
+        id = get!(stamp_id, (n, hash(raw))) do
+            append!(stamps, vec(raw)); Int32(length(stamp_id))
+        end
         push!(patches, CPatch(p.bitmap_offset[1], p.bitmap_offset[2], size(bm, 1), size(bm, 2), pointer(bm),
                               tuple(p.wcs_jacobian...), tuple(p.world_center...), tuple(p.pixel_center...),
-                              pointer(psf), length(patches), 0))
+                              pointer(psf), id, 0))
     end
     # patches is laid out [s * N + n] (row s = source): transpose of Julia's column-major ea.patches
     off = Int64[0; fill(ea.S - 1, ea.S)]                 # CSR offsets: only source 1 has neighbours
     idx = Int32[1:(ea.S - 1);]
-    push!(keep, imgs, patches, stamps, off, idx)
-    prob = CProblem(ea.N, ea.S, ea.psf_K, length(patches), pointer(imgs), pointer(patches), pointer(stamps),
+    prob = CProblem(ea.N, ea.S, ea.psf_K, length(stamp_id), C_NULL, pointer(patches), pointer(stamps),
                     pointer(off), pointer(idx), C_NULL, 0, C_NULL, C_NULL)
     h = Ref{Ptr{Void}}(C_NULL)
-    st = ccall((:celeste_ctx_create, libceleste), Cint, (Ref{CProblem}, Cint, Ref{Ptr{Void}}), prob, device, h)
-    st == 0 || error(unsafe_string(ccall((:celeste_strerror, libceleste), Cstring, (Cint,), st)))
-    ctx = MI355XContext(h[], keep)
+    check(ccall((:celeste_ctx_create_on, libceleste), Cint, (Ptr{Void}, Ref{CProblem}, Ref{Ptr{Void}}),
+                imgs.handle, prob, h))
+    ctx = MI355XContext(h[], imgs)
     finalizer(ctx, c -> ccall((:celeste_ctx_destroy, libceleste), Void, (Ptr{Void},), c.handle))
     ctx
 end
@@ -87,36 +109,48 @@ function elbo(ea::ElboArgs, vp::VariationalParams{Float64}, ctx::MI355XContext,
 end
 
 
-# ---- whole-box entry points (one context per box; see INTEGRATION.md) ----------------------------------------
+# ---- whole-box entry points (one context over every catalogued source of the box; see INTEGRATION.md) ----------
 
-"""elbo() for a conflict-free batch of targets; `targets0` are 0-based source ids."""
-function elbo_batch(ctx::MI355XContext, vp_all::Matrix{Float64}, targets0::Vector{Int32}; flags::UInt32 = UInt32(7))
-    n = length(targets0)
-    v = zeros(n); d = zeros(44, n); h = zeros(44, 44, n)
-    counters = zeros(Int64, 2, n); status = zeros(Int32, n); targets = targets0
+"""Page-locked output buffers (celeste_host_alloc): the library DMAs results straight into them, overlapped with the
+kernels of the next part of the batch.  Allocate once per box and reuse."""
+struct PinnedOutputs
+    v::Vector{Float64}; d::Matrix{Float64}; h::Matrix{Float64}; counters::Matrix{Int64}; status::Vector{Int32}
+end
+function PinnedOutputs(n::Int; packed::Bool = true)
+    hs = packed ? 990 : 44 * 44                          # CELESTE_FLAG_PACKED_HESS: upper triangle by columns
+    pin(T, dims...) = unsafe_wrap(Array, convert(Ptr{T}, ccall((:celeste_host_alloc, libceleste), Ptr{Void},
+                                                               (Csize_t,), sizeof(T) * prod(dims))), dims)
+    PinnedOutputs(pin(Float64, n), pin(Float64, 44, n), pin(Float64, hs, n), pin(Int64, 2, n), pin(Int32, n))
+end
+
+"""elbo() for a conflict-free batch of targets; `targets0` are 0-based source ids.  flags: 1 gradient, 2 Hessian,
+4 KL, 32 packed Hessian (element (i, j), i <= j, 0-based, at j (j + 1) / 2 + i of column t of out.h)."""
+function elbo_batch!(out::PinnedOutputs, ctx::MI355XContext, vp_all::Matrix{Float64}, targets0::Vector{Int32};
+                     flags::UInt32 = UInt32(7 | 32))
     st = ccall((:celeste_elbo_eval_batch, libceleste), Cint,
                (Ptr{Void}, Ptr{Float64}, Int32, Ptr{Int32}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                 Ptr{Int64}, Ptr{Int32}),
-               ctx.handle, vp_all, length(targets), targets0, flags, v, d, h, counters, status)
-    return st, v, d, h, counters, status
+               ctx.handle, vp_all, length(targets0), targets0, flags, out.v, out.d, out.h, out.counters, out.status)
+    return st      # first non-zero per-target status; out.status[t] tells which (the other targets are valid)
 end
 
 struct COptimConfig                # celeste_optim_config_t
     loc_width::Float64; loc_scale::Float64; max_iters::Int32; include_kl::Int32
     xtol_abs::Float64; ftol_rel::Float64; gtol::Float64; initial_delta::Float64; delta_hat::Float64
+    tr_secular_iters::Int32; reserved::Int32     # 0: multiplier iterations to convergence; 5: Optim.jl's cap
 end
 
-"""ElboMaximize.maximize! for a conflict-free batch; vp_all (44 x S) is updated in place for the targets."""
+"""ElboMaximize.maximize! for a conflict-free batch; vp_all (44 x S) is updated in place for the targets whose status
+is 0 (a failing target keeps its column and is logged by the caller, ParallelRun.jl:389-396)."""
 function maximize_batch!(ctx::MI355XContext, vp_all::Matrix{Float64}, targets0::Vector{Int32};
                          vp_frozen_neighbors = C_NULL, box_centres = C_NULL, include_kl::Bool = true)
-    targets = targets0
-    iterations = zeros(Int32, length(targets)); f_calls = zeros(Int32, length(targets))
-    max_values = zeros(length(targets)); status = zeros(Int32, length(targets))
-    cfgc = Ref(COptimConfig(1e-4, 1.0, 50, include_kl, 1e-7, 1e-6, 1e-8, 1.0, 1e9))   # ElboConfig defaults
+    n = length(targets0)
+    iterations = zeros(Int32, n); f_calls = zeros(Int32, n); max_values = zeros(n); status = zeros(Int32, n)
+    cfgc = Ref(COptimConfig(1e-4, 1.0, 50, include_kl, 1e-7, 1e-6, 1e-8, 1.0, 1e9, 0, 0))   # ElboConfig defaults
     st = ccall((:celeste_maximize_batch, libceleste), Cint,
                (Ptr{Void}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Int32}, Ref{COptimConfig},
                 Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}),
                ctx.handle, vp_all, vp_frozen_neighbors #= or C_NULL =#, box_centres #= or C_NULL =#,
-               length(targets), targets0, cfgc, iterations, f_calls, max_values, status)
+               n, targets0, cfgc, iterations, f_calls, max_values, status)
     return st, iterations, f_calls, max_values, status
 end

@@ -40,3 +40,18 @@ def test_bench_refuses_to_run_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_config5_mode_small_grid():
+    """bench.py --config 5: overlapping fields through the sparse patch list, fp32 component loop, the 1e-4 check
+    against the fp64 device path inside the run (a 2 x 2 grid of small fields so that it runs in seconds)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--grid", "2,2", "--height", "260",
+                          "--width", "240", "--sources", "150", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["dtype"] == "f32" and "configs[4]" in d["config"]["workload"] and d["config"]["shard_sizes"] == [150]
+    chk = d["fp32_vs_fp64_device"]
+    assert chk["sources_checked"] == 150 and max(chk["v"], chk["d"], chk["h"]) <= 1e-4
+    assert d["roofline"]["kernel"] == "pixel_kernel<2, float>" and d["value"] > 0

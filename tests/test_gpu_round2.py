@@ -269,7 +269,9 @@ def test_variable_sky_calibration_and_psf_map_on_the_device(oracle):
     print("split", assert_parity(ctx.eval_batch(f.vp, tg, ALL | cabi.FLAG_SPLIT), ref, "variable field, split"))
     v32, d32, h32, c32, s32 = ctx.eval_batch(f.vp, tg, ALL | cabi.FLAG_FP32)
     assert np.array_equal(c32, ref[3]) and np.max(np.abs(v32 - ref[0]) / np.abs(ref[0])) <= 1e-4
-    assert max(rel_err(d32[t], ref[1][t]) for t in tg) <= 1e-4 and max(rel_err(h32[t], ref[2][t]) for t in tg) <= 1e-4
+    # (the fp32 mode's stated tolerance is norm-scaled: SURVEY.md 8(d) config 5, "1e-4 relative on v and on |d|_inf-scaled d")
+    assert max(np.abs(d32[t] - ref[1][t]).max() / np.abs(ref[1][t]).max() for t in tg) <= 1e-4
+    assert max(np.abs(h32[t] - ref[2][t]).max() / np.abs(ref[2][t]).max() for t in tg) <= 1e-4
     g = ctx.eval_batch(f.vp, tg, 1 | 4)
     assert np.max(np.abs(g[0] - ref[0]) / np.abs(ref[0])) <= 1e-8 and max(rel_err(g[1][t], ref[1][t]) for t in tg) <= 1e-8
     # two overlapping active sources (Sa = 2) on the same planes
@@ -287,3 +289,55 @@ def test_variable_sky_calibration_and_psf_map_on_the_device(oracle):
     vp, its, _, el, st = ctx.maximize_batch(f.vp, [a], cel.ElboConfig(max_iters=6))
     o = oracle.maximize(ctx.problem, f.vp, a, oracle.OptCfg(max_iters=6))
     assert st[0] == 0 and its[0] == o[1] and abs(el[0] - o[3]) <= 1e-9 * abs(o[3])
+
+
+def test_joint_inference_on_the_device_equals_the_cpu_restatement(oracle):
+    """the joint-inference schedule (Cyclades batches, components processed source by source,
+    position boxes pinned at the initial positions, ParallelRun.jl:135-196, 302-397) driven once by the device
+    optimiser and once by the CPU restatement of maximize!: the shared parameter table must come out the same --
+    every layer's result feeds the next layers, so this checks the whole chain, not single optimisations"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.infer import joint_infer_sweeps
+    from celeste_jl_amd.params import catalog_init_source, generic_init_source
+    f = synthetic.make_field(110, 120, 12, seed=19, margin=30)       # crowded: every source has neighbours
+    assert min(len(n) for n in f.neighbors) >= 2
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    targets = [0, 1, 2, 4, 5, 7, 8, 9, 11]                           # three sources stay frozen neighbours
+    vp0 = np.stack([catalog_init_source(ce) for ce in f.catalog])
+    for t in targets:
+        vp0[t] = generic_init_source(f.catalog[t].pos)
+    cfg_kw = dict(max_iters=6)
+    calls = {"dev": 0, "cpu": 0}
+
+    def layer_dev(vp, layer, pc):
+        calls["dev"] += 1
+        new, _, _, _, st = ctx.maximize_batch(vp, layer, cel.ElboConfig(**cfg_kw), pos_centers=pc)
+        assert (st == 0).all()
+        return new[layer]
+
+    def layer_cpu(vp, layer, pc):
+        calls["cpu"] += 1
+        rows = []
+        for t, c in zip(layer, pc):
+            r = oracle.maximize(ctx.problem, vp, t, oracle.OptCfg(**cfg_kw), pos_center=c)
+            assert r[4] == 0
+            rows.append(r[0][t])
+        return np.stack(rows)
+    out = {}
+    for name, fn in (("dev", layer_dev), ("cpu", layer_cpu)):
+        out[name] = joint_infer_sweeps(fn, vp0.copy(), targets, f.neighbors, batch_size=5, n_iters=2,
+                                       rng=np.random.default_rng(3))
+    assert calls["dev"] == calls["cpu"] > 4
+    moved = np.abs(out["cpu"][targets] - vp0[targets]).max()
+    err = np.abs(out["dev"] - out["cpu"]) / np.maximum(np.abs(out["cpu"]), 1e-3)
+    print("joint inference, 2 sweeps, %d layers: max relative difference device vs CPU %.2e (parameters moved by up to %.2g)"
+          % (calls["dev"], err.max(), moved))
+    worst = np.unravel_index(np.argmax(err), err.shape)
+    print("largest difference: source %d parameter %d: %r vs %r" % (worst[0], worst[1], out["dev"][worst], out["cpu"][worst]))
+    # the bar of test_randomised_optimiser_against_cpu: every parameter within 1e-6 (absolute; the largest relative
+    # differences sit in weakly determined simplex weights of the type a source is not)
+    absdiff = np.abs(out["dev"] - out["cpu"]).max()
+    assert moved > 0.1 and absdiff <= 1e-6 and np.median(err[targets]) <= 1e-9, (absdiff, np.median(err[targets]))
+    frozen = [s for s in range(12) if s not in targets]
+    assert np.array_equal(out["dev"][frozen], vp0[frozen])

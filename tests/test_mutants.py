@@ -28,9 +28,15 @@ tg = list(range(len(f.catalog)))
 worst = 0.0
 for flags in ((7, 7 | 16, 7 | 8) if len(sys.argv) < 3 else (7,)):
     v, d, h, cnt, st = ctx.eval_batch(f.vp, tg, flags)
-    tol = 1e-4 if flags & 8 else RTOL
-    e = max(float(np.max(np.abs(v - z["v7"]) / np.abs(z["v7"]))),
-            max(rel_err(d[t], z["d7"][t]) for t in tg), max(rel_err(h[t], z["h7"][t]) for t in tg))
+    if flags & 8:   # fp32 component loop: the mode's stated tolerance is 1e-4, norm-scaled (SURVEY.md 8(d) config 5)
+        tol = 1e-4
+        e = max(float(np.max(np.abs(v - z["v7"]) / np.abs(z["v7"]))),
+                max(np.abs(d[t] - z["d7"][t]).max() / np.abs(z["d7"][t]).max() for t in tg),
+                max(np.abs(h[t] - z["h7"][t]).max() / np.abs(z["h7"][t]).max() for t in tg))
+    else:
+        tol = RTOL
+        e = max(float(np.max(np.abs(v - z["v7"]) / np.abs(z["v7"]))),
+                max(rel_err(d[t], z["d7"][t]) for t in tg), max(rel_err(h[t], z["h7"][t]) for t in tg))
     worst = max(worst, e / tol)
 print("worst error / tolerance: %%.3g" %% worst)
 sys.exit(0 if worst <= 1.0 else 3)
