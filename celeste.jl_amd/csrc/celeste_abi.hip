@@ -73,7 +73,8 @@ struct celeste_ctx {
     SrcGeo *d_geo = nullptr;
     int64_t *d_val_off = nullptr;   // per (source, image): offset of the patch in d_val
     double2 *d_val = nullptr;       // pre-rendered (E_G_s.v, var_G_s.v) of neighbour sources, per patch pixel
-    int32_t *d_needed = nullptr;    // per source: is a target of the current batch
+    int32_t *d_needed = nullptr;    // per source: stamp of the last batch it was a target of
+    int32_t stamp = 0;
     int32_t *d_link_src = nullptr;  // per neighbour link: the source that owns it (CSR row)
     int64_t n_links = 0;
     // visit lists: the images each source has a non-empty patch in (grids run over these, tables stay S x N)
@@ -415,6 +416,7 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         CTX_TRY(dev_upload(&c->d_val_off, voff.data(), voff.size()));
         CTX_TRY(dev_upload<double2>(&c->d_val, nullptr, (size_t)tot));
         CTX_TRY(dev_upload<int32_t>(&c->d_needed, nullptr, (size_t)c->S));
+        if (hipMemset(c->d_needed, 0, (size_t)c->S * sizeof(int32_t)) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
         std::vector<int32_t> lsrc(c->h_nbr_idx.size());
         for (int s = 0; s < c->S; ++s)
             for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q) lsrc[q] = s;
@@ -617,18 +619,26 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         }
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
-    if (render_neighbors) HIP_TRY(hipMemsetAsync(c->d_needed, 0, (size_t)c->S * sizeof(int32_t), stream));
-    {
-        const size_t nthreads = std::max<size_t>((size_t)c->S, (size_t)n_targets * (c->dense ? 1 : c->M));
-        hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, d_vp, c->S, c->d_geo,
-                           d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
-                           render_neighbors ? c->d_needed : nullptr);
+    if (render_neighbors && ++c->stamp == 0x7fffffff) {   // (the marks are batch stamps; 0 = never a target)
+        HIP_TRY(hipMemsetAsync(c->d_needed, 0, (size_t)c->S * sizeof(int32_t), stream));
+        c->stamp = 1;
     }
-    hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
-                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, G, (int)c->dense, c->d_work_blk, d_live);
-    hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * n_classes, c->d_work_total);
-    hipLaunchKernelGGL(work_fill_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
-                       c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, G, (int)c->dense, c->d_work_blk, c->d_work, d_live);
+    const size_t setup_threads = std::max<size_t>((size_t)c->S, (size_t)n_targets * (c->dense ? 1 : c->M));
+    if (n_visits <= WORK1_MAX_VISITS && !getenv("CELESTE_PARALLEL_WORKLIST")) {
+        hipLaunchKernelGGL(setup_worklist_kernel, dim3(1 + (unsigned)((setup_threads + WORK1_NT - 1) / WORK1_NT)), dim3(WORK1_NT),
+                           0, stream, d_vp, c->S, c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M,
+                           c->dense ? nullptr : c->d_items, render_neighbors ? c->d_needed : nullptr, c->stamp, c->d_patches,
+                           c->N, c->CH, c->chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live);
+    } else {
+        hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 255) / 256)), dim3(256), 0, stream, d_vp, c->S,
+                           c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
+                           render_neighbors ? c->d_needed : nullptr, c->stamp);
+        hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
+                           c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, G, (int)c->dense, c->d_work_blk, d_live);
+        hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * n_classes, c->d_work_total);
+        hipLaunchKernelGGL(work_fill_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
+                           c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, G, (int)c->dense, c->d_work_blk, c->d_work, d_live);
+    }
     // per-(source, image) constants: of every source when the neighbours are (re)rendered, else of the targets only
     if (render_neighbors) {
         if (c->V > 0 && !tables_current)
@@ -643,7 +653,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     if (render_neighbors) {
     if (c->n_value_items > 0)
         hipLaunchKernelGGL(value_kernel, dim3((unsigned)c->n_value_items), dim3(64), 0, stream,
-                           c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->d_link_src, c->d_nbr_idx,
+                           c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_link_src, c->d_nbr_idx,
                            c->d_val_off, c->d_item_link, c->d_item_img_chunk, c->N, c->NC, c->chunk_px, c->d_val);
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));

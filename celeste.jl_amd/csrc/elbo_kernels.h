@@ -281,19 +281,15 @@ __global__ void visit_items_kernel(const int32_t *__restrict__ targets, int n_ta
     items[k] = j < vis_off[t + 1] - vo ? vis_img[vo + j] : -1;
 }
 
-__global__ void mark_kernel(const int32_t *__restrict__ targets, int n_targets, int32_t *__restrict__ is_target) {
-    const int ti = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ti < n_targets) is_target[targets[ti]] = 1;
-}
-
 // One launch for the per-batch bookkeeping: SrcGeo of every source, the visit items of the batch (unless every
 // source is listed in every image), the target flags (is_target == nullptr: keep an earlier rendering)
 __device__ inline void source_geo(const double *vp, int s, SrcGeo *geo);
-__global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo,
-                             const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
-                             const int32_t *__restrict__ vis_img, int M, int32_t *__restrict__ items,
-                             int32_t *__restrict__ is_target) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// The target marks are batch stamps (is_target[s] == stamp: s is a target of THIS launch): no clearing pass between
+// launches.
+__device__ inline void setup_thread(int k, const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo,
+                                    const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
+                                    const int32_t *__restrict__ vis_img, int M, int32_t *__restrict__ items,
+                                    int32_t *__restrict__ is_target, int32_t stamp) {
     if (k < S) source_geo(vp, k, geo);
     if (items && k < n_targets * M) {
         const int ti = k / M, j = k - ti * M;
@@ -301,7 +297,14 @@ __global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__res
         const int vo = vis_off[t];
         items[k] = j < vis_off[t + 1] - vo ? vis_img[vo + j] : -1;
     }
-    if (is_target && k < n_targets) is_target[targets[k]] = 1;
+    if (is_target && k < n_targets) is_target[targets[k]] = stamp;
+}
+__global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo,
+                             const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
+                             const int32_t *__restrict__ vis_img, int M, int32_t *__restrict__ items,
+                             int32_t *__restrict__ is_target, int32_t stamp) {
+    setup_thread(blockIdx.x * blockDim.x + threadIdx.x, vp, S, geo, targets, n_targets, vis_off, vis_img, M, items, is_target,
+                 stamp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -442,6 +445,72 @@ work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPat
     }
 }
 
+// setup_kernel and the three work-list kernels in ONE launch, for batches of up to WORK1_MAX_VISITS candidate visits
+// (a rank's shard of a field, an optimiser iteration, a Cyclades layer): block 0 (1024 threads, every thread a
+// contiguous run of visits) counts, scans and fills the list; blocks 1.. are setup_kernel.  Four launches and their
+// drain / fill gaps become one: 44 -> 35 us in front of the pixel kernel for a 250-target shard.  Larger batches keep
+// the parallel three-kernel path (for the 2000-target sweep it is 13 us faster than one block looping).  Same list, same
+// order.
+#define WORK1_NT 1024
+#define WORK1_MAX_VISITS 4096
+__global__ void __launch_bounds__(WORK1_NT)
+setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo, const int32_t *__restrict__ targets,
+                      int n_targets, const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int M,
+                      int32_t *__restrict__ items, int32_t *__restrict__ is_target, int32_t stamp,
+                      const DevPatch *__restrict__ patches, int N, int CH, int chunk_px, int G, int dense,
+                      int32_t *__restrict__ work, int32_t *__restrict__ work_total, const int32_t *__restrict__ live) {
+    if (blockIdx.x > 0) {
+        setup_thread((blockIdx.x - 1) * WORK1_NT + threadIdx.x, vp, S, geo, targets, n_targets, vis_off, vis_img, M, items,
+                     is_target, stamp);
+        return;
+    }
+    __shared__ int s_part[WORK1_NT / 64];
+    __shared__ int s_base[WORK_CLASSES + 1];
+    int n_visits = n_targets * M;
+    if (live) n_visits = min(n_visits, *live * M);
+    const int per = (n_visits + WORK1_NT - 1) / WORK1_NT;
+    const int k0 = threadIdx.x * per, k1 = min(n_visits, k0 + per);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int cnt[WORK_CLASSES];
+#pragma unroll
+    for (int c = 0; c < WORK_CLASSES; ++c) cnt[c] = 0;
+    for (int k = k0; k < k1; ++k) {
+        int n_full, lc;
+        visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc);
+        cnt[0] += n_full;
+#pragma unroll
+        for (int c = 1; c < WORK_CLASSES; ++c) cnt[c] += lc == c;
+    }
+    // exclusive scan over (class, thread): class totals first, then the threads inside each class
+    int off[WORK_CLASSES];
+    if (threadIdx.x == 0) s_base[0] = 0;
+#pragma unroll
+    for (int c = 0; c < WORK_CLASSES; ++c) {
+        int x = cnt[c];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+        __syncthreads();
+        if (lane == 63) s_part[wv] = x;
+        __syncthreads();
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < WORK1_NT / 64; ++w) { const int v = s_part[w]; before += w < wv ? v : 0; tot += v; }
+        off[c] = before + x - cnt[c];
+        if (threadIdx.x == 0) s_base[c + 1] = s_base[c] + tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *work_total = s_base[WORK_CLASSES];
+#pragma unroll
+    for (int c = 0; c < WORK_CLASSES; ++c) off[c] += s_base[c];
+    for (int k = k0; k < k1; ++k) {
+        int n_full, lc;
+        visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc);
+        for (int g = 0; g < n_full; ++g) work[off[0]++] = k * CH + g * G;
+#pragma unroll
+        for (int c = 1; c < WORK_CLASSES; ++c) if (lc == c) work[off[c]++] = k * CH + n_full * G;
+    }
+}
+
 // One wavefront per work item (neighbour link t -> s2, image, chunk of the overlap): renders s2's value-only
 // light on the rectangle where s2's patch (minus its last column, elbo_objective.jl:349) overlaps target t's
 // patch, into s2's own patch buffer.  The items with a non-empty overlap are listed once per context
@@ -451,14 +520,14 @@ work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPat
 __global__ void __launch_bounds__(64)
 value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
-             const int32_t *__restrict__ is_target, const int32_t *__restrict__ link_src,
+             const int32_t *__restrict__ is_target, int32_t stamp, const int32_t *__restrict__ link_src,
              const int32_t *__restrict__ nbr_idx, const int64_t *__restrict__ val_off,
              const int32_t *__restrict__ item_link, const int32_t *__restrict__ item_img_chunk, int N, int NC,
              int chunk_px, double2 *__restrict__ val) {
     __shared__ double etab[64];
     const int q = item_link[blockIdx.x];
     const int t = link_src[q];
-    if (!is_target[t]) return;
+    if (is_target[t] != stamp) return;
     const int nc = item_img_chunk[blockIdx.x];
     const int n = nc & 0xffff, ch = nc >> 16;
     const int s = nbr_idx[q];

@@ -341,3 +341,41 @@ def test_joint_inference_on_the_device_equals_the_cpu_restatement(oracle):
     assert moved > 0.1 and absdiff <= 1e-6 and np.median(err[targets]) <= 1e-9, (absdiff, np.median(err[targets]))
     frozen = [s for s in range(12) if s not in targets]
     assert np.array_equal(out["dev"][frozen], vp0[frozen])
+
+
+def test_repeated_device_launches_track_the_parameters():
+    """celeste_elbo_eval_batch_device called again and again with the same pointers (an evaluation loop over a resident
+    parameter table): every launch must see the CURRENT contents of the parameter table and of the target list, also
+    after a larger batch through the same context has moved the scratch buffers"""
+    import torch
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(256, 300, 70, seed=23)
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    dev = torch.device("cuda:0")
+    n = 40
+    d_vp = torch.tensor(f.vp, dtype=torch.float64, device=dev)
+    d_tg = torch.arange(n, dtype=torch.int32, device=dev)
+    d_v = torch.zeros(n, dtype=torch.float64, device=dev); d_d = torch.zeros(n, 44, dtype=torch.float64, device=dev)
+    d_h = torch.zeros(n, 44, 44, dtype=torch.float64, device=dev)
+    d_c = torch.zeros(n, 2, dtype=torch.int64, device=dev); d_s = torch.zeros(n, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def launch():
+        ctx.eval_batch_device(d_vp.data_ptr(), n, d_tg.data_ptr(), ALL, d_v.data_ptr(), d_d.data_ptr(), d_h.data_ptr(),
+                              d_c.data_ptr(), d_s.data_ptr(), stream)
+        torch.cuda.synchronize(dev)
+        return d_v.cpu().numpy(), d_d.cpu().numpy(), d_h.cpu().numpy()
+    rng = np.random.default_rng(1)
+    vp = f.vp.copy()
+    for it in range(6):
+        if it == 3:                         # same pointers, new targets
+            d_tg.copy_(torch.arange(20, 20 + n, dtype=torch.int32, device=dev))
+        if it == 4:                         # a larger batch through the same context moves the scratch buffers
+            ctx.eval_batch(vp, np.arange(70), ALL)
+        vp[:, 6:8] += 0.01 * rng.normal(size=(70, 2))
+        d_vp.copy_(torch.tensor(vp, dtype=torch.float64, device=dev))
+        got = launch()
+        tg = d_tg.cpu().numpy()
+        ref = ctx.eval_batch(vp, tg, ALL)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), it
