@@ -50,11 +50,13 @@ struct DevPatch {
 // one PSF component (x) one galaxy prototype component (fsm_util.jl:37-65)
 struct Comp {
     double p11, p12, p22;  // precision = inv(tauBar_k + nuBar_j XiXi)
-    double xi1, xi2;       // xiBar_k: the mean is xi + m_pos (m_pos lives in SrcImg, so coordinates stay centred)
     double w0;             // z * gal_frac_dev_i      (f = w0 * exp(...))
     double wd;             // z * gal_frac_dev_dir    (d f / d gal_frac_dev = wd * exp(...))
     double nu;             // nuBar_j
-};                         // 64 bytes = one scalar-cache line = one s_load_dwordx16
+    double xi1, xi2;       // xiBar_k: the mean is xi + m_pos (m_pos lives in SrcImg, so coordinates stay centred);
+                           // last, because the pixel kernel reads it once per run of prototypes (3 x 16-byte reads per
+                           // component instead of 4)
+};                         // 64 bytes
 
 struct SrcImg {
     double m1, m2;          // linear_world_to_pix(pos)

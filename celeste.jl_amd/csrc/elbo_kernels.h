@@ -103,10 +103,12 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
     double x11, x12, x22;
     bvn_cov(vs[3], vs[4], vs[5], x11, x12, x22);
     if (c < NC) {
-        // component order of populate_gal_fsm!: type i, prototype j, psf k (k fastest)
+        // component order: type i, psf component k, prototype j (j fastest) -- the 8 / 6 prototypes that share a PSF
+        // component (hence its offset xiBar_k) are consecutive, so the pixel kernel forms pixel - mean once per run
+        // (populate_gal_fsm! loops i, j, k; the sum does not care)
         int i, j, k;
-        if (c < 8 * K) { i = 0; j = c / K; k = c - j * K; }
-        else { int cc = c - 8 * K; i = 1; j = cc / K; k = cc - j * K; }
+        if (c < 8 * K) { i = 0; k = c / 8; j = c - 8 * k; }
+        else { int cc = c - 8 * K; i = 1; k = cc / 6; j = cc - 6 * k; }
         const double *pc = p.psf + 6 * k;
         const double nu = c_nu[8 * i + j];
         const double s11 = pc[3] + nu * x11, s12 = pc[4] + nu * x12, s22 = pc[5] + nu * x22;
@@ -201,9 +203,13 @@ __device__ inline void bspline_dw(double f, double dw[4], double ddw[4]) {
 }
 
 // exp(x) for x <= 0 in fp64.  x = (64 m + j) ln2/64 + r with |r| <= ln2/128, so
-// exp(x) = 2^m * 2^(j/64) * exp(r): a 64-entry table in LDS (filled by exp_table_init), a degree-5
-// Taylor polynomial (truncation 3.5e-17) and v_ldexp_f64.  About 1 ulp; 17 VALU + 1 LDS instruction
-// instead of ~31 for the library exp.  Inputs below -745 give exactly 0 like the reference's exp.
+// exp(x) = 2^m * 2^(j/64) * exp(r): a 64-entry table in LDS (filled by exp_table_init), a degree-4
+// Taylor polynomial (truncation 3.9e-14 relative; EXP_DEGREE 5 gives 3.5e-17 for one more FMA) and
+// v_ldexp_f64.  16 VALU + 1 LDS instruction instead of ~31 for the library exp.  Inputs below -745 give
+// exactly 0 like the reference's exp.
+#ifndef EXP_DEGREE
+#define EXP_DEGREE 4   // Taylor degree of exp(r), |r| <= ln2 / 128: truncation 3.9e-14 relative (degree 5: 3.5e-17, 1 % slower)
+#endif
 __device__ double g_exp2_table[64];  // 2^(j/64), filled once per context by exp_table_kernel
 __global__ void exp_table_kernel() { g_exp2_table[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0)); }
 __device__ __forceinline__ void exp_table_init(double *tab) {
@@ -217,8 +223,12 @@ __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
     r = __builtin_fma(n, 2.0164562921995537e-13, r);           // minus the low part of ln2/64 (lo = -2.0164562921995537e-13)
     const int ni = (int)n;
     const double tj = tab[ni & 63];
+#if EXP_DEGREE == 5
     double p = 8.333333333333333e-03;                // 1/5!
     p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
+#else
+    double p = 4.1666666666666664e-02;               // 1/4!: truncation |r|^5 / 120 <= 3.9e-14 for |r| <= ln2 / 128
+#endif
     p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
@@ -712,7 +722,7 @@ __device__ __forceinline__ void store_entries(const PixelTerms &T, double *__res
 
 // Component record in the arithmetic type of the pixel math (double, or float for CELESTE_FLAG_FP32)
 template <typename R>
-struct CompR { R p11, p12, p22, xi1, xi2, w0, wd, nu; };
+struct CompR { R p11, p12, p22, w0, wd, nu, xi1, xi2; };
 
 template <typename R> __device__ __forceinline__ R exp_np(R x, const double *tab);
 template <> __device__ __forceinline__ double exp_np<double>(double x, const double *tab) { return exp_nonpos(x, tab); }
@@ -739,9 +749,8 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
         // 18 accumulations per component instead of 24.
         R U0[6] = {0, 0, 0, 0, 0, 0}, U1[6] = {0, 0, 0, 0, 0, 0};
         R S2a = 0, S2b = 0, S2c = 0, S3a = 0, S3b = 0, S3c = 0, S3d = 0, S4a = 0, S4b = 0, S4c = 0, S4d = 0, S4e = 0;
-        auto body = [&](int c, R (&U)[6]) {
+        auto body = [&](int c, R (&U)[6], R d1, R d2) {
             const CompR<R> k = tc[c];
-            const R d1 = dx - k.xi1, d2 = dy - k.xi2;
             const R u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
             const R e = exp_np<R>((R)-0.5 * (d1 * u + d2 * v), etab);   // eval_bvn_pdf!
             const R f = k.w0 * e, g = k.wd * e, fn = f * k.nu, gn = g * k.nu, fnn = fn * k.nu;
@@ -768,8 +777,15 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             S4c = fma_r<R>(h4c, fnn, S4c); S4d = fma_r<R>(h4d, fnn, S4d);
             S4e = fma_r<R>(h4e, fnn, S4e);
         };
-        for (int c = 0; c < n_dev; ++c) body(c, U0);
-        for (int c = n_dev; c < nc; ++c) body(c, U1);
+        // runs of 8 (de Vaucouleurs) / 6 (exponential) prototypes share a PSF component, i.e. the offset xiBar_k
+        for (int c0 = 0; c0 < n_dev; c0 += 8) {
+            const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+            for (int c = c0; c < c0 + 8; ++c) body(c, U0, d1, d2);
+        }
+        for (int c0 = n_dev; c0 < nc; c0 += 6) {
+            const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+            for (int c = c0; c < c0 + 6; ++c) body(c, U1, d1, d2);
+        }
         const R th0 = dev, th1 = (R)1.0 - dev;
         T.S0d = U0[0] + U1[0]; T.S1xd = U0[1] + U1[1]; T.S1yd = U0[2] + U1[2];
         T.S2ad = U0[3] + U1[3]; T.S2bd = U0[4] + U1[4]; T.S2cd = U0[5] + U1[5];

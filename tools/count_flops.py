@@ -46,7 +46,8 @@ def main():
     # (de Vaucouleurs: 8 psf_K components, exponential: 6 psf_K), same body
     comp = [(a, b) for a, b in loops if any("ds_read_b128" in l for l in lines[a:b])
             and not any(a < a2 and b2 < b for a2, b2 in loops)]
-    outer = max((l for l in loops if any(l[0] < a and b < l[1] for a, b in comp)), key=lambda l: l[1] - l[0])
+    # the pixel loop: the innermost loop around the component loops (the loop over a group's chunks encloses it)
+    outer = min((l for l in loops if all(l[0] < a and b < l[1] for a, b in comp)), key=lambda l: l[1] - l[0])
     body = stats(lines[outer[0]:outer[1]])
     psf_k = 2
     trips = [8 * psf_k, 6 * psf_k] if len(comp) == 2 else [14 * psf_k]
