@@ -738,6 +738,26 @@ template <> __device__ __forceinline__ float fma_r<float>(float a, float b, floa
 // weighted sum over components of spatial derivatives up to order 4 (24 sums instead of 1+6+21,
 // and no 3x3 transforms inside the loop).  Weights: w0 = z theta_i, wd = +-z, and their products with
 // nu, nu^2.  (dx, dy) = pixel - m_pos.  Returns sum f; fills the S* members of T.
+// ---- explicit LDS reads of a component record (PIXEL_LDS_PINGPONG) -------------------------------------------
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+struct LdsComp { dbl2 a, b, c; };   // {p11, p12} {p22, w0} {wd, nu}
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ void lds_issue_comp(LdsComp &r, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32"
+                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_wait_comp(LdsComp &r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c));
+}
+#ifndef PIXEL_LDS_PINGPONG
+#define PIXEL_LDS_PINGPONG 1
+#endif
+#ifndef PIXEL_SCHED_BARRIER
+#define PIXEL_SCHED_BARRIER 1
+#endif
+
 template <int MODE, typename R>
 __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int nc, R dx, R dy, R dev, const double *etab,
                                               PixelTerms &T) {
@@ -749,23 +769,29 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
         // 18 accumulations per component instead of 24.
         R U0[6] = {0, 0, 0, 0, 0, 0}, U1[6] = {0, 0, 0, 0, 0, 0};
         R S2a = 0, S2b = 0, S2c = 0, S3a = 0, S3b = 0, S3c = 0, S3d = 0, S4a = 0, S4b = 0, S4c = 0, S4d = 0, S4e = 0;
-        auto body = [&](int c, R (&U)[6], R d1, R d2) {
-            const CompR<R> k = tc[c];
+        auto body_regs = [&](R p11, R p12, R p22, R w0, R wd, R nu, R (&U)[6], R d1, R d2, auto &&after_exp_issue) {
+            struct { R p11, p12, p22, w0, wd, nu; } k = {p11, p12, p22, w0, wd, nu};
             const R u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
-            const R e = exp_np<R>((R)-0.5 * (d1 * u + d2 * v), etab);   // eval_bvn_pdf!
-            const R f = k.w0 * e, g = k.wd * e, fn = f * k.nu, gn = g * k.nu, fnn = fn * k.nu;
+            // exp_nonpos in two halves: the table entry is requested as soon as its index is known, the Hermite
+            // polynomials (which do not depend on the exponential) are evaluated while it is on its way
+            R xr, tj = 0, pe = 0;
+            int ni = 0;
+            if constexpr (sizeof(R) == 8) {
+                const double x = -0.5 * (d1 * u + d2 * v);
+                const double n = rint(x * 92.33248261689366);
+                double r = __builtin_fma(n, -0.010830424696450791, x);
+                xr = __builtin_fma(n, 2.0164562921995537e-13, r);
+                ni = (int)n;
+                tj = etab[ni & 63];
+            } else xr = (R)-0.5 * (d1 * u + d2 * v);
+            after_exp_issue();
             const R ha = fma_r<R>(u, u, -k.p11), hb = fma_r<R>(u, v, -k.p12), hc = fma_r<R>(v, v, -k.p22);
-            U[0] += g; U[1] = fma_r<R>(u, g, U[1]); U[2] = fma_r<R>(v, g, U[2]);
-            U[3] = fma_r<R>(ha, gn, U[3]); U[4] = fma_r<R>(hb, gn, U[4]); U[5] = fma_r<R>(hc, gn, U[5]);
-            S2a = fma_r<R>(ha, f, S2a); S2b = fma_r<R>(hb, f, S2b); S2c = fma_r<R>(hc, f, S2c);
             // third order: u^3 - 3 p11 u, u^2 v - p11 v - 2 p12 u, u v^2 - p22 u - 2 p12 v, v^3 - 3 p22 v
             const R tu = (R)-2.0 * u, tv = (R)-2.0 * v;
             const R h3a = u * fma_r<R>((R)-2.0, k.p11, ha);
             const R h3b = fma_r<R>(v, ha, tu * k.p12);
             const R h3c = fma_r<R>(u, hc, tv * k.p12);
             const R h3d = v * fma_r<R>((R)-2.0, k.p22, hc);
-            S3a = fma_r<R>(h3a, fn, S3a); S3b = fma_r<R>(h3b, fn, S3b);
-            S3c = fma_r<R>(h3c, fn, S3c); S3d = fma_r<R>(h3d, fn, S3d);
             // fourth order
             const R m3a = (R)-3.0 * ha, m3c = (R)-3.0 * hc;
             const R h4a = fma_r<R>(u, h3a, m3a * k.p11);
@@ -773,11 +799,64 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             const R h4c = fma_r<R>(u, h3c, fma_r<R>((R)-2.0 * hb, k.p12, -hc * k.p11));
             const R h4d = fma_r<R>(u, h3d, m3c * k.p12);
             const R h4e = fma_r<R>(v, h3d, m3c * k.p22);
+            R e;
+            if constexpr (sizeof(R) == 8) {
+#if EXP_DEGREE == 5
+                double p = 8.333333333333333e-03;
+                p = __builtin_fma(p, xr, 4.1666666666666664e-02);
+#else
+                double p = 4.1666666666666664e-02;
+#endif
+                p = __builtin_fma(p, xr, 1.6666666666666666e-01);
+                p = __builtin_fma(p, xr, 0.5);
+                p = __builtin_fma(p, xr, 1.0);
+                pe = __builtin_fma(p, xr, 1.0);
+#if PIXEL_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);   // nothing that needs the table entry moves above this point
+#endif
+                e = ldexp(pe * tj, ni >> 6);   // eval_bvn_pdf!
+            } else e = exp_np<R>(xr, etab);
+            const R f = k.w0 * e, g = k.wd * e, fn = f * k.nu, gn = g * k.nu, fnn = fn * k.nu;
+            U[0] += g; U[1] = fma_r<R>(u, g, U[1]); U[2] = fma_r<R>(v, g, U[2]);
+            U[3] = fma_r<R>(ha, gn, U[3]); U[4] = fma_r<R>(hb, gn, U[4]); U[5] = fma_r<R>(hc, gn, U[5]);
+            S2a = fma_r<R>(ha, f, S2a); S2b = fma_r<R>(hb, f, S2b); S2c = fma_r<R>(hc, f, S2c);
+            S3a = fma_r<R>(h3a, fn, S3a); S3b = fma_r<R>(h3b, fn, S3b);
+            S3c = fma_r<R>(h3c, fn, S3c); S3d = fma_r<R>(h3d, fn, S3d);
             S4a = fma_r<R>(h4a, fnn, S4a); S4b = fma_r<R>(h4b, fnn, S4b);
             S4c = fma_r<R>(h4c, fnn, S4c); S4d = fma_r<R>(h4d, fnn, S4d);
             S4e = fma_r<R>(h4e, fnn, S4e);
         };
+        auto body = [&](int c, R (&U)[6], R d1, R d2) {
+            const CompR<R> k = tc[c];
+            body_regs(k.p11, k.p12, k.p22, k.w0, k.wd, k.nu, U, d1, d2, []() {});
+        };
         // runs of 8 (de Vaucouleurs) / 6 (exponential) prototypes share a PSF component, i.e. the offset xiBar_k
+#if PIXEL_LDS_PINGPONG
+        if constexpr (sizeof(R) == 8) {
+            // The record of component c + 1 is requested while component c is computed (two register sets, the loop
+            // unrolled by two): the compiler neither rotates the loop nor leaves a hand-hoisted load where it is put,
+            // so the reads are volatile asm, and every set passes through the "+v" operands of an explicit s_waitcnt
+            // before it is used (free when the data has already arrived under the exponential's table read).
+            const unsigned base = lds_addr(tc);
+            LdsComp ra, rb;
+            lds_issue_comp(ra, base);
+            auto half = [&](LdsComp &k, LdsComp &nxt, int c_next, R (&U)[6], R d1, R d2) {
+                lds_wait_comp(k);
+                body_regs(k.a.x, k.a.y, k.b.x, k.b.y, k.c.x, k.c.y, U, d1, d2,
+                          [&]() { lds_issue_comp(nxt, base + 64u * (unsigned)(c_next < nc ? c_next : nc - 1)); });
+            };
+            for (int c0 = 0; c0 < n_dev; c0 += 8) {
+                const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+                for (int c = c0; c < c0 + 8; c += 2) { half(ra, rb, c + 1, U0, d1, d2); half(rb, ra, c + 2, U0, d1, d2); }
+            }
+            for (int c0 = n_dev; c0 < nc; c0 += 6) {
+                const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+                for (int c = c0; c < c0 + 6; c += 2) { half(ra, rb, c + 1, U1, d1, d2); half(rb, ra, c + 2, U1, d1, d2); }
+            }
+            lds_wait_comp(ra);   // the last (unused) request must land before its registers are reused
+        } else
+#endif
+        {
         for (int c0 = 0; c0 < n_dev; c0 += 8) {
             const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
             for (int c = c0; c < c0 + 8; ++c) body(c, U0, d1, d2);
@@ -785,6 +864,7 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
         for (int c0 = n_dev; c0 < nc; c0 += 6) {
             const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
             for (int c = c0; c < c0 + 6; ++c) body(c, U1, d1, d2);
+        }
         }
         const R th0 = dev, th1 = (R)1.0 - dev;
         T.S0d = U0[0] + U1[0]; T.S1xd = U0[1] + U1[1]; T.S1yd = U0[2] + U1[2];
@@ -1072,11 +1152,11 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             const double xh = hh + sh0, xw = ww + sw0;
             int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
             int iy = (int)floor(xw); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
+            const double *cc = tcoef + (ix - 1) + CEL_COEF * (iy - 1);
             const double fx = xh - ix, fy = xw - iy;
             double wx[4], wy[4], dwx[4], ddwx[4], dwy[4], ddwy[4];
             bspline_w(fx, wx); bspline_w(fy, wy);
             bspline_dw(fx, dwx, ddwx); bspline_dw(fy, dwy, ddwy);
-            const double *cc = tcoef + (ix - 1) + CEL_COEF * (iy - 1);
             double y = 0, yx = 0, yy = 0, yxx = 0, yxy = 0, yyy = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
