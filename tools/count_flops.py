@@ -50,12 +50,15 @@ def main():
     outer = min((l for l in loops if all(l[0] < a and b < l[1] for a, b in comp)), key=lambda l: l[1] - l[0])
     body = stats(lines[outer[0]:outer[1]])
     psf_k = 2
-    trips = [8 * psf_k, 6 * psf_k] if len(comp) == 2 else [14 * psf_k]
+    n_comp = [8 * psf_k, 6 * psf_k] if len(comp) == 2 else [14 * psf_k]
     per_visit = body[0]
-    for (a, b), n in zip(sorted(comp), trips):
+    for (a, b), n in zip(sorted(comp), n_comp):
         c = stats(lines[a:b + 1])
-        print("component loop (%d trips): %d flops, %d FP64 instructions, %d VALU" % ((n,) + c))
-        per_visit += (n - 1) * c[0]
+        unroll = max(1, sum("ds_read_b64" in l for l in lines[a:b + 1]))   # one exp-table read per component
+        trips = n // unroll
+        print("component loop (%d trips of %d component%s): %d flops, %d FP64 instructions, %d VALU per trip"
+              % ((trips, unroll, "s" if unroll > 1 else "") + c))
+        per_visit += (trips - 1) * c[0]
     print("pixel loop body (one copy of each component loop inside): %d flops, %d FP64 instructions, %d VALU" % body)
     print("FP64 flops per pixel visit (psf_K = 2): %d" % per_visit)
     return per_visit
