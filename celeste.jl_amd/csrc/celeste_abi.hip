@@ -131,6 +131,8 @@ struct celeste_ctx {
         int32_t *h_count = nullptr;
         hipEvent_t ev[RING] = {};
     } opt;
+    // device scratch of the less travelled entry points (eval_multi, render_expected): grown on demand, kept
+    struct Scratch { void *p = nullptr; size_t cap = 0; } scratch[13];
     // timing
     int timing = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -529,6 +531,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
         for (void *q : hptr) if (q) (void)hipHostFree(q);
         for (int k = 0; k < celeste_ctx::OptBuffers::RING; ++k) if (o.ev[k]) (void)hipEventDestroy(o.ev[k]);
     }
+    for (auto &sc : c->scratch) if (sc.p) (void)hipFree(sc.p);
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < celeste_ctx::MAX_PARTS; ++i) {
         if (c->part_done[i]) (void)hipEventDestroy(c->part_done[i]);
@@ -540,6 +543,22 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     images_release(c->imgs);
     delete c;
+}
+
+// slot `k` of the context's scratch arena, at least `bytes` large (the stream is drained before a buffer moves)
+template <class T>
+static hipError_t scratch_get(celeste_ctx_t *c, int k, size_t bytes, T **out) {
+    auto &s = c->scratch[k];
+    if (bytes > s.cap) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return e;
+        if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
+        e = hipMalloc(&s.p, std::max<size_t>(bytes, 256));
+        if (e != hipSuccess) return e;
+        s.cap = std::max<size_t>(bytes, 256);
+    }
+    *out = (T *)s.p;
+    return hipSuccess;
 }
 
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
@@ -889,24 +908,24 @@ extern "C" int celeste_elbo_eval_multi(celeste_ctx_t *c, const double *vp, int32
     int rc = CELESTE_OK;
     std::vector<double> hx(np * LIFT_NP * LIFT_NP);
 #define MU_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto done; } } while (0)
-    MU_TRY(hipMalloc((void **)&d_vp, (size_t)c->S * CEL_P * sizeof(double)));
-    MU_TRY(hipMalloc((void **)&d_v, Sa * sizeof(double)));
-    MU_TRY(hipMalloc((void **)&d_d, (size_t)Sa * CEL_P * sizeof(double)));
-    MU_TRY(hipMalloc((void **)&d_h, (size_t)Sa * CEL_P * CEL_P * sizeof(double)));
-    MU_TRY(hipMalloc((void **)&d_t, Sa * sizeof(int32_t)));
-    MU_TRY(hipMalloc((void **)&d_st, Sa * sizeof(int32_t)));
-    MU_TRY(hipMalloc((void **)&d_cnt, (size_t)Sa * 2 * sizeof(int64_t)));
-    MU_TRY(hipMalloc((void **)&d_rank, (size_t)c->S * sizeof(int32_t)));
+    MU_TRY(scratch_get(c, 0, (size_t)c->S * CEL_P * sizeof(double), &d_vp));
+    MU_TRY(scratch_get(c, 1, Sa * sizeof(double), &d_v));
+    MU_TRY(scratch_get(c, 2, (size_t)Sa * CEL_P * sizeof(double), &d_d));
+    MU_TRY(scratch_get(c, 3, (size_t)Sa * CEL_P * CEL_P * sizeof(double), &d_h));
+    MU_TRY(scratch_get(c, 4, Sa * sizeof(int32_t), &d_t));
+    MU_TRY(scratch_get(c, 5, Sa * sizeof(int32_t), &d_st));
+    MU_TRY(scratch_get(c, 6, (size_t)Sa * 2 * sizeof(int64_t), &d_cnt));
+    MU_TRY(scratch_get(c, 7, (size_t)c->S * sizeof(int32_t), &d_rank));
     MU_TRY(hipMemcpyAsync(d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice, c->stream));
     MU_TRY(hipMemcpyAsync(d_t, active, Sa * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     MU_TRY(hipMemcpyAsync(d_rank, rank.data(), (size_t)c->S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     rc = launch_eval(c, d_vp, Sa, d_t, flags, d_v, d_d, d_h, d_cnt, d_st, c->stream, true, d_rank);
     if (rc != CELESTE_OK) goto done;
     if (np > 0) {
-        MU_TRY(hipMalloc((void **)&d_pa, np * sizeof(int32_t)));
-        MU_TRY(hipMalloc((void **)&d_pb, np * sizeof(int32_t)));
-        MU_TRY(hipMalloc((void **)&d_rec, np * c->N * ZV * ZV * sizeof(double)));
-        MU_TRY(hipMalloc((void **)&d_x, np * LIFT_NP * LIFT_NP * sizeof(double)));
+        MU_TRY(scratch_get(c, 8, np * sizeof(int32_t), &d_pa));
+        MU_TRY(scratch_get(c, 9, np * sizeof(int32_t), &d_pb));
+        MU_TRY(scratch_get(c, 10, np * c->N * ZV * ZV * sizeof(double), &d_rec));
+        MU_TRY(scratch_get(c, 11, np * LIFT_NP * LIFT_NP * sizeof(double), &d_x));
         MU_TRY(hipMemcpyAsync(d_pa, pa.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         MU_TRY(hipMemcpyAsync(d_pb, pb.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(cross_kernel, dim3((unsigned)(np * c->N)), dim3(64), 0, c->stream, c->d_images, c->d_patches,
@@ -948,11 +967,7 @@ extern "C" int celeste_elbo_eval_multi(celeste_ctx_t *c, const double *vp, int32
     }
 done:
 #undef MU_TRY
-    (void)hipStreamSynchronize(c->stream);   // nothing of this call is in flight when its buffers are released
-    {
-        void *ptrs[] = {d_vp, d_v, d_d, d_h, d_rec, d_x, d_t, d_st, d_rank, d_pa, d_pb, d_cnt};
-        for (void *q : ptrs) if (q) (void)hipFree(q);
-    }
+    (void)hipStreamSynchronize(c->stream);   // nothing of this call is in flight when it returns
     return rc;
 }
 
@@ -1181,7 +1196,7 @@ extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32
     double *d_plane = nullptr;
     if (!c->d_vp) HIP_TRY(hipMalloc((void **)&c->d_vp, (size_t)c->S * CEL_P * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(c->d_vp, vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMalloc((void **)&d_plane, npix * sizeof(double)));
+    HIP_TRY(scratch_get(c, 12, npix * sizeof(double), &d_plane));
     int rc = CELESTE_OK;
     if (hipMemsetAsync(d_plane, 0, npix * sizeof(double), c->stream) != hipSuccess) rc = CELESTE_ERR_HIP;
     if (rc == CELESTE_OK) {
@@ -1195,6 +1210,5 @@ extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32
         if (hipMemcpyAsync(out_plane, d_plane, npix * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = CELESTE_ERR_HIP;
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = CELESTE_ERR_HIP;
-    (void)hipFree(d_plane);
     return rc;
 }

@@ -30,6 +30,14 @@
 #include "../../include/celeste_mi355x.h"
 
 #define NF 41
+#ifndef OPTIM_UNROLL_RECURRENCES
+#define OPTIM_UNROLL_RECURRENCES 1
+#endif
+#if OPTIM_UNROLL_RECURRENCES
+#define OPTIM_UNROLL _Pragma("unroll")
+#else
+#define OPTIM_UNROLL
+#endif
 #define LDA 45  // leading dimension of the LDS matrix (holds the 44 x 44 bound-space Hessian first; odd: no bank conflicts)
 
 struct OptState {                 // per target slot
@@ -304,6 +312,7 @@ __device__ __forceinline__ void tri_factor(const double *__restrict__ td, const 
                                            int ln) {
     double pm = 1.0, pc = td[0] + lam;
     pa[0] = pm; pb[0] = pc;
+    OPTIM_UNROLL
     for (int k = 1; k < NF; ++k) {
         const double pn = __builtin_fma(td[k] + lam, pc, -te2[k] * pm);
         pa[k] = pc; pb[k] = pn;
@@ -323,9 +332,11 @@ __device__ __forceinline__ void tri_solve(const double *__restrict__ te, const d
                                           double *__restrict__ r, double *__restrict__ y) {
     double prev = sign * rhs[0];
     r[0] = prev;
+    OPTIM_UNROLL
     for (int k = 1; k < NF; ++k) { prev = __builtin_fma(-mk[k], prev, sign * rhs[k]); r[k] = prev; }
     double yn = prev * ip[NF - 1];
     y[NF - 1] = yn;
+    OPTIM_UNROLL
     for (int k = NF - 2; k >= 0; --k) { yn = __builtin_fma(-te[k + 1], yn, r[k]) * ip[k]; y[k] = yn; }
     __syncthreads();
 }
@@ -335,6 +346,7 @@ __device__ __forceinline__ int sturm_count(const double *__restrict__ td, const 
     if (pc == 0.0) pc = -1e-300;
     bool negp = pc < 0;
     int c = negp;
+    OPTIM_UNROLL
     for (int k = 1; k < NF; ++k) {
         double pn = __builtin_fma(td[k] - x, pc, -te2[k] * pm);
         if (pn == 0.0) pn = pc > 0 ? -1e-300 : 1e-300;
