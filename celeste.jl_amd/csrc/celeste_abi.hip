@@ -86,6 +86,7 @@ struct celeste_ctx {
     size_t items_cap = 0;
     // work list of pixel_kernel (work_count / work_scan / work_fill kernels), per batch
     std::vector<int32_t> h_src_chunks;   // per source: chunks of all its patches
+    std::vector<int64_t> h_top_chunks;   // [k]: chunks of the k sources that have most (bound for k unknown targets)
     int max_src_chunks = 0;
     int32_t *d_work = nullptr, *d_work_blk = nullptr, *d_work_total = nullptr;
     size_t work_cap = 0, work_blk_cap = 0;
@@ -460,6 +461,12 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         }
         c->max_src_chunks = std::max(c->max_src_chunks, c->h_src_chunks[s]);
     }
+    {
+        std::vector<int32_t> sorted(c->h_src_chunks);
+        std::sort(sorted.begin(), sorted.end(), [](int32_t a, int32_t b) { return a > b; });
+        c->h_top_chunks.assign((size_t)c->S + 1, 0);
+        for (int s = 0; s < c->S; ++s) c->h_top_chunks[s + 1] = c->h_top_chunks[s] + sorted[s];
+    }
     CTX_TRY(dev_upload<int32_t>(&c->d_work_total, nullptr, 1));
     {
         // work items of value_kernel: (link, image, chunk) with a non-empty overlap rectangle, longest first (by the
@@ -603,7 +610,12 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     // by the largest source (workgroups past the device-side total exit on one scalar load)
     const int n_visits = n_targets * c->M;
     const int n_wblk = (n_visits + WORK_NT - 1) / WORK_NT;
+    // n_chunks: exact when the caller knows its targets on the host; else the chunks of the n_targets chunk-richest
+    // sources (a bound for distinct targets; with repeated targets the list can be longer: the buffer is sized for
+    // that, the pixel kernel's stride loop covers it)
     const size_t work_need = (size_t)(n_chunks >= 0 ? n_chunks : (int64_t)n_targets * c->max_src_chunks);
+    const size_t grid_need = (size_t)(n_chunks >= 0 ? n_chunks
+                                      : n_targets <= c->S ? c->h_top_chunks[n_targets] : (int64_t)n_targets * c->max_src_chunks);
     if ((size_t)n_targets * c->M * c->CH > 0x7fffffffull) return CELESTE_ERR_INVALID_ARG;
     if (work_need > c->work_cap) {
         if (c->d_work) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_work)); c->d_work = nullptr; }
@@ -676,7 +688,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            c->d_val_off, c->d_item_link, c->d_item_img_chunk, c->N, c->NC, c->chunk_px, c->d_val);
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
-    const dim3 grid((unsigned)std::max<size_t>(work_need, 1));
+    const dim3 grid((unsigned)std::max<size_t>(grid_need, 1));
 #define PIXEL_ARGS                                                                                                \
     c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx,       \
     c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, G, c->d_acc, c->d_tile_off, c->d_rec, \

@@ -1032,19 +1032,23 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const int32_t *__restrict__ work, const int32_t *__restrict__ work_total) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
     __shared__ double etab[64];
-    // work list (work_fill_kernel): groups of up to G chunks that exist, longest first; the grid is an upper bound
-    if ((int)blockIdx.x >= *work_total) return;
-    const int wg0 = work[blockIdx.x];  // record index of the group's first chunk, as the lift kernel expects: ((ti * M + j) * CH + ch)
+    // work list (work_fill_kernel): groups of up to G chunks that exist, longest first.  The grid is the host's bound on
+    // the list's length: exact when it knows the targets, else the chunk count of the n_targets chunk-richest sources --
+    // which a list with repeated targets can exceed, hence the stride loop (one trip in every other case).
+    const int n_items = *work_total;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    if (item != (int)blockIdx.x) __syncthreads();      // second trip: every lane is done with the LDS tables
+    const int wg0 = work[item];  // record index of the group's first chunk, as the lift kernel expects: ((ti * M + j) * CH + ch)
     const int tn = wg0 / CH;
     const int ch0 = wg0 - tn * CH;
     const int ti = tn / M;                     // tn = ti * M + j: target, j-th image it appears in (tables stay dense)
     const int n = items ? items[tn] : tn - ti * M;   // items == nullptr: every source is listed in all M = N images
-    if (n < 0) return;
+    if (n < 0) continue;
     const int t = targets[ti];
     const DevPatch &P = patches[(size_t)t * N + n];
     const int H2 = P.H2, W2 = P.W2;
     const int npx = H2 * W2;
-    if (ch0 * chunk_px >= npx) return;  // the lift kernel recomputes this predicate
+    if (ch0 * chunk_px >= npx) continue;  // the lift kernel recomputes this predicate
     const DevImage &img = images[n];
     const int lane = threadIdx.x;
     const SrcImg si = srcimg[(size_t)t * N + n];
@@ -1241,6 +1245,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     }
     __syncthreads();   // the slots are zeroed again for the next chunk of the group
     }
+    }   // work item
 }
 
 // ---------------------------------------------------------------------------------------------

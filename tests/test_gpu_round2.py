@@ -379,3 +379,10 @@ def test_repeated_device_launches_track_the_parameters():
         tg = d_tg.cpu().numpy()
         ref = ctx.eval_batch(vp, tg, ALL)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), it
+    # repeated targets: the work list is longer than the grid the host can bound without knowing the targets (the
+    # chunks of the n chunk-richest sources) -- the pixel kernel's stride loop covers the rest
+    big = int(np.argmax([sum(p.active_pixel_bitmap.size for p in row) for row in f.patches]))
+    d_tg.copy_(torch.full((n,), big, dtype=torch.int32, device=dev))
+    got = launch()
+    ref = ctx.eval_batch(vp, [big], ALL)
+    assert (got[0] == ref[0][0]).all() and (got[2] == ref[2][0]).all()
