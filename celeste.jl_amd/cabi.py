@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "celeste_version", "celeste_strerror", "celeste_ctx_create", "celeste_ctx_destroy", "celeste_elbo_eval",
     "celeste_elbo_eval_batch", "celeste_elbo_eval_multi", "celeste_elbo_eval_batch_device", "celeste_ctx_enable_timing",
     "celeste_ctx_last_kernel_ms", "celeste_ctx_last_record_sum_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter", "celeste_psf_raster",
-    "celeste_maximize_batch", "celeste_render_expected", "celeste_optim_stats",
+    "celeste_maximize_batch", "celeste_render_expected", "celeste_optim_stats", "celeste_tr_solve_batch",
     "celeste_images_create", "celeste_images_destroy", "celeste_ctx_create_on",
     "celeste_host_alloc", "celeste_host_free", "celeste_host_register", "celeste_host_unregister",
 ]
@@ -133,6 +133,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.celeste_maximize_batch.argtypes = [vp, c_double_p, c_double_p, c_double_p, C.c_int32, c_int32_p,
                                            C.POINTER(OptimConfigT), c_int32_p, c_int32_p, c_double_p, c_int32_p]
     lib.celeste_optim_stats.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+    lib.celeste_tr_solve_batch.argtypes = [C.c_int, C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int32, C.c_int32,
+                                           c_double_p, c_double_p, c_int32_p, c_int32_p]
     lib.celeste_render_expected.argtypes = [vp, c_double_p, C.c_int32, c_double_p]
     lib.celeste_images_create.argtypes = [C.c_int32, C.POINTER(ImageT), C.c_int, C.POINTER(vp)]
     lib.celeste_images_destroy.argtypes = [vp]
@@ -254,6 +256,26 @@ def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
     buf = (C.c_char * nbytes).from_address(ptr)
     buf._celeste_block = block   # ties the block's lifetime to the ctypes buffer numpy keeps as its base
     return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
+NF = 41   # free parameters of the optimiser (CELESTE_NF)
+
+
+def tr_solve_batch(H, g, delta, solver=0, secular_iters=0, device=0):
+    """celeste_tr_solve_batch: the optimiser's trust-region sub-problem on its own (Optim.jl's solve_tr_subproblem!).
+    H [n, 41, 41] symmetric, g [n, 41], delta [n] -> (p [n, 41], model value [n], interior [n], fell_back [n])."""
+    H = np.ascontiguousarray(H, dtype=np.float64).reshape(-1, NF, NF)
+    n = H.shape[0]
+    g = np.ascontiguousarray(g, dtype=np.float64).reshape(n, NF)
+    delta = np.ascontiguousarray(np.broadcast_to(np.asarray(delta, dtype=np.float64), (n,)))
+    p = np.zeros((n, NF)); m = np.zeros(n); interior = np.zeros(n, dtype=np.int32); fell = np.zeros(n, dtype=np.int32)
+    dp = lambda a: a.ctypes.data_as(c_double_p)
+    lib = load_library()
+    st = lib.celeste_tr_solve_batch(int(device), n, dp(H), dp(g), dp(delta), int(solver), int(secular_iters), dp(p), dp(m),
+                                    interior.ctypes.data_as(c_int32_p), fell.ctypes.data_as(c_int32_p))
+    if st != 0:
+        raise CelesteError(st, lib.celeste_strerror(st).decode())
+    return p, m, interior, fell
 
 
 def unpack_hessian(hp: np.ndarray) -> np.ndarray:

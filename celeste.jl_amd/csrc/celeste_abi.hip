@@ -1199,6 +1199,60 @@ extern "C" int celeste_optim_stats(int reset, uint64_t out[5]) {
     return CELESTE_OK;
 }
 
+extern "C" int celeste_tr_solve_batch(int device, int32_t n, const double *H, const double *g, const double *delta,
+                                      int32_t solver, int32_t secular_iters, double *p, double *m, int32_t *interior,
+                                      int32_t *fell_back) {
+    if (n < 0 || !H || !g || !delta || !p || solver < 0 || solver > 2 || secular_iters < 0) return CELESTE_ERR_INVALID_ARG;
+    if (n == 0) return CELESTE_OK;
+    int st = select_device(device);
+    if (st != CELESTE_OK) return st;
+    double *d_H = nullptr, *d_g = nullptr, *d_delta = nullptr, *d_p = nullptr, *d_m = nullptr;
+    int32_t *d_i = nullptr, *d_f = nullptr;
+    st = dev_upload(&d_H, H, (size_t)n * NF * NF);
+    if (st == CELESTE_OK) st = dev_upload(&d_g, g, (size_t)n * NF);
+    if (st == CELESTE_OK) st = dev_upload(&d_delta, delta, (size_t)n);
+    if (st == CELESTE_OK) st = dev_upload<double>(&d_p, nullptr, (size_t)n * NF);
+    if (st == CELESTE_OK) st = dev_upload<double>(&d_m, nullptr, (size_t)n);
+    if (st == CELESTE_OK) st = dev_upload<int32_t>(&d_i, nullptr, (size_t)n);
+    if (st == CELESTE_OK) st = dev_upload<int32_t>(&d_f, nullptr, (size_t)n);
+    if (st == CELESTE_OK) {
+        hipLaunchKernelGGL(tr_solve_kernel, dim3((unsigned)n), dim3(64), 0, nullptr, d_H, d_g, d_delta, (int)solver,
+                           secular_iters > 0 ? (int)secular_iters : 20, d_p, d_m, d_i, d_f);
+        std::vector<int32_t> hi((size_t)n), hf((size_t)n);
+        std::vector<double> hm((size_t)n);
+        if (hipMemcpy(p, d_p, (size_t)n * NF * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hm.data(), d_m, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hi.data(), d_i, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hf.data(), d_f, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) st = CELESTE_ERR_HIP;
+        for (int k = 0; k < n && st == CELESTE_OK; ++k) {
+            if (m) m[k] = hm[k];
+            if (interior) interior[k] = hi[k];
+            if (fell_back) fell_back[k] = hf[k];
+        }
+    }
+    (void)hipFree(d_H); (void)hipFree(d_g); (void)hipFree(d_delta); (void)hipFree(d_p); (void)hipFree(d_m);
+    (void)hipFree(d_i); (void)hipFree(d_f);
+    return st;
+}
+
+#ifdef OPTIM_DEBUG_T
+extern "C" int celeste_debug_T(int32_t n, double *out) {   // n = 0: allocate for 4096 problems; n > 0: fetch n records
+    static double *buf = nullptr;
+    if (!buf) { HIP_TRY(hipMalloc((void **)&buf, (size_t)4096 * 4 * NF * sizeof(double))); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_T), &buf, sizeof buf)); }
+    if (n > 0) HIP_TRY(hipMemcpy(out, buf, (size_t)n * 4 * NF * sizeof(double), hipMemcpyDeviceToHost));
+    return CELESTE_OK;
+}
+#endif
+#ifdef OPTIM_TIMING
+extern "C" int celeste_optim_clocks(int reset, uint64_t out[16]) {   // debug builds only (tools/variants)
+    unsigned long long h[16] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_optim_clk), sizeof h));
+    for (int i = 0; i < 16; ++i) out[i] = h[i];
+    if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_optim_clk), z, sizeof z)); }
+    return CELESTE_OK;
+}
+#endif
+
 // ---- expected-image renderer (bin/write_celeste_expectation.jl:112-156, fsm_util.jl:349-400) ------------
 extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32_t image, double *out_plane) {
     if (!c || !vp || !out_plane || image < 0 || image >= c->N) return CELESTE_ERR_INVALID_ARG;

@@ -38,6 +38,18 @@
 #else
 #define OPTIM_UNROLL
 #endif
+#ifndef OPTIM_TRED_LDS
+#define OPTIM_TRED_LDS 0   // 1: the LDS-resident tridiagonalisation (tred_wave) in the trust-region solve too
+#endif
+#ifndef OPTIM_UPDATE_FMA2
+#define OPTIM_UPDATE_FMA2 1   // rank-2 update of the tridiagonalisation as two FMAs per entry (0: tred_wave's rounding)
+#endif
+#ifndef OPTIM_HARD_SCREEN
+#define OPTIM_HARD_SCREEN 1   // 0: run the eigenvector test of the hard case whenever the smallest eigenvalue is negative
+#endif
+#ifndef OPTIM_Q3_SOLVE
+#define OPTIM_Q3_SOLVE 0      // 1: y' (T + lambda I)^-1 y by a second full solve instead of the forward sweep
+#endif
 #define LDA 45  // leading dimension of the LDS matrix (holds the 44 x 44 bound-space Hessian first; odd: no bank conflicts)
 
 struct OptState {                 // per target slot
@@ -213,6 +225,78 @@ __device__ inline void tred_wave(double *A, double *hv, double *e, double *q, in
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same reduction with the matrix in registers: lane ln holds row ln (NF doubles, every index static: the NF - 1
+// steps are unrolled by template recursion), the Householder vector's entries and the entries of q reach the other
+// lanes through scalar registers (v_readlane), so a step costs 7 (l + 1) VALU instructions and three wave sums
+// instead of 4 (l + 1) LDS round trips whose latency the LDS version could not hide (76 us per matrix alone on a
+// CU, 86 us with 8 wavefronts per CU sharing the LDS pipe; measured with -DOPTIM_TIMING).  Same arithmetic in the
+// same order as tred_wave.  The reflections are applied to the vector v as they are formed (v <- Q' v), which is
+// their order in Q' and puts that wave sum in the shadow of the matrix-vector product.
+// Out: row i of the LDS matrix A (columns < i) = u_i (for p = Q y later); in lane ln: td = diagonal entry ln,
+// ev = sub-diagonal entry (ln - 1, ln), hvv = |u_ln|^2 / 2 (0: no reflection).
+// ---------------------------------------------------------------------------------------------------------
+template <int I>
+__device__ __forceinline__ void tred_reg_steps(double (&a)[NF], double *__restrict__ A, double &ev, double &hvv,
+                                               double &v, double &td, int ln) {
+    if constexpr (I >= 1) {
+        constexpr int l = I - 1;
+        const bool act = ln <= l;
+        if (ln == I) td = a[I];                              // row I and column I are final from here on
+        const double x = act ? a[I] : 0.0;                   // A(ln, I) = A(I, ln): row I left of the diagonal
+        if constexpr (l == 0) {
+            const double f = lane_bcast_u(x, 0);   // (outside the lane-dependent branch: inside it, x is only
+            if (ln == I) { ev = f; hvv = 0.0; }    // guaranteed to be computed for the lanes that take the branch)
+        } else {
+            const double f = lane_bcast_u(x, l);
+            const double hoff = wave_sum_dpp(ln < l ? x * x : 0.0);
+            if (hoff == 0.0) { if (ln == I) { ev = f; hvv = 0.0; } }   // nothing left of column l: already tridiagonal here
+            else {
+                double h = hoff + f * f;
+                const double g = f >= 0 ? -sqrt(h) : sqrt(h);
+                h -= f * g;
+                const double u = (ln == l) ? f - g : x;      // Householder vector (0 beyond l)
+                if (act) A[I + LDA * ln] = u;
+                if (ln == I) { ev = g; hvv = h; }
+                const double vu = wave_sum_dpp(u * v);       // v <- (I - u u' / h) v
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int k = 0; k <= l; ++k) {
+                    const double uk = lane_bcast_u(u, k);
+                    if (k & 1) acc1 = __builtin_fma(a[k], uk, acc1);
+                    else acc0 = __builtin_fma(a[k], uk, acc0);
+                }
+                v -= (vu / h) * u;
+                const double rh = 1.0 / h;
+                const double p = act ? (acc0 + acc1) * rh : 0.0;
+                const double hh = wave_sum_dpp(p * u) * (0.5 * rh);
+                const double qv = p - hh * u;
+#pragma unroll
+                for (int k = 0; k <= l; ++k) {
+                    const double uk = lane_bcast_u(u, k), qk = lane_bcast_u(qv, k);
+#if OPTIM_UPDATE_FMA2
+                    a[k] = __builtin_fma(-qv, uk, __builtin_fma(-u, qk, a[k]));
+#else
+                    a[k] -= u * qk + qv * uk;
+#endif
+                }
+            }
+        }
+        tred_reg_steps<I - 1>(a, A, ev, hvv, v, td, ln);
+    }
+}
+__device__ __forceinline__ void tred_reg(double *__restrict__ A, double &v, double &td, double &ev, double &hvv, int ln) {
+    double a[NF];
+    const int row = ln < NF ? ln : 0;                        // lanes >= NF: never active, any finite values do
+#pragma unroll
+    for (int k = 0; k < NF; ++k) a[k] = A[row + LDA * k];
+    __syncthreads();                                         // rows of A are overwritten with the u_i below
+    td = 0.0; ev = 0.0; hvv = 0.0;                           // e[ln], hv[ln]: each lane keeps its own (lane 0: none)
+    tred_reg_steps<NF - 1>(a, A, ev, hvv, v, td, ln);
+    if (ln == 0) td = a[0];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Full symmetric eigen-decomposition by one wavefront: tred_wave, accumulation of the transformation,
 // implicit-shift QL.  On exit w = eigenvalues (unordered), column i of A = eigenvector i.  Lane j owns row j
 // (QL) or column j (accumulation); every lane carries the scalar recurrences redundantly, so all control flow
@@ -298,55 +382,87 @@ __device__ inline void eig_sym_wave(double *A, double *w, double *e, double *q, 
 // The serial recurrences are carried redundantly by every lane (uniform values, identical LDS writes).
 // ---------------------------------------------------------------------------------------------------------
 // Both serial recurrences below run on the characteristic polynomials P_k of the leading k x k blocks
-// (P_{k+1} = (d_k - x) P_k - e_k^2 P_{k-1}, rescaled by a power of two at every step) instead of on their ratios:
-// the chain then holds two FMAs and an exponent fix per step, no division.
+// (P_{k+1} = (d_k - x) P_k - e_k^2 P_{k-1}) instead of on their ratios: the chain then holds a multiplication and an
+// FMA per step, no division.  The pair (P_{k-1}, P_k) is rescaled by a power of two -- exactly, so nothing below
+// depends on when -- every POLY_PERIOD steps while the matrix entries are within 2^+-200 of one (a step changes the
+// magnitude by at most the norm of T), else after every step (`wide`).
+// The vectors of the tridiagonal problem live one element per lane (td_l = T(ln, ln), te_l = T(ln - 1, ln), ...).
+// The serial chains are carried by every lane redundantly; element k reaches them through a scalar register pair
+// (v_readlane, k static), not through LDS: a broadcast LDS read in front of every other step of a chain is a
+// ~100-cycle wait the compiler would not hoist (17 k cycles per secular iteration, measured), and the element of a
+// result that lane k needs is kept by lane k (no 64-lanes-to-one-address stores).
+#ifndef POLY_PERIOD
+#define POLY_PERIOD 4
+#endif
 __device__ __forceinline__ void poly_rescale(double &pm, double &pc) {
     const int ex = __builtin_amdgcn_frexp_exp(fmax(fabs(pc), fabs(pm)));
     pm = __builtin_ldexp(pm, -ex); pc = __builtin_ldexp(pc, -ex);
 }
-// LDL' of T + lam I (positive definite by construction of lam): ip[k] = 1 / pivot k = P_k / P_{k+1} (one division
-// per lane, in parallel), mk[k] = multiplier
-__device__ __forceinline__ void tri_factor(const double *__restrict__ td, const double *__restrict__ te,
-                                           const double *__restrict__ te2, double lam, double *__restrict__ ip,
-                                           double *__restrict__ mk, double *__restrict__ pa, double *__restrict__ pb,
-                                           int ln) {
-    double pm = 1.0, pc = td[0] + lam;
-    pa[0] = pm; pb[0] = pc;
-    OPTIM_UNROLL
-    for (int k = 1; k < NF; ++k) {
-        const double pn = __builtin_fma(td[k] + lam, pc, -te2[k] * pm);
-        pa[k] = pc; pb[k] = pn;
-        pm = pc; pc = pn;
-        poly_rescale(pm, pc);
+__device__ __forceinline__ bool poly_wide_range(double norm_bound) { return !(norm_bound > 1e-60 && norm_bound < 1e60); }
+// LDL' of T + lam I (positive definite by construction of lam): ip_l = 1 / pivot ln = P_ln / P_{ln+1} (one division
+// per lane, in parallel), mk_l = multiplier ln
+__device__ __forceinline__ void tri_factor(double td_l, double te_l, double te2_l, double lam, bool wide, int ln,
+                                           double &ip_l, double &mk_l) {
+    double pm = 1.0, pc = lane_bcast_u(td_l, 0) + lam;
+    double pa = pm, pb = pc;                  // lane k: P_k and P_{k+1} at one scale
+    if (!wide) {
+#pragma unroll
+        for (int k = 1; k < NF; ++k) {
+            const double pn = __builtin_fma(lane_bcast_u(td_l, k) + lam, pc, -lane_bcast_u(te2_l, k) * pm);
+            if (ln == k) { pa = pc; pb = pn; }
+            pm = pc; pc = pn;
+            if (k % POLY_PERIOD == 0) poly_rescale(pm, pc);
+        }
+    } else {
+#pragma unroll 1
+        for (int k = 1; k < NF; ++k) {
+            const double pn = __builtin_fma(lane_bcast_u(td_l, k) + lam, pc, -lane_bcast_u(te2_l, k) * pm);
+            if (ln == k) { pa = pc; pb = pn; }
+            pm = pc; pc = pn;
+            poly_rescale(pm, pc);
+        }
     }
-    __syncthreads();
-    double inv = 0.0;
-    if (ln < NF) { inv = pa[ln] / pb[ln]; ip[ln] = inv; }
-    __syncthreads();
-    if (ln >= 1 && ln < NF) mk[ln] = te[ln] * ip[ln - 1];
-    __syncthreads();
+    ip_l = pa / pb;
+    const double ip_prev = __shfl_up(ip_l, 1, 64);
+    mk_l = ln >= 1 ? te_l * ip_prev : 0.0;
 }
-// y = (T + lam I)^-1 (sign * rhs)
-__device__ __forceinline__ void tri_solve(const double *__restrict__ te, const double *__restrict__ ip,
-                                          const double *__restrict__ mk, const double *__restrict__ rhs, double sign,
-                                          double *__restrict__ r, double *__restrict__ y) {
-    double prev = sign * rhs[0];
+// y = (T + lam I)^-1 rhs; in: rhs_l = element ln of the right-hand side, returns element ln of y.  The forward
+// sweep stays in registers.
+__device__ __forceinline__ double tri_solve(double te_l, double ip_l, double mk_l, double rhs_l, int ln) {
+    double r[NF];
+    double prev = lane_bcast_u(rhs_l, 0);
     r[0] = prev;
-    OPTIM_UNROLL
-    for (int k = 1; k < NF; ++k) { prev = __builtin_fma(-mk[k], prev, sign * rhs[k]); r[k] = prev; }
-    double yn = prev * ip[NF - 1];
-    y[NF - 1] = yn;
-    OPTIM_UNROLL
-    for (int k = NF - 2; k >= 0; --k) { yn = __builtin_fma(-te[k + 1], yn, r[k]) * ip[k]; y[k] = yn; }
-    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < NF; ++k) { prev = __builtin_fma(-lane_bcast_u(mk_l, k), prev, lane_bcast_u(rhs_l, k)); r[k] = prev; }
+    double yn = prev * lane_bcast_u(ip_l, NF - 1);
+    double mine = ln == NF - 1 ? yn : 0.0;
+#pragma unroll
+    for (int k = NF - 2; k >= 0; --k) {
+        yn = __builtin_fma(-lane_bcast_u(te_l, k + 1), yn, r[k]) * lane_bcast_u(ip_l, k);
+        if (ln == k) mine = yn;
+    }
+    return mine;
 }
-// Sturm count #{eigenvalues of T < x} = number of sign changes in P_0 .. P_n (an exact zero counts as a change)
-__device__ __forceinline__ int sturm_count(const double *__restrict__ td, const double *__restrict__ te2, double x) {
+// y' (T + lam I)^-1 y = |D^-1/2 L^-1 y|^2 from the factorisation: one forward sweep, no back substitution
+__device__ __forceinline__ double tri_quad(double ip_l, double mk_l, double y_l) {
+    double w = lane_bcast_u(y_l, 0);
+    double q0 = w * w * lane_bcast_u(ip_l, 0), q1 = 0.0;
+#pragma unroll
+    for (int k = 1; k < NF; ++k) {
+        w = __builtin_fma(-lane_bcast_u(mk_l, k), w, lane_bcast_u(y_l, k));
+        const double ipk = lane_bcast_u(ip_l, k);
+        if (k & 1) q1 = __builtin_fma(w * w, ipk, q1); else q0 = __builtin_fma(w * w, ipk, q0);
+    }
+    return q0 + q1;
+}
+// Sturm count #{eigenvalues of T < x} = number of sign changes in P_0 .. P_n; an exact zero takes the sign opposite to
+// its predecessor's.  The unrolled form only notes that a zero occurred and leaves the count to the careful loop.
+__device__ __noinline__ int sturm_count_careful(const double *__restrict__ td, const double *__restrict__ te2, double x) {
     double pm = 1.0, pc = td[0] - x;
     if (pc == 0.0) pc = -1e-300;
     bool negp = pc < 0;
     int c = negp;
-    OPTIM_UNROLL
+#pragma unroll 1
     for (int k = 1; k < NF; ++k) {
         double pn = __builtin_fma(td[k] - x, pc, -te2[k] * pm);
         if (pn == 0.0) pn = pc > 0 ? -1e-300 : 1e-300;
@@ -358,12 +474,33 @@ __device__ __forceinline__ int sturm_count(const double *__restrict__ td, const 
     }
     return c;
 }
+__device__ __forceinline__ int sturm_count(const double *__restrict__ td, const double *__restrict__ te2, double x,
+                                           bool wide) {
+    if (!wide) {
+        double pm = 1.0, pc = td[0] - x;
+        bool zero = pc == 0.0;
+        bool negp = pc < 0;
+        int c = negp;
+#pragma unroll
+        for (int k = 1; k < NF; ++k) {
+            const double pn = __builtin_fma(td[k] - x, pc, -te2[k] * pm);
+            zero |= pn == 0.0;
+            pm = pc; pc = pn;
+            if (k % POLY_PERIOD == 0) poly_rescale(pm, pc);
+            const bool neg = pn < 0;
+            c += neg != negp;
+            negp = neg;
+        }
+        if (__ballot(zero) == 0ull) return c;
+    }
+    return sturm_count_careful(td, te2, x);
+}
 // Smallest (thr = 1) or largest (thr = NF) eigenvalue of T inside [a, b] by 64-way multisection on the Sturm count
 __device__ inline double tri_extreme(const double *__restrict__ td, const double *__restrict__ te2, double a, double b,
-                                     int thr, int passes, int ln, double &lower) {
+                                     int thr, int passes, int ln, bool wide, double &lower) {
     for (int pass = 0; pass < passes; ++pass) {
         const double x = a + (b - a) * ((double)(ln + 1) * (1.0 / 65.0));
-        const int c = sturm_count(td, te2, x);
+        const int c = sturm_count(td, te2, x, wide);
         const unsigned long long mask = __ballot(c >= thr);
         double na, nb;
         if (mask) {
@@ -382,11 +519,20 @@ __device__ inline double tri_extreme(const double *__restrict__ td, const double
 // diagnostics: sub-problems solved as interior Newton steps / on the boundary / hard case, total and maximum
 // number of secular-equation iterations (celeste_optim_stats)
 __device__ unsigned long long g_optim_stats[5];
+#ifdef OPTIM_TIMING   // debug builds (tools/variants): shader-clock cycles per section of the step kernel, lane 0
+__device__ unsigned long long g_optim_clk[16];
+#define OPT_TICK(k) do { const long long now__ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_optim_clk[k], (unsigned long long)(now__ - tick__)); tick__ = clock64(); } while (0)
+#define OPT_TICK_DECL long long tick__ = clock64()
+#else
+#define OPT_TICK(k) do { } while (0)
+#define OPT_TICK_DECL do { } while (0)
+#endif
 
+#ifdef OPTIM_DEBUG_T
+__device__ double *g_dbg_T;   // debug builds: (td, te, Q'g, hv) of every sub-problem, 4 x NF doubles per workgroup
+#endif
 #define TRI_MAXC 4   // largest cluster of lowest eigenvalues the hard-case test handles in the tridiagonal basis
-// their eigenvectors live in the spare rows NF .. NF + 3 of the LDA x NF matrix (free once the chain rule is done)
-#define TRI_ZC(L, j, ln) (L).A[(NF + (j)) + LDA * (ln)]
-struct TriLds { double *A, *hv, *td, *te, *te2, *ip, *mk, *r, *y, *gt, *q, *gq, *pa, *pb; };
+struct TriLds { double *A, *hv, *td, *te, *te2, *q; };   // hv, te, q: tred_wave's (OPTIM_TRED_LDS builds only)
 
 // Trust-region step in the tridiagonal basis.  In: L.A = H (destroyed), g (lane register), delta.
 // Out: step p (lane register), model decrease m, interior flag.  Returns false in the hard case (caller falls
@@ -394,87 +540,102 @@ struct TriLds { double *A, *hv, *td, *te, *te2, *ip, *mk, *r, *y, *gt, *q, *gq, 
 __device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int ln, int secular_iters, double &p_out,
                                     double &m_out, int &interior_out) {
     const bool fr = ln < NF;
+    OPT_TICK_DECL;
+    // T = Q' H Q and gt = Q' g (reflections n-1 ... 2 in turn) in one pass
+    double gt_l = fr ? g : 0.0, td_l, te_l, hv_l;
+#if OPTIM_TRED_LDS
     tred_wave(L.A, L.hv, L.te, L.q, ln);
-    if (fr) { const double ek = L.te[ln]; L.td[ln] = L.A[ln + LDA * ln]; L.te2[ln] = ek * ek; }
-    // gt = Q' g: reflections n-1 ... 2 in turn
-    double v = fr ? g : 0.0;
+    td_l = fr ? L.A[ln + LDA * ln] : 0.0; te_l = fr ? L.te[ln] : 0.0; hv_l = fr ? L.hv[ln] : 0.0;
     for (int i = NF - 1; i >= 2; --i) {
         const double h = L.hv[i];
         if (h == 0.0) continue;
         const double u = ln < i ? L.A[i + LDA * ln] : 0.0;
-        v -= (wave_sum_dpp(u * v) / h) * u;
+        gt_l -= (wave_sum_dpp(u * gt_l) / h) * u;
     }
-    if (fr) L.gt[ln] = v;
+#else
+    tred_reg(L.A, gt_l, td_l, te_l, hv_l, ln);
+#endif
+    OPT_TICK(3);
+    const double te2_l = te_l * te_l;
+#ifdef OPTIM_DEBUG_T
+    if (fr && g_dbg_T) { double *o = g_dbg_T + (size_t)blockIdx.x * 4 * NF; o[ln] = td_l; o[NF + ln] = te_l; o[2 * NF + ln] = gt_l; o[3 * NF + ln] = hv_l; }
+#endif
+    if (fr) { L.td[ln] = td_l; L.te2[ln] = te2_l; }   // the Sturm passes read T from LDS (hoisted: loop invariant)
     __syncthreads();
+    OPT_TICK(4);
     // Gershgorin interval, extreme eigenvalues
     double wmin, wmax, wmin_lower, norm_bound;
+    bool wide;
     {
-        const double ea = fr ? fabs(L.te[ln]) : 0.0, eb = (ln + 1 < NF) ? fabs(L.te[ln + 1]) : 0.0;
-        const double dk = fr ? L.td[ln] : 0.0;
-        double lo = fr ? dk - ea - eb : INFINITY, hi = fr ? dk + ea + eb : -INFINITY;
+        const double te_next = __shfl_down(te_l, 1, 64);
+        const double ea = fabs(te_l), eb = (ln + 1 < NF) ? fabs(te_next) : 0.0;
+        double lo = fr ? td_l - ea - eb : INFINITY, hi = fr ? td_l + ea + eb : -INFINITY;
         for (int o = 32; o >= 1; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
         const double pad = 4.440892098500626e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300;
         lo -= pad; hi += pad;
         double unused;
         norm_bound = fmax(fabs(lo), fabs(hi));
-        wmin = tri_extreme(L.td, L.te2, lo, hi, 1, 12, ln, wmin_lower);
-        wmax = tri_extreme(L.td, L.te2, lo, hi, NF, 3, ln, unused);
+        wide = poly_wide_range(norm_bound);
+        wmin = tri_extreme(L.td, L.te2, lo, hi, 1, 12, ln, wide, wmin_lower);
+        wmax = tri_extreme(L.td, L.te2, lo, hi, NF, 3, ln, wide, unused);
     }
     const double d2 = delta * delta;
     int interior = 0;
-    double y = 0.0;
+    double y = 0.0, ip_l, mk_l;
+    OPT_TICK(5);
     if (wmin >= 1e-8) {
-        tri_factor(L.td, L.te, L.te2, 0.0, L.ip, L.mk, L.pa, L.pb, ln);
-        tri_solve(L.te, L.ip, L.mk, L.gt, -1.0, L.r, L.y);
-        y = fr ? L.y[ln] : 0.0;
+        tri_factor(td_l, te_l, te2_l, 0.0, wide, ln, ip_l, mk_l);
+        y = tri_solve(te_l, ip_l, mk_l, -gt_l, ln);
         interior = wave_sum_dpp(y * y) <= d2;
     }
     if (!interior) {
         const double lambda_lb = -wmin + fmax(1e-8, 1e-8 * (wmax - wmin));
         double lambda = lambda_lb;
         bool hard = false;
-        if (wmin < 0) {
-            // Hard-case candidate: g orthogonal (1e-10) to the eigenvectors of every eigenvalue within 1e-10 of the
-            // smallest.  Their number is a Sturm count; an orthonormal basis z_0 .. z_{mc-1} of their span comes
-            // from inverse iteration with the shift just below the smallest eigenvalue (the Sturm count at
-            // wmin_lower is 0, so T - shift I is positive definite) and Gram-Schmidt.
-            int mc = sturm_count(L.td, L.te2, wmin + 1e-10);
+        // first iterate of the secular equation, at lambda_lb
+        tri_factor(td_l, te_l, te2_l, lambda, wide, ln, ip_l, mk_l);
+        y = tri_solve(te_l, ip_l, mk_l, -gt_l, ln);
+        double q2 = wave_sum_dpp(y * y);
+        bool fresh = true;                                       // (ip_l, mk_l, y, q2) belong to `lambda`
+        // Hard-case candidate: g orthogonal (1e-10) to the eigenvectors of every eigenvalue within 1e-10 of the
+        // smallest, AND the step at lambda_lb without its components along them no longer than delta.  Those
+        // components are at most 1e-10 / (lambda_lb + wmin) each, so a step at lambda_lb that is longer than delta by
+        // more than that cannot be a hard case: the common situation, screened here without any eigenvector.
+        const double gap = lambda_lb + wmin;
+        if (wmin < 0 && (!OPTIM_HARD_SCREEN || q2 <= d2 * (1.0 + 1e-6) + TRI_MAXC * (1e-10 / gap) * (1e-10 / gap))) {
+            // Their number is a Sturm count; an orthonormal basis z_0 .. z_{mc-1} of their span comes from inverse
+            // iteration with the shift just below the smallest eigenvalue (the Sturm count at wmin_lower is 0, so
+            // T - shift I is positive definite) and Gram-Schmidt.
+            int mc = sturm_count(L.td, L.te2, wmin + 1e-10, wide);
             if (mc < 1) mc = 1;
             if (mc > TRI_MAXC) { if (ln == 0) atomicAdd(&g_optim_stats[2], 1ull); return false; }
             const double shift = wmin_lower - 4.440892098500626e-16 * norm_bound;
-            tri_factor(L.td, L.te, L.te2, -shift, L.ip, L.mk, L.pa, L.pb, ln);
+            double ips, mks;
+            tri_factor(td_l, te_l, te2_l, -shift, wide, ln, ips, mks);
             bool orth = true;
+            double zc[TRI_MAXC];
             for (int j = 0; j < mc && orth; ++j) {
                 double z = fr ? 1.0 + 0.5 * sin(1.7 * ln + 0.3 + 2.1 * j) : 0.0;
                 for (int it = 0; it < 4; ++it) {
-                    if (fr) L.q[ln] = z;
-                    __syncthreads();
-                    tri_solve(L.te, L.ip, L.mk, L.q, 1.0, L.r, L.gq);
-                    z = fr ? L.gq[ln] : 0.0;
-                    for (int jj = 0; jj < j; ++jj) {
-                        const double zo = fr ? TRI_ZC(L, jj, ln) : 0.0;
-                        z -= wave_sum_dpp(z * zo) * zo;
-                    }
+                    z = tri_solve(te_l, ips, mks, z, ln);
+#pragma unroll
+                    for (int jj = 0; jj < TRI_MAXC; ++jj)
+                        if (jj < j) z -= wave_sum_dpp(z * zc[jj]) * zc[jj];
                     z *= 1.0 / sqrt(wave_sum_dpp(z * z));
                 }
-                if (fabs(wave_sum_dpp(fr ? z * L.gt[ln] : 0.0)) > 1e-10) orth = false;
-                if (fr) TRI_ZC(L, j, ln) = z;
-                __syncthreads();
+                if (fabs(wave_sum_dpp(z * gt_l)) > 1e-10) orth = false;
+#pragma unroll
+                for (int jj = 0; jj < TRI_MAXC; ++jj) if (jj == j) zc[jj] = z;
             }
             if (orth) {
-                tri_factor(L.td, L.te, L.te2, lambda, L.ip, L.mk, L.pa, L.pb, ln);
-                tri_solve(L.te, L.ip, L.mk, L.gt, -1.0, L.r, L.y);
-                y = fr ? L.y[ln] : 0.0;
-                for (int j = 0; j < mc; ++j) {
-                    const double zo = fr ? TRI_ZC(L, j, ln) : 0.0;
-                    y -= wave_sum_dpp(y * zo) * zo;
-                }
-                const double p2 = wave_sum_dpp(y * y);
+                double yh = y;
+#pragma unroll
+                for (int j = 0; j < TRI_MAXC; ++j)
+                    if (j < mc) yh -= wave_sum_dpp(yh * zc[j]) * zc[j];
+                const double p2 = wave_sum_dpp(yh * yh);
                 if (p2 <= d2) {   // N&W (4.45): to the boundary along the lowest eigenvector
                     hard = true;
-                    y += sqrt(d2 - p2) * (fr ? TRI_ZC(L, 0, ln) : 0.0);
-                    if (fr) L.y[ln] = y;
-                    __syncthreads();
+                    y = yh + sqrt(d2 - p2) * zc[0];
                     if (ln == 0) atomicAdd(&g_optim_stats[2], 1ull);
                 }
             }
@@ -482,12 +643,17 @@ __device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int
         if (!hard) {
         int it = 0;
         for (; it < secular_iters; ++it) {
-            tri_factor(L.td, L.te, L.te2, lambda, L.ip, L.mk, L.pa, L.pb, ln);
-            tri_solve(L.te, L.ip, L.mk, L.gt, -1.0, L.r, L.y);
-            y = fr ? L.y[ln] : 0.0;
-            const double q2 = wave_sum_dpp(y * y);
-            tri_solve(L.te, L.ip, L.mk, L.y, 1.0, L.r, L.q);     // (T + lambda)^-1 y
-            const double q3 = wave_sum_dpp(fr ? y * L.q[ln] : 0.0);
+            if (!fresh) {
+                tri_factor(td_l, te_l, te2_l, lambda, wide, ln, ip_l, mk_l);
+                y = tri_solve(te_l, ip_l, mk_l, -gt_l, ln);
+                q2 = wave_sum_dpp(y * y);
+            }
+            fresh = false;
+#if OPTIM_Q3_SOLVE
+            const double q3 = wave_sum_dpp(y * tri_solve(te_l, ip_l, mk_l, y, ln));
+#else
+            const double q3 = tri_quad(ip_l, mk_l, y);           // y' (T + lambda)^-1 y
+#endif
             const double prev = lambda;
             lambda += q2 * (sqrt(q2) - delta) / (delta * q3);
             if (lambda < lambda_lb) lambda = 0.5 * (prev - lambda_lb) + lambda_lb;
@@ -499,27 +665,94 @@ __device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int
         }
         }
     }
+    OPT_TICK(6);
     // model value g'p + p'Hp / 2 in the tridiagonal basis
     {
-        double ty = 0.0;
-        if (fr) {
-            ty = L.td[ln] * y;
-            if (ln > 0) ty += L.te[ln] * L.y[ln - 1];
-            if (ln + 1 < NF) ty += L.te[ln + 1] * L.y[ln + 1];
+        const double y_prev = __shfl_up(y, 1, 64), y_next = __shfl_down(y, 1, 64), te_next = __shfl_down(te_l, 1, 64);
+        double ty = td_l * y;
+        if (ln > 0) ty += te_l * y_prev;
+        if (ln + 1 < NF) ty += te_next * y_next;
+        m_out = wave_sum_dpp(fr ? gt_l * y + 0.5 * y * ty : 0.0);
+    }
+    // p = Q y: reflections 2 ... n-1 in turn (the vectors are fetched first: the chain of wave sums then runs
+    // without an LDS wait per reflection)
+    {
+        double uu[NF];
+#pragma unroll
+        for (int i = 2; i < NF; ++i) uu[i] = ln < i ? L.A[i + LDA * ln] : 0.0;
+#pragma unroll
+        for (int i = 2; i < NF; ++i) {
+            const double h = lane_bcast_u(hv_l, i);
+            if (h != 0.0) y -= (wave_sum_dpp(uu[i] * y) / h) * uu[i];
         }
-        m_out = wave_sum_dpp(fr ? L.gt[ln] * y + 0.5 * y * ty : 0.0);
     }
-    // p = Q y: reflections 2 ... n-1 in turn
-    for (int i = 2; i < NF; ++i) {
-        const double h = L.hv[i];
-        if (h == 0.0) continue;
-        const double u = ln < i ? L.A[i + LDA * ln] : 0.0;
-        y -= (wave_sum_dpp(u * y) / h) * u;
-    }
+    OPT_TICK(7);
     if (interior && ln == 0) atomicAdd(&g_optim_stats[0], 1ull);
     p_out = y;
     interior_out = interior;
     return true;
+}
+
+// The same sub-problem through the full eigen-decomposition (Optim.jl's own route): the hard-case fallback of
+// tri_tr_solve, and OptParams.solver = 1.  In: A = H (LDS, destroyed), g, delta.  w, e, q, cv: NF doubles of LDS each.
+__device__ inline void eig_tr_solve(double *A, double *w, double *e, double *q, double *cvs, double g, double delta_in,
+                                    int tid, int secular_iters, double &step, double &m, int &interior) {
+    const bool fr = tid < NF;
+    __shared__ double s_g[NF];
+    if (fr) s_g[tid] = g;
+    eig_sym_wave(A, w, e, q, tid);
+    double qg = 0.0;
+    if (fr) for (int k = 0; k < NF; ++k) qg += A[k + LDA * tid] * s_g[k];
+    const double wi = fr ? w[tid] : 0.0;
+    // extreme eigenvalues (and the lane of the smallest)
+    double wmin = fr ? wi : INFINITY, wmax = fr ? wi : -INFINITY;
+    int imin = tid;
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double om = __shfl_xor(wmin, o, 64);
+        const int oi = __shfl_xor(imin, o, 64);
+        if (om < wmin || (om == wmin && oi < imin)) { wmin = om; imin = oi; }
+        wmax = fmax(wmax, __shfl_xor(wmax, o, 64));
+    }
+    const double delta = delta_in, d2 = delta * delta;
+    interior = 0;
+    if (wmin >= 1e-8) {
+        const double r = fr ? qg / wi : 0.0;
+        interior = wave_sum(r * r) <= d2;
+    }
+    double cv;
+    if (interior) cv = fr ? -qg / wi : 0.0;
+    else {
+        const double lambda_lb = -wmin + fmax(1e-8, 1e-8 * (wmax - wmin));
+        double lambda = lambda_lb;
+        bool hard = false;
+        cv = 0.0;
+        if (wmin < 0) {
+            const bool low = fr && fabs(wi - wmin) <= 1e-10;          // eigenvalues tied with the smallest
+            if (__ballot(low && fabs(qg) > 1e-10) == 0ull) {          // g orthogonal to all their eigenvectors
+                const double r = (fr && !low) ? qg / (wi + lambda) : 0.0;
+                const double p2 = wave_sum(r * r);
+                if (p2 <= d2) {   // N&W (4.45): to the boundary along the lowest eigenvector
+                    hard = true;
+                    cv = tid == imin ? sqrt(d2 - p2) : -r;
+                }
+            }
+        }
+        if (!hard) {
+            for (int it = 0; it < secular_iters; ++it) {
+                cv = fr ? -qg / (wi + lambda) : 0.0;
+                const double q2 = wave_sum(cv * cv), q3 = wave_sum(fr ? cv * cv / (wi + lambda) : 0.0);
+                const double prev = lambda;
+                lambda += q2 * (sqrt(q2) - delta) / (delta * q3);
+                if (lambda < lambda_lb) lambda = 0.5 * (prev - lambda_lb) + lambda_lb;
+                if (fabs(lambda - prev) < 1e-10 || lambda <= prev) break;
+            }
+        }
+    }
+    m = wave_sum(fr ? qg * cv + 0.5 * wi * cv * cv : 0.0);
+    if (fr) cvs[tid] = cv;
+    __syncthreads();
+    step = 0.0;
+    if (fr) for (int i = 0; i < NF; ++i) step += A[tid + LDA * i] * cvs[i];
 }
 
 // to_bound! by one wavefront: x (41, LDS) -> vs (44)
@@ -541,7 +774,7 @@ __device__ inline void to_bound_wave(const double *x, const double *pos0, const 
 // ---------------------------------------------------------------------------------------------------------
 // optim_step_kernel
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)   // 2 waves per SIMD: 8 workgroups per CU (see the LDS budget below)
 optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, const int32_t *__restrict__ active,
                   const double *__restrict__ ev_v, const double *__restrict__ ev_d, const double *__restrict__ ev_h,
                   const int32_t *__restrict__ ev_status, OptParams op, OptState *__restrict__ st,
@@ -558,11 +791,11 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
     double *const sd = sU, *const sJb = sU + 44, *const sHb = sU + 70;                   // 44 + 26 + 26
     double (*const sp)[8] = reinterpret_cast<double (*)[8]>(sU + 96);                    // 3 x 8
     double (*const sJs)[8][7] = reinterpret_cast<double (*)[8][7]>(sU + 120);            // 3 x 8 x 7 (ends at 288)
-    double *const std_ = sU, *const ste2 = sU + NF, *const sip = sU + 2 * NF, *const smk = sU + 3 * NF, *const sr = sU + 4 * NF,
-           *const sy = sU + 5 * NF, *const sgt2 = sU + 6 * NF, *const spa = sU + 7 * NF, *const spb = sU + 8 * NF;
+    double *const std_ = sU, *const ste2 = sU + NF;
     __shared__ int s_flag[2];             // 0: accept, 1: done
     __shared__ double s_delta;            // trust-region radius after the update
 
+    OPT_TICK_DECL;
     const int li = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int slot = active[li];
     OptState &S = st[slot];
@@ -655,6 +888,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
     if (tid < NF) for (int i = 0; i < tid; ++i) sA[tid + LDA * i] = sA[i + LDA * tid];   // exactly symmetric
     __syncthreads();
 
+    OPT_TICK(0);
     // ---- accept / reject, radius update, convergence (N&W Alg. 4.1 as in Optim.jl's NewtonTrustRegion) ----
     {
         const double dxl = tid < NF ? fabs(sx[tid] - S.x[tid]) : 0.0, gl = tid < NF ? fabs(sgt[tid]) : 0.0;
@@ -694,6 +928,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         if (!done) for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hs[k]; }
     }
     __syncthreads();
+    OPT_TICK(1);
     if (done) {
         if (tid == 0) S.done = 1;
         to_bound_wave(sx, S.pos0, op, vp + (size_t)t * CEL_P, tid);
@@ -706,68 +941,15 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
     int interior = 0;
     bool solved = false;
     if (op.solver != 1) {
-        const TriLds L = {sA, sw, std_, se, ste2, sip, smk, sr, sy, sgt2, sq, scv, spa, spb};
+        const TriLds L = {sA, sw, std_, se, ste2, sq};
         solved = tri_tr_solve(L, fr ? sg[tid] : 0.0, s_delta, tid, op.secular_iters, step, m, interior);
         if (!solved) {   // hard case: restore H and diagonalise it
             for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hs[k]; }
             __syncthreads();
         }
     }
-    if (!solved) {
-        eig_sym_wave(sA, sw, se, sq, tid);
-        double qg = 0.0;
-        if (fr) for (int k = 0; k < NF; ++k) qg += sA[k + LDA * tid] * sg[k];
-        const double wi = fr ? sw[tid] : 0.0;
-        // extreme eigenvalues (and the lane of the smallest)
-        double wmin = fr ? wi : INFINITY, wmax = fr ? wi : -INFINITY;
-        int imin = tid;
-        for (int o = 32; o >= 1; o >>= 1) {
-            const double om = __shfl_xor(wmin, o, 64);
-            const int oi = __shfl_xor(imin, o, 64);
-            if (om < wmin || (om == wmin && oi < imin)) { wmin = om; imin = oi; }
-            wmax = fmax(wmax, __shfl_xor(wmax, o, 64));
-        }
-        const double delta = s_delta, d2 = delta * delta;
-        interior = 0;
-        if (wmin >= 1e-8) {
-            const double r = fr ? qg / wi : 0.0;
-            interior = wave_sum(r * r) <= d2;
-        }
-        double cv;
-        if (interior) cv = fr ? -qg / wi : 0.0;
-        else {
-            const double lambda_lb = -wmin + fmax(1e-8, 1e-8 * (wmax - wmin));
-            double lambda = lambda_lb;
-            bool hard = false;
-            cv = 0.0;
-            if (wmin < 0) {
-                const bool low = fr && fabs(wi - wmin) <= 1e-10;          // eigenvalues tied with the smallest
-                if (__ballot(low && fabs(qg) > 1e-10) == 0ull) {          // g orthogonal to all their eigenvectors
-                    const double r = (fr && !low) ? qg / (wi + lambda) : 0.0;
-                    const double p2 = wave_sum(r * r);
-                    if (p2 <= d2) {   // N&W (4.45): to the boundary along the lowest eigenvector
-                        hard = true;
-                        cv = tid == imin ? sqrt(d2 - p2) : -r;
-                    }
-                }
-            }
-            if (!hard) {
-                for (int it = 0; it < op.secular_iters; ++it) {
-                    cv = fr ? -qg / (wi + lambda) : 0.0;
-                    const double q2 = wave_sum(cv * cv), q3 = wave_sum(fr ? cv * cv / (wi + lambda) : 0.0);
-                    const double prev = lambda;
-                    lambda += q2 * (sqrt(q2) - delta) / (delta * q3);
-                    if (lambda < lambda_lb) lambda = 0.5 * (prev - lambda_lb) + lambda_lb;
-                    if (fabs(lambda - prev) < 1e-10 || lambda <= prev) break;
-                }
-            }
-        }
-
-        m = wave_sum(fr ? qg * cv + 0.5 * wi * cv * cv : 0.0);
-        if (fr) scv[tid] = cv;
-        __syncthreads();
-        if (fr) for (int i = 0; i < NF; ++i) step += sA[tid + LDA * i] * scv[i];
-    }
+    if (!solved) eig_tr_solve(sA, sw, se, sq, scv, fr ? sg[tid] : 0.0, s_delta, tid, op.secular_iters, step, m, interior);
+    OPT_TICK(2);   // the whole sub-problem (sections 3-7 are its parts)
     if (tid == 0) { S.m = m; S.interior = interior; }
     if (fr) {
         const double xn = sx[tid] + step;
@@ -779,4 +961,45 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         const int pos = atomicAdd(next_count, 1);
         next_active[pos] = slot; next_targets[pos] = t;
     }
+    OPT_TICK(8);
+#ifdef OPTIM_TIMING
+    if (tid == 0) atomicAdd(&g_optim_clk[15], 1ull);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tr_solve_kernel (celeste_tr_solve_batch): the trust-region sub-problem alone, one wavefront per problem -- the
+// solver of optim_step_kernel exposed for tests (tests/test_gpu_tr_subproblem.py compare it with the CPU restatement
+// and with a 60-digit solution).  solver 0: tridiagonal-space solve with the eigen-decomposition as the hard-case
+// fallback, exactly as the optimiser; 1: eigen-decomposition; 2: tridiagonal-space solve only (status 1 = fell back).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64, 2)
+tr_solve_kernel(const double *__restrict__ H, const double *__restrict__ g, const double *__restrict__ delta, int solver,
+                int secular_iters, double *__restrict__ p, double *__restrict__ m_out, int32_t *__restrict__ interior_out,
+                int32_t *__restrict__ fallback_out) {
+    __shared__ double sA[LDA * NF];
+    __shared__ double sw[NF], se[NF], scv[NF], sq[NF], sU[2 * NF];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool fr = tid < NF;
+    const double *Hb = H + (size_t)b * NF * NF;
+    for (int k = tid; k < NF * NF; k += 64) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hb[k]; }
+    for (int k = tid; k < (LDA - NF) * NF; k += 64) { const int j = k / (LDA - NF); sA[NF + (k - j * (LDA - NF)) + LDA * j] = 0.0; }
+    const double gl = fr ? g[(size_t)b * NF + tid] : 0.0;
+    const double dl = delta[b];
+    __syncthreads();
+    double step = 0.0, m = 0.0;
+    int interior = 0;
+    bool solved = false;
+    if (solver != 1) {
+        const TriLds L = {sA, sw, sU, se, sU + NF, sq};
+        solved = tri_tr_solve(L, gl, dl, tid, secular_iters, step, m, interior);
+        if (!solved && solver == 0) {
+            for (int k = tid; k < NF * NF; k += 64) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hb[k]; }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) fallback_out[b] = !solved && solver != 1;
+    if (!solved && solver != 2) eig_tr_solve(sA, sw, se, sq, scv, gl, dl, tid, secular_iters, step, m, interior);
+    if (fr) p[(size_t)b * NF + tid] = step;
+    if (tid == 0) { m_out[b] = m; interior_out[b] = interior; }
 }

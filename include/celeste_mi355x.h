@@ -301,6 +301,19 @@ int celeste_maximize_batch(celeste_ctx_t *ctx, double *vp, const double *vp_neig
  * maximum number of secular-equation iterations. */
 int celeste_optim_stats(int reset, uint64_t out[5]);
 
+/* The trust-region sub-problem of the optimiser on its own (diagnostic / test entry; Optim.jl's solve_tr_subproblem!,
+ * third-party and unvendored, restated from N&W section 4.3): for each of n problems minimise g'p + p'Hp/2 subject to
+ * |p| <= delta over the CELESTE_NF = 41 free parameters.  H: n x 41 x 41 (symmetric, either order), g: n x 41,
+ * delta: n; out p: n x 41, m (may be NULL): model value, interior (may be NULL): 1 = plain Newton step inside the
+ * region, fell_back (may be NULL): 1 = the tridiagonal-space solver handed the problem to the eigen-decomposition.
+ * solver 0: as celeste_maximize_batch (tridiagonal space, eigen-decomposition for clusters of > 4 lowest
+ * eigenvalues), 1: eigen-decomposition, 2: tridiagonal space only (p = 0 where fell_back).  secular_iters 0 = to
+ * convergence (celeste_optim_config_t.tr_secular_iters).  Host pointers. */
+#define CELESTE_NF 41
+int celeste_tr_solve_batch(int device, int32_t n, const double *H, const double *g, const double *delta,
+                           int32_t solver, int32_t secular_iters, double *p, double *m, int32_t *interior,
+                           int32_t *fell_back);
+
 /* Expected light of all sources on image `image` (0-based): out[h,w] = sum_s E_G_s.v in nanomaggies, i.e.
  * elbo_vars.E_G.v - sky of the value-only add_pixel_term! sweep in bin/write_celeste_expectation.jl:112-156
  * (every source contributes on its own patch, last column and inactive pixels excluded).  out: H x W doubles,

@@ -296,6 +296,7 @@ def test_joint_inference_on_the_device_equals_the_cpu_restatement(oracle):
     position boxes pinned at the initial positions, ParallelRun.jl:135-196, 302-397) driven once by the device
     optimiser and once by the CPU restatement of maximize!: the shared parameter table must come out the same --
     every layer's result feeds the next layers, so this checks the whole chain, not single optimisations"""
+    # (eval_batch below evaluates each target's ELBO with its neighbours at the table's values)
     import celeste_jl_amd as cel
     from celeste_jl_amd import synthetic
     from celeste_jl_amd.infer import joint_infer_sweeps
@@ -307,40 +308,57 @@ def test_joint_inference_on_the_device_equals_the_cpu_restatement(oracle):
     vp0 = np.stack([catalog_init_source(ce) for ce in f.catalog])
     for t in targets:
         vp0[t] = generic_init_source(f.catalog[t].pos)
-    cfg_kw = dict(max_iters=6)
-    calls = {"dev": 0, "cpu": 0}
-
-    def layer_dev(vp, layer, pc):
-        calls["dev"] += 1
-        new, _, _, _, st = ctx.maximize_batch(vp, layer, cel.ElboConfig(**cfg_kw), pos_centers=pc)
-        assert (st == 0).all()
-        return new[layer]
-
-    def layer_cpu(vp, layer, pc):
-        calls["cpu"] += 1
-        rows = []
-        for t, c in zip(layer, pc):
-            r = oracle.maximize(ctx.problem, vp, t, oracle.OptCfg(**cfg_kw), pos_center=c)
-            assert r[4] == 0
-            rows.append(r[0][t])
-        return np.stack(rows)
-    out = {}
-    for name, fn in (("dev", layer_dev), ("cpu", layer_cpu)):
-        out[name] = joint_infer_sweeps(fn, vp0.copy(), targets, f.neighbors, batch_size=5, n_iters=2,
-                                       rng=np.random.default_rng(3))
-    assert calls["dev"] == calls["cpu"] > 4
-    moved = np.abs(out["cpu"][targets] - vp0[targets]).max()
-    err = np.abs(out["dev"] - out["cpu"]) / np.maximum(np.abs(out["cpu"]), 1e-3)
-    print("joint inference, 2 sweeps, %d layers: max relative difference device vs CPU %.2e (parameters moved by up to %.2g)"
-          % (calls["dev"], err.max(), moved))
-    worst = np.unravel_index(np.argmax(err), err.shape)
-    print("largest difference: source %d parameter %d: %r vs %r" % (worst[0], worst[1], out["dev"][worst], out["cpu"][worst]))
-    # the bar of test_randomised_optimiser_against_cpu: every parameter within 1e-6 (absolute; the largest relative
-    # differences sit in weakly determined simplex weights of the type a source is not)
-    absdiff = np.abs(out["dev"] - out["cpu"]).max()
-    assert moved > 0.1 and absdiff <= 1e-6 and np.median(err[targets]) <= 1e-9, (absdiff, np.median(err[targets]))
     frozen = [s for s in range(12) if s not in targets]
-    assert np.array_equal(out["dev"][frozen], vp0[frozen])
+
+    def run(max_iters):
+        cfg_kw = dict(max_iters=max_iters)
+        calls = {"dev": 0, "cpu": 0}
+
+        def layer_dev(vp, layer, pc):
+            calls["dev"] += 1
+            new, _, _, _, st = ctx.maximize_batch(vp, layer, cel.ElboConfig(**cfg_kw), pos_centers=pc)
+            assert (st == 0).all()
+            return new[layer]
+
+        def layer_cpu(vp, layer, pc):
+            calls["cpu"] += 1
+            rows = []
+            for t, c in zip(layer, pc):
+                r = oracle.maximize(ctx.problem, vp, t, oracle.OptCfg(**cfg_kw), pos_center=c)
+                assert r[4] == 0
+                rows.append(r[0][t])
+            return np.stack(rows)
+        out = {}
+        for name, fn in (("dev", layer_dev), ("cpu", layer_cpu)):
+            out[name] = joint_infer_sweeps(fn, vp0.copy(), targets, f.neighbors, batch_size=5, n_iters=2,
+                                           rng=np.random.default_rng(3))
+        assert calls["dev"] == calls["cpu"] > 4
+        moved = np.abs(out["cpu"][targets] - vp0[targets]).max()
+        err = np.abs(out["dev"] - out["cpu"]) / np.maximum(np.abs(out["cpu"]), 1e-3)
+        absdiff = np.abs(out["dev"] - out["cpu"])
+        worst = np.unravel_index(np.argmax(absdiff), absdiff.shape)
+        print("joint inference, 2 sweeps, %d layers, max_iters %d: max |device - CPU| %.2e (source %d parameter %d), median "
+              "relative %.1e; parameters moved by up to %.2g" % (calls["dev"], max_iters, absdiff.max(), worst[0], worst[1],
+                                                               np.median(err[targets]), moved))
+        assert moved > 0.1 and np.array_equal(out["dev"][frozen], vp0[frozen])
+        return out, absdiff.max(), np.median(err[targets])
+
+    # (a) the bar of test_randomised_optimiser_against_cpu -- every parameter within 1e-6 -- while the trust-region
+    # sub-problems are well conditioned (the first Newton iterations of every layer)
+    _, absdiff, med = run(3)
+    assert absdiff <= 1e-6 and med <= 1e-9, (absdiff, med)
+    # (b) six iterations per layer: some late sub-problems sit next to the hard case (smallest eigenvalue of
+    # H + lambda I ~1e-8 of the largest), where rounding-level differences between two eigen-solvers move the step by
+    # ~1e-9 and the following iterations amplify that ~1000x each along flat directions (tools/diag_joint.py prints it
+    # layer by layer: 1e-12 after four iterations, 1e-7 .. 1e-6 after six).  Measured 9.5e-7; besides the parameters,
+    # what must agree is what the optimiser is for: the objective reached.
+    out, absdiff, med = run(6)
+    tg = np.array(targets, dtype=np.int32)
+    e_dev = ctx.eval_batch(out["dev"], tg, 4)[0]
+    e_cpu = ctx.eval_batch(out["cpu"], tg, 4)[0]
+    rel = np.abs(e_dev - e_cpu) / np.abs(e_cpu)
+    print("    ELBO reached, device vs CPU tables: max relative difference %.1e" % rel.max())
+    assert absdiff <= 2e-6 and med <= 1e-9 and rel.max() <= 1e-9, (absdiff, med, rel.max())
 
 
 def test_repeated_device_launches_track_the_parameters():
