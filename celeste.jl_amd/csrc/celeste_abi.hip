@@ -711,6 +711,9 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
 #undef LAUNCH_PIXEL_T
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
     c->ev_split = 0;
+    // every gradient / Hessian entry is owned by one thread whatever the block size: 512 threads halve the latency of
+    // a batch that leaves the chip mostly idle anyway; 256 keep 8 workgroups per CU for a 2000-target sweep
+    const int lift_nt = n_targets <= 1024 ? 512 : 256;
     if (split) {
         // per-patch sums of the records, then the lift reads one record per (target, image): CH = 1
         // its own (part, patch) grid, part index slowest: streaming order matters more to this kernel than the idle
@@ -719,12 +722,12 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            stream, c->d_patches, d_targets, c->d_tile_off, reinterpret_cast<const double2 *>(c->d_rec),
                            c->d_items, c->N, c->M, c->RCH, c->sum_tiles, c->d_acc_split, nullptr, c->d_work_total);
         if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], stream)); c->ev_split = 1; }
-        hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
+        hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                            c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M,
                            c->RCH, c->sum_tiles * 64, flags,
                            d_v, d_d, d_h, d_counters, d_status, d_live);
     } else
-    hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(256), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
+    hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                        c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH,
                        c->chunk_px, flags,
                        d_v, d_d, d_h, d_counters, d_status, d_live);
@@ -1117,7 +1120,7 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double
         ob.cap = n;
     }
     if (!ob.d_vp) MX_TRY(hipMalloc((void **)&ob.d_vp, vp_bytes));
-    if (!ob.d_count) MX_TRY(hipMalloc((void **)&ob.d_count, 2 * sizeof(int32_t)));
+    if (!ob.d_count) MX_TRY(hipMalloc((void **)&ob.d_count, 3 * sizeof(int32_t)));   // two counters + blocks_done
     if (!ob.h_vp) MX_TRY(hipHostMalloc((void **)&ob.h_vp, 2 * vp_bytes, hipHostMallocDefault));
     if (!ob.h_count) {
         MX_TRY(hipHostMalloc((void **)&ob.h_count, celeste_ctx::OptBuffers::RING * sizeof(int32_t), hipHostMallocDefault));
@@ -1132,6 +1135,7 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double
     OptState *const d_state = (OptState *)ob.d_state;
     double *const h_vp0 = ob.h_vp, *const h_vp1 = ob.h_vp + (size_t)c->S * CEL_P;
     constexpr int RING = celeste_ctx::OptBuffers::RING;
+    MX_TRY(hipMemsetAsync(ob.d_count, 0, 3 * sizeof(int32_t), stream));   // (an earlier call may have stopped mid-loop)
     MX_TRY(hipMemcpyAsync(d_targets, targets, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     if (pos_centers) MX_TRY(hipMemcpyAsync(d_pos, pos_centers, n * 2 * sizeof(double), hipMemcpyHostToDevice, stream));
     {
@@ -1159,10 +1163,9 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double
             int st1 = launch_eval(c, d_vp, n_upper, d_evt[cur], flags, d_v, d_d, d_h, nullptr, d_st, stream, false, nullptr,
                                   -1, false, d_live);
             if (st1 != CELESTE_OK) { rc = st1; goto cleanup; }
-            MX_TRY(hipMemsetAsync(d_cnt[1 - cur], 0, sizeof(int32_t), stream));
             hipLaunchKernelGGL(optim_step_kernel, dim3(n_upper), dim3(64), 0, stream, d_vp, d_targets, d_act[cur],
-                               d_v, d_d, d_h, d_st, op, d_state, d_H, d_act[1 - cur], d_evt[1 - cur], d_cnt[1 - cur], d_live);
-            MX_TRY(hipMemcpyAsync(&ob.h_count[it % RING], d_cnt[1 - cur], sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                               d_v, d_d, d_h, d_st, op, d_state, d_H, d_act[1 - cur], d_evt[1 - cur], d_cnt[1 - cur],
+                               it == 0 ? nullptr : d_cnt[cur], ob.d_count + 2, &ob.h_count[it % RING]);
             MX_TRY(hipEventRecord(ob.ev[it % RING], stream));
             cur = 1 - cur;
         }
@@ -1240,6 +1243,15 @@ extern "C" int celeste_debug_T(int32_t n, double *out) {   // n = 0: allocate fo
     static double *buf = nullptr;
     if (!buf) { HIP_TRY(hipMalloc((void **)&buf, (size_t)4096 * 4 * NF * sizeof(double))); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_T), &buf, sizeof buf)); }
     if (n > 0) HIP_TRY(hipMemcpy(out, buf, (size_t)n * 4 * NF * sizeof(double), hipMemcpyDeviceToHost));
+    return CELESTE_OK;
+}
+#endif
+#ifdef LIFT_TIMING
+extern "C" int celeste_lift_clocks(int reset, uint64_t out[16]) {   // debug builds only (tools/variants)
+    unsigned long long h[16] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lift_clk), sizeof h));
+    for (int i = 0; i < 16; ++i) out[i] = h[i];
+    if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lift_clk), z, sizeof z)); }
     return CELESTE_OK;
 }
 #endif

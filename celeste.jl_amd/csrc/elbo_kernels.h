@@ -1443,9 +1443,18 @@ __device__ inline double kl_grad(const KLShared &K, const PriorDev *prior, const
     return -a * (K.t[8 * i + d] + 1.0 + K.m[8 * i + d]);
 }
 
+#ifdef LIFT_TIMING   // debug builds (tools/variants): shader clocks per phase of the lift kernel, thread 0
+__device__ unsigned long long g_lift_clk[16];
+#define LIFT_TICK(k) do { const long long now__ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_lift_clk[k], (unsigned long long)(now__ - ltick__)); ltick__ = clock64(); } while (0)
+#define LIFT_TICK_DECL long long ltick__ = clock64()
+#else
+#define LIFT_TICK(k) do { } while (0)
+#define LIFT_TICK_DECL do { } while (0)
+#endif
+
 // 8 waves per SIMD (64 VGPRs, a 52-byte spill) and 17.7 KB of LDS: 8 workgroups per CU, so that a 2000-target batch is
 // resident in one round (with 5 per CU it ran in two: 76 -> 65 us)
-__global__ void __launch_bounds__(256, 8)
+__global__ void __launch_bounds__(512, 8)
 lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
             const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
@@ -1455,6 +1464,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             double *__restrict__ out_v, double *__restrict__ out_d, double *__restrict__ out_h,
             int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status, const int32_t *__restrict__ live) {
     if (live && (int)blockIdx.x >= *live) return;
+    LIFT_TICK_DECL;
     __shared__ double sh_h[LIFT_NP * LIFT_NP];         // likelihood Hessian, upper triangle, params < 28
     __shared__ double sh_d[LIFT_NP];
     __shared__ double s_vs[CEL_P], s_jsh[9], s_tsh[27];
@@ -1481,7 +1491,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
     const double *vs = s_vs;
 
     // KL per (type, component) terms: 16 threads of the last wave, concurrent with the first lift pass
-    if (want_kl && tid >= 240) {
+    if (want_kl && tid >= 240 && tid < 256) {
         const int q = tid - 240, i = q >> 3, d = q & 7;
         const celeste_prior_t &pr = prior->p;
         const double k = vs[28 + 8 * i + d];
@@ -1511,6 +1521,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         K.g_v[i] = .5 * (-1.0 / var1 + 1.0 / var2);
     }
 
+    LIFT_TICK(0);
     // the images the target appears in (its visit list), LIFT_NT at a time
     const int vo = vis_off[t], n_vis = vis_off[t + 1] - vo;
     for (int n0 = 0; n0 < n_vis; n0 += LIFT_NT) {
@@ -1541,6 +1552,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             }
         }
         __syncthreads();
+        LIFT_TICK(1);
         if (tid == 0) for (int i = 0; i < nt; ++i) { sh_v += s_rec[i][0]; sh_cnt[0] += s_rec[i][ACC_CNT]; sh_cnt[1] += s_rec[i][ACC_CNT + 1]; }
         if (want_grad) {
             // pass 2: the non-zero entries of the 10 x 28 Jacobians of the reduced variables
@@ -1569,6 +1581,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
                 s_jz[i][slot] = v;
             }
             __syncthreads();
+            LIFT_TICK(2);
             // pass 3: gradient and upper-triangle Hessian; every entry is owned by one thread
             const int n_pairs = LIFT_NP * (LIFT_NP + 1) / 2;
             for (int k = tid; k < n_pairs + LIFT_NP; k += nthr) {
@@ -1625,6 +1638,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             }
         }
         __syncthreads();
+        LIFT_TICK(3);
     }
 
     // ---- KL value (elbo_kl.jl:140-154) ----
@@ -1644,6 +1658,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         sh_v += kl;
     }
     __syncthreads();
+    LIFT_TICK(4);
 
     // ---- assemble, check finiteness (elbo_objective.jl:487,490), store exactly symmetric ----
     int bad = 0;
@@ -1676,6 +1691,10 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         out_v[ti] = sh_v;
         if (out_cnt) { out_cnt[2 * ti] = (int64_t)(sh_cnt[0] + 0.5); out_cnt[2 * ti + 1] = (int64_t)(sh_cnt[1] + 0.5); }
     }
+    LIFT_TICK(5);
+#ifdef LIFT_TIMING
+    if (tid == 0) atomicAdd(&g_lift_clk[15], 1ull);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

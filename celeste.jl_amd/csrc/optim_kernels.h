@@ -779,8 +779,22 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
                   const double *__restrict__ ev_v, const double *__restrict__ ev_d, const double *__restrict__ ev_h,
                   const int32_t *__restrict__ ev_status, OptParams op, OptState *__restrict__ st,
                   double *__restrict__ Hstate, int32_t *__restrict__ next_active, int32_t *__restrict__ next_targets,
-                  int32_t *__restrict__ next_count, const int32_t *__restrict__ live) {
-    if (live && (int)blockIdx.x >= *live) return;   // the grid is sized by an older, larger count
+                  int32_t *__restrict__ next_count, int32_t *__restrict__ live, int32_t *__restrict__ blocks_done,
+                  volatile int32_t *__restrict__ host_count) {
+    // The launch's last workgroup to finish publishes the number of targets still running to page-locked host memory
+    // (the host sizes later launches by it), clears the counter this launch read (`live`: the launch after next
+    // counts into it) and re-arms blocks_done: no memset and no copy between two Newton iterations.
+    auto finish = [&]() {
+        if (threadIdx.x != 0) return;
+        __threadfence();
+        if (atomicAdd(blocks_done, 1) == (int)gridDim.x - 1) {
+            *host_count = atomicAdd(next_count, 0);
+            if (live) *live = 0;
+            *blocks_done = 0;
+            __threadfence_system();
+        }
+    };
+    if (live && (int)blockIdx.x >= *live) { finish(); return; }   // the grid is sized by an older, larger count
     // LDS budget: 19.7 KB per workgroup so that 8 workgroups (2 waves per SIMD, the VGPR limit) fit a CU and a batch
     // of 2000 targets is resident in one round.
     __shared__ double sA[LDA * NF];       // rows 0..43: H J (44 x 41) -> J'HJ (41 x 41, negated) -> solver; rows 41..44 spare
@@ -932,6 +946,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
     if (done) {
         if (tid == 0) S.done = 1;
         to_bound_wave(sx, S.pos0, op, vp + (size_t)t * CEL_P, tid);
+        finish();
         return;
     }
 
@@ -961,6 +976,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         const int pos = atomicAdd(next_count, 1);
         next_active[pos] = slot; next_targets[pos] = t;
     }
+    finish();
     OPT_TICK(8);
 #ifdef OPTIM_TIMING
     if (tid == 0) atomicAdd(&g_optim_clk[15], 1ull);

@@ -24,16 +24,32 @@ def clocks(reset=True):
     return np.array(out[:], dtype=np.float64)
 
 
+has_lift = hasattr(lib, "celeste_lift_clocks")
+LIFT_NAMES = ["load + KL terms", "pass 1: records, brightness", "pass 2: Jacobians", "pass 3: gradient + Hessian", "KL value", "assemble + store"]
+
+
+def lift_clocks():
+    if not has_lift:
+        return None
+    out = (C.c_uint64 * 16)()
+    lib.celeste_lift_clocks(1, out)
+    return np.array(out[:], dtype=np.float64)
+
+
 def run(tg, label, reps=3):
     cfg = cel.ElboConfig(max_iters=50)
     ctx.maximize_batch(fld.vp, tg, cfg)
-    clocks()
+    clocks(); lift_clocks()
     t0 = time.time()
     for _ in range(reps):
         vp, its, evals, elbo, st = ctx.maximize_batch(fld.vp, tg, cfg)
     dt = (time.time() - t0) / reps
     print("%s: %d targets, %.3f ms per call, max iters %d, mean %.1f -> %.1f us per Newton iteration of the longest target"
           % (label, len(tg), dt * 1e3, its.max(), its.mean(), dt * 1e6 / (its.max() + 1)))
+    c = lift_clocks()
+    if c is not None and c[15] > 0:
+        for k, name in enumerate(LIFT_NAMES):
+            print("    lift %-28s %8.0f cycles per workgroup (%.1f us at 2.4 GHz)" % (name, c[k] / c[15], c[k] / c[15] / 2400))
     c = clocks()
     if c is not None and c[15] > 0:
         n = c[15]
