@@ -80,8 +80,9 @@ struct celeste_ctx {
     // visit lists: the images each source has a non-empty patch in (grids run over these, tables stay S x N)
     std::vector<int32_t> h_vis_off, h_vis_img, h_vis_src;
     int32_t *d_vis_off = nullptr, *d_vis_img = nullptr, *d_vis_src = nullptr;
-    int32_t *d_item_link = nullptr, *d_item_img_chunk = nullptr;   // value_kernel work items: link, image | chunk << 16
+    int4 *d_value_items = nullptr;  // value_kernel work items: {neighbour's table entry, target's, chunk, target}
     int64_t n_value_items = 0;
+    int32_t *d_prep_mark = nullptr; // per source: stamp of the last batch that read its per-image tables
     int32_t *d_items = nullptr;      // [ti * M + j] of the current batch
     size_t items_cap = 0;
     // work list of pixel_kernel (work_count / work_scan / work_fill kernels), per batch
@@ -489,11 +490,19 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
                     }
                 }
             }
-        std::vector<int32_t> il, ic;
-        for (auto &v : by_len) for (auto &e : v) { il.push_back(e.first); ic.push_back(e.second); }
-        c->n_value_items = (int64_t)il.size();
-        CTX_TRY(dev_upload(&c->d_item_link, il.data(), il.size()));
-        CTX_TRY(dev_upload(&c->d_item_img_chunk, ic.data(), ic.size()));
+        std::vector<int32_t> link_src(c->h_nbr_idx.size());
+        for (int s = 0; s < c->S; ++s)
+            for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q) link_src[q] = s;
+        std::vector<int4> desc;
+        for (auto &v : by_len)
+            for (auto &e : v) {
+                const int t = link_src[e.first], s2 = c->h_nbr_idx[e.first], n = e.second & 0xffff, ch = e.second >> 16;
+                desc.push_back(make_int4(s2 * c->N + n, t * c->N + n, ch, t));
+            }
+        c->n_value_items = (int64_t)desc.size();
+        CTX_TRY(dev_upload(&c->d_value_items, desc.data(), desc.size()));
+        CTX_TRY(dev_upload<int32_t>(&c->d_prep_mark, nullptr, (size_t)c->S));
+        if (hipMemset(c->d_prep_mark, 0, (size_t)c->S * sizeof(int32_t)) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
     }
     {
         c->h_tile_off.resize(c->h_patches.size());
@@ -526,7 +535,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *ptrs[] = {c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_item_link, c->d_item_img_chunk, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_prep_mark, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     {
@@ -571,7 +580,8 @@ static hipError_t scratch_get(celeste_ctx_t *c, int k, size_t bytes, T **out) {
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
                        void *stream_, bool render_neighbors, const int32_t *d_active_rank = nullptr,
-                       int64_t n_chunks = -1, bool tables_current = false, const int32_t *d_live = nullptr);
+                       int64_t n_chunks = -1, bool tables_current = false, const int32_t *d_live = nullptr,
+                       bool prep_all = false);
 
 extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_vp, int32_t n_targets,
                                               const int32_t *d_targets, uint32_t flags, double *d_v, double *d_d,
@@ -584,7 +594,9 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
                        void *stream_, bool render_neighbors, const int32_t *d_active_rank, int64_t n_chunks,
-                       bool tables_current, const int32_t *d_live) {
+                       bool tables_current, const int32_t *d_live, bool prep_all) {
+    // prep_all: the per-(source, image) tables of EVERY source are filled (the first part of a host batch does it for
+    // the parts that follow, which pass tables_current); else only those of the targets and their neighbours
     // d_live (device, optional): the number of leading entries of d_targets that are live; n_targets is then an upper
     // bound known to the host (the optimiser loop runs ahead of the device)
     // tables_current: the per-(source, image) tables were filled from this very vp by an earlier launch of the same
@@ -655,15 +667,18 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         c->stamp = 1;
     }
     const size_t setup_threads = std::max<size_t>((size_t)c->S, (size_t)n_targets * (c->dense ? 1 : c->M));
+    // the sources whose tables this launch fills are marked by the setup kernel (targets + neighbours)
+    int32_t *const prep_mark = render_neighbors && !tables_current && !prep_all ? c->d_prep_mark : nullptr;
     if (n_visits <= WORK1_MAX_VISITS && !getenv("CELESTE_PARALLEL_WORKLIST")) {
         hipLaunchKernelGGL(setup_worklist_kernel, dim3(1 + (unsigned)((setup_threads + WORK1_NT - 1) / WORK1_NT)), dim3(WORK1_NT),
                            0, stream, d_vp, c->S, c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M,
                            c->dense ? nullptr : c->d_items, render_neighbors ? c->d_needed : nullptr, c->stamp, c->d_patches,
-                           c->N, c->CH, c->chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live);
+                           c->N, c->CH, c->chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live, prep_mark,
+                           c->d_nbr_off, c->d_nbr_idx);
     } else {
         hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 255) / 256)), dim3(256), 0, stream, d_vp, c->S,
                            c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
-                           render_neighbors ? c->d_needed : nullptr, c->stamp);
+                           render_neighbors ? c->d_needed : nullptr, c->stamp, prep_mark, c->d_nbr_off, c->d_nbr_idx);
         hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
                            c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, G, (int)c->dense, c->d_work_blk, d_live);
         hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * n_classes, c->d_work_total);
@@ -675,17 +690,17 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         if (c->V > 0 && !tables_current)
             hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches,
                                c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr, c->d_vis_off, c->M,
-                               (int)c->dense, nullptr);
+                               (int)c->dense, nullptr, prep_mark, c->stamp);
     } else {
         hipLaunchKernelGGL(prep_kernel, dim3((unsigned)std::max(n_visits, 1)), dim3(64), 0, stream, d_vp, c->d_images,
                            c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, d_targets,
-                           c->d_vis_off, c->M, (int)c->dense, d_live);
+                           c->d_vis_off, c->M, (int)c->dense, d_live, nullptr, 0);
     }
     if (render_neighbors) {
     if (c->n_value_items > 0)
         hipLaunchKernelGGL(value_kernel, dim3((unsigned)c->n_value_items), dim3(64), 0, stream,
-                           c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_link_src, c->d_nbr_idx,
-                           c->d_val_off, c->d_item_link, c->d_item_img_chunk, c->N, c->NC, c->chunk_px, c->d_val);
+                           c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_val_off,
+                           c->d_value_items, c->NC, c->chunk_px, c->d_val);
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     const dim3 grid((unsigned)std::max<size_t>(grid_need, 1));
@@ -841,7 +856,7 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
         for (int t = lo; t < lo + cnt; ++t) n_chunks += c->h_src_chunks[targets[t]];
         int st = launch_eval(c, c->d_vp, cnt, c->d_targets + lo, flags, c->d_v + lo, c->d_d + (size_t)lo * CEL_P,
                              c->d_h + (size_t)lo * HS, c->d_cnt + 2 * (size_t)lo, c->d_status + lo, c->stream, true,
-                             nullptr, n_chunks, k > 0);
+                             nullptr, n_chunks, k > 0, nullptr, n_parts > 1);
         if (st != CELESTE_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy_stream); return st; }
         HIP_TRY(hipEventRecord(c->part_done[k], c->stream));
         HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->part_done[k], 0));
@@ -1281,7 +1296,7 @@ extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32
         if (c->V > 0)
             hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, c->stream, c->d_vp, c->d_images,
                                c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr,
-                               c->d_vis_off, c->M, (int)c->dense, nullptr);
+                               c->d_vis_off, c->M, (int)c->dense, nullptr, nullptr, 0);
         hipLaunchKernelGGL(render_kernel, dim3((unsigned)((size_t)c->S * c->CH)), dim3(64), 0, c->stream, c->d_patches,
                            c->d_coefs, c->d_bitmaps, im.pixels, c->d_srcimg, c->d_comps, (int)image, c->N, c->NC,
                            c->CH, c->chunk_px, im.H, d_plane);

@@ -72,7 +72,7 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const int32_t *__restrict__ vis_img, int N, int K,
             SrcImg *__restrict__ srcimg, Comp *__restrict__ comps,
             const int32_t *__restrict__ targets, const int32_t *__restrict__ vis_off, int M, int dense,
-            const int32_t *__restrict__ live) {
+            const int32_t *__restrict__ live, const int32_t *__restrict__ mark, int32_t stamp) {
     const int NC = 14 * K;
     // one workgroup per visit = (source, image) pair with a non-empty patch; the tables stay dense (s * N + n).
     // targets == nullptr: every visit of the context (neighbours are about to be rendered).  Otherwise one workgroup
@@ -92,6 +92,8 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         if (q.H2 * q.W2 <= 0) return;
     } else {
         s = vis_src[blockIdx.x]; n = vis_img[blockIdx.x];
+        // mark (optional): only the sources this batch reads -- its targets and their neighbours (setup_thread)
+        if (mark && mark[s] != stamp) return;
     }
     const int sn = s * N + n;
     const int c = threadIdx.x;
@@ -299,8 +301,14 @@ __device__ inline void source_geo(const double *vp, int s, SrcGeo *geo);
 __device__ inline void setup_thread(int k, const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo,
                                     const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
                                     const int32_t *__restrict__ vis_img, int M, int32_t *__restrict__ items,
-                                    int32_t *__restrict__ is_target, int32_t stamp) {
+                                    int32_t *__restrict__ is_target, int32_t stamp, int32_t *__restrict__ prep_mark,
+                                    const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx) {
     if (k < S) source_geo(vp, k, geo);
+    if (prep_mark && k < n_targets) {   // the sources whose per-image tables this batch reads
+        const int t = targets[k];
+        prep_mark[t] = stamp;
+        for (int64_t q = nbr_off[t]; q < nbr_off[t + 1]; ++q) prep_mark[nbr_idx[q]] = stamp;
+    }
     if (items && k < n_targets * M) {
         const int ti = k / M, j = k - ti * M;
         const int t = targets[ti];
@@ -312,9 +320,10 @@ __device__ inline void setup_thread(int k, const double *__restrict__ vp, int S,
 __global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo,
                              const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
                              const int32_t *__restrict__ vis_img, int M, int32_t *__restrict__ items,
-                             int32_t *__restrict__ is_target, int32_t stamp) {
+                             int32_t *__restrict__ is_target, int32_t stamp, int32_t *__restrict__ prep_mark,
+                             const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx) {
     setup_thread(blockIdx.x * blockDim.x + threadIdx.x, vp, S, geo, targets, n_targets, vis_off, vis_img, M, items, is_target,
-                 stamp);
+                 stamp, prep_mark, nbr_off, nbr_idx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -468,10 +477,12 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
                       int n_targets, const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int M,
                       int32_t *__restrict__ items, int32_t *__restrict__ is_target, int32_t stamp,
                       const DevPatch *__restrict__ patches, int N, int CH, int chunk_px, int G, int dense,
-                      int32_t *__restrict__ work, int32_t *__restrict__ work_total, const int32_t *__restrict__ live) {
+                      int32_t *__restrict__ work, int32_t *__restrict__ work_total, const int32_t *__restrict__ live,
+                      int32_t *__restrict__ prep_mark, const int64_t *__restrict__ nbr_off,
+                      const int32_t *__restrict__ nbr_idx) {
     if (blockIdx.x > 0) {
         setup_thread((blockIdx.x - 1) * WORK1_NT + threadIdx.x, vp, S, geo, targets, n_targets, vis_off, vis_img, M, items,
-                     is_target, stamp);
+                     is_target, stamp, prep_mark, nbr_off, nbr_idx);
         return;
     }
     __shared__ int s_part[WORK1_NT / 64];
@@ -530,20 +541,16 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
 __global__ void __launch_bounds__(64)
 value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
-             const int32_t *__restrict__ is_target, int32_t stamp, const int32_t *__restrict__ link_src,
-             const int32_t *__restrict__ nbr_idx, const int64_t *__restrict__ val_off,
-             const int32_t *__restrict__ item_link, const int32_t *__restrict__ item_img_chunk, int N, int NC,
-             int chunk_px, double2 *__restrict__ val) {
+             const int32_t *__restrict__ is_target, int32_t stamp, const int64_t *__restrict__ val_off,
+             const int4 *__restrict__ items, int NC, int chunk_px, double2 *__restrict__ val) {
     __shared__ double etab[64];
-    const int q = item_link[blockIdx.x];
-    const int t = link_src[q];
+    // an item = {table index of the neighbour's (source, image) entry, of the target's, chunk, target}: one 16-byte
+    // load instead of a chain link -> source, link -> neighbour, item -> image | chunk
+    const int4 it = items[blockIdx.x];
+    const int sn = it.x, ch = it.z, t = it.w;
     if (is_target[t] != stamp) return;
-    const int nc = item_img_chunk[blockIdx.x];
-    const int n = nc & 0xffff, ch = nc >> 16;
-    const int s = nbr_idx[q];
-    const int sn = s * N + n;
     const DevPatch &P = patches[sn];
-    const DevPatch &T = patches[(size_t)t * N + n];
+    const DevPatch &T = patches[it.y];
     // overlap rectangle in 0-based image coordinates [h_lo, h_hi) x [w_lo, w_hi)
     const int h_lo = max(P.off_h, T.off_h), h_hi = min(P.off_h + P.H2, T.off_h + T.H2);
     const int w_lo = max(P.off_w, T.off_w), w_hi = min(P.off_w + P.W2 - 1, T.off_w + T.W2);
