@@ -83,7 +83,9 @@ struct celeste_ctx {
     int4 *d_value_items = nullptr;  // value_kernel work items: {neighbour's table entry, target's, chunk, target}
     int64_t n_value_items = 0;
     int32_t *d_prep_mark = nullptr; // per source: stamp of the last batch that read its per-image tables
-    int32_t *d_items = nullptr;      // [ti * M + j] of the current batch
+    int64_t *d_nv_base = nullptr;   // visit-list mode: per source, start of its rows in d_nbr_vis
+    int32_t *d_nbr_vis = nullptr;   // visit-list mode: [visit of s][neighbour of s] -> the neighbour's visit in that image
+    int2 *d_items = nullptr;         // [ti * M + j] of the current batch: {visit, image}
     size_t items_cap = 0;
     // work list of pixel_kernel (work_count / work_scan / work_fill kernels), per batch
     std::vector<int32_t> h_src_chunks;   // per source: chunks of all its patches
@@ -328,16 +330,16 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         celeste_ctx_destroy(c); return CELESTE_ERR_HIP;
     }
 
-    // patches + explicit bitmaps (dense [s * N + n] table, or the sparse list sorted by (source, image))
-    {
-        DevPatch empty; memset(&empty, 0, sizeof empty);
-        empty.bitmap_off = -1;
-        c->h_patches.assign((size_t)c->S * c->N, empty);
-    }
+    // patches + explicit bitmaps (dense [s * N + n] table, or the sparse list sorted by (source, image)).
+    // Every per-(source, image) table of the context is indexed by VISIT: the v-th non-empty patch in (source, image)
+    // order (h_vis_off / h_vis_img / h_vis_src).  When every source appears in (nearly) every image the visit lists
+    // simply enumerate all S x N pairs (empty patches included), visit id = s * N + n, and the kernels skip the lists.
     std::vector<uint8_t> pool;
     const bool sparse = pr->n_patch_entries > 0;
     if (sparse && (!pr->patch_source || !pr->patch_image)) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }
-    const size_t n_entries = sparse ? (size_t)pr->n_patch_entries : c->h_patches.size();
+    const size_t n_entries = sparse ? (size_t)pr->n_patch_entries : (size_t)c->S * c->N;
+    std::vector<int64_t> ent_key; std::vector<DevPatch> ent;     // the non-empty patches, by key s * N + n
+    std::vector<int32_t> n_vis((size_t)c->S, 0);
     int64_t prev = -1;
     for (size_t k = 0; k < n_entries; ++k) {
         size_t q = k;
@@ -358,9 +360,10 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
             celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG;
         }
         if (p.stamp < 0 || p.stamp >= pr->n_stamps || !p.psf) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }
+        if (d.H2 * d.W2 <= 0) continue;                          // an empty patch is no visit
         d.stamp = p.stamp;
         d.bitmap_off = -1;
-        if (p.bitmap && d.H2 * d.W2 > 0) {
+        if (p.bitmap) {
             d.bitmap_off = (int64_t)pool.size();
             pool.insert(pool.end(), p.bitmap, p.bitmap + (size_t)d.H2 * d.W2);
         }
@@ -368,9 +371,34 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         memcpy(d.wc, p.world_center, sizeof d.wc);
         memcpy(d.pc, p.pixel_center, sizeof d.pc);
         memcpy(d.psf, p.psf, sizeof(double) * 6 * c->K);
-        c->h_patches[q] = d;
+        ent_key.push_back((int64_t)q); ent.push_back(d);
+        n_vis[q / c->N]++;
         if (d.H2 * d.W2 > c->max_npx) c->max_npx = d.H2 * d.W2;
     }
+    for (int s = 0; s < c->S; ++s) c->M = std::max(c->M, n_vis[s]);
+    // single-field problems (every source in every image, or nearly: M == N): list all N images for every source
+    // and let the kernels map (target, j) -> image j directly
+    c->dense = c->M == c->N && !getenv("CELESTE_FORCE_VISIT_LISTS");   // (the variable exists for testing)
+    c->h_vis_off.assign((size_t)c->S + 1, 0);
+    if (c->dense) {
+        DevPatch empty; memset(&empty, 0, sizeof empty);
+        empty.bitmap_off = -1;
+        c->h_patches.assign((size_t)c->S * c->N, empty);
+        for (size_t k = 0; k < ent.size(); ++k) c->h_patches[(size_t)ent_key[k]] = ent[k];
+        for (int s = 0; s < c->S; ++s) {
+            for (int n = 0; n < c->N; ++n) { c->h_vis_img.push_back(n); c->h_vis_src.push_back(s); }
+            c->h_vis_off[s + 1] = (int32_t)c->h_vis_img.size();
+        }
+    } else {
+        c->h_patches.swap(ent);
+        for (size_t k = 0; k < ent_key.size(); ++k) {
+            c->h_vis_src.push_back((int32_t)(ent_key[k] / c->N)); c->h_vis_img.push_back((int32_t)(ent_key[k] % c->N));
+            c->h_vis_off[(size_t)(ent_key[k] / c->N) + 1] = (int32_t)(k + 1);
+        }
+        for (int s = 0; s < c->S; ++s) c->h_vis_off[s + 1] = std::max(c->h_vis_off[s + 1], c->h_vis_off[s]);
+    }
+    c->V = (int64_t)c->h_vis_img.size();
+    if (c->V > 0x7fffffffll / std::max(c->NC, 1)) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }
     CTX_TRY(dev_upload(&c->d_patches, c->h_patches.data(), c->h_patches.size()));
     CTX_TRY(dev_upload(&c->d_bitmaps, pool.data(), pool.size()));
 
@@ -410,8 +438,8 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         }
     }
     hipLaunchKernelGGL(exp_table_kernel, dim3(1), dim3(64), 0, nullptr);
-    CTX_TRY(dev_upload<SrcImg>(&c->d_srcimg, nullptr, (size_t)c->S * c->N));
-    CTX_TRY(dev_upload<Comp>(&c->d_comps, nullptr, (size_t)c->S * c->N * c->NC));
+    CTX_TRY(dev_upload<SrcImg>(&c->d_srcimg, nullptr, (size_t)c->V));
+    CTX_TRY(dev_upload<Comp>(&c->d_comps, nullptr, (size_t)c->V * c->NC));
     CTX_TRY(dev_upload<SrcGeo>(&c->d_geo, nullptr, (size_t)c->S));
     {
         std::vector<int64_t> voff(c->h_patches.size());
@@ -428,26 +456,6 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         CTX_TRY(dev_upload(&c->d_link_src, lsrc.data(), lsrc.size()));
     }
 
-    c->h_vis_off.assign((size_t)c->S + 1, 0);
-    for (int s = 0; s < c->S; ++s) {
-        for (int n = 0; n < c->N; ++n) {
-            const DevPatch &q = c->h_patches[(size_t)s * c->N + n];
-            if (q.H2 * q.W2 > 0) { c->h_vis_img.push_back(n); c->h_vis_src.push_back(s); }
-        }
-        c->h_vis_off[s + 1] = (int32_t)c->h_vis_img.size();
-        c->M = std::max(c->M, c->h_vis_off[s + 1] - c->h_vis_off[s]);
-    }
-    // single-field problems (every source in every image, or nearly: M == N): list all N images for every source
-    // and let the kernels map (target, j) -> image j directly
-    c->dense = c->M == c->N && !getenv("CELESTE_FORCE_VISIT_LISTS");   // (the variable exists for testing)
-    if (c->dense) {
-        c->h_vis_img.clear(); c->h_vis_src.clear();
-        for (int s = 0; s < c->S; ++s) {
-            for (int n = 0; n < c->N; ++n) { c->h_vis_img.push_back(n); c->h_vis_src.push_back(s); }
-            c->h_vis_off[s + 1] = (int32_t)c->h_vis_img.size();
-        }
-    }
-    c->V = (int64_t)c->h_vis_img.size();
     CTX_TRY(dev_upload(&c->d_vis_off, c->h_vis_off.data(), c->h_vis_off.size()));
     CTX_TRY(dev_upload(&c->d_vis_img, c->h_vis_img.data(), c->h_vis_img.size()));
     CTX_TRY(dev_upload(&c->d_vis_src, c->h_vis_src.data(), c->h_vis_src.size()));
@@ -456,11 +464,34 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
     c->CH = c->max_npx > 0 ? (c->max_npx + c->chunk_px - 1) / c->chunk_px : 1;
     c->h_src_chunks.assign((size_t)c->S, 0);
     for (int s = 0; s < c->S; ++s) {
-        for (int n = 0; n < c->N; ++n) {
-            const DevPatch &q = c->h_patches[(size_t)s * c->N + n];
+        for (int v = c->h_vis_off[s]; v < c->h_vis_off[s + 1]; ++v) {
+            const DevPatch &q = c->h_patches[v];
             c->h_src_chunks[s] += (q.H2 * q.W2 + c->chunk_px - 1) / c->chunk_px;
         }
         c->max_src_chunks = std::max(c->max_src_chunks, c->h_src_chunks[s]);
+    }
+    // visit of (source, image), -1: none
+    auto hv = [c](int s, int n) -> int64_t {
+        if (c->dense) return (int64_t)s * c->N + n;
+        const int32_t *b = c->h_vis_img.data() + c->h_vis_off[s], *e = c->h_vis_img.data() + c->h_vis_off[s + 1];
+        const int32_t *it = std::lower_bound(b, e, n);
+        return it != e && *it == n ? (int64_t)(it - c->h_vis_img.data()) : -1;
+    };
+    if (!c->dense) {
+        // the visits of every source's neighbours, image by image: row j (= visit vis_off[s] + j) of source s holds the
+        // visit of each of its K neighbours in that visit's image (-1: the neighbour is not in it), at nv_base[s] + j K
+        std::vector<int64_t> base((size_t)c->S + 1, 0);
+        for (int s = 0; s < c->S; ++s)
+            base[s + 1] = base[s] + (int64_t)(c->h_vis_off[s + 1] - c->h_vis_off[s]) * (c->h_nbr_off[s + 1] - c->h_nbr_off[s]);
+        std::vector<int32_t> nv((size_t)base[c->S]);
+        for (int s = 0; s < c->S; ++s) {
+            const int64_t K = c->h_nbr_off[s + 1] - c->h_nbr_off[s];
+            for (int v = c->h_vis_off[s]; v < c->h_vis_off[s + 1]; ++v)
+                for (int64_t q = 0; q < K; ++q)
+                    nv[base[s] + (int64_t)(v - c->h_vis_off[s]) * K + q] = (int32_t)hv(c->h_nbr_idx[c->h_nbr_off[s] + q], c->h_vis_img[v]);
+        }
+        CTX_TRY(dev_upload(&c->d_nv_base, base.data(), base.size()));
+        CTX_TRY(dev_upload(&c->d_nbr_vis, nv.data(), nv.size()));
     }
     {
         std::vector<int32_t> sorted(c->h_src_chunks);
@@ -478,8 +509,11 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         for (int s = 0; s < c->S; ++s)
             for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q) {
                 const int s2 = c->h_nbr_idx[q];
-                for (int n = 0; n < c->N; ++n) {
-                    const DevPatch &a = c->h_patches[(size_t)s * c->N + n], &b = c->h_patches[(size_t)s2 * c->N + n];
+                for (int va = c->h_vis_off[s]; va < c->h_vis_off[s + 1]; ++va) {
+                    const int n = c->h_vis_img[va];
+                    const int64_t vb = hv(s2, n);
+                    if (vb < 0) continue;
+                    const DevPatch &a = c->h_patches[va], &b = c->h_patches[vb];
                     const int rh = std::min(a.off_h + a.H2, b.off_h + b.H2) - std::max(a.off_h, b.off_h);
                     const int rw = std::min(a.off_w + a.W2, b.off_w + b.W2 - 1) - std::max(a.off_w, b.off_w);
                     if (rh <= 0 || rw <= 0) continue;
@@ -497,7 +531,7 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         for (auto &v : by_len)
             for (auto &e : v) {
                 const int t = link_src[e.first], s2 = c->h_nbr_idx[e.first], n = e.second & 0xffff, ch = e.second >> 16;
-                desc.push_back(make_int4(s2 * c->N + n, t * c->N + n, ch, t));
+                desc.push_back(make_int4((int)hv(s2, n), (int)hv(t, n), ch, t));
             }
         c->n_value_items = (int64_t)desc.size();
         CTX_TRY(dev_upload(&c->d_value_items, desc.data(), desc.size()));
@@ -535,7 +569,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *ptrs[] = {c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_prep_mark, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_prep_mark, c->d_nv_base, c->d_nbr_vis, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     {
@@ -615,7 +649,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     }
     if (!c->dense && (size_t)n_targets * c->M > c->items_cap) {
         if (c->d_items) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_items)); c->d_items = nullptr; }
-        HIP_TRY(hipMalloc((void **)&c->d_items, (size_t)n_targets * c->M * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&c->d_items, (size_t)n_targets * c->M * sizeof(int2)));
         c->items_cap = (size_t)n_targets * c->M;
     }
     // work list: n_chunks = number of chunks of the batch when the caller knows its targets on the host, else bounded
@@ -707,7 +741,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
 #define PIXEL_ARGS                                                                                                \
     c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx,       \
     c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, G, c->d_acc, c->d_tile_off, c->d_rec, \
-    d_active_rank, c->d_items, c->M, c->d_work, c->d_work_total
+    d_active_rank, c->d_items, c->M, c->d_work, c->d_work_total, c->d_nv_base, c->d_nbr_vis
 #define LAUNCH_PIXEL_T(MODE, R) hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL_M(MODE) hipLaunchKernelGGL((pixel_kernel<MODE, double, true>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL(MODE) do { if (flags & CELESTE_FLAG_FP32) LAUNCH_PIXEL_T(MODE, float); else LAUNCH_PIXEL_T(MODE, double); } while (0)
@@ -960,9 +994,9 @@ extern "C" int celeste_elbo_eval_multi(celeste_ctx_t *c, const double *vp, int32
         MU_TRY(hipMemcpyAsync(d_pb, pb.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(cross_kernel, dim3((unsigned)(np * c->N)), dim3(64), 0, c->stream, c->d_images, c->d_patches,
                            c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx, c->d_val_off,
-                           c->d_val, d_pa, d_pb, c->N, c->NC, d_rec);
+                           c->d_val, d_pa, d_pb, c->N, c->NC, d_rec, c->d_vis_off, c->d_vis_img, (int)c->dense);
         hipLaunchKernelGGL(cross_lift_kernel, dim3((unsigned)np), dim3(256), 0, c->stream, d_vp, c->d_images, c->d_patches,
-                           c->d_geo, d_pa, d_pb, d_rec, c->N, d_x);
+                           c->d_geo, d_pa, d_pb, d_rec, c->N, d_x, c->d_vis_off, c->d_vis_img, (int)c->dense);
         MU_TRY(hipMemcpyAsync(hx.data(), d_x, hx.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     MU_TRY(hipMemcpyAsync(hv.data(), d_v, Sa * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1032,8 +1066,8 @@ extern "C" int celeste_ctx_work_stats(celeste_ctx_t *c, int32_t n_targets, const
         const int t = targets[q];
         if (t < 0 || t >= c->S) return CELESTE_ERR_INVALID_ARG;
         int64_t A = 0, R = 0, PC = 0;   // PC: non-empty (source, image) patches whose constants are read
-        for (int n = 0; n < c->N; ++n) {
-            const DevPatch &p = c->h_patches[(size_t)t * c->N + n];
+        for (int v = c->h_vis_off[t]; v < c->h_vis_off[t + 1]; ++v) {
+            const DevPatch &p = c->h_patches[v];
             if (p.H2 * p.W2 > 0) {
                 A += (int64_t)p.H2 * p.W2;  // upper bound of visited pixels (NaN / masked pixels are skipped)
                 R += p.H2;
@@ -1043,11 +1077,10 @@ extern "C" int celeste_ctx_work_stats(celeste_ctx_t *c, int32_t n_targets, const
             }
         }
         const int64_t Kn = c->h_nbr_off[t + 1] - c->h_nbr_off[t];
-        for (int64_t q2 = c->h_nbr_off[t]; q2 < c->h_nbr_off[t + 1]; ++q2)
-            for (int n = 0; n < c->N; ++n) {
-                const DevPatch &p = c->h_patches[(size_t)c->h_nbr_idx[q2] * c->N + n];
-                PC += p.H2 * p.W2 > 0;
-            }
+        for (int64_t q2 = c->h_nbr_off[t]; q2 < c->h_nbr_off[t + 1]; ++q2) {
+            const int s2 = c->h_nbr_idx[q2];
+            for (int v = c->h_vis_off[s2]; v < c->h_vis_off[s2 + 1]; ++v) PC += c->h_patches[v].H2 * c->h_patches[v].W2 > 0;
+        }
         out->active_pixel_visits += A;
         out->patch_rows += R;
         out->neighbor_links += Kn;
@@ -1299,7 +1332,7 @@ extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32
                                c->d_vis_off, c->M, (int)c->dense, nullptr, nullptr, 0);
         hipLaunchKernelGGL(render_kernel, dim3((unsigned)((size_t)c->S * c->CH)), dim3(64), 0, c->stream, c->d_patches,
                            c->d_coefs, c->d_bitmaps, im.pixels, c->d_srcimg, c->d_comps, (int)image, c->N, c->NC,
-                           c->CH, c->chunk_px, im.H, d_plane);
+                           c->CH, c->chunk_px, im.H, d_plane, c->d_vis_off, c->d_vis_img, (int)c->dense);
         if (hipMemcpyAsync(out_plane, d_plane, npix * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = CELESTE_ERR_HIP;
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = CELESTE_ERR_HIP;

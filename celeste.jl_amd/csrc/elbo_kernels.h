@@ -74,10 +74,10 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const int32_t *__restrict__ targets, const int32_t *__restrict__ vis_off, int M, int dense,
             const int32_t *__restrict__ live, const int32_t *__restrict__ mark, int32_t stamp) {
     const int NC = 14 * K;
-    // one workgroup per visit = (source, image) pair with a non-empty patch; the tables stay dense (s * N + n).
+    // one workgroup per visit = (source, image) pair with a non-empty patch; the tables are indexed by visit (sn).
     // targets == nullptr: every visit of the context (neighbours are about to be rendered).  Otherwise one workgroup
     // per candidate visit k = ti * M + j of the batch's targets only (neighbours frozen).
-    int s, n;
+    int s, n, sn;
     if (targets) {
         const int k = blockIdx.x, ti = k / M, j = k - ti * M;
         if (live && ti >= *live) return;
@@ -88,14 +88,15 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             if (j >= vis_off[s + 1] - vo) return;
             n = vis_img[vo + j];
         }
-        const DevPatch &q = patches[(size_t)s * N + n];
+        sn = dense ? s * N + n : vis_off[s] + j;
+        const DevPatch &q = patches[sn];
         if (q.H2 * q.W2 <= 0) return;
     } else {
         s = vis_src[blockIdx.x]; n = vis_img[blockIdx.x];
+        sn = blockIdx.x;
         // mark (optional): only the sources this batch reads -- its targets and their neighbours (setup_thread)
         if (mark && mark[s] != stamp) return;
     }
-    const int sn = s * N + n;
     const int c = threadIdx.x;
     const double *vs = vp + (size_t)s * CEL_P;
     const DevPatch &p = patches[sn];
@@ -281,16 +282,25 @@ __device__ inline double wave_sum(double x) {
 // per batch on the source's own patch so that the pixel kernel gathers two doubles per covering
 // neighbour instead of re-evaluating 14 psf_K exponentials per (pixel, neighbour) pair.
 // ---------------------------------------------------------------------------------------------
-// items[ti * M + j] = image of the j-th visit of target ti (-1: none), so that the pixel kernels find their
+// items[ti * M + j] = {visit id, image} of the j-th visit of target ti (-1: none), so that the pixel kernels find their
 // (target, image) with two independent loads instead of a chain through the visit lists
 __global__ void visit_items_kernel(const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
-                                   const int32_t *__restrict__ vis_img, int M, int32_t *__restrict__ items) {
+                                   const int32_t *__restrict__ vis_img, int M, int2 *__restrict__ items) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_targets * M) return;
     const int ti = k / M, j = k - ti * M;
     const int t = targets[ti];
     const int vo = vis_off[t];
-    items[k] = j < vis_off[t + 1] - vo ? vis_img[vo + j] : -1;
+    items[k] = j < vis_off[t + 1] - vo ? make_int2(vo + j, vis_img[vo + j]) : make_int2(-1, -1);
+}
+
+// Table entry (visit) of (source, image) for the kernels off the hot path: s N + n when every source is listed in
+// every image, else a search of the source's visit list (-1: the source has no patch in that image)
+__device__ __forceinline__ int table_entry(const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img,
+                                           int dense, int N, int s, int n) {
+    if (dense) return s * N + n;
+    for (int v = vis_off[s]; v < vis_off[s + 1]; ++v) if (vis_img[v] == n) return v;
+    return -1;
 }
 
 // One launch for the per-batch bookkeeping: SrcGeo of every source, the visit items of the batch (unless every
@@ -300,7 +310,7 @@ __device__ inline void source_geo(const double *vp, int s, SrcGeo *geo);
 // launches.
 __device__ inline void setup_thread(int k, const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo,
                                     const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
-                                    const int32_t *__restrict__ vis_img, int M, int32_t *__restrict__ items,
+                                    const int32_t *__restrict__ vis_img, int M, int2 *__restrict__ items,
                                     int32_t *__restrict__ is_target, int32_t stamp, int32_t *__restrict__ prep_mark,
                                     const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx) {
     if (k < S) source_geo(vp, k, geo);
@@ -313,13 +323,13 @@ __device__ inline void setup_thread(int k, const double *__restrict__ vp, int S,
         const int ti = k / M, j = k - ti * M;
         const int t = targets[ti];
         const int vo = vis_off[t];
-        items[k] = j < vis_off[t + 1] - vo ? vis_img[vo + j] : -1;
+        items[k] = j < vis_off[t + 1] - vo ? make_int2(vo + j, vis_img[vo + j]) : make_int2(-1, -1);
     }
     if (is_target && k < n_targets) is_target[targets[k]] = stamp;
 }
 __global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo,
                              const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
-                             const int32_t *__restrict__ vis_img, int M, int32_t *__restrict__ items,
+                             const int32_t *__restrict__ vis_img, int M, int2 *__restrict__ items,
                              int32_t *__restrict__ is_target, int32_t stamp, int32_t *__restrict__ prep_mark,
                              const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx) {
     setup_thread(blockIdx.x * blockDim.x + threadIdx.x, vp, S, geo, targets, n_targets, vis_off, vis_img, M, items, is_target,
@@ -356,7 +366,7 @@ __device__ inline void visit_chunks(int k, const int32_t *__restrict__ targets, 
         if (j >= vis_off[t + 1] - vo) return;
         n = vis_img[vo + j];
     }
-    const DevPatch &P = patches[(size_t)t * N + n];
+    const DevPatch &P = patches[dense ? t * N + n : vis_off[t] + j];
     const int npx = P.H2 * P.W2;
     if (npx <= 0) return;
     const int gpx = chunk_px * G;                        // pixels of a full group
@@ -475,7 +485,7 @@ work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPat
 __global__ void __launch_bounds__(WORK1_NT)
 setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo, const int32_t *__restrict__ targets,
                       int n_targets, const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int M,
-                      int32_t *__restrict__ items, int32_t *__restrict__ is_target, int32_t stamp,
+                      int2 *__restrict__ items, int32_t *__restrict__ is_target, int32_t stamp,
                       const DevPatch *__restrict__ patches, int N, int CH, int chunk_px, int G, int dense,
                       int32_t *__restrict__ work, int32_t *__restrict__ work_total, const int32_t *__restrict__ live,
                       int32_t *__restrict__ prep_mark, const int64_t *__restrict__ nbr_off,
@@ -958,7 +968,8 @@ struct PixelInputs {
 template <bool MULTI>
 __device__ __forceinline__ PixelInputs load_pixel_inputs(
         const DevImage &img, const DevPatch &P, const DevPatch *__restrict__ patches, const uint8_t *__restrict__ bitmaps,
-        const int32_t *__restrict__ nbr_idx, int64_t nb0, int64_t nb1, const int64_t *__restrict__ val_off,
+        const int32_t *__restrict__ nbr_idx, const int32_t *__restrict__ nv, int64_t nb0, int64_t nb1,
+        const int64_t *__restrict__ val_off,
         const double2 *__restrict__ val, const int32_t *__restrict__ active_rank, int my_rank, int N, int n, int H2,
         int h, int w, int h2, int w2, bool in_range) {
     PixelInputs I;
@@ -988,7 +999,9 @@ __device__ __forceinline__ PixelInputs load_pixel_inputs(
     // ---- neighbours: gather their pre-rendered (E_G_s.v, var_G_s.v) ----
     for (int64_t q = nb0; q < nb1; ++q) {
         const int s2 = nbr_idx[q];
-        const DevPatch &Q = patches[(size_t)s2 * N + n];
+        const int v2 = nv ? nv[q - nb0] : s2 * N + n;    // the neighbour's table entry for this image (visit lists: -1 = none)
+        if (v2 < 0) continue;
+        const DevPatch &Q = patches[v2];
         const int ph2 = h - Q.off_h, pw2 = w - Q.off_w;  // 1-based in the neighbour's patch
         bool in = valid & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 < Q.W2);  // strict: elbo_objective.jl:349
         if (in && Q.bitmap_off >= 0) in = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
@@ -1002,7 +1015,7 @@ __device__ __forceinline__ PixelInputs load_pixel_inputs(
             }
         }
         if (in) {
-            const double2 ev = val[val_off[(size_t)s2 * N + n] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
+            const double2 ev = val[val_off[v2] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
             Ebar += ev.x;
             Vbar += ev.y;
             n_inact += MULTI ? (r2 < 0) : 1;
@@ -1035,8 +1048,9 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const int64_t *__restrict__ val_off, const double2 *__restrict__ val,
              const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px, int G,
              double *__restrict__ acc, const int64_t *__restrict__ tile_off, double *__restrict__ rec,
-             const int32_t *__restrict__ active_rank, const int32_t *__restrict__ items, int M,
-             const int32_t *__restrict__ work, const int32_t *__restrict__ work_total) {
+             const int32_t *__restrict__ active_rank, const int2 *__restrict__ items, int M,
+             const int32_t *__restrict__ work, const int32_t *__restrict__ work_total,
+             const int64_t *__restrict__ nv_base, const int32_t *__restrict__ nbr_vis) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
     __shared__ double etab[64];
     // work list (work_fill_kernel): groups of up to G chunks that exist, longest first.  The grid is the host's bound on
@@ -1048,24 +1062,25 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const int wg0 = work[item];  // record index of the group's first chunk, as the lift kernel expects: ((ti * M + j) * CH + ch)
     const int tn = wg0 / CH;
     const int ch0 = wg0 - tn * CH;
-    const int ti = tn / M;                     // tn = ti * M + j: target, j-th image it appears in (tables stay dense)
-    const int n = items ? items[tn] : tn - ti * M;   // items == nullptr: every source is listed in all M = N images
-    if (n < 0) continue;
+    const int ti = tn / M;                     // tn = ti * M + j: target, j-th image it appears in
     const int t = targets[ti];
-    const DevPatch &P = patches[(size_t)t * N + n];
+    int n = tn - ti * M, v = t * N + n;        // items == nullptr: every source is listed in all M = N images, visit = t N + n
+    if (items) { const int2 e = items[tn]; v = e.x; n = e.y; }
+    if (v < 0) continue;
+    const DevPatch &P = patches[v];
     const int H2 = P.H2, W2 = P.W2;
     const int npx = H2 * W2;
     if (ch0 * chunk_px >= npx) continue;  // the lift kernel recomputes this predicate
     const DevImage &img = images[n];
     const int lane = threadIdx.x;
-    const SrcImg si = srcimg[(size_t)t * N + n];
+    const SrcImg si = srcimg[v];
     // Workgroup prologue: the exp table and the target's components (64-byte records) are staged in LDS with
     // one coalesced read each and a single barrier (the scalar data cache cannot hold 8 waves x 1.8 KB per CU:
     // 68 % of per-component s_loads missed to L2).
     __shared__ Comp tc[14 * CEL_MAXK];
     __shared__ CompR<R> tcr_f[sizeof(R) == 4 ? 14 * CEL_MAXK : 1];
     {
-        const double *src = reinterpret_cast<const double *>(comps + ((size_t)t * N + n) * NC);
+        const double *src = reinterpret_cast<const double *>(comps + (size_t)v * NC);
         double *dst = reinterpret_cast<double *>(tc);
         R *dstf = reinterpret_cast<R *>(tcr_f);
         const double tabv = g_exp2_table[lane];
@@ -1080,6 +1095,8 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     const CompR<R> *tcr = sizeof(R) == 4 ? tcr_f : reinterpret_cast<const CompR<R> *>(tc);
     const double *__restrict__ tcoef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
     const int64_t nb0 = nbr_off[t], nb1 = nbr_off[t + 1];
+    // visit lists: the row of this visit in the table of the neighbours' visits
+    const int32_t *__restrict__ nv = nbr_vis ? nbr_vis + nv_base[t] + (int64_t)(tn - ti * M) * (nb1 - nb0) : nullptr;
     // several active sources (celeste_elbo_eval_multi): a pixel of two active patches is visited by the earlier
     // one only (elbo_objective.jl:430-470) -- its value term and inactive-source count are dropped here
     const int my_rank = MULTI ? active_rank[t] : 0;
@@ -1106,7 +1123,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         const int w2 = idx / H2, h2 = idx - w2 * H2;        // 0-based patch coordinates, h fastest
         const int h = P.off_h + h2 + 1, w = P.off_w + w2 + 1;  // 1-based image coordinates
         const double hh = (double)h, ww = (double)w;
-#define LOAD_PIXEL_INPUTS() load_pixel_inputs<MULTI>(img, P, patches, bitmaps, nbr_idx, nb0, nb1, val_off, val, active_rank, \
+#define LOAD_PIXEL_INPUTS() load_pixel_inputs<MULTI>(img, P, patches, bitmaps, nbr_idx, nv, nb0, nb1, val_off, val, active_rank, \
                                                      my_rank, N, n, H2, h, w, h2, w2, in_range)
         // ---- the active source ----
         const bool own_geo = in_range && (w2 < W2 - 1);  // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
@@ -1227,7 +1244,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             }
         }
         if constexpr (MODE == 3)
-            store_entries<0>(T, rec + (size_t)(tile_off[(size_t)t * N + n] + (base >> 6)) * (ACC_N * 64) + lane);
+            store_entries<0>(T, rec + (size_t)(tile_off[v] + (base >> 6)) * (ACC_N * 64) + lane);
         else
             accum_entries<MODE, 0>(T, slot);
     }
@@ -1268,7 +1285,7 @@ typedef double d2v __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(RSUM_NT)
 record_sum_kernel(const DevPatch *__restrict__ patches, const int32_t *__restrict__ targets,
                   const int64_t *__restrict__ tile_off, const double2 *__restrict__ rec,
-                  const int32_t *__restrict__ items, int N, int M, int RCH, int sum_tiles,
+                  const int2 *__restrict__ items, int N, int M, int RCH, int sum_tiles,
                   double *__restrict__ acc, const int32_t *__restrict__ work, const int32_t *__restrict__ work_total) {
     // part index is the slow grid axis: every patch's first part is launched before any second part.  When a part
     // is a chunk of the pixel kernel (sum_tiles * 64 == chunk_px) the grid runs over that kernel's work list.
@@ -1283,17 +1300,17 @@ record_sum_kernel(const DevPatch *__restrict__ patches, const int32_t *__restric
         tn = blockIdx.x - part * TN;
     }
     const int ti = tn / M;
-    const int n = items ? items[tn] : tn - ti * M;
-    if (n < 0) return;
     const int t = targets[ti];
-    const DevPatch &P = patches[(size_t)t * N + n];
+    const int vis = items ? items[tn].x : t * N + (tn - ti * M);   // table entry (visit) of (target, image)
+    if (vis < 0) return;
+    const DevPatch &P = patches[vis];
     const int npx = P.H2 * P.W2;
     const int tile0 = part * sum_tiles;
     const int ntiles = min(sum_tiles, ((npx + 63) >> 6) - tile0);
     if (ntiles <= 0) return;  // the lift kernel recomputes this predicate (part * sum_tiles * 64 < npx)
     const int tid = threadIdx.x;
     const d2v *__restrict__ src = reinterpret_cast<const d2v *>(rec) +
-                                  (size_t)(tile_off[(size_t)t * N + n] + tile0) * (ACC_N * 32) + tid;
+                                  (size_t)(tile_off[vis] + tile0) * (ACC_N * 32) + tid;
     d2v a[RSUM_K];
 #pragma unroll
     for (int k = 0; k < RSUM_K; ++k) a[k] = (d2v)(0.0);
@@ -1535,8 +1552,8 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         const int nt = min(LIFT_NT, n_vis - n0);
         // pass 1: chunk records -> per-image record; brightness moments and exponent coefficients
         for (int k = tid; k < nt * ACC_N; k += nthr) {
-            const int i = k / ACC_N, e = k - i * ACC_N, n = vis_img[vo + n0 + i];
-            const DevPatch &P = patches[(size_t)t * N + n];
+            const int i = k / ACC_N, e = k - i * ACC_N;
+            const DevPatch &P = patches[vo + n0 + i];   // tables are indexed by visit
             const int npx = P.H2 * P.W2;
             double s = 0.0;
             for (int ch = 0; ch < CH; ++ch)
@@ -1570,7 +1587,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
                 param_rows(p, st0, cn0, sd0, cls0);
                 const int r = st0 + a * sd0;
                 double v = 0.0;
-                if (r >= 4 && r < 6) { if (p < 2) v = patches[(size_t)t * N + vis_img[vo + n0 + i]].J[(r - 4) + 2 * p]; }
+                if (r >= 4 && r < 6) { if (p < 2) v = patches[vo + n0 + i].J[(r - 4) + 2 * p]; }
                 else if (r == 6) { if (p == 2) v = 1.0; }
                 else if (r >= 7) { if (p >= 3 && p < 6) v = s_jsh[(r - 7) + 3 * (p - 3)]; }
                 else {
@@ -1756,25 +1773,28 @@ cross_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const uint8_t *__restrict__ bitmaps, const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
              const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
              const int64_t *__restrict__ val_off, const double2 *__restrict__ val, const int32_t *__restrict__ pair_a,
-             const int32_t *__restrict__ pair_b, int N, int NC, double *__restrict__ out) {
+             const int32_t *__restrict__ pair_b, int N, int NC, double *__restrict__ out,
+             const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int dense) {
     __shared__ double etab[64];
     __shared__ double sX[2 * ZV][64], sY[2 * ZV][64];
     const int pair = blockIdx.x / N, n = blockIdx.x - pair * N;
     const int a = pair_a[pair], b = pair_b[pair];
     const int lane = threadIdx.x;
     etab[lane] = g_exp2_table[lane];
-    const DevPatch &Pa = patches[(size_t)a * N + n], &Pb = patches[(size_t)b * N + n];
+    const int va = table_entry(vis_off, vis_img, dense, N, a, n), vb = table_entry(vis_off, vis_img, dense, N, b, n);
+    const bool both = va >= 0 && vb >= 0;                  // else: one of them has no patch in this image
+    const DevPatch &Pa = patches[both ? va : 0], &Pb = patches[both ? vb : 0];
     const DevImage &img = images[n];
     // pixels both sources light up: rows of both patches, columns of both minus each one's last
     const int h_lo = max(Pa.off_h, Pb.off_h), h_hi = min(Pa.off_h + Pa.H2, Pb.off_h + Pb.H2);
     const int w_lo = max(Pa.off_w, Pb.off_w), w_hi = min(Pa.off_w + Pa.W2 - 1, Pb.off_w + Pb.W2 - 1);
-    const int rh = h_hi - h_lo, rw = w_hi - w_lo;
+    const int rh = both ? h_hi - h_lo : 0, rw = w_hi - w_lo;
     double acc0 = 0.0, acc1 = 0.0;
     const int e0 = lane, e1 = lane + 64;                   // entries r1 * 10 + r2 owned by this lane
     __syncthreads();
     if (rh > 0 && rw > 0) {
-        const SrcImg sa = srcimg[(size_t)a * N + n], sb = srcimg[(size_t)b * N + n];
-        const Comp *ca = comps + ((size_t)a * N + n) * NC, *cb = comps + ((size_t)b * N + n) * NC;
+        const SrcImg sa = srcimg[va], sb = srcimg[vb];
+        const Comp *ca = comps + (size_t)va * NC, *cb = comps + (size_t)vb * NC;
         const double *ta = coefs + (size_t)Pa.stamp * (CEL_COEF * CEL_COEF), *tb = coefs + (size_t)Pb.stamp * (CEL_COEF * CEL_COEF);
         const int npx = rh * rw;
         for (int base = 0; base < npx; base += 64) {
@@ -1794,12 +1814,14 @@ cross_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             double E = (double)img.sky[gi] + Fa.A, V = Fa.B - Fa.A * Fa.A;
             for (int64_t q = nbr_off[a]; q < nbr_off[a + 1]; ++q) {
                 const int s2 = nbr_idx[q];
-                const DevPatch &Q = patches[(size_t)s2 * N + n];
+                const int v2 = table_entry(vis_off, vis_img, dense, N, s2, n);
+                if (v2 < 0) continue;
+                const DevPatch &Q = patches[v2];
                 const int ph2 = h - Q.off_h, pw2 = w - Q.off_w;
                 bool in = ok & (ph2 >= 1) & (ph2 <= Q.H2) & (pw2 >= 1) & (pw2 < Q.W2);
                 if (in && Q.bitmap_off >= 0) in = bitmaps[Q.bitmap_off + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)] != 0;
                 if (in) {
-                    const double2 ev = val[val_off[(size_t)s2 * N + n] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
+                    const double2 ev = val[val_off[v2] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
                     E += ev.x; V += ev.y;
                 }
             }
@@ -1855,7 +1877,8 @@ __global__ void __launch_bounds__(256)
 cross_lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
                   const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
                   const int32_t *__restrict__ pair_a, const int32_t *__restrict__ pair_b,
-                  const double *__restrict__ rec, int N, double *__restrict__ out) {
+                  const double *__restrict__ rec, int N, double *__restrict__ out,
+                  const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int dense) {
     __shared__ double sJa[ZV * LIFT_NP], sJb[ZV * LIFT_NP], sM[ZV * ZV], sva[CEL_P], svb[CEL_P];
     const int pair = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int a = pair_a[pair], b = pair_b[pair];
@@ -1865,10 +1888,12 @@ cross_lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ im
     __syncthreads();
     for (int n = 0; n < N; ++n) {
         const int band0 = images[n].band - 1;
+        const int va = table_entry(vis_off, vis_img, dense, N, a, n), vb = table_entry(vis_off, vis_img, dense, N, b, n);
+        if (va < 0 || vb < 0) continue;   // (uniform) no common image: the record is zero
         for (int k = tid; k < ZV * LIFT_NP; k += nthr) {
             const int r = k / LIFT_NP, p = k - r * LIFT_NP;
-            sJa[k] = zjac_entry(r, p, sva, patches[(size_t)a * N + n], geo[a].jsh, band0);
-            sJb[k] = zjac_entry(r, p, svb, patches[(size_t)b * N + n], geo[b].jsh, band0);
+            sJa[k] = zjac_entry(r, p, sva, patches[va], geo[a].jsh, band0);
+            sJb[k] = zjac_entry(r, p, svb, patches[vb], geo[b].jsh, band0);
         }
         for (int k = tid; k < ZV * ZV; k += nthr) sM[k] = rec[((size_t)pair * N + n) * (ZV * ZV) + k];
         __syncthreads();
@@ -1901,12 +1926,14 @@ __global__ void __launch_bounds__(64)
 render_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
               const uint8_t *__restrict__ bitmaps, const float *__restrict__ pixels, const SrcImg *__restrict__ srcimg,
               const Comp *__restrict__ comps, int n, int N, int NC, int CH, int chunk_px, int imgH,
-              double *__restrict__ plane) {
+              double *__restrict__ plane, const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img,
+              int dense) {
     __shared__ double etab[64];
     const int S = gridDim.x / CH;
     const int ch = blockIdx.x / S;
     const int s = blockIdx.x - ch * S;
-    const int sn = s * N + n;
+    const int sn = table_entry(vis_off, vis_img, dense, N, s, n);
+    if (sn < 0) return;                    // the source has no patch in this image
     const DevPatch &P = patches[sn];
     const int H2 = P.H2, W2 = P.W2;
     const int npx = H2 * (W2 - 1);
