@@ -83,6 +83,7 @@ struct celeste_ctx {
     int4 *d_value_items = nullptr;  // value_kernel work items: {neighbour's table entry, target's, chunk, target}
     int64_t n_value_items = 0;
     int32_t *d_prep_mark = nullptr; // per source: stamp of the last batch that read its per-image tables
+    double *d_lg_sum = nullptr;     // per visit: sum of lgamma(pixel + 1) over the patch's visited pixels
     int64_t *d_nv_base = nullptr;   // visit-list mode: per source, start of its rows in d_nbr_vis
     int32_t *d_nbr_vis = nullptr;   // visit-list mode: [visit of s][neighbour of s] -> the neighbour's visit in that image
     int2 *d_items = nullptr;         // [ti * M + j] of the current batch: {visit, image}
@@ -275,15 +276,10 @@ extern "C" int celeste_images_create(int32_t n_images, const celeste_image_t *im
         IMG_TRY(dev_upload(&ds, im.sky, (size_t)im.H * im.W)); c->plane_allocs.push_back(ds);
         IMG_TRY(dev_upload(&di, im.nelec_per_nmgy, (size_t)im.H)); c->plane_allocs.push_back(di);
         d.pixels = dp; d.sky = ds; d.iota = di;
-        double *dl = nullptr, *dli = nullptr;
-        IMG_TRY(dev_upload<double>(&dl, nullptr, (size_t)im.H * im.W)); c->plane_allocs.push_back(dl);
+        double *dli = nullptr;
         IMG_TRY(dev_upload<double>(&dli, nullptr, (size_t)im.H)); c->plane_allocs.push_back(dli);
-        {
-            const size_t npix = (size_t)im.H * im.W;
-            hipLaunchKernelGGL(plane_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, nullptr, dp, di, im.H,
-                               im.W, dl, dli);
-        }
-        d.lgx = dl; d.log_iota = dli;
+        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((im.H + 255) / 256)), dim3(256), 0, nullptr, di, im.H, dli);
+        d.log_iota = dli;
         c->h_images[n] = d;
     }
     IMG_TRY(dev_upload(&c->d_images, c->h_images.data(), c->h_images.size()));
@@ -459,6 +455,10 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
     CTX_TRY(dev_upload(&c->d_vis_off, c->h_vis_off.data(), c->h_vis_off.size()));
     CTX_TRY(dev_upload(&c->d_vis_img, c->h_vis_img.data(), c->h_vis_img.size()));
     CTX_TRY(dev_upload(&c->d_vis_src, c->h_vis_src.data(), c->h_vis_src.size()));
+    CTX_TRY(dev_upload<double>(&c->d_lg_sum, nullptr, (size_t)c->V));
+    if (c->V > 0)
+        hipLaunchKernelGGL(patch_lgamma_kernel, dim3((unsigned)c->V), dim3(256), 0, nullptr, c->d_images, c->d_patches,
+                           c->d_vis_img, c->d_bitmaps, c->d_lg_sum);
     const char *env_chunk = getenv("CELESTE_CHUNK_PX");
     if (env_chunk && atoi(env_chunk) >= 64) c->chunk_px = (atoi(env_chunk) + 63) / 64 * 64;
     c->CH = c->max_npx > 0 ? (c->max_npx + c->chunk_px - 1) / c->chunk_px : 1;
@@ -569,7 +569,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *ptrs[] = {c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_prep_mark, c->d_nv_base, c->d_nbr_vis, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_prep_mark, c->d_lg_sum, c->d_nv_base, c->d_nbr_vis, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     {
@@ -774,12 +774,12 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                            c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M,
                            c->RCH, c->sum_tiles * 64, flags,
-                           d_v, d_d, d_h, d_counters, d_status, d_live);
+                           d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum);
     } else
     hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                        c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH,
                        c->chunk_px, flags,
-                       d_v, d_d, d_h, d_counters, d_status, d_live);
+                       d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum);
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[3], stream)); c->ev_valid = 1; }
     HIP_TRY(hipGetLastError());
     return CELESTE_OK;

@@ -32,8 +32,7 @@ struct DevImage {
     const float *pixels;
     const float *sky;
     const float *iota;
-    // parameter-independent per-pixel / per-row terms, computed once at context creation:
-    const double *lgx;       // lgamma(pixel + 1)   (elbo_objective.jl:391), 0 for NaN pixels
+    // parameter-independent per-row term, computed once at context creation:
     const double *log_iota;  // Float32 log(iota[h]) widened (elbo_objective.jl:292)
 };
 

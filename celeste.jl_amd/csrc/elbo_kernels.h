@@ -178,17 +178,41 @@ __device__ inline void source_geo(const double *vp, int s, SrcGeo *geo) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// plane_kernel: parameter-independent terms, once per context
+// Parameter-independent terms, once per context.
+// iota_kernel: log(iota) per image row.
+// patch_lgamma_kernel: sum of lgamma(pixel + 1) over the visited pixels of every (source, image) patch
+// (elbo_objective.jl:391 subtracts it pixel by pixel; it depends on no parameter, so the pixel kernel neither reads an
+// 8-byte plane for it nor carries it through the component loop: the lift subtracts the patch's constant).  One
+// workgroup per visit, fixed-order reduction.
 // ---------------------------------------------------------------------------------------------
-__global__ void plane_kernel(const float *__restrict__ pixels, const float *__restrict__ iota, int H, int W,
-                             double *__restrict__ lgx, double *__restrict__ log_iota) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (size_t)H * W) {
-        const float x = pixels[i];
-        lgx[i] = isnan(x) ? 0.0 : lgamma((double)x + 1.0);
-    }
+__global__ void iota_kernel(const float *__restrict__ iota, int H, double *__restrict__ log_iota) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // log(iota) is a Float32 log in the reference (iota::Float32, elbo_objective.jl:292)
-    if (i < (size_t)H) log_iota[i] = (double)(float)log((double)iota[i]);
+    if (i < H) log_iota[i] = (double)(float)log((double)iota[i]);
+}
+__global__ void __launch_bounds__(256)
+patch_lgamma_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ patches,
+                    const int32_t *__restrict__ vis_img, const uint8_t *__restrict__ bitmaps, double *__restrict__ out) {
+    __shared__ double s_part[256];
+    const int v = blockIdx.x;
+    const DevPatch &P = patches[v];
+    const DevImage &img = images[vis_img[v]];
+    const int npx = P.H2 * P.W2;
+    double s = 0.0;
+    for (int idx = threadIdx.x; idx < npx; idx += 256) {
+        const int w2 = idx / P.H2, h2 = idx - w2 * P.H2;
+        const float x = img.pixels[(size_t)(P.off_h + h2) + (size_t)img.H * (P.off_w + w2)];
+        bool valid = !isnan(x);                              // elbo_objective.jl:459
+        if (valid && P.bitmap_off >= 0) valid = bitmaps[P.bitmap_off + h2 + (int64_t)P.H2 * w2] != 0;   // :445
+        if (valid) s += lgamma((double)x + 1.0);
+    }
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[v] = s_part[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -961,7 +985,7 @@ __device__ __forceinline__ double galaxy_sums_pk(const CompR<float> *tc, int nc,
 // Per-pixel inputs of the pixel term: the pixel itself, sky + the pre-rendered light of the covering neighbours, the
 // per-row calibration; `valid` = the pixel is visited (elbo_objective.jl:445, 459).
 struct PixelInputs {
-    double x, Ebar, Vbar, lgx, iota, log_iota;
+    double x, Ebar, Vbar, lgx, iota, log_iota;   // lgx: several active sources only (else the lift subtracts the patch's sum)
     int n_inact;
     bool valid, dup;
 };
@@ -981,7 +1005,6 @@ __device__ __forceinline__ PixelInputs load_pixel_inputs(
 #else
     const float skyf = img.sky[gi];
 #endif
-    I.lgx = img.lgx[gi];
 #if CELESTE_MUTANT == 1
     const int irow = min(w, img.H);
 #else
@@ -1023,6 +1046,8 @@ __device__ __forceinline__ PixelInputs load_pixel_inputs(
     }
     if (MULTI && dup) n_inact = 0;
     I.x = (double)xf; I.Ebar = Ebar; I.Vbar = Vbar; I.n_inact = n_inact; I.valid = valid; I.dup = dup;
+    // several active sources: a pixel two of them cover is counted by the earlier one only, so the term stays per pixel
+    I.lgx = (MULTI && valid && !dup) ? lgamma((double)xf + 1.0) : 0.0;
     return I;
 }
 
@@ -1486,7 +1511,9 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const PriorDev *__restrict__ prior, const int32_t *__restrict__ vis_off,
             const int32_t *__restrict__ vis_img, int N, int M, int CH, int chunk_px, uint32_t flags,
             double *__restrict__ out_v, double *__restrict__ out_d, double *__restrict__ out_h,
-            int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status, const int32_t *__restrict__ live) {
+            int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status, const int32_t *__restrict__ live,
+            const double *__restrict__ lg_sum) {
+    // lg_sum (per visit, patch_lgamma_kernel; nullptr: the records already hold the term, several active sources)
     if (live && (int)blockIdx.x >= *live) return;
     LIFT_TICK_DECL;
     __shared__ double sh_h[LIFT_NP * LIFT_NP];         // likelihood Hessian, upper triangle, params < 28
@@ -1577,7 +1604,10 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         }
         __syncthreads();
         LIFT_TICK(1);
-        if (tid == 0) for (int i = 0; i < nt; ++i) { sh_v += s_rec[i][0]; sh_cnt[0] += s_rec[i][ACC_CNT]; sh_cnt[1] += s_rec[i][ACC_CNT + 1]; }
+        if (tid == 0) for (int i = 0; i < nt; ++i) {
+            sh_v += lg_sum ? s_rec[i][0] - lg_sum[vo + n0 + i] : s_rec[i][0];
+            sh_cnt[0] += s_rec[i][ACC_CNT]; sh_cnt[1] += s_rec[i][ACC_CNT + 1];
+        }
         if (want_grad) {
             // pass 2: the non-zero entries of the 10 x 28 Jacobians of the reduced variables
             for (int k = tid; k < nt * LIFT_JZ; k += nthr) {

@@ -104,7 +104,7 @@ def test_hundred_contexts_on_one_image_handle(oracle):
     whole = cel.FieldContext(f.images, f.patches, f.neighbors)
     rv, rd, rh, rcnt, _ = whole.eval_batch(f.vp, np.arange(100), ALL)
     iset = cabi.ImageSet(f.images)
-    plane_bytes = sum(im.pixels.size for im in f.images) * (4 + 4 + 8)
+    plane_bytes = sum(im.pixels.size for im in f.images) * (4 + 4)     # pixels + sky, f32
     base = _free_device_bytes()
     ctxs = []
     for t in range(100):
@@ -113,9 +113,9 @@ def test_hundred_contexts_on_one_image_handle(oracle):
         nbrs = [list(range(1, len(loc)))] + [[] for _ in loc[1:]]
         ctxs.append((cel.FieldContext(f.images, patches, nbrs, image_set=iset), loc))
     used = base - _free_device_bytes()
-    # a context costs its patch tables and scratch (a few MB), not a copy of the planes (74 MB here, 244 MB for an
+    # a context costs its patch tables and scratch (a few MB), not a copy of the planes (37 MB here, 122 MB for an
     # SDSS-size field)
-    assert used < 100 * 0.06 * plane_bytes, (used, plane_bytes)
+    assert used < 100 * 0.1 * plane_bytes, (used, plane_bytes)
     for t, (ctx, loc) in enumerate(ctxs):
         v, d, h, cnt, st = ctx.eval_batch(f.vp[loc], [0], ALL)
         assert st[0] == 0 and np.array_equal(cnt[0], rcnt[t])
