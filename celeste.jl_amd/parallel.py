@@ -7,6 +7,8 @@ path, mirroring the reference's thread-level independence (ParallelRun.jl:546-60
 """
 from typing import Callable, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 
 from .partition import shard_targets
@@ -120,7 +122,13 @@ class DeviceShardedSweep:
         self.n = int(self.mine.size)
         self.width = max(1, max(len(s) for s in self.shards))
         self.dev = torch.device("cuda", ctx.device)
-        if world > 1:
+        # CELESTE_GATHER_SINGLE=1 (tests): a process group of ONE rank still runs the catalog gather, so that the
+        # RCCL path -- gather stream, events, all_gather_into_tensor -- is exercised on a one-GPU box
+        self.gather = world > 1
+        if world == 1 and os.environ.get("CELESTE_GATHER_SINGLE") == "1":
+            import torch.distributed as dist
+            self.gather = dist.is_available() and dist.is_initialized()
+        if self.gather:
             import torch.distributed as dist
             self.dist = dist
             self.backend = backend or dist.get_backend()
@@ -135,18 +143,18 @@ class DeviceShardedSweep:
             self.d_cnt = torch.zeros(max(self.n, 1), 2, dtype=torch.int64, device=self.dev)
             self.d_st = torch.zeros(max(self.n, 1), dtype=torch.int32, device=self.dev)
             self.compute_stream = torch.cuda.current_stream(self.dev)
-            if world > 1 and self.backend == "nccl":
+            if self.gather and self.backend == "nccl":
                 self.comm_stream = torch.cuda.Stream(self.dev)
                 self.gathered = torch.zeros(world * W * (1 + P), dtype=torch.float64, device=self.dev)
                 self.buf_free = [torch.cuda.Event(), torch.cuda.Event()]
                 for e in self.buf_free:
                     e.record(self.compute_stream)
-            elif world > 1:
+            elif self.gather:
                 self.h_block = torch.zeros(W * (1 + P), dtype=torch.float64).pin_memory()
                 self.gathered = torch.zeros(world * W * (1 + P), dtype=torch.float64)
         self.k = 0
         self.last = 0
-        self.gather_bytes = world * W * (1 + P) * 8 if world > 1 else 0
+        self.gather_bytes = world * W * (1 + P) * 8 if self.gather else 0
 
     def step(self, d_vp_ptr: int):
         """One sweep: evaluate this rank's shard against the parameter table at device pointer `d_vp_ptr`
@@ -156,7 +164,7 @@ class DeviceShardedSweep:
         self.k += 1
         self.last = k
         blk = self.blocks[k]
-        nccl = self.world > 1 and self.backend == "nccl"
+        nccl = self.gather and self.backend == "nccl"
         if nccl:
             self.compute_stream.wait_event(self.buf_free[k])   # the gather that last read this block is through
         if self.n > 0:
@@ -171,7 +179,7 @@ class DeviceShardedSweep:
                 self.comm_stream.wait_event(done)
                 self.dist.all_gather_into_tensor(self.gathered, blk)
                 self.buf_free[k].record(self.comm_stream)
-        elif self.world > 1:   # gloo: stage through the host (two ranks on one GPU in the tests)
+        elif self.gather:   # gloo: stage through the host (two ranks on one GPU in the tests)
             self.h_block.copy_(blk, non_blocking=True)
             self.compute_stream.synchronize()
             outs = list(self.gathered.view(self.world, -1).unbind(0))
@@ -179,7 +187,7 @@ class DeviceShardedSweep:
 
     def wait(self):
         """Every launched sweep and every gather is complete when this returns."""
-        if self.world > 1 and self.backend == "nccl":
+        if self.gather and self.backend == "nccl":
             self.comm_stream.synchronize()
         self.torch.cuda.synchronize(self.dev)
 
@@ -188,7 +196,7 @@ class DeviceShardedSweep:
         (identical on every rank), plus the status codes and pixel counters of this rank's shard."""
         self.wait()
         W = self.width
-        g = (self.gathered if self.world > 1 else self.blocks[self.last]).cpu().numpy().reshape(self.world, W * (1 + P))
+        g = (self.gathered if self.gather else self.blocks[self.last]).cpu().numpy().reshape(self.world, W * (1 + P))
         v = np.zeros(len(self.targets))
         d = np.zeros((len(self.targets), P))
         for r in range(self.world):

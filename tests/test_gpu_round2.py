@@ -27,8 +27,8 @@ def _free_device_bytes():
     return free.value
 
 
-def _launch_bench(tmp_path, nproc, extra):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _launch_bench(tmp_path, nproc, extra, **more_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **more_env)
     port = 29700 + os.getpid() % 200
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
@@ -74,6 +74,25 @@ def test_bench_single_rank_under_the_launcher(tmp_path):
                                     "--no-extras"])
     assert d["n_gpus"] == 1 and d["config"]["shard_sizes"] == [60] and d["value"] > 0
     assert d["config"]["catalog_gather_bytes_per_step"] == 0
+
+
+def test_bench_rccl_gather_path_on_a_group_of_one(tmp_path):
+    """the device-side catalog gather exactly as N > 1 runs it -- RCCL all_gather_into_tensor on its own stream, two
+    alternating blocks, events both ways -- on a process group of one rank (CELESTE_GATHER_SINGLE=1; RCCL refuses two
+    ranks on one device, so this is as close as a one-GPU box gets): the gathered catalog is the host API's"""
+    import celeste_jl_amd as cel
+    sys.path.insert(0, ROOT)
+    import bench
+    shape = ["--height", "300", "--width", "260", "--sources", "60", "--seed", "9"]
+    d = _launch_bench(tmp_path, 1, shape + ["--steps", "4", "--warmup", "2", "--no-extras", "--check-dir", str(tmp_path)],
+                      CELESTE_GATHER_SINGLE="1")
+    assert d["n_gpus"] == 1 and d["config"]["gather_backend"] == "nccl"
+    assert d["config"]["catalog_gather_bytes_per_step"] == 60 * 45 * 8
+    fld = bench.build_field(300, 260, 60, 9)
+    ctx = cel.FieldContext(fld.images, fld.patches, fld.neighbors)
+    v, dd, h, cnt, st = ctx.eval_batch(fld.vp, np.arange(60), ALL)
+    z = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    assert np.array_equal(z["v"], v) and np.array_equal(z["d"], dd) and np.array_equal(z["h"], h[z["mine"]])
 
 
 def test_device_sharded_sweep_single_process_matches_host_api():
