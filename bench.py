@@ -49,6 +49,49 @@ def profile_facts():
         return None
 
 
+def live_pmc(args, timeout_s=150):
+    """HBM traffic and VALU issue utilisation of pixel_kernel<2, double> measured in THIS run: three rocprofv3 --pmc
+    passes (FETCH_SIZE, WRITE_SIZE, SQ counters -- separate passes with --kernel-trace only, as the guide's HBM
+    section prescribes) over a few sweeps of the same field in a child process.  None when rocprofv3 is absent, fails
+    or times out; the line then falls back to the committed figures of profiles/hbm_traffic.json and says so."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = {}
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "3", "--warmup", "1", "--height", str(args.height),
+             "--width", str(args.width), "--sources", str(args.sources), "--seed", str(args.seed)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")):
+            with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+                cmd = [exe, "--pmc"] + list(counters) + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--"] + child
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+                files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    return None
+                rows = [row for f in files for row in csv.DictReader(open(f))
+                        if row["Kernel_Name"].replace("void ", "").startswith("pixel_kernel<2, double")]
+                if not rows:
+                    return None
+                gmax = max(int(row["Grid_Size"]) for row in rows)
+                for c in counters:
+                    vals = [float(row["Counter_Value"]) for row in rows if row["Counter_Name"] == c and int(row["Grid_Size"]) == gmax]
+                    if not vals:
+                        return None
+                    out[c] = sum(vals) / len(vals)
+    except Exception:
+        return None
+    return {"pixel_kernel_bytes_per_launch": (out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0,
+            "fetch_bytes": out["FETCH_SIZE"] * 1024.0, "write_bytes": out["WRITE_SIZE"] * 1024.0,
+            "pixel_kernel_valu_utilization": out["SQ_ACTIVE_INST_VALU"] * 4.0 / (out["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
+            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE "
+                      "(separate passes, --kernel-trace only) over 3 sweeps of the same field in a child process; "
+                      "KiB x 1024, uncorrected (4-8 B/lane loads); per-launch means of the full-grid dispatches"}
+
+
 def _cached(path, make, cache=True):
     import pickle
     if cache and os.path.exists(path):
@@ -148,6 +191,9 @@ def main():
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed sweep and the roofline")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the rocprofv3 counter passes; report the committed profiles/hbm_traffic.json figures")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the profiled child of live_pmc
     ap.add_argument("--check-dir", default=None,
                     help="every rank writes its gathered (v, d) of the last sweep to <dir>/rank<r>.npz (tests)")
     args = ap.parse_args()
@@ -232,6 +278,8 @@ def main():
         sweep.step(d_vp.data_ptr())
     sync()
     dt = time.perf_counter() - t0
+    if args.pmc_child:     # the profiled child of live_pmc(): the sweeps are all rocprofv3 needs
+        return
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -300,6 +348,13 @@ def main():
     # HBM-bound kernel of the path; a measurement aid next to the fused throughput configuration
     split = None
     facts = profile_facts() or {}
+    # HBM bytes and VALU utilisation of the dominant kernel: measured now when rocprofv3 can run here, else the
+    # committed figures (the flop count per pixel visit always comes from the ISA of the tree, tools/count_flops.py)
+    pmc_live = None
+    if world == 1 and rank == 0 and args.config == 3 and args.dtype == "f64" and extras and not args.no_live_pmc:
+        pmc_live = live_pmc(args)
+        if pmc_live:
+            facts = dict(facts, **pmc_live)
     if extras and args.config == 3:
         d_h = sweep.d_h
 
@@ -374,12 +429,13 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": facts.get("pixel_kernel_bytes_per_launch") if (world == 1 and args.config == 3 and
                                                                                      args.dtype == "f64") else None,
-                         "traffic_source": facts.get("source"),
+                         "traffic_source": facts.get("source"), "traffic_measured_in_this_run": bool(pmc_live),
                          "kernel": kname, "kernel_ms": float(kms[1]),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "valu_utilization": facts.get("pixel_kernel_valu_utilization") if args.dtype == "f64" else None,
                          "note": "the fused kernel is FP64-VALU bound, not HBM- or MFMA-bound (SURVEY.md F8, DESIGN.md 4.3): "
-                                 "valu_utilization = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles from the committed PMC pass; "
+                                 "valu_utilization = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles (traffic_source says where the "
+                                 "counters come from); "
                                  "the HBM-bound kernel of the path is split_variant.kernel; figures are rank 0's launch"},
             "kernels_ms": {"prep": float(kms[0]), "pixel": float(kms[1]), "lift": float(kms[2])},
             "pixel_visits_per_sec_rank0": pixel_visits_local / (kms[1] * 1e-3),
