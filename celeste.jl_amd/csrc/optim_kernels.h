@@ -537,7 +537,7 @@ struct TriLds { double *A, *hv, *td, *te, *te2, *q; };   // hv, te, q: tred_wave
 // Trust-region step in the tridiagonal basis.  In: L.A = H (destroyed), g (lane register), delta.
 // Out: step p (lane register), model decrease m, interior flag.  Returns false in the hard case (caller falls
 // back to the eigen-decomposition).
-__device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int ln, int secular_iters, double &p_out,
+__device__ __forceinline__ bool tri_tr_solve(const TriLds &L, double g, double delta, int ln, int secular_iters, double &p_out,
                                     double &m_out, int &interior_out) {
     const bool fr = ln < NF;
     OPT_TICK_DECL;
@@ -695,7 +695,7 @@ __device__ inline bool tri_tr_solve(const TriLds &L, double g, double delta, int
 
 // The same sub-problem through the full eigen-decomposition (Optim.jl's own route): the hard-case fallback of
 // tri_tr_solve, and OptParams.solver = 1.  In: A = H (LDS, destroyed), g, delta.  w, e, q, cv: NF doubles of LDS each.
-__device__ inline void eig_tr_solve(double *A, double *w, double *e, double *q, double *cvs, double g, double delta_in,
+__device__ __forceinline__ void eig_tr_solve(double *A, double *w, double *e, double *q, double *cvs, double g, double delta_in,
                                     int tid, int secular_iters, double &step, double &m, int &interior) {
     const bool fr = tid < NF;
     __shared__ double s_g[NF];
