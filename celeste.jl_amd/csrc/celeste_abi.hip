@@ -372,9 +372,10 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         if (d.H2 * d.W2 > c->max_npx) c->max_npx = d.H2 * d.W2;
     }
     for (int s = 0; s < c->S; ++s) c->M = std::max(c->M, n_vis[s]);
-    // single-field problems (every source in every image, or nearly: M == N): list all N images for every source
-    // and let the kernels map (target, j) -> image j directly
-    c->dense = c->M == c->N && !getenv("CELESTE_FORCE_VISIT_LISTS");   // (the variable exists for testing)
+    // single-field problems (every source in every image, or nearly: at least 3/4 of the S x N pairs exist): list all
+    // N images for every source and let the kernels map (target, j) -> image j directly
+    c->dense = (int64_t)ent.size() * 4 >= (int64_t)c->S * c->N * 3 && !getenv("CELESTE_FORCE_VISIT_LISTS");   // (the variable exists for testing)
+    if (c->dense) c->M = c->N;
     c->h_vis_off.assign((size_t)c->S + 1, 0);
     if (c->dense) {
         DevPatch empty; memset(&empty, 0, sizeof empty);

@@ -456,6 +456,36 @@ def test_randomised_multi_active(oracle, seed):
     print("multi fuzz", seed, "S", S, "active", act, "flags", flags, abs(v - ov) / abs(ov), rel_err(h, oh) if flags & 2 else None)
 
 
+def test_multi_active_and_renderer_with_visit_lists(oracle):
+    """the kernels off the hot path on a many-image problem, where the per-(source, image) tables are indexed by visit
+    and a source's neighbour may be missing from an image: several active sources (cross terms between sources that
+    share only some of their images) against the CPU restatement, the expected-image renderer against numpy"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    from joint_objective import expected_planes
+    f = synthetic.make_multifield((2, 2), 128, 128, 0.10, 24, seed=13)
+    S = len(f.catalog)
+    n_img = np.array([sum(p.active_pixel_bitmap.size > 0 for p in row) for row in f.patches])
+    assert n_img.min() < n_img.max() and n_img.sum() < 0.75 * S * len(f.images)   # visit lists, not the dense mode
+    # active sets: two sources in different numbers of images that are neighbours, plus a third one
+    pairs = [(a, b) for a in range(S) for b in f.neighbors[a] if n_img[a] != n_img[b]]
+    assert pairs, "the scene has neighbours that do not share all their images"
+    a, b = pairs[0]
+    third = next(s for s in range(S) if s not in (a, b))
+    nbrs = [[s for s in range(S) if s != t] for t in range(S)]
+    ctx = cel.FieldContext(f.images, f.patches, nbrs)
+    for act in ([a, b], [b, third, a]):
+        v, d, h, cnt = ctx.eval_multi(f.vp, act, ALL)
+        ov, od, oh, ocnt, ost = oracle.elbo_multi(ctx.problem, f.vp, act, ALL)
+        assert ost == 0 and np.array_equal(cnt, ocnt)
+        assert abs(v - ov) <= 1e-8 * abs(ov) and np.array_equal(h, h.T) and rel_err(h, oh) <= 1e-8
+        assert max(rel_err(d[:, k], od[k]) for k in range(len(act))) <= 1e-8
+    ref = expected_planes(f.images, f.patches, f.vp)
+    for n in (0, 7, len(f.images) - 1):
+        got = ctx.render_expected(f.vp, n)
+        assert np.abs(got - ref[n]).max() <= 1e-12 * max(np.abs(ref[n]).max(), 1e-300)
+
+
 def test_invalid_arguments_are_refused():
     """status codes instead of the reference's assertion failures (include/celeste_mi355x.h)"""
     import ctypes as C
