@@ -108,6 +108,8 @@ struct celeste_ctx {
     // per-batch scratch (grown on demand)
     double *d_acc = nullptr;
     size_t acc_cap = 0;
+    int32_t *d_rec_off = nullptr;    // [ti * M + j]: first chunk record of the j-th visit of target ti in d_acc
+    size_t rec_off_cap = 0;
     // staging for the host-pointer API: device side, and page-locked host side
     double *d_vp = nullptr;
     int32_t *d_targets = nullptr;
@@ -570,7 +572,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *ptrs[] = {c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_prep_mark, c->d_lg_sum, c->d_nv_base, c->d_nbr_vis, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_prep_mark, c->d_rec_off, c->d_lg_sum, c->d_nv_base, c->d_nbr_vis, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     {
@@ -642,7 +644,16 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     if (n_targets == 0) return CELESTE_OK;
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t need = (size_t)n_targets * c->M * c->CH * ACC_N;
+    // one 68-double record per chunk that exists (rec_off = prefix sum of the visits' chunk counts): exactly n_chunks
+    // when the caller knows its targets on the host, else at most n_targets x the chunk count of the richest source
+    const size_t rec_cap = n_chunks >= 0 ? (size_t)n_chunks
+                                         : std::min((size_t)n_targets * c->max_src_chunks, (size_t)n_targets * c->M * c->CH);
+    const size_t need = std::max<size_t>(rec_cap, 1) * ACC_N;
+    if ((size_t)n_targets * c->M > c->rec_off_cap) {
+        if (c->d_rec_off) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_rec_off)); c->d_rec_off = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_rec_off, (size_t)n_targets * c->M * sizeof(int32_t)));
+        c->rec_off_cap = (size_t)n_targets * c->M;
+    }
     if (need > c->acc_cap) {
         if (c->d_acc) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_acc)); c->d_acc = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_acc, need * sizeof(double)));
@@ -674,10 +685,10 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     int G = n_targets >= 512 ? 4 : 1;
     if (const char *e = getenv("CELESTE_CHUNK_GROUP")) if (atoi(e) >= 1 && atoi(e) <= 16) G = atoi(e);
     const int n_classes = WORK_CLASSES;   // work-list classes: full groups, then the patches' last groups by length
-    if ((size_t)n_wblk * n_classes > c->work_blk_cap) {
+    if ((size_t)n_wblk * (n_classes + 1) > c->work_blk_cap) {   // + the row of chunk counts (rec_off)
         if (c->d_work_blk) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_work_blk)); c->d_work_blk = nullptr; }
-        HIP_TRY(hipMalloc((void **)&c->d_work_blk, (size_t)n_wblk * n_classes * sizeof(int32_t)));
-        c->work_blk_cap = (size_t)n_wblk * n_classes;
+        HIP_TRY(hipMalloc((void **)&c->d_work_blk, (size_t)n_wblk * (n_classes + 1) * sizeof(int32_t)));
+        c->work_blk_cap = (size_t)n_wblk * (n_classes + 1);
     }
     const bool derivs = (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) != 0;
     const bool split = (flags & CELESTE_FLAG_SPLIT) != 0;
@@ -709,16 +720,18 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            0, stream, d_vp, c->S, c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M,
                            c->dense ? nullptr : c->d_items, render_neighbors ? c->d_needed : nullptr, c->stamp, c->d_patches,
                            c->N, c->CH, c->chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live, prep_mark,
-                           c->d_nbr_off, c->d_nbr_idx);
+                           c->d_nbr_off, c->d_nbr_idx, c->d_rec_off);
     } else {
         hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 255) / 256)), dim3(256), 0, stream, d_vp, c->S,
                            c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
                            render_neighbors ? c->d_needed : nullptr, c->stamp, prep_mark, c->d_nbr_off, c->d_nbr_idx);
         hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
                            c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, G, (int)c->dense, c->d_work_blk, d_live);
-        hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * n_classes, c->d_work_total);
+        hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * (n_classes + 1),
+                           c->d_work_total, n_wblk * n_classes);
         hipLaunchKernelGGL(work_fill_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
-                           c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, G, (int)c->dense, c->d_work_blk, c->d_work, d_live);
+                           c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, G, (int)c->dense, c->d_work_blk, c->d_work, d_live,
+                           c->d_rec_off);
     }
     // per-(source, image) constants: of every source when the neighbours are (re)rendered, else of the targets only
     if (render_neighbors) {
@@ -742,7 +755,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
 #define PIXEL_ARGS                                                                                                \
     c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx,       \
     c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, G, c->d_acc, c->d_tile_off, c->d_rec, \
-    d_active_rank, c->d_items, c->M, c->d_work, c->d_work_total, c->d_nv_base, c->d_nbr_vis
+    d_active_rank, c->d_items, c->M, c->d_work, c->d_work_total, c->d_nv_base, c->d_nbr_vis, c->d_rec_off
 #define LAUNCH_PIXEL_T(MODE, R) hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL_M(MODE) hipLaunchKernelGGL((pixel_kernel<MODE, double, true>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL(MODE) do { if (flags & CELESTE_FLAG_FP32) LAUNCH_PIXEL_T(MODE, float); else LAUNCH_PIXEL_T(MODE, double); } while (0)
@@ -775,12 +788,12 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                            c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M,
                            c->RCH, c->sum_tiles * 64, flags,
-                           d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum);
+                           d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum, nullptr);
     } else
     hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                        c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH,
                        c->chunk_px, flags,
-                       d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum);
+                       d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum, c->d_rec_off);
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[3], stream)); c->ev_valid = 1; }
     HIP_TRY(hipGetLastError());
     return CELESTE_OK;

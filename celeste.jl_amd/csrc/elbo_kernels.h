@@ -380,8 +380,9 @@ __global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__res
 // last_class > 0, one last group of that class (first chunk n_full * G) which is last_class pixel-loop iterations short.
 __device__ inline void visit_chunks(int k, const int32_t *__restrict__ targets, const DevPatch *__restrict__ patches,
                                     const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M,
-                                    int chunk_px, int G, bool dense, int &n_full, int &last_class) {
+                                    int chunk_px, int G, bool dense, int &n_full, int &last_class, int *n_chunks = nullptr) {
     n_full = 0; last_class = 0;
+    if (n_chunks) *n_chunks = 0;
     const int ti = k / M, j = k - ti * M;
     const int t = targets[ti];
     int n = j;
@@ -393,6 +394,7 @@ __device__ inline void visit_chunks(int k, const int32_t *__restrict__ targets, 
     const DevPatch &P = patches[dense ? t * N + n : vis_off[t] + j];
     const int npx = P.H2 * P.W2;
     if (npx <= 0) return;
+    if (n_chunks) *n_chunks = (npx + chunk_px - 1) / chunk_px;
     const int gpx = chunk_px * G;                        // pixels of a full group
     const int ngr = (npx + gpx - 1) / gpx;
     const int last_px = npx - (ngr - 1) * gpx;           // 1 .. gpx pixels in the last group
@@ -443,8 +445,8 @@ work_count_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPa
     __shared__ int s_wave[WORK_NT / 64];
     const int k = blockIdx.x * WORK_NT + threadIdx.x;
     if (live) n_visits = min(n_visits, *live * M);   // the host's target count is an upper bound (device-resident loops)
-    int n_full = 0, lc = 0;
-    if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc);
+    int n_full = 0, lc = 0, nch = 0;
+    if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc, &nch);
     int tot;
     block_prefix(n_full, s_wave, tot);
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
@@ -452,10 +454,16 @@ work_count_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPa
         block_rank(lc == c, s_wave, tot);
         if (threadIdx.x == 0) blk_cnt[(size_t)c * gridDim.x + blockIdx.x] = tot;
     }
+    // row WORK_CLASSES: chunks per block, for the record offsets of the visits (rec_off: a visit's chunk records are
+    // consecutive, visits in order -- the record buffer holds exactly the chunks that exist)
+    block_prefix(nch, s_wave, tot);
+    if (threadIdx.x == 0) blk_cnt[(size_t)WORK_CLASSES * gridDim.x + blockIdx.x] = tot;
 }
 
 // exclusive scan of cnt[0 .. n) in place, total -> *total (one workgroup)
-__global__ void __launch_bounds__(1024) work_scan_kernel(int32_t *__restrict__ cnt, int n, int32_t *__restrict__ total) {
+// total_at: *total = the exclusive prefix at that index (= the sum of the rows before it); total_at == n: the grand total
+__global__ void __launch_bounds__(1024) work_scan_kernel(int32_t *__restrict__ cnt, int n, int32_t *__restrict__ total,
+                                                         int total_at) {
     __shared__ int s_part[16];
     __shared__ int s_run;
     if (threadIdx.x == 0) s_run = 0;
@@ -472,24 +480,30 @@ __global__ void __launch_bounds__(1024) work_scan_kernel(int32_t *__restrict__ c
         int off = s_run;
         for (int w = 0; w < wv; ++w) off += s_part[w];
         if (i < n) cnt[i] = off + x - v;
+        if (i == total_at) *total = off + x - v;
         __syncthreads();
         if (threadIdx.x == 1023) s_run = off + x;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = s_run;
+    if (threadIdx.x == 0 && total_at >= n) *total = s_run;
 }
 
 __global__ void __launch_bounds__(WORK_NT)
 work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPatch *__restrict__ patches,
                  const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int N, int M, int CH,
                  int chunk_px, int G, int dense, const int32_t *__restrict__ blk_base, int32_t *__restrict__ work,
-                 const int32_t *__restrict__ live) {
+                 const int32_t *__restrict__ live, int32_t *__restrict__ rec_off) {
     __shared__ int s_wave[WORK_NT / 64];
     const int k = blockIdx.x * WORK_NT + threadIdx.x;
     if (live) n_visits = min(n_visits, *live * M);
-    int n_full = 0, lc = 0;
-    if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc);
+    int n_full = 0, lc = 0, nch = 0;
+    if (k < n_visits) visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc, &nch);
     int tot;
+    {   // first chunk record of visit k: chunks of the blocks before (scanned row WORK_CLASSES, minus the rows before it) + in-block prefix
+        const int base = blk_base[(size_t)WORK_CLASSES * gridDim.x + blockIdx.x] - blk_base[(size_t)WORK_CLASSES * gridDim.x];
+        const int pre = block_prefix(nch, s_wave, tot);
+        if (k < n_visits) rec_off[k] = base + pre;
+    }
     const int p0 = blk_base[blockIdx.x] + block_prefix(n_full, s_wave, tot);
     for (int g = 0; g < n_full; ++g) work[p0 + g] = k * CH + g * G;     // record index of the group's first chunk
     for (int c = 1; c < WORK_CLASSES; ++c) {
@@ -513,34 +527,36 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
                       const DevPatch *__restrict__ patches, int N, int CH, int chunk_px, int G, int dense,
                       int32_t *__restrict__ work, int32_t *__restrict__ work_total, const int32_t *__restrict__ live,
                       int32_t *__restrict__ prep_mark, const int64_t *__restrict__ nbr_off,
-                      const int32_t *__restrict__ nbr_idx) {
+                      const int32_t *__restrict__ nbr_idx, int32_t *__restrict__ rec_off) {
     if (blockIdx.x > 0) {
         setup_thread((blockIdx.x - 1) * WORK1_NT + threadIdx.x, vp, S, geo, targets, n_targets, vis_off, vis_img, M, items,
                      is_target, stamp, prep_mark, nbr_off, nbr_idx);
         return;
     }
     __shared__ int s_part[WORK1_NT / 64];
-    __shared__ int s_base[WORK_CLASSES + 1];
+    __shared__ int s_base[WORK_CLASSES + 2];
     int n_visits = n_targets * M;
     if (live) n_visits = min(n_visits, *live * M);
     const int per = (n_visits + WORK1_NT - 1) / WORK1_NT;
     const int k0 = threadIdx.x * per, k1 = min(n_visits, k0 + per);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int cnt[WORK_CLASSES];
+    constexpr int NCL = WORK_CLASSES + 1;   // class WORK_CLASSES counts chunks: the record offsets of the visits (rec_off)
+    int cnt[NCL];
 #pragma unroll
-    for (int c = 0; c < WORK_CLASSES; ++c) cnt[c] = 0;
+    for (int c = 0; c < NCL; ++c) cnt[c] = 0;
     for (int k = k0; k < k1; ++k) {
-        int n_full, lc;
-        visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc);
+        int n_full, lc, nch;
+        visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc, &nch);
         cnt[0] += n_full;
 #pragma unroll
         for (int c = 1; c < WORK_CLASSES; ++c) cnt[c] += lc == c;
+        cnt[WORK_CLASSES] += nch;
     }
     // exclusive scan over (class, thread): class totals first, then the threads inside each class
-    int off[WORK_CLASSES];
+    int off[NCL];
     if (threadIdx.x == 0) s_base[0] = 0;
 #pragma unroll
-    for (int c = 0; c < WORK_CLASSES; ++c) {
+    for (int c = 0; c < NCL; ++c) {
         int x = cnt[c];
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
@@ -558,11 +574,13 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
 #pragma unroll
     for (int c = 0; c < WORK_CLASSES; ++c) off[c] += s_base[c];
     for (int k = k0; k < k1; ++k) {
-        int n_full, lc;
-        visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc);
+        int n_full, lc, nch;
+        visit_chunks(k, targets, patches, vis_off, vis_img, N, M, chunk_px, G, dense != 0, n_full, lc, &nch);
         for (int g = 0; g < n_full; ++g) work[off[0]++] = k * CH + g * G;
 #pragma unroll
         for (int c = 1; c < WORK_CLASSES; ++c) if (lc == c) work[off[c]++] = k * CH + n_full * G;
+        rec_off[k] = off[WORK_CLASSES];      // (not offset by s_base: the chunk class starts at 0)
+        off[WORK_CLASSES] += nch;
     }
 }
 
@@ -1075,7 +1093,8 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              double *__restrict__ acc, const int64_t *__restrict__ tile_off, double *__restrict__ rec,
              const int32_t *__restrict__ active_rank, const int2 *__restrict__ items, int M,
              const int32_t *__restrict__ work, const int32_t *__restrict__ work_total,
-             const int64_t *__restrict__ nv_base, const int32_t *__restrict__ nbr_vis) {
+             const int64_t *__restrict__ nv_base, const int32_t *__restrict__ nbr_vis,
+             const int32_t *__restrict__ rec_off) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
     __shared__ double etab[64];
     // work list (work_fill_kernel): groups of up to G chunks that exist, longest first.  The grid is the host's bound on
@@ -1092,6 +1111,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     int n = tn - ti * M, v = t * N + n;        // items == nullptr: every source is listed in all M = N images, visit = t N + n
     if (items) { const int2 e = items[tn]; v = e.x; n = e.y; }
     if (v < 0) continue;
+    const int rec_base = rec_off[tn];
     const DevPatch &P = patches[v];
     const int H2 = P.H2, W2 = P.W2;
     const int npx = H2 * W2;
@@ -1134,7 +1154,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     for (int ch = ch0; ch < ch0 + G && ch * chunk_px < npx; ++ch) {   // every chunk of the group writes its own record
     const int p0 = ch * chunk_px;
     const int p1 = min(npx, p0 + chunk_px);
-    const int wg = wg0 + (ch - ch0);
+    const int wg = rec_base + ch;            // the visit's records are consecutive (rec_off: prefix sum of the chunk counts)
     if constexpr (MODE == 1 || MODE == 2) {
 #pragma unroll
         for (int i = 0; i < ACC_N * ACC_SLOTS / 64; ++i) sacc[lane + 64 * i] = 0.0;
@@ -1512,7 +1532,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const int32_t *__restrict__ vis_img, int N, int M, int CH, int chunk_px, uint32_t flags,
             double *__restrict__ out_v, double *__restrict__ out_d, double *__restrict__ out_h,
             int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status, const int32_t *__restrict__ live,
-            const double *__restrict__ lg_sum) {
+            const double *__restrict__ lg_sum, const int32_t *__restrict__ rec_off) {
     // lg_sum (per visit, patch_lgamma_kernel; nullptr: the records already hold the term, several active sources)
     if (live && (int)blockIdx.x >= *live) return;
     LIFT_TICK_DECL;
@@ -1584,7 +1604,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const int npx = P.H2 * P.W2;
             double s = 0.0;
             for (int ch = 0; ch < CH; ++ch)
-                if (ch * chunk_px < npx) s += acc[((size_t)(ti * M + n0 + i) * CH + ch) * ACC_N + e];
+                if (ch * chunk_px < npx) s += acc[(rec_off ? (size_t)rec_off[ti * M + n0 + i] + ch : (size_t)(ti * M + n0 + i) * CH + ch) * ACC_N + e];
             s_rec[i][e] = s;
         }
         if (want_grad) {
