@@ -405,6 +405,93 @@ class Problem:
         self.n_images, self.n_sources = N, S
 
 
+PATCH_DTYPE = np.dtype([("off_h", "<i4"), ("off_w", "<i4"), ("H2", "<i4"), ("W2", "<i4"), ("bitmap", "<u8"),
+                        ("wcs_jacobian", "<f8", 4), ("world_center", "<f8", 2), ("pixel_center", "<f8", 2), ("psf", "<u8"),
+                        ("stamp", "<i4"), ("reserved", "<i4")])   # celeste_patch_t, field for field
+
+
+def problem_from_table(images, table, neighbors: Optional[Sequence[Sequence[int]]] = None, psf_K: int = 2,
+                       prior: Optional[dict] = None, marshal_images: bool = True) -> "Problem":
+    """A celeste_problem_t straight from a model.PatchTable (the geometry of get_sky_patches as arrays): the same
+    struct Problem(images, get_sky_patches(...), neighbor_map(...)) builds, without one Python object and two dozen
+    ctypes assignments per (source, image) pair.  Bitmaps are never explicit here (a patch of get_sky_patches masks
+    exactly the NaN pixels, which is the library's default).  Dense tables become the dense patch array, the others the
+    sparse patch list."""
+    assert PATCH_DTYPE.itemsize == C.sizeof(PatchT)
+    pb = Problem.__new__(Problem)
+    N, S = len(images), table.n_sources
+    assert table.n_images == N
+    pb.images, pb.patches = images, None
+    pb._keep = []
+    pb.c_images = marshal_image_structs(images, pb._keep) if marshal_images else None
+    E = len(table.source)
+    if E == 0:
+        raise ValueError("no source overlaps any image")
+    arr = np.zeros(E, dtype=PATCH_DTYPE)
+    arr["off_h"] = table.box[:, 0] - 1; arr["off_w"] = table.box[:, 2] - 1
+    arr["H2"] = table.H2; arr["W2"] = table.W2
+    arr["world_center"] = table.world_center; arr["pixel_center"] = table.pixel_center
+    # per-image constants; the raw stamp at the patch centre (one per image for a constant PSF map), deduplicated by
+    # content like Problem does
+    stamps, stamp_key = [], {}
+
+    def stamp_index(raw):
+        st = np.ascontiguousarray(np.asfortranarray(raw, dtype=np.float64).T)
+        key = st.tobytes()
+        if key not in stamp_key:
+            stamp_key[key] = len(stamps)
+            stamps.append(st.reshape(-1))
+        return stamp_key[key]
+    from .model import ConstantPSFMap
+    for n, im in enumerate(images):
+        e = np.flatnonzero(table.image == n)
+        J = np.asarray(im.wcs_jacobian, dtype=np.float64)
+        arr["wcs_jacobian"][e] = [J[0, 0], J[1, 0], J[0, 1], J[1, 1]]
+        psf = np.ascontiguousarray(im.psf, dtype=np.float64)
+        assert psf.shape == (psf_K, 6)
+        pb._keep.append(psf)
+        arr["psf"][e] = psf.ctypes.data
+        if isinstance(im.psfmap, ConstantPSFMap):
+            arr["stamp"][e] = stamp_index(im.psfmap.stamp)
+        else:
+            for k in e.tolist():
+                arr["stamp"][k] = stamp_index(im.psfmap(table.pixel_center[k, 0], table.pixel_center[k, 1]))
+    pb._keep.append(arr)
+    pb.c_patches = (PatchT * E).from_buffer(arr)
+    pb.sparse = not table.dense
+    if pb.sparse:
+        pb.patch_source = np.ascontiguousarray(table.source, dtype=np.int32)
+        pb.patch_image = np.ascontiguousarray(table.image, dtype=np.int32)
+    else:
+        assert E == S * N
+    pb.stamps = np.ascontiguousarray(np.stack(stamps))
+    if neighbors is None:
+        neighbors = [[] for _ in range(S)]
+    off = np.zeros(S + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(r) for r in neighbors])
+    idx = np.array([j for row in neighbors for j in row], dtype=np.int32)
+    if idx.size == 0:
+        idx = np.zeros(1, dtype=np.int32)
+    pb.nbr_off, pb.nbr_idx = off, idx
+    pb.neighbors = [list(r) for r in neighbors]
+    pb.c_prior = prior_struct(prior) if prior is not None else None
+    pb.c = ProblemT()
+    pb.c.n_images, pb.c.n_sources, pb.c.psf_K, pb.c.n_stamps = N, S, psf_K, len(stamps)
+    if pb.c_images is not None:
+        pb.c.images = pb.c_images
+    pb.c.patches = pb.c_patches
+    pb.c.stamps = _dp(pb.stamps)
+    pb.c.nbr_offsets = off.ctypes.data_as(c_int64_p)
+    pb.c.nbr_index = idx.ctypes.data_as(c_int32_p)
+    pb.c.prior = C.pointer(pb.c_prior) if pb.c_prior is not None else None
+    if pb.sparse:
+        pb.c.n_patch_entries = E
+        pb.c.patch_source = pb.patch_source.ctypes.data_as(c_int32_p)
+        pb.c.patch_image = pb.patch_image.ctypes.data_as(c_int32_p)
+    pb.n_images, pb.n_sources = N, S
+    return pb
+
+
 def spline_prefilter(stamp: np.ndarray) -> np.ndarray:
     """ImagePatch ctor arithmetic (imaged_sources.jl:97-107) -> 53 x 53 B-spline coefficients."""
     lib = load_library()

@@ -44,12 +44,13 @@ class FieldContext:
     """Device-resident problem: images, all patches, neighbour graph (celeste_ctx_t)."""
 
     def __init__(self, images, patches, neighbors=None, psf_K: int = 2, prior: Optional[dict] = None,
-                 device: int = 0, image_set: Optional["cabi.ImageSet"] = None):
+                 device: int = 0, image_set: Optional["cabi.ImageSet"] = None, problem: Optional["cabi.Problem"] = None):
         """image_set: a shared image handle (cabi.ImageSet over the same `images`); the context then costs a patch-table
-        upload instead of a copy of every plane -- the per-source ElboArgs of ParallelRun.jl:468-488."""
+        upload instead of a copy of every plane -- the per-source ElboArgs of ParallelRun.jl:468-488.
+        problem: an already marshalled celeste_problem_t (from_catalog)."""
         self.lib = cabi.load_library()
-        self.problem = cabi.Problem(images, patches, neighbors, psf_K=psf_K, prior=prior,
-                                    marshal_images=image_set is None)
+        self.problem = problem if problem is not None else cabi.Problem(images, patches, neighbors, psf_K=psf_K, prior=prior,
+                                                                        marshal_images=image_set is None)
         self.S, self.N = self.problem.n_sources, self.problem.n_images
         h = C.c_void_p()
         if image_set is None:
@@ -60,6 +61,25 @@ class FieldContext:
             self.device = image_set.device
             cabi.check(self.lib.celeste_ctx_create_on(image_set.handle, C.byref(self.problem.c), C.byref(h)), self.lib)
         self.handle = h
+
+    @classmethod
+    def from_catalog(cls, images, catalog, psf_K: int = 2, prior: Optional[dict] = None, device: int = 0,
+                     image_set: Optional["cabi.ImageSet"] = None, sparse: Optional[bool] = None):
+        """The context of ParallelRun's box inference for a catalog: get_sky_patches + find_neighbors
+        (imaged_sources.jl:165-182, 232-244) through model.patch_table -- the same patches and neighbour lists as
+        FieldContext(images, get_sky_patches(images, catalog), neighbor_map(patches)), an order of magnitude less host
+        time (no per-patch objects).  sparse (default: when there are more than 8 images) selects the sparse patch
+        list.  The table stays available as `ctx.table` (costs(), neighbors)."""
+        from . import model
+        if sparse is None:
+            sparse = len(images) > 8
+        table = model.patch_table(images, catalog, sparse=sparse)
+        neighbors = table.neighbors()
+        problem = cabi.problem_from_table(images, table, neighbors, psf_K=psf_K, prior=prior,
+                                          marshal_images=image_set is None)
+        ctx = cls(images, None, neighbors, psf_K=psf_K, prior=prior, device=device, image_set=image_set, problem=problem)
+        ctx.table = table
+        return ctx
 
     def close(self):
         if getattr(self, "handle", None):

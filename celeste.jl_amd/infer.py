@@ -173,13 +173,13 @@ def infer_box(images, box: BoundingBox, catalog, method: str = "joint_vi", cfg: 
     """infer_box / _infer_box (ParallelRun.jl:610-672) for a given catalog: patches for every catalog entry, targets
     = entries strictly inside the box, neighbours may lie outside it, then joint or single variational inference
     on the device.  (Source detection and MCMC are out of scope: `catalog` is required, method in {joint_vi, single_vi}.)"""
-    from .model import get_sky_patches, neighbor_map
-    patches = get_sky_patches(images, catalog, sparse=len(images) > 5)   # several fields: sources see a few images each
-    neighbors = neighbor_map(patches)
     targets = [i for i, ce in enumerate(catalog) if box.contains(ce.pos)]
     if not targets:
         return []
-    ctx = FieldContext(images, patches, neighbors, device=device)
+    # patches and neighbour lists as arrays (model.patch_table: the geometry of get_sky_patches / find_neighbors
+    # without a Python object per patch); several fields: sources see a few images each -> sparse patch list
+    ctx = FieldContext.from_catalog(images, catalog, device=device, sparse=len(images) > 5)
+    neighbors = ctx.problem.neighbors
     failed: set = set()
     try:
         if method == "joint_vi":

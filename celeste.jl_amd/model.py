@@ -269,15 +269,22 @@ def box_around_point(img: Image, world_center, pixel_radius: float) -> Box:
             (julia_round(pc[1] - pixel_radius), julia_round(pc[1] + pixel_radius)))
 
 
-def choose_patch_radius(ce: CatalogEntry, img: Image, width_scale=1.0, max_radius=25) -> float:
-    """imaged_sources.jl:197-223"""
-    psf_width = get_psf_width(img.psf, width_scale=width_scale)
+def choose_patch_radius(ce: CatalogEntry, img: Image, width_scale=1.0, max_radius=25, _cache=None) -> float:
+    """imaged_sources.jl:197-223.  _cache (a dict, optional): the image's PSF width and sky level, which do not
+    depend on the source, are computed once per image by callers that loop over a catalog."""
+    key = (id(img), width_scale)
+    if _cache is not None and key in _cache:
+        psf_width, epsilon = _cache[key]
+    else:
+        psf_width = get_psf_width(img.psf, width_scale=width_scale)
+        epsilon = float(img.sky[img.H // 2 - 1, img.W // 2 - 1])
+        if _cache is not None:
+            _cache[key] = (psf_width, epsilon)
     obj_width = 0.0 if ce.is_star else width_scale * ce.gal_radius_px / 0.67
     obj_width += psf_width
     flux = ce.star_fluxes[img.b - 1] if ce.is_star else ce.gal_fluxes[img.b - 1]
     if not flux > 0.:
         raise AssertionError("flux > 0")
-    epsilon = float(img.sky[img.H // 2 - 1, img.W // 2 - 1])
     pdf_90 = math.exp(-0.5 * 1.64 ** 2) / (math.sqrt(2 * math.pi) * obj_width)
     pdf_target = min(pdf_90, epsilon / (20 * flux))
     rhs = math.log(pdf_target) + 0.5 * math.log(2 * math.pi) + math.log(obj_width)
@@ -285,9 +292,9 @@ def choose_patch_radius(ce: CatalogEntry, img: Image, width_scale=1.0, max_radiu
     return min(radius_req, max_radius)
 
 
-def box_from_catalog(img: Image, ce: CatalogEntry, width_scale=1.0, max_radius=25) -> Box:
+def box_from_catalog(img: Image, ce: CatalogEntry, width_scale=1.0, max_radius=25, _cache=None) -> Box:
     """imaged_sources.jl:147-160"""
-    r = choose_patch_radius(ce, img, width_scale=width_scale, max_radius=max_radius)
+    r = choose_patch_radius(ce, img, width_scale=width_scale, max_radius=max_radius, _cache=_cache)
     return box_around_point(img, ce.pos, r)
 
 
@@ -296,9 +303,11 @@ def get_sky_patches(images: Sequence[Image], catalog: Sequence[CatalogEntry],
     """imaged_sources.jl:165-182.  Returns patches[s][n]; with sparse=True every row is a `PatchRow` that only
     stores the patches that cover at least one pixel (same boxes: a source is tried against an image whenever it
     lies within max_radius + 1 pixels of it)."""
+    cache = {}
+
     def patch(img, ce):
         if math.isnan(radius_override_pix):
-            box = box_from_catalog(img, ce, width_scale=1.2)
+            box = box_from_catalog(img, ce, width_scale=1.2, _cache=cache)
         else:
             box = box_around_point(img, ce.pos, radius_override_pix)
         return ImagePatch.from_box(img, box)
@@ -316,6 +325,119 @@ def get_sky_patches(images: Sequence[Image], catalog: Sequence[CatalogEntry],
             if p.active_pixel_bitmap.size > 0:
                 entries[s][n] = p
     return [PatchRow(images, e) for e in entries]
+
+
+@dataclass
+class PatchTable:
+    """The geometry of get_sky_patches for a whole catalog as flat arrays -- what the device library needs of the
+    patches, without an ImagePatch object (51 x 51 stamp reference, bitmap array, ...) per (source, image) pair.
+    Entries are ordered by (source, image); `source` / `image` index them.  dense: one entry for EVERY pair (empty
+    boxes included), else only the pairs whose box covers at least one pixel (the sparse patch list)."""
+    n_sources: int
+    n_images: int
+    dense: bool
+    source: np.ndarray        # [E] int32
+    image: np.ndarray         # [E] int32
+    box: np.ndarray           # [E, 4] int64: first row, last row, first column, last column (1-based, inclusive, clamped)
+    pixel_center: np.ndarray  # [E, 2]
+    world_center: np.ndarray  # [E, 2]
+    active_pixels: np.ndarray  # [E] int64: pixels of the box that are not NaN (ParallelRun.jl:45-47's cost)
+
+    @property
+    def H2(self):
+        return np.maximum(self.box[:, 1] - self.box[:, 0] + 1, 0)
+
+    @property
+    def W2(self):
+        return np.maximum(self.box[:, 3] - self.box[:, 2] + 1, 0)
+
+    def costs(self) -> np.ndarray:
+        """estimate_time of every source"""
+        return np.bincount(self.source, weights=self.active_pixels, minlength=self.n_sources).astype(np.int64)
+
+    def neighbors(self) -> List[List[int]]:
+        """find_neighbors for every source (imaged_sources.jl:232-244): sources whose boxes overlap in some image;
+        ascending, empty boxes overlap nothing"""
+        ok = (self.H2 > 0) & (self.W2 > 0)
+        pairs = []
+        for n in range(self.n_images):
+            e = np.flatnonzero(ok & (self.image == n))
+            if e.size < 2:
+                continue
+            b = self.box[e]
+            # sweep over the boxes sorted by first row: b can only overlap a (a before b) if it starts before a ends
+            o = np.argsort(b[:, 0], kind="stable")
+            b = b[o]; src = self.source[e[o]].astype(np.int64)
+            end = np.searchsorted(b[:, 0], b[:, 1], side="right")
+            cnt = np.maximum(end - (np.arange(e.size) + 1), 0)
+            ia = np.repeat(np.arange(e.size), cnt)
+            ib = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt) + ia + 1
+            hit = (b[ia, 2] <= b[ib, 3]) & (b[ib, 2] <= b[ia, 3])
+            si, sj = src[ia[hit]], src[ib[hit]]
+            pairs.append(si * self.n_sources + sj); pairs.append(sj * self.n_sources + si)
+        out = [[] for _ in range(self.n_sources)]
+        if pairs:
+            u = np.unique(np.concatenate(pairs))       # sorted by (source, neighbour)
+            a, b = u // self.n_sources, u % self.n_sources
+            cut = np.searchsorted(a, np.arange(self.n_sources + 1))
+            bl = b.tolist()
+            out = [bl[cut[s]:cut[s + 1]] for s in range(self.n_sources)]
+        return out
+
+
+def patch_table(images: Sequence[Image], catalog: Sequence[CatalogEntry], radius_override_pix: float = math.nan,
+                sparse: bool = False) -> PatchTable:
+    """get_sky_patches (imaged_sources.jl:165-182) without the per-patch objects: the same boxes (box_from_catalog /
+    box_around_point / clamp_box, called as the object path calls them), centres and active-pixel counts, as arrays.
+    sparse=True keeps only the pairs that cover a pixel, tried for the same sources as get_sky_patches(sparse=True)."""
+    S, N = len(catalog), len(images)
+    src, img_i, boxes = [], [], []
+    cache = {}
+    reach = (25.0 if math.isnan(radius_override_pix) else radius_override_pix) + 1.0
+    pos = np.array([ce.pos for ce in catalog], dtype=float).reshape(-1, 2)
+    for n, img in enumerate(images):
+        if sparse:
+            pc = (pos - img.wcs_world0) @ img.wcs_jacobian.T + img.wcs_pix0
+            cand = np.flatnonzero((pc[:, 0] > -reach) & (pc[:, 0] < img.H + 1 + reach) &
+                                  (pc[:, 1] > -reach) & (pc[:, 1] < img.W + 1 + reach)).tolist()
+        else:
+            cand = range(S)
+        dims = (img.H, img.W)
+        for s in cand:
+            ce = catalog[s]
+            if math.isnan(radius_override_pix):
+                box = box_from_catalog(img, ce, width_scale=1.2, _cache=cache)
+            else:
+                box = box_around_point(img, ce.pos, radius_override_pix)
+            box = clamp_box(box, dims)
+            if sparse and (box[0][1] < box[0][0] or box[1][1] < box[1][0]):
+                continue
+            src.append(s); img_i.append(n); boxes.append((box[0][0], box[0][1], box[1][0], box[1][1]))
+    source = np.array(src, dtype=np.int32); image = np.array(img_i, dtype=np.int32)
+    box = np.array(boxes, dtype=np.int64).reshape(-1, 4)
+    order = np.lexsort((image, source))
+    source, image, box = source[order], image[order], box[order]
+    pixel_center = np.stack([(box[:, 0] + box[:, 1]) / 2, (box[:, 2] + box[:, 3]) / 2], axis=1)
+    world_center = np.zeros_like(pixel_center)
+    active = np.zeros(len(source), dtype=np.int64)
+    h2 = np.maximum(box[:, 1] - box[:, 0] + 1, 0); w2 = np.maximum(box[:, 3] - box[:, 2] + 1, 0)
+    for n, img in enumerate(images):
+        e = np.flatnonzero(image == n)
+        if e.size == 0:
+            continue
+        # pix_to_world, one LAPACK solve per centre exactly as Image.pix_to_world does it
+        rhs = (pixel_center[e] - img.wcs_pix0)[:, :, None]
+        world_center[e] = np.linalg.solve(np.broadcast_to(img.wcs_jacobian, (e.size, 2, 2)), rhs)[:, :, 0] + img.wcs_world0
+        nan = np.isnan(img.pixels)
+        if not nan.any():
+            active[e] = h2[e] * w2[e]
+        else:   # non-NaN pixels of every box from one summed-area table
+            sat = np.zeros((img.H + 1, img.W + 1), dtype=np.int64)
+            sat[1:, 1:] = np.cumsum(np.cumsum(~nan, axis=0, dtype=np.int64), axis=1)
+            r0, r1 = box[e, 0] - 1, np.maximum(box[e, 1], box[e, 0] - 1)
+            c0, c1 = box[e, 2] - 1, np.maximum(box[e, 3], box[e, 2] - 1)
+            active[e] = np.where((h2[e] > 0) & (w2[e] > 0), sat[r1, c1] - sat[r0, c1] - sat[r1, c0] + sat[r0, c0], 0)
+    return PatchTable(S, N, not sparse, source, image, box, pixel_center, world_center, active)
 
 
 def find_neighbors(patches: List[List[ImagePatch]], target: int) -> List[int]:

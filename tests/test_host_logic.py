@@ -328,3 +328,42 @@ def test_parallel_image_generation_is_deterministic():
     assert all(np.array_equal(x.pixels, y.pixels) for x, y in zip(a.images, b.images))
     assert all(x.pixels.dtype == np.float32 and np.isfinite(x.pixels).all() for x in a.images)
     assert np.array_equal(a.vp, b.vp) and a.neighbors == b.neighbors
+
+
+def test_patch_table_is_get_sky_patches_without_the_objects():
+    """model.patch_table / cabi.problem_from_table (the fast host path of infer_box) marshal byte for byte the
+    celeste_problem_t that get_sky_patches + neighbor_map + cabi.Problem build: dense field with NaN pixels and sources
+    off the image, and a many-image problem through the sparse patch list"""
+    import ctypes as C
+    from celeste_jl_amd import model, cabi, synthetic
+    from celeste_jl_amd.partition import estimate_time
+
+    def same(pa, pb, n):
+        a = np.frombuffer(C.string_at(C.addressof(pa.c_patches), n * C.sizeof(cabi.PatchT)), dtype=cabi.PATCH_DTYPE)
+        b = np.frombuffer(C.string_at(C.addressof(pb.c_patches), n * C.sizeof(cabi.PatchT)), dtype=cabi.PATCH_DTYPE)
+        for f in cabi.PATCH_DTYPE.names:
+            if f != "psf":      # a pointer
+                assert np.array_equal(a[f], b[f]), f
+        assert np.array_equal(pa.stamps, pb.stamps) and np.array_equal(pa.nbr_off, pb.nbr_off)
+        assert np.array_equal(pa.nbr_idx, pb.nbr_idx) and pa.c.n_stamps == pb.c.n_stamps
+    assert cabi.PATCH_DTYPE.itemsize == C.sizeof(cabi.PatchT)
+    f = synthetic.make_field(150, 170, 25, seed=5, nan_fraction=0.02, margin=4)
+    cat = list(f.catalog) + [synthetic.sample_ce([900.0, -40.0], False), synthetic.sample_ce([-3.0, 80.0], True)]
+    patches = model.get_sky_patches(f.images, cat)
+    tab = model.patch_table(f.images, cat)
+    assert tab.dense and tab.neighbors() == model.neighbor_map(patches)
+    assert np.array_equal(tab.costs(), [estimate_time(r) for r in patches])
+    same(cabi.problem_from_table(f.images, tab, tab.neighbors(), marshal_images=False),
+         cabi.Problem(f.images, patches, model.neighbor_map(patches), marshal_images=False), len(cat) * len(f.images))
+    m = synthetic.make_multifield((2, 2), 96, 96, 0.10, 30, seed=3, sparse=True)
+    tab = model.patch_table(m.images, m.catalog, sparse=True)
+    po = cabi.Problem(m.images, m.patches, m.neighbors, marshal_images=False)
+    pf = cabi.problem_from_table(m.images, tab, tab.neighbors(), marshal_images=False)
+    assert not tab.dense and pf.sparse and tab.neighbors() == [list(r) for r in m.neighbors]
+    assert np.array_equal(pf.patch_source, po.patch_source) and np.array_equal(pf.patch_image, po.patch_image)
+    same(pf, po, len(tab.source))
+    assert np.array_equal(tab.costs(), [estimate_time(r) for r in m.patches])
+    # a fixed radius (the tests' radius_override_pix) goes through the same code
+    t2 = model.patch_table(f.images, f.catalog, radius_override_pix=6.0)
+    p2 = model.get_sky_patches(f.images, f.catalog, radius_override_pix=6.0)
+    assert all(p2[s][n].box == ((b[0], b[1]), (b[2], b[3])) for (s, n, b) in zip(t2.source, t2.image, t2.box))

@@ -32,3 +32,18 @@ nb = np.array([len(n) > 0 for n in fld.neighbors])
 d = np.abs(vs_joint - vs_single).max(axis=1)
 print("sources with neighbours: %d; max |joint - single| per source: median %.2e (with neighbours) vs %.2e (without)"
       % (nb.sum(), np.median(d[nb]), np.median(d[~nb])))
+
+# end to end, host side included: infer_box = patches + neighbours + context + inference + result rows
+from celeste_jl_amd.infer import infer_box, BoundingBox
+for method in ("single_vi", "joint_vi"):
+    t7 = time.time()
+    res = infer_box(fld.images, BoundingBox(0, 2049, 0, 1490), fld.catalog, method=method)
+    t8 = time.time()
+    print("infer_box(%s), %d sources, host side included: %.2f s" % (method, len(res), t8 - t7))
+import time as _t
+from celeste_jl_amd import model, cabi
+t0 = _t.time(); tab = model.patch_table(fld.images, fld.catalog); t1 = _t.time(); nb = tab.neighbors(); t2 = _t.time()
+pb = cabi.problem_from_table(fld.images, tab, nb); t3 = _t.time()
+c2 = cel.FieldContext(fld.images, None, nb, problem=pb); t4 = _t.time()
+print("  of which: patch table %.2f s, neighbours %.3f s, marshalling (image planes to column-major) %.2f s, context creation %.2f s"
+      % (t1 - t0, t2 - t1, t3 - t2, t4 - t3))
