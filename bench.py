@@ -478,7 +478,7 @@ def secondary_figures(ctx, fld, targets, args):
     if args.config == 3:
         # ElboMaximize.maximize! (Newton trust region, <= 50 iterations, KL on) for every source of the field,
         # neighbours frozen; wall time includes H2D/D2H
-        ctx.maximize_batch(fld.vp, targets[:64], cel.ElboConfig(max_iters=3))  # warm-up
+        ctx.maximize_batch(fld.vp, targets, cel.ElboConfig(max_iters=1))  # warm-up: the call's buffers at full size
         t1 = time.perf_counter()
         _, its, evals, _, ost = ctx.maximize_batch(fld.vp, targets, cel.ElboConfig())
         dt_opt = time.perf_counter() - t1
