@@ -49,7 +49,7 @@ def profile_facts():
         return None
 
 
-def live_pmc(args, timeout_s=150):
+def live_pmc(args, timeout_s=60):
     """HBM traffic and VALU issue utilisation of pixel_kernel<2, double> measured in THIS run: three rocprofv3 --pmc
     passes (FETCH_SIZE, WRITE_SIZE, SQ counters -- separate passes with --kernel-trace only, as the guide's HBM
     section prescribes) over a few sweeps of the same field in a child process.  None when rocprofv3 is absent, fails
