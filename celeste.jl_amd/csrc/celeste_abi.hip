@@ -716,13 +716,13 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     // the sources whose tables this launch fills are marked by the setup kernel (targets + neighbours)
     int32_t *const prep_mark = render_neighbors && !tables_current && !prep_all ? c->d_prep_mark : nullptr;
     if (n_visits <= WORK1_MAX_VISITS && !getenv("CELESTE_PARALLEL_WORKLIST")) {
-        hipLaunchKernelGGL(setup_worklist_kernel, dim3(1 + (unsigned)((setup_threads + WORK1_NT - 1) / WORK1_NT)), dim3(WORK1_NT),
+        hipLaunchKernelGGL(setup_worklist_kernel, dim3(1 + (unsigned)((setup_threads + WORK1_SETUP - 1) / WORK1_SETUP)), dim3(WORK1_NT),
                            0, stream, d_vp, c->S, c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M,
                            c->dense ? nullptr : c->d_items, render_neighbors ? c->d_needed : nullptr, c->stamp, c->d_patches,
                            c->N, c->CH, c->chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live, prep_mark,
                            c->d_nbr_off, c->d_nbr_idx, c->d_rec_off);
     } else {
-        hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 255) / 256)), dim3(256), 0, stream, d_vp, c->S,
+        hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 63) / 64)), dim3(64), 0, stream, d_vp, c->S,
                            c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
                            render_neighbors ? c->d_needed : nullptr, c->stamp, prep_mark, c->d_nbr_off, c->d_nbr_idx);
         hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,

@@ -519,6 +519,7 @@ work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPat
 // the parallel three-kernel path (for the 2000-target sweep it is 13 us faster than one block looping).  Same list, same
 // order.
 #define WORK1_NT 1024
+#define WORK1_SETUP 64        // setup_thread items per block of the fused launch (blocks 1 ..)
 #define WORK1_MAX_VISITS 4096
 __global__ void __launch_bounds__(WORK1_NT)
 setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo, const int32_t *__restrict__ targets,
@@ -529,8 +530,12 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
                       int32_t *__restrict__ prep_mark, const int64_t *__restrict__ nbr_off,
                       const int32_t *__restrict__ nbr_idx, int32_t *__restrict__ rec_off) {
     if (blockIdx.x > 0) {
-        setup_thread((blockIdx.x - 1) * WORK1_NT + threadIdx.x, vp, S, geo, targets, n_targets, vis_off, vis_img, M, items,
-                     is_target, stamp, prep_mark, nbr_off, nbr_idx);
+        // one wavefront of setup work per block: a thread reads 44 and writes 37 doubles of ITS source, every wave
+        // instruction touches 64 cache lines -- 16 such waves on one CU queued behind each other on its memory
+        // pipeline (26 us for 2000 sources in two 1024-thread blocks; spread over 32 CUs the same work takes 3 us)
+        if (threadIdx.x < WORK1_SETUP)
+            setup_thread((blockIdx.x - 1) * WORK1_SETUP + threadIdx.x, vp, S, geo, targets, n_targets, vis_off, vis_img, M,
+                         items, is_target, stamp, prep_mark, nbr_off, nbr_idx);
         return;
     }
     __shared__ int s_part[WORK1_NT / 64];
