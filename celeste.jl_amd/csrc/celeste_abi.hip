@@ -682,7 +682,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     }
     // a workgroup handles a group of up to G consecutive chunks of a patch (results do not depend on G, see
     // visit_chunks): 4 for large sweeps, 1 for small batches whose critical path is one patch
-    int G = n_targets >= 512 ? 4 : 1;
+    int G = n_targets >= 1536 ? 4 : n_targets >= 768 ? 2 : 1;   // (measured on the bench field's shards: 1000 targets 0.287 ms with 2, 0.315 with 4)
     if (const char *e = getenv("CELESTE_CHUNK_GROUP")) if (atoi(e) >= 1 && atoi(e) <= 16) G = atoi(e);
     const int n_classes = WORK_CLASSES;   // work-list classes: full groups, then the patches' last groups by length
     if ((size_t)n_wblk * (n_classes + 1) > c->work_blk_cap) {   // + the row of chunk counts (rec_off)
