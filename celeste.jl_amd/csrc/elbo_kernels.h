@@ -234,33 +234,48 @@ __device__ inline void bspline_dw(double f, double dw[4], double ddw[4]) {
 // Taylor polynomial (truncation 3.9e-14 relative; EXP_DEGREE 5 gives 3.5e-17 for one more FMA) and
 // v_ldexp_f64.  16 VALU + 1 LDS instruction instead of ~31 for the library exp.  Inputs below -745 give
 // exactly 0 like the reference's exp.
-#ifndef EXP_DEGREE
-#define EXP_DEGREE 4   // Taylor degree of exp(r), |r| <= ln2 / 128: truncation 3.9e-14 relative (degree 5: 3.5e-17, 1 % slower)
+#ifndef EXP_TAB_LOG2
+#define EXP_TAB_LOG2 6   // table of 2^(j / T), T = 2^EXP_TAB_LOG2 entries (the 64-double LDS array holds 64 / T copies)
 #endif
-__device__ double g_exp2_table[64];  // 2^(j/64), filled once per context by exp_table_kernel
-__global__ void exp_table_kernel() { g_exp2_table[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0)); }
+#ifndef EXP_DEGREE
+#define EXP_DEGREE (EXP_TAB_LOG2 == 6 ? 4 : EXP_TAB_LOG2 == 5 ? 5 : 6)   // Taylor degree of exp(r), |r| <= ln2 / 2T: truncation <= 4.5e-14 relative
+#endif
+#define EXP_T (1 << EXP_TAB_LOG2)
+#define EXP_INV_STEP (92.33248261689366 / (64 / EXP_T))              // T / ln 2
+#define EXP_STEP_HI (0.010830424696450791 * (64 / EXP_T))            // ln2 / T, high part (n * hi exact for |n| < 2^17)
+#define EXP_STEP_LO (2.0164562921995537e-13 * (64 / EXP_T))          // minus its low part
+__device__ double g_exp2_table[64];  // 2^((j mod T) / T), filled once per context by exp_table_kernel
+__global__ void exp_table_kernel() { g_exp2_table[threadIdx.x] = exp2((double)(threadIdx.x & (EXP_T - 1)) * (1.0 / EXP_T)); }
 __device__ __forceinline__ void exp_table_init(double *tab) {
     if (threadIdx.x < 64) tab[threadIdx.x] = g_exp2_table[threadIdx.x];  // one coalesced 512-byte read
     __syncthreads();
 }
-__device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
-    // no clamp is needed: for x << -745 the integer part saturates and v_ldexp_f64 returns 0
-    const double n = rint(x * 92.33248261689366);             // 64 / ln 2
-    double r = __builtin_fma(n, -0.010830424696450791, x);      // ln2/64, 35-bit high part: n * hi is exact for |n| < 2^17
-    r = __builtin_fma(n, 2.0164562921995537e-13, r);           // minus the low part of ln2/64 (lo = -2.0164562921995537e-13)
-    const int ni = (int)n;
-    const double tj = tab[ni & 63];
-#if EXP_DEGREE == 5
-    double p = 8.333333333333333e-03;                // 1/5!
+// exp(r) - as a polynomial in r of degree EXP_DEGREE (Horner)
+__device__ __forceinline__ double exp_poly(double r) {
+    double p;
+#if EXP_DEGREE >= 6
+    p = 1.3888888888888889e-03;                      // 1/6!
+    p = __builtin_fma(p, r, 8.333333333333333e-03);  // 1/5!
     p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
+#elif EXP_DEGREE == 5
+    p = 8.333333333333333e-03;
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
 #else
-    double p = 4.1666666666666664e-02;               // 1/4!: truncation |r|^5 / 120 <= 3.9e-14 for |r| <= ln2 / 128
+    p = 4.1666666666666664e-02;                      // truncation |r|^5 / 120 <= 3.9e-14 for |r| <= ln2 / 128
 #endif
     p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    return ldexp(p * tj, ni >> 6);
+    return __builtin_fma(p, r, 1.0);
+}
+__device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
+    // no clamp is needed: for x << -745 the integer part saturates and v_ldexp_f64 returns 0
+    const double n = rint(x * EXP_INV_STEP);
+    double r = __builtin_fma(n, -EXP_STEP_HI, x);
+    r = __builtin_fma(n, EXP_STEP_LO, r);
+    const int ni = (int)n;
+    const double tj = tab[ni & (EXP_T - 1)];
+    return ldexp(exp_poly(r) * tj, ni >> EXP_TAB_LOG2);
 }
 
 // star_light_density! value only (fsm_util.jl:221-237): softpluslikeinv(itp[h - m1 + 26, w - m2 + 26])
@@ -842,11 +857,11 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             int ni = 0;
             if constexpr (sizeof(R) == 8) {
                 const double x = -0.5 * (d1 * u + d2 * v);
-                const double n = rint(x * 92.33248261689366);
-                double r = __builtin_fma(n, -0.010830424696450791, x);
-                xr = __builtin_fma(n, 2.0164562921995537e-13, r);
+                const double n = rint(x * EXP_INV_STEP);
+                double r = __builtin_fma(n, -EXP_STEP_HI, x);
+                xr = __builtin_fma(n, EXP_STEP_LO, r);
                 ni = (int)n;
-                tj = etab[ni & 63];
+                tj = etab[ni & (EXP_T - 1)];
             } else xr = (R)-0.5 * (d1 * u + d2 * v);
             after_exp_issue();
             const R ha = fma_r<R>(u, u, -k.p11), hb = fma_r<R>(u, v, -k.p12), hc = fma_r<R>(v, v, -k.p22);
@@ -865,20 +880,11 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             const R h4e = fma_r<R>(v, h3d, m3c * k.p22);
             R e;
             if constexpr (sizeof(R) == 8) {
-#if EXP_DEGREE == 5
-                double p = 8.333333333333333e-03;
-                p = __builtin_fma(p, xr, 4.1666666666666664e-02);
-#else
-                double p = 4.1666666666666664e-02;
-#endif
-                p = __builtin_fma(p, xr, 1.6666666666666666e-01);
-                p = __builtin_fma(p, xr, 0.5);
-                p = __builtin_fma(p, xr, 1.0);
-                pe = __builtin_fma(p, xr, 1.0);
+                pe = exp_poly(xr);
 #if PIXEL_SCHED_BARRIER
                 __builtin_amdgcn_sched_barrier(0);   // nothing that needs the table entry moves above this point
 #endif
-                e = ldexp(pe * tj, ni >> 6);   // eval_bvn_pdf!
+                e = ldexp(pe * tj, ni >> EXP_TAB_LOG2);   // eval_bvn_pdf!
             } else e = exp_np<R>(xr, etab);
             const R f = k.w0 * e, g = k.wd * e, fn = f * k.nu, gn = g * k.nu, fnn = fn * k.nu;
             U[0] += g; U[1] = fma_r<R>(u, g, U[1]); U[2] = fma_r<R>(v, g, U[2]);
