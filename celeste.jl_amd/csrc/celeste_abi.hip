@@ -1308,6 +1308,15 @@ extern "C" int celeste_debug_T(int32_t n, double *out) {   // n = 0: allocate fo
     return CELESTE_OK;
 }
 #endif
+#ifdef VALUE_TIMING
+extern "C" int celeste_value_clocks(int reset, uint64_t out[8]) {   // debug builds only (tools/variants)
+    unsigned long long h[8] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_value_clk), sizeof h));
+    for (int i = 0; i < 8; ++i) out[i] = h[i];
+    if (reset) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_value_clk), z, sizeof z)); }
+    return CELESTE_OK;
+}
+#endif
 #ifdef LIFT_TIMING
 extern "C" int celeste_lift_clocks(int reset, uint64_t out[16]) {   // debug builds only (tools/variants)
     unsigned long long h[16] = {0};

@@ -610,12 +610,21 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
 // (geometry only; celeste_ctx_create), first chunks first.  Items whose source t is not a target of this batch
 // exit immediately.  Two targets that overlap the same part of s2 write identical values to the same addresses
 // (benign).
+#ifdef VALUE_TIMING   // debug builds (tools/variants): shader clocks per section of the value kernel
+__device__ unsigned long long g_value_clk[8];
+#endif
 __global__ void __launch_bounds__(64)
 value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
              const int32_t *__restrict__ is_target, int32_t stamp, const int64_t *__restrict__ val_off,
              const int4 *__restrict__ items, int NC, int chunk_px, double2 *__restrict__ val) {
     __shared__ double etab[64];
+#ifdef VALUE_TIMING
+    long long vts[4]; vts[0] = clock64();     // stamps only; the (contended) atomics all come at the very end
+#define VT(k) do { vts[(k) + 1] = clock64(); } while (0)
+#else
+#define VT(k) do { } while (0)
+#endif
     // an item = {table index of the neighbour's (source, image) entry, of the target's, chunk, target}: one 16-byte
     // load instead of a chain link -> source, link -> neighbour, item -> image | chunk
     const int4 it = items[blockIdx.x];
@@ -631,6 +640,7 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
     const int npx = RH * RW;
     const int p0 = ch * chunk_px;
     if (p0 >= npx) return;
+    VT(0);
     exp_table_init(etab);
     const int p1 = min(npx, p0 + chunk_px);
     const SrcImg si = srcimg[sn];
@@ -641,6 +651,7 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
         for (int i = threadIdx.x; i < NC * 8; i += 64) dst[i] = src[i];
         __syncthreads();
     }
+    VT(1);
     const double *__restrict__ coef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
     double2 *__restrict__ out = val + val_off[sn];
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
@@ -654,6 +665,14 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
         const double E2n = si.q0 * (f0 * f0) + si.q1 * (f1 * f1);
         out[(h0 - P.off_h) + (int64_t)P.H2 * (w0 - P.off_w)] = make_double2(En, E2n - En * En);  // var_G_s.v (:204)
     }
+    VT(2);
+#ifdef VALUE_TIMING
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 3; ++k) atomicAdd(&g_value_clk[k], (unsigned long long)(vts[k + 1] - vts[k]));
+        atomicAdd(&g_value_clk[7], 1ull); atomicAdd(&g_value_clk[6], (unsigned long long)((p1 - p0 + 63) / 64));
+    }
+#endif
+#undef VT
 }
 
 // ---------------------------------------------------------------------------------------------
