@@ -835,6 +835,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         sHb[tid] = w * s * (1 - s) * (1 - 2 * s) / (sc * sc);
     } else if (tid < 29) simplex_probs(sx, tid - 26, sp[tid - 26]);
     __syncthreads();
+    OPT_TICK(9);
     // simplex Jacobians d bound_{b0+a} / d free_{f0+j} = (1 - n lo) p_a ((a == j) - p_j)
     for (int k = tid; k < 3 * 56; k += nthr) {
         const int g = k / 56, r = k - g * 56, a = r / 7, j = r - a * 7;
@@ -852,6 +853,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         }
         sgt[tid] = -s;  // minimise -elbo
     }
+    OPT_TICK(10);
     // J' H J, J block diagonal (26 scalars + simplex blocks 2x1, 8x7, 8x7): rows first (lane = row) ...
     if (tid < CEL_P) {   // row `tid` of the bound-space Hessian straight from HBM (lanes read consecutive addresses)
         for (int i = 0; i < 26; ++i) sA[tid + LDA * i] = h[tid + CEL_P * i] * sJb[i];
@@ -869,25 +871,38 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         }
     }
     __syncthreads();
+    OPT_TICK(11);
     // ... then columns (lane = column), plus the second derivatives of the transform contracted with the bound
     // gradient, negated (minimise -elbo)
     if (tid < NF) {
+        // the lane's column is fetched in one batch of independent LDS reads and worked on in registers (entry by
+        // entry through LDS, with loop bounds the compiler could not see, this pass was a chain of ~300 exposed LDS
+        // latencies: 7.2 us of the kernel's 95)
         double *col = sA + LDA * tid;
-        for (int i = 0; i < 26; ++i) col[i] = -(col[i] * sJb[i]);
-        if (tid < 26) col[tid] -= sd[tid] * sHb[tid];
-        for (int g = 0; g < 3; ++g) {
-            const int n = c_simplex_n[g], b0 = c_simplex_b0[g], f0 = c_simplex_f0[g];
-            double mv[8];
+        double cv[CEL_P];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) mv[a] = a < n ? col[b0 + a] : 0.0;
+        for (int i = 0; i < CEL_P; ++i) cv[i] = col[i];
+#pragma unroll
+        for (int i = 0; i < 26; ++i) {
+            double o = -(cv[i] * sJb[i]);
+            if (i == tid) o -= sd[i] * sHb[i];
+            col[i] = o;
+        }
+        constexpr int GN[3] = {2, 8, 8}, GB0[3] = {26, 28, 36}, GF0[3] = {26, 27, 34};
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            constexpr double lo_[3] = {0.005, 0.01 / 8, 0.01 / 8};
+            const int n = GN[g], b0 = GB0[g], f0 = GF0[g];
             const int kk = tid - f0;
             const bool own = kk >= 0 && kk < n - 1;
             const double *pp = sp[g];
-            const double scl = 1 - n * c_simplex_lo[g];
-            for (int jj = 0; jj < n - 1; ++jj) {
+            const double scl = 1 - n * lo_[g];
+#pragma unroll
+            for (int jj = 0; jj < 7; ++jj) {
+                if (jj >= n - 1) break;
                 double o = 0;
 #pragma unroll
-                for (int a = 0; a < 8; ++a) o += sJs[g][a][jj] * mv[a];
+                for (int a = 0; a < 8; ++a) if (a < n) o += sJs[g][a][jj] * cv[b0 + a];
                 if (own) {
                     for (int a = 0; a < n; ++a) {
                         const double d2 = pp[a] * (((a == jj) - pp[jj]) * ((a == kk) - pp[kk]) - pp[jj] * ((jj == kk) - pp[kk]));
@@ -899,6 +914,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         }
     }
     __syncthreads();
+    OPT_TICK(12);
     if (tid < NF) for (int i = 0; i < tid; ++i) sA[tid + LDA * i] = sA[i + LDA * tid];   // exactly symmetric
     __syncthreads();
 

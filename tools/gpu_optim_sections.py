@@ -12,8 +12,9 @@ S = len(fld.catalog)
 ctx = cel.FieldContext(fld.images, fld.patches, fld.neighbors)
 lib = cabi.load_library()
 has_clk = hasattr(lib, "celeste_optim_clocks")
-NAMES = ["load+chain rule", "accept/copy H", "sub-problem total", "  tridiagonalisation", "  Q'g", "  extreme eigenvalues",
-         "  interior try + secular", "  model + Qy", "tail"]
+NAMES = ["chain rule: symmetrise (+ rest)", "accept/copy H", "sub-problem total", "  tridiagonalisation", "  Q'g", "  extreme eigenvalues",
+         "  interior try + secular", "  model + Qy", "tail", "chain rule: loads, box / simplex transforms",
+         "chain rule: simplex Jacobians, gradient", "chain rule: H J (rows, from HBM)", "chain rule: J' (H J) (columns)"]
 
 
 def clocks(reset=True):
