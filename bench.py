@@ -197,6 +197,12 @@ def main():
     ap.add_argument("--check-dir", default=None,
                     help="every rank writes its gathered (v, d) of the last sweep to <dir>/rank<r>.npz (tests)")
     args = ap.parse_args()
+    # Libraries write to file descriptor 1 behind Python's back (RCCL prints a five-line version banner when its first
+    # communicator comes up): until the result line is due, fd 1 points at stderr, so that rank 0's stdout carries the
+    # one JSON line and nothing else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if args.dtype is None:
         args.dtype = "f32" if args.config == 5 else "f64"
     if args.steps is None:
@@ -454,7 +460,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             tg_cpu = targets if args.config == 3 else targets[:: max(1, S // 2000)]
             out["cpu_baseline"] = cpu_baseline(ctx.problem, fld.vp, tg_cpu)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(2, 1)    # (teardown messages, if any, stay off stdout as well)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

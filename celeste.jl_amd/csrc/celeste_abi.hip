@@ -75,8 +75,6 @@ struct celeste_ctx {
     double2 *d_val = nullptr;       // pre-rendered (E_G_s.v, var_G_s.v) of neighbour sources, per patch pixel
     int32_t *d_needed = nullptr;    // per source: stamp of the last batch it was a target of
     int32_t stamp = 0;
-    int32_t *d_link_src = nullptr;  // per neighbour link: the source that owns it (CSR row)
-    int64_t n_links = 0;
     // visit lists: the images each source has a non-empty patch in (grids run over these, tables stay S x N)
     std::vector<int32_t> h_vis_off, h_vis_img, h_vis_src;
     int32_t *d_vis_off = nullptr, *d_vis_img = nullptr, *d_vis_src = nullptr;
@@ -448,11 +446,6 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         CTX_TRY(dev_upload<double2>(&c->d_val, nullptr, (size_t)tot));
         CTX_TRY(dev_upload<int32_t>(&c->d_needed, nullptr, (size_t)c->S));
         if (hipMemset(c->d_needed, 0, (size_t)c->S * sizeof(int32_t)) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
-        std::vector<int32_t> lsrc(c->h_nbr_idx.size());
-        for (int s = 0; s < c->S; ++s)
-            for (int64_t q = c->h_nbr_off[s]; q < c->h_nbr_off[s + 1]; ++q) lsrc[q] = s;
-        c->n_links = (int64_t)lsrc.size();
-        CTX_TRY(dev_upload(&c->d_link_src, lsrc.data(), lsrc.size()));
     }
 
     CTX_TRY(dev_upload(&c->d_vis_off, c->h_vis_off.data(), c->h_vis_off.size()));
@@ -572,7 +565,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *ptrs[] = {c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_link_src, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_prep_mark, c->d_rec_off, c->d_lg_sum, c->d_nv_base, c->d_nbr_vis, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_prep_mark, c->d_rec_off, c->d_lg_sum, c->d_nv_base, c->d_nbr_vis, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     {

@@ -323,15 +323,7 @@ __device__ inline double wave_sum(double x) {
 // ---------------------------------------------------------------------------------------------
 // items[ti * M + j] = {visit id, image} of the j-th visit of target ti (-1: none), so that the pixel kernels find their
 // (target, image) with two independent loads instead of a chain through the visit lists
-__global__ void visit_items_kernel(const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
-                                   const int32_t *__restrict__ vis_img, int M, int2 *__restrict__ items) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_targets * M) return;
-    const int ti = k / M, j = k - ti * M;
-    const int t = targets[ti];
-    const int vo = vis_off[t];
-    items[k] = j < vis_off[t + 1] - vo ? make_int2(vo + j, vis_img[vo + j]) : make_int2(-1, -1);
-}
+// (filled by setup_thread)
 
 // Table entry (visit) of (source, image) for the kernels off the hot path: s N + n when every source is listed in
 // every image, else a search of the source's visit list (-1: the source has no patch in that image)
