@@ -22,8 +22,9 @@ def check(name, solve, H, g, delta):
     return err / bound, ref["kind"]
 
 
-def test_oracle_sub_problem_against_60_digits(oracle):
-    rng = np.random.default_rng(11)
+@pytest.mark.parametrize("seed", [11, 12])
+def test_oracle_sub_problem_against_60_digits(oracle, seed):
+    rng = np.random.default_rng(seed)
     kinds = set()
     for name, H, g, delta in R.random_problems(rng):
         ratio, kind = check(name, lambda H, g, d: oracle.solve_tr(g, H, d)[::2], H, g, delta)
@@ -31,6 +32,7 @@ def test_oracle_sub_problem_against_60_digits(oracle):
     assert kinds == {"interior", "boundary", "hard"} or kinds == {"interior", "boundary", "hard", "lb"}
 
 
-def test_oracle_sub_problem_on_celeste_hessians(oracle):
-    for name, H, g, delta in R.celeste_problems(oracle, "star", points=2):
+@pytest.mark.parametrize("scene", ["star", "galaxy"])
+def test_oracle_sub_problem_on_celeste_hessians(oracle, scene):
+    for name, H, g, delta in R.celeste_problems(oracle, scene, points=2):
         check(name, lambda H, g, d: oracle.solve_tr(g, H, d)[::2], H, g, delta)
