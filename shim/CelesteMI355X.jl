@@ -154,3 +154,16 @@ function maximize_batch!(ctx::MI355XContext, vp_all::Matrix{Float64}, targets0::
                n, targets0, cfgc, iterations, f_calls, max_values, status)
     return st, iterations, f_calls, max_values, status
 end
+
+"""The optimiser's trust-region sub-problem on its own (what Optim.jl's NewtonTrustRegion solves per iteration):
+H is 41 x 41 x n in the free parameters, g 41 x n, delta n.  For comparing single Newton steps of a Julia run
+with the device (solver 0: as celeste_maximize_batch, 1: eigen-decomposition)."""
+function tr_solve_batch(H::Array{Float64,3}, g::Matrix{Float64}, delta::Vector{Float64}; solver::Int = 0, device::Int = 0)
+    n = length(delta)
+    p = zeros(41, n); m = zeros(n); interior = zeros(Int32, n); fell_back = zeros(Int32, n)
+    check(ccall((:celeste_tr_solve_batch, libceleste), Cint,
+                (Cint, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Int32}, Ptr{Int32}),
+                device, n, H, g, delta, solver, 0, p, m, interior, fell_back))
+    p, m, interior, fell_back
+end
