@@ -708,12 +708,18 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     const size_t setup_threads = std::max<size_t>((size_t)c->S, (size_t)n_targets * (c->dense ? 1 : c->M));
     // the sources whose tables this launch fills are marked by the setup kernel (targets + neighbours)
     int32_t *const prep_mark = render_neighbors && !tables_current && !prep_all ? c->d_prep_mark : nullptr;
+    bool prep_fused = false;
     if (n_visits <= WORK1_MAX_VISITS && !getenv("CELESTE_PARALLEL_WORKLIST")) {
-        hipLaunchKernelGGL(setup_worklist_kernel, dim3(1 + (unsigned)((setup_threads + WORK1_SETUP - 1) / WORK1_SETUP)), dim3(WORK1_NT),
+        const unsigned setup_blocks = (unsigned)((setup_threads + WORK1_SETUP - 1) / WORK1_SETUP);
+        // neighbours frozen: the targets' tables are filled by extra blocks of this launch (one launch less per iteration)
+        prep_fused = !render_neighbors && !getenv("CELESTE_NO_FUSED_PREP");
+        const unsigned prep_blocks = prep_fused ? (unsigned)((n_visits + WORK1_NT / 64 - 1) / (WORK1_NT / 64)) : 0u;
+        hipLaunchKernelGGL(setup_worklist_kernel, dim3(1 + setup_blocks + prep_blocks), dim3(WORK1_NT),
                            0, stream, d_vp, c->S, c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M,
                            c->dense ? nullptr : c->d_items, render_neighbors ? c->d_needed : nullptr, c->stamp, c->d_patches,
                            c->N, c->CH, c->chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live, prep_mark,
-                           c->d_nbr_off, c->d_nbr_idx, c->d_rec_off);
+                           c->d_nbr_off, c->d_nbr_idx, c->d_rec_off, (int)setup_blocks, c->d_images, c->K, c->d_srcimg,
+                           c->d_comps);
     } else {
         hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 63) / 64)), dim3(64), 0, stream, d_vp, c->S,
                            c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
@@ -732,7 +738,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
             hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches,
                                c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr, c->d_vis_off, c->M,
                                (int)c->dense, nullptr, prep_mark, c->stamp);
-    } else {
+    } else if (!prep_fused) {
         hipLaunchKernelGGL(prep_kernel, dim3((unsigned)std::max(n_visits, 1)), dim3(64), 0, stream, d_vp, c->d_images,
                            c->d_patches, c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, d_targets,
                            c->d_vis_off, c->M, (int)c->dense, d_live, nullptr, 0);

@@ -66,38 +66,11 @@ __device__ inline void brightness(const double *vs, int i, int b, double &El, do
     El = e; Ell = ee;
 }
 
-__global__ void __launch_bounds__(64)
-prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
-            const DevPatch *__restrict__ patches, const int32_t *__restrict__ vis_src,
-            const int32_t *__restrict__ vis_img, int N, int K,
-            SrcImg *__restrict__ srcimg, Comp *__restrict__ comps,
-            const int32_t *__restrict__ targets, const int32_t *__restrict__ vis_off, int M, int dense,
-            const int32_t *__restrict__ live, const int32_t *__restrict__ mark, int32_t stamp) {
+// the tables of one (source, image) visit: lane c < NC computes component c, lane 63 the brightness moments
+__device__ __forceinline__ void prep_visit(int c, int s, int n, int sn, const double *__restrict__ vp,
+                                           const DevImage *__restrict__ images, const DevPatch *__restrict__ patches, int K,
+                                           SrcImg *__restrict__ srcimg, Comp *__restrict__ comps) {
     const int NC = 14 * K;
-    // one workgroup per visit = (source, image) pair with a non-empty patch; the tables are indexed by visit (sn).
-    // targets == nullptr: every visit of the context (neighbours are about to be rendered).  Otherwise one workgroup
-    // per candidate visit k = ti * M + j of the batch's targets only (neighbours frozen).
-    int s, n, sn;
-    if (targets) {
-        const int k = blockIdx.x, ti = k / M, j = k - ti * M;
-        if (live && ti >= *live) return;
-        s = targets[ti];
-        n = j;
-        if (!dense) {
-            const int vo = vis_off[s];
-            if (j >= vis_off[s + 1] - vo) return;
-            n = vis_img[vo + j];
-        }
-        sn = dense ? s * N + n : vis_off[s] + j;
-        const DevPatch &q = patches[sn];
-        if (q.H2 * q.W2 <= 0) return;
-    } else {
-        s = vis_src[blockIdx.x]; n = vis_img[blockIdx.x];
-        sn = blockIdx.x;
-        // mark (optional): only the sources this batch reads -- its targets and their neighbours (setup_thread)
-        if (mark && mark[s] != stamp) return;
-    }
-    const int c = threadIdx.x;
     const double *vs = vp + (size_t)s * CEL_P;
     const DevPatch &p = patches[sn];
     const double d0 = vs[0] - p.wc[0], d1 = vs[1] - p.wc[1];
@@ -139,6 +112,39 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
         o.dev = vs[2]; o.pad1 = 0;
         srcimg[sn] = o;
     }
+}
+
+__global__ void __launch_bounds__(64)
+prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
+            const DevPatch *__restrict__ patches, const int32_t *__restrict__ vis_src,
+            const int32_t *__restrict__ vis_img, int N, int K,
+            SrcImg *__restrict__ srcimg, Comp *__restrict__ comps,
+            const int32_t *__restrict__ targets, const int32_t *__restrict__ vis_off, int M, int dense,
+            const int32_t *__restrict__ live, const int32_t *__restrict__ mark, int32_t stamp) {
+    // one workgroup per visit = (source, image) pair with a non-empty patch; the tables are indexed by visit (sn).
+    // targets == nullptr: every visit of the context (neighbours are about to be rendered).  Otherwise one workgroup
+    // per candidate visit k = ti * M + j of the batch's targets only (neighbours frozen).
+    int s, n, sn;
+    if (targets) {
+        const int k = blockIdx.x, ti = k / M, j = k - ti * M;
+        if (live && ti >= *live) return;
+        s = targets[ti];
+        n = j;
+        if (!dense) {
+            const int vo = vis_off[s];
+            if (j >= vis_off[s + 1] - vo) return;
+            n = vis_img[vo + j];
+        }
+        sn = dense ? s * N + n : vis_off[s] + j;
+        const DevPatch &q = patches[sn];
+        if (q.H2 * q.W2 <= 0) return;
+    } else {
+        s = vis_src[blockIdx.x]; n = vis_img[blockIdx.x];
+        sn = blockIdx.x;
+        // mark (optional): only the sources this batch reads -- its targets and their neighbours (setup_thread)
+        if (mark && mark[s] != stamp) return;
+    }
+    prep_visit(threadIdx.x, s, n, sn, vp, images, patches, K, srcimg, comps);
 }
 
 // per-source shape derivatives and the finiteness flag of its parameters
@@ -535,7 +541,28 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
                       const DevPatch *__restrict__ patches, int N, int CH, int chunk_px, int G, int dense,
                       int32_t *__restrict__ work, int32_t *__restrict__ work_total, const int32_t *__restrict__ live,
                       int32_t *__restrict__ prep_mark, const int64_t *__restrict__ nbr_off,
-                      const int32_t *__restrict__ nbr_idx, int32_t *__restrict__ rec_off) {
+                      const int32_t *__restrict__ nbr_idx, int32_t *__restrict__ rec_off,
+                      int setup_blocks, const DevImage *__restrict__ images, int K, SrcImg *__restrict__ srcimg,
+                      Comp *__restrict__ comps) {
+    if ((int)blockIdx.x > setup_blocks) {
+        // frozen neighbours (an optimiser iteration): the tables of the targets' own visits are filled by this launch
+        // too, one wavefront per candidate visit -- prep_kernel's targets mode without a launch of its own
+        const int k = ((int)blockIdx.x - setup_blocks - 1) * (WORK1_NT / 64) + (int)(threadIdx.x >> 6);
+        const int ti = k / M, j = k - ti * M;
+        if (ti >= n_targets || (live && ti >= *live)) return;
+        const int s = targets[ti];
+        int n = j;
+        if (!dense) {
+            const int vo = vis_off[s];
+            if (j >= vis_off[s + 1] - vo) return;
+            n = vis_img[vo + j];
+        }
+        const int sn = dense ? s * N + n : vis_off[s] + j;
+        const DevPatch &q = patches[sn];
+        if (q.H2 * q.W2 <= 0) return;
+        prep_visit(threadIdx.x & 63, s, n, sn, vp, images, patches, K, srcimg, comps);
+        return;
+    }
     if (blockIdx.x > 0) {
         // one wavefront of setup work per block: a thread reads 44 and writes 37 doubles of ITS source, every wave
         // instruction touches 64 cache lines -- 16 such waves on one CU queued behind each other on its memory
