@@ -81,7 +81,9 @@ EXPORTED_SYMBOLS = [
     "celeste_maximize_batch", "celeste_render_expected", "celeste_optim_stats", "celeste_tr_solve_batch",
     "celeste_images_create", "celeste_images_destroy", "celeste_ctx_create_on",
     "celeste_host_alloc", "celeste_host_free", "celeste_host_register", "celeste_host_unregister",
+    "celeste_maximize_batch_device", "celeste_joint_infer",
 ]
+ABI_VERSION = 200   # CELESTE_ABI_VERSION of include/celeste_mi355x.h these structs were written against
 
 _lib = None
 
@@ -111,6 +113,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib = C.CDLL(path)
     vp = C.c_void_p
     lib.celeste_version.restype = C.c_int
+    if lib.celeste_version() // 100 != ABI_VERSION // 100:
+        raise ImportError("%s has ABI version %d, this binding was written against %d: the struct layouts "
+                          "(celeste_optim_config_t ...) may differ -- rebuild the library" % (path, lib.celeste_version(), ABI_VERSION))
     lib.celeste_strerror.restype = C.c_char_p
     lib.celeste_strerror.argtypes = [C.c_int]
     lib.celeste_ctx_create.argtypes = [C.POINTER(ProblemT), C.c_int, C.POINTER(vp)]
@@ -132,6 +137,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                        C.c_int32, c_double_p]
     lib.celeste_maximize_batch.argtypes = [vp, c_double_p, c_double_p, c_double_p, C.c_int32, c_int32_p,
                                            C.POINTER(OptimConfigT), c_int32_p, c_int32_p, c_double_p, c_int32_p]
+    lib.celeste_maximize_batch_device.argtypes = [vp, vp, vp, vp, C.c_int32, vp, C.POINTER(OptimConfigT), vp, vp, vp, vp, vp]
+    lib.celeste_joint_infer.argtypes = [vp, c_double_p, C.c_int32, c_int64_p, c_int32_p, c_double_p,
+                                        C.POINTER(OptimConfigT), c_int32_p, c_int32_p, c_double_p, c_int32_p]
     lib.celeste_optim_stats.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.celeste_tr_solve_batch.argtypes = [C.c_int, C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int32, C.c_int32,
                                            c_double_p, c_double_p, c_int32_p, c_int32_p]

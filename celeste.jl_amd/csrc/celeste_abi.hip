@@ -15,6 +15,7 @@
 
 #include "elbo_kernels.h"
 #include "optim_kernels.h"
+#include "fused_kernels.h"
 
 #define HIP_TRY(expr)                                                                    \
     do {                                                                                 \
@@ -136,6 +137,15 @@ struct celeste_ctx {
         int32_t *h_count = nullptr;
         hipEvent_t ev[RING] = {};
     } opt;
+    // buffers of the fused optimiser launch (optim_fused_kernel), kept between calls (grown on demand)
+    struct FusedBuffers {
+        size_t cap_t = 0, cap_rec = 0, cap_q = 0, cap_saved = 0;
+        int2 *d_chunk_desc = nullptr, *d_tgt_rec = nullptr;
+        int32_t *d_q_items = nullptr, *d_q_ctl = nullptr, *d_arrivals = nullptr;
+        double *d_saved = nullptr;          // the targets' rows before the optimisation
+        int32_t *h_ctl = nullptr;           // page-locked copy of the queue control words of the last launch
+        int max_resident = 0;               // workgroups of optim_fused_kernel the device holds at once
+    } fused;
     // device scratch of the less travelled entry points (eval_multi, render_expected): grown on demand, kept
     struct Scratch { void *p = nullptr; size_t cap = 0; } scratch[13];
     // timing
@@ -145,7 +155,7 @@ struct celeste_ctx {
     int ev_valid = 0;
 };
 
-extern "C" int celeste_version(void) { return 101; }
+extern "C" int celeste_version(void) { return CELESTE_ABI_VERSION; }
 
 extern "C" const char *celeste_strerror(int status) {
     switch (status) {
@@ -576,6 +586,10 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
         void *hptr[] = {o.h_vp, o.h_state, o.h_count};
         for (void *q : hptr) if (q) (void)hipHostFree(q);
         for (int k = 0; k < celeste_ctx::OptBuffers::RING; ++k) if (o.ev[k]) (void)hipEventDestroy(o.ev[k]);
+        auto &f = c->fused;
+        void *fptr[] = {f.d_chunk_desc, f.d_tgt_rec, f.d_q_items, f.d_q_ctl, f.d_arrivals, f.d_saved};
+        for (void *q : fptr) if (q) (void)hipFree(q);
+        if (f.h_ctl) (void)hipHostFree(f.h_ctl);
     }
     for (auto &sc : c->scratch) if (sc.p) (void)hipFree(sc.p);
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -611,7 +625,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
                        void *stream_, bool render_neighbors, const int32_t *d_active_rank = nullptr,
                        int64_t n_chunks = -1, bool tables_current = false, const int32_t *d_live = nullptr,
-                       bool prep_all = false);
+                       bool prep_all = false, bool render_only = false);
 
 extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_vp, int32_t n_targets,
                                               const int32_t *d_targets, uint32_t flags, double *d_v, double *d_d,
@@ -624,7 +638,10 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
                        void *stream_, bool render_neighbors, const int32_t *d_active_rank, int64_t n_chunks,
-                       bool tables_current, const int32_t *d_live, bool prep_all) {
+                       bool tables_current, const int32_t *d_live, bool prep_all, bool render_only) {
+    // render_only: the batch's bookkeeping (SrcGeo, visit items, record offsets, marks), the per-image tables of the
+    // targets and their neighbours and the neighbours' pre-rendered light -- everything the optimiser needs before its
+    // first evaluation -- and no evaluation
     // prep_all: the per-(source, image) tables of EVERY source are filled (the first part of a host batch does it for
     // the parts that follow, which pass tables_current); else only those of the targets and their neighbours
     // d_live (device, optional): the number of leading entries of d_targets that are live; n_targets is then an upper
@@ -749,6 +766,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_val_off,
                            c->d_value_items, c->NC, c->chunk_px, c->d_val);
     }
+    if (render_only) { HIP_TRY(hipGetLastError()); return CELESTE_OK; }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     const dim3 grid((unsigned)std::max<size_t>(grid_need, 1));
 #define PIXEL_ARGS                                                                                                \
@@ -1126,43 +1144,40 @@ extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, cons
 
 
 // ---- maximize! for a batch of targets (ElboMaximize.jl:228-242; neighbours frozen at the input vp) ----------
-// The Newton loop is device resident: the host enqueues iteration `it` while the device is still two iterations
-// behind, sizing the grids by the number of unconverged targets two iterations ago (an upper bound: the count never
-// grows); the true count lives in device memory and the kernels that depend on it read it there.  The counts come
-// back through page-locked slots with an event each, so the host never waits for the iteration it just enqueued.
-extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double *vp_neighbors,
-                                      const double *pos_centers, int32_t n_targets, const int32_t *targets,
-                                      const celeste_optim_config_t *cfg_in, int32_t *iterations, int32_t *f_evals,
-                                      double *elbo, int32_t *status) {
-    if (!c || !vp || !targets || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
-    if (n_targets == 0) return CELESTE_OK;
-    {
-        std::vector<uint8_t> seen((size_t)c->S, 0);   // two optimisations of one source would share its row of vp
-        for (int t = 0; t < n_targets; ++t) {
-            if (targets[t] < 0 || targets[t] >= c->S || seen[targets[t]]) return CELESTE_ERR_INVALID_ARG;
-            seen[targets[t]] = 1;
-        }
-    }
+// Two drivers of the same device functions:
+//  * fused (optim_fused_kernel, fused_kernels.h): ONE persistent launch in which every target iterates at its own pace --
+//    the default for batches of up to FUSED_AUTO_MAX targets (Cyclades layers, a rank's shard), where the chained
+//    driver's four dependent launches per Newton iteration leave the chip idle;
+//  * chained: work list -> pixel_kernel -> lift_kernel -> optim_step_kernel per Newton iteration, all targets in
+//    lock-step, for large batches that fill the chip kernel by kernel.  Its Newton loop is device resident: the host
+//    enqueues iteration `it` while the device is still two iterations behind, sizing the grids by the number of
+//    unconverged targets two iterations ago (an upper bound: the count never grows); the true count lives in device
+//    memory and the kernels that depend on it read it there.  The counts come back through page-locked slots with an
+//    event each, so the host never waits for the iteration it just enqueued.
+// Results are bit-identical (tests/test_gpu_fused.py).  CELESTE_OPT_FUSED=0 / 1 forces one or the other.
+#define FUSED_AUTO_MAX 1024
+
+static int optim_config(const celeste_optim_config_t *cfg_in, OptParams *op, uint32_t *flags) {
     celeste_optim_config_t cfg = {1e-4, 1.0, 50, 1, 1e-7, 1e-6, 1e-8, 1.0, 1e9, 0, 0};
     if (cfg_in) cfg = *cfg_in;
     if (!(cfg.loc_width > 0) || !(cfg.loc_scale > 0) || cfg.max_iters < 0 || cfg.tr_secular_iters < 0)
         return CELESTE_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(c->device));
-    OptParams op;
-    op.loc_width = cfg.loc_width; op.loc_scale = cfg.loc_scale; op.xtol_abs = cfg.xtol_abs; op.ftol_rel = cfg.ftol_rel;
-    op.gtol = cfg.gtol; op.initial_delta = cfg.initial_delta; op.delta_hat = cfg.delta_hat; op.max_iters = cfg.max_iters;
-    op.secular_iters = cfg.tr_secular_iters > 0 ? cfg.tr_secular_iters : 20;
+    op->loc_width = cfg.loc_width; op->loc_scale = cfg.loc_scale; op->xtol_abs = cfg.xtol_abs; op->ftol_rel = cfg.ftol_rel;
+    op->gtol = cfg.gtol; op->initial_delta = cfg.initial_delta; op->delta_hat = cfg.delta_hat; op->max_iters = cfg.max_iters;
+    op->secular_iters = cfg.tr_secular_iters > 0 ? cfg.tr_secular_iters : 20;
     // CELESTE_TR_SOLVER=eig: full eigen-decomposition for every sub-problem (cross-check of the default
     // tridiagonal-space solve)
     const char *env_solver = getenv("CELESTE_TR_SOLVER");
-    op.solver = (env_solver && strcmp(env_solver, "eig") == 0) ? 1 : 0;
-    const uint32_t flags = CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS | (cfg.include_kl ? CELESTE_FLAG_KL : 0);
-    const size_t n = (size_t)n_targets;
-    const size_t vp_bytes = (size_t)c->S * CEL_P * sizeof(double);
+    op->solver = (env_solver && strcmp(env_solver, "eig") == 0) ? 1 : 0;
+    op->pad = 0;
+    *flags = CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS | (cfg.include_kl ? CELESTE_FLAG_KL : 0);
+    return CELESTE_OK;
+}
+
+// per-target buffers of the optimiser at capacity >= n
+static int optim_buffers(celeste_ctx_t *c, size_t n, hipStream_t stream) {
     auto &ob = c->opt;
-    hipStream_t stream = c->stream;
-    int rc = CELESTE_OK;
-#define MX_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto cleanup; } } while (0)
+    const size_t vp_bytes = (size_t)c->S * CEL_P * sizeof(double);
     if (n > ob.cap) {   // (re)allocate every per-target buffer at the new capacity
         void **grow[] = {(void **)&ob.d_v, (void **)&ob.d_d, (void **)&ob.d_h, (void **)&ob.d_H, (void **)&ob.d_pos,
                          (void **)&ob.d_targets, (void **)&ob.d_act[0], (void **)&ob.d_act[1], (void **)&ob.d_evt[0],
@@ -1170,80 +1185,274 @@ extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double
         const size_t bytes[] = {sizeof(double), CEL_P * sizeof(double), CEL_P * CEL_P * sizeof(double), NF * NF * sizeof(double),
                                 2 * sizeof(double), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t),
                                 sizeof(int32_t), sizeof(int32_t), sizeof(OptState)};
-        MX_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         ob.cap = 0;
         for (int k = 0; k < 12; ++k) {
             if (*grow[k]) { (void)hipFree(*grow[k]); *grow[k] = nullptr; }
-            MX_TRY(hipMalloc(grow[k], n * bytes[k]));
+            HIP_TRY(hipMalloc(grow[k], n * bytes[k]));
         }
         if (ob.h_state) { (void)hipHostFree(ob.h_state); ob.h_state = nullptr; }
-        MX_TRY(hipHostMalloc(&ob.h_state, n * sizeof(OptState), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&ob.h_state, n * sizeof(OptState), hipHostMallocDefault));
         ob.cap = n;
     }
-    if (!ob.d_vp) MX_TRY(hipMalloc((void **)&ob.d_vp, vp_bytes));
-    if (!ob.d_count) MX_TRY(hipMalloc((void **)&ob.d_count, 3 * sizeof(int32_t)));   // two counters + blocks_done
-    if (!ob.h_vp) MX_TRY(hipHostMalloc((void **)&ob.h_vp, 2 * vp_bytes, hipHostMallocDefault));
+    if (!ob.d_vp) HIP_TRY(hipMalloc((void **)&ob.d_vp, vp_bytes));
+    if (!ob.d_count) HIP_TRY(hipMalloc((void **)&ob.d_count, 3 * sizeof(int32_t)));   // two counters + blocks_done
+    if (!ob.h_vp) HIP_TRY(hipHostMalloc((void **)&ob.h_vp, 2 * vp_bytes, hipHostMallocDefault));
     if (!ob.h_count) {
-        MX_TRY(hipHostMalloc((void **)&ob.h_count, celeste_ctx::OptBuffers::RING * sizeof(int32_t), hipHostMallocDefault));
-        for (int k = 0; k < celeste_ctx::OptBuffers::RING; ++k) MX_TRY(hipEventCreateWithFlags(&ob.ev[k], hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void **)&ob.h_count, celeste_ctx::OptBuffers::RING * sizeof(int32_t), hipHostMallocDefault));
+        for (int k = 0; k < celeste_ctx::OptBuffers::RING; ++k) HIP_TRY(hipEventCreateWithFlags(&ob.ev[k], hipEventDisableTiming));
     }
-    {
-    double *const d_vp = ob.d_vp, *const d_v = ob.d_v, *const d_d = ob.d_d, *const d_h = ob.d_h, *const d_H = ob.d_H;
-    double *const d_pos = pos_centers ? ob.d_pos : nullptr;
-    int32_t *const d_targets = ob.d_targets, *const d_st = ob.d_st;
+    return CELESTE_OK;
+}
+
+// the neighbours of the batch's targets as they act during the optimisation: rendered once, from the table at d_table
+// (ParallelRun.process_source, ParallelRun.jl:468-498), together with the batch's bookkeeping
+static int optim_render(celeste_ctx_t *c, const double *d_table, int32_t n_targets, const int32_t *d_targets,
+                        int64_t n_chunks, hipStream_t stream) {
+    return launch_eval(c, d_table, n_targets, d_targets, 0, c->opt.d_v, nullptr, nullptr, nullptr, c->opt.d_st, stream, true,
+                       nullptr, n_chunks, false, nullptr, false, /*render_only=*/true);
+}
+
+// how the batch is optimised: 1 = fused launch, 0 = chained
+static bool optim_use_fused(celeste_ctx_t *c, int32_t n_targets, int64_t n_chunks, const OptParams &op) {
+    int mode = -1;
+    if (const char *e = getenv("CELESTE_OPT_FUSED")) mode = atoi(e);
+    if (mode == 0) return false;
+    const int64_t rec = n_chunks >= 0 ? n_chunks : std::min<int64_t>((int64_t)n_targets * c->max_src_chunks, (int64_t)n_targets * c->M * c->CH);
+    const int64_t q = (rec + n_targets) * ((int64_t)op.max_iters + 2) + 4096;
+    if (q > (int64_t)1 << 28) return false;   // a queue of more than 1 GiB of tickets: lock-step is the better tool
+    if (mode == 1) return true;
+    return n_targets <= FUSED_AUTO_MAX;
+}
+
+// The fused launch.  The targets have been initialised (optim_init_kernel) and rendered (optim_render) on `stream`;
+// asynchronous.  c->fused.h_ctl[FQC_ABORT] != 0 after the stream has drained: the launch gave up (see fused_kernels.h).
+static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, const int32_t *d_targets, int64_t n_chunks,
+                           const OptParams &op, uint32_t flags, hipStream_t stream) {
+    auto &fb = c->fused;
+    auto &ob = c->opt;
+    const size_t n = (size_t)n_targets;
+    const size_t rec = (size_t)(n_chunks >= 0 ? n_chunks
+                                              : std::min<int64_t>((int64_t)n_targets * c->max_src_chunks, (int64_t)n_targets * c->M * c->CH));
+    if (!fb.max_resident) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, optim_fused_kernel, FUSED_NT, 0));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        fb.max_resident = std::max(1, std::min(per_cu, 2) * cus);
+        if (const char *e = getenv("CELESTE_FUSED_GRID")) if (atoi(e) > 0) fb.max_resident = atoi(e);
+    }
+    const int G = (int)std::max<size_t>(1, std::min<size_t>((size_t)fb.max_resident, rec + n));
+    const size_t q_cap = (rec + n) * ((size_t)op.max_iters + 2) + (size_t)G + 64;
+    if (n > fb.cap_t) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        void **ps[] = {(void **)&fb.d_tgt_rec, (void **)&fb.d_arrivals};
+        for (void **q : ps) if (*q) { (void)hipFree(*q); *q = nullptr; }
+        fb.cap_t = 0;
+        HIP_TRY(hipMalloc((void **)&fb.d_tgt_rec, n * sizeof(int2)));
+        HIP_TRY(hipMalloc((void **)&fb.d_arrivals, n * sizeof(int32_t)));
+        fb.cap_t = n;
+    }
+    if (rec > fb.cap_rec) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (fb.d_chunk_desc) { (void)hipFree(fb.d_chunk_desc); fb.d_chunk_desc = nullptr; }
+        fb.cap_rec = 0;
+        HIP_TRY(hipMalloc((void **)&fb.d_chunk_desc, std::max<size_t>(rec, 1) * sizeof(int2)));
+        fb.cap_rec = rec;
+    }
+    if (q_cap > fb.cap_q) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (fb.d_q_items) { (void)hipFree(fb.d_q_items); fb.d_q_items = nullptr; }
+        fb.cap_q = 0;
+        HIP_TRY(hipMalloc((void **)&fb.d_q_items, q_cap * sizeof(int32_t)));
+        fb.cap_q = q_cap;
+    }
+    if (!fb.d_q_ctl) HIP_TRY(hipMalloc((void **)&fb.d_q_ctl, FQC_WORDS * sizeof(int32_t)));
+    if (!fb.h_ctl) HIP_TRY(hipHostMalloc((void **)&fb.h_ctl, FQC_WORDS * sizeof(int32_t), hipHostMallocDefault));
+    // every polled word is reset before every launch
+    HIP_TRY(hipMemsetAsync(fb.d_q_items, 0xFF, q_cap * sizeof(int32_t), stream));
+    HIP_TRY(hipMemsetAsync(fb.d_q_ctl, 0, FQC_WORDS * sizeof(int32_t), stream));
+    HIP_TRY(hipMemsetAsync(fb.d_arrivals, 0, n * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(fused_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_targets, n_targets,
+                       c->d_patches, c->d_vis_off, c->dense ? nullptr : c->d_items, c->N, c->M, c->chunk_px, c->d_rec_off,
+                       fb.d_chunk_desc, fb.d_tgt_rec, fb.d_q_items, fb.d_q_ctl);
+    FusedArgs A;
+    A.images = c->d_images; A.patches = c->d_patches; A.coefs = c->d_coefs; A.bitmaps = c->d_bitmaps;
+    A.nbr_off = c->d_nbr_off; A.nbr_idx = c->d_nbr_idx; A.val_off = c->d_val_off; A.val = c->d_val;
+    A.nv_base = c->d_nv_base; A.nbr_vis = c->d_nbr_vis; A.items = c->dense ? nullptr : c->d_items; A.geo = c->d_geo;
+    A.prior = c->d_prior; A.vis_off = c->d_vis_off; A.vis_img = c->d_vis_img; A.lg_sum = c->d_lg_sum; A.rec_off = c->d_rec_off;
+    A.N = c->N; A.NC = c->NC; A.K = c->K; A.M = c->M; A.CH = c->CH; A.chunk_px = c->chunk_px;
+    A.targets = d_targets; A.n_targets = n_targets; A.vp = d_vp; A.acc = c->d_acc;
+    A.chunk_desc = fb.d_chunk_desc; A.tgt_rec = fb.d_tgt_rec;
+    A.st = (OptState *)ob.d_state; A.Hstate = ob.d_H; A.op = op; A.flags = flags;
+    A.q_items = fb.d_q_items; A.q_ctl = fb.d_q_ctl; A.arrivals = fb.d_arrivals; A.q_cap = (int)std::min<size_t>(q_cap, 0x7fffffff);
+    double tmo_s = 10.0;
+    if (const char *e = getenv("CELESTE_FUSED_TIMEOUT_S")) if (atof(e) > 0) tmo_s = atof(e);
+    A.timeout_ticks = (long long)(tmo_s * 1e8);   // wall_clock64: 100 MHz
+    hipLaunchKernelGGL(optim_fused_kernel, dim3((unsigned)G), dim3(FUSED_NT), 0, stream, A);
+    HIP_TRY(hipMemcpyAsync(fb.h_ctl, fb.d_q_ctl, FQC_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipGetLastError());
+    return CELESTE_OK;
+}
+
+// The chained driver.  Blocks the host until the batch has converged.
+static int optim_run_chained(celeste_ctx_t *c, double *d_vp, int32_t n_targets, const int32_t *d_targets, const OptParams &op,
+                             uint32_t flags, hipStream_t stream) {
+    auto &ob = c->opt;
+    const size_t n = (size_t)n_targets;
+    double *const d_v = ob.d_v, *const d_d = ob.d_d, *const d_h = ob.d_h, *const d_H = ob.d_H;
+    int32_t *const d_st = ob.d_st;
     int32_t *const d_cnt[2] = {ob.d_count, ob.d_count + 1};
     int32_t *const *d_act = ob.d_act, *const *d_evt = ob.d_evt;
     OptState *const d_state = (OptState *)ob.d_state;
-    double *const h_vp0 = ob.h_vp, *const h_vp1 = ob.h_vp + (size_t)c->S * CEL_P;
     constexpr int RING = celeste_ctx::OptBuffers::RING;
-    MX_TRY(hipMemsetAsync(ob.d_count, 0, 3 * sizeof(int32_t), stream));   // (an earlier call may have stopped mid-loop)
+    HIP_TRY(hipMemsetAsync(ob.d_count, 0, 3 * sizeof(int32_t), stream));   // (an earlier call may have stopped mid-loop)
+    HIP_TRY(hipMemcpyAsync(d_evt[0], d_targets, n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    int32_t n_upper = n_targets;
+    int cur = 0;
+    for (int it = 0; it <= op.max_iters + 1; ++it) {
+        if (it >= 2) {   // the count two iterations back: an upper bound of the live targets, 0 = all converged
+            HIP_TRY(hipEventSynchronize(ob.ev[(it - 2) % RING]));
+            n_upper = ob.h_count[(it - 2) % RING];
+            if (n_upper <= 0) break;
+        }
+        const int32_t *d_live = it == 0 ? nullptr : d_cnt[cur];
+        int st1 = launch_eval(c, d_vp, n_upper, d_evt[cur], flags, d_v, d_d, d_h, nullptr, d_st, stream, false, nullptr,
+                              -1, false, d_live);
+        if (st1 != CELESTE_OK) return st1;
+        hipLaunchKernelGGL(optim_step_kernel, dim3(n_upper), dim3(64), 0, stream, d_vp, d_targets, d_act[cur],
+                           d_v, d_d, d_h, d_st, op, d_state, d_H, d_act[1 - cur], d_evt[1 - cur], d_cnt[1 - cur],
+                           it == 0 ? nullptr : d_cnt[cur], ob.d_count + 2, &ob.h_count[it % RING]);
+        HIP_TRY(hipEventRecord(ob.ev[it % RING], stream));
+        cur = 1 - cur;
+    }
+    return CELESTE_OK;
+}
+
+// maximize! of the targets against the table at d_vp (rendering done): save the rows, initialise, run, write the
+// per-target outputs (device pointers, may be NULL) and give failed targets their rows back.  *fused_out: which driver.
+static int optim_run(celeste_ctx_t *c, double *d_vp, const double *d_pos, int32_t n_targets, const int32_t *d_targets,
+                     int64_t n_chunks, const OptParams &op, uint32_t flags, int32_t *d_iterations, int32_t *d_f_evals,
+                     double *d_elbo, int32_t *d_status, hipStream_t stream, bool *fused_out) {
+    auto &ob = c->opt;
+    auto &fb = c->fused;
+    const size_t n = (size_t)n_targets;
+    if (n * CEL_P > fb.cap_saved) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (fb.d_saved) { (void)hipFree(fb.d_saved); fb.d_saved = nullptr; }
+        fb.cap_saved = 0;
+        HIP_TRY(hipMalloc((void **)&fb.d_saved, n * CEL_P * sizeof(double)));
+        fb.cap_saved = n * CEL_P;
+    }
+    hipLaunchKernelGGL(save_rows_kernel, dim3((unsigned)((n * CEL_P + 255) / 256)), dim3(256), 0, stream, d_vp, d_targets,
+                       n_targets, fb.d_saved);
+    hipLaunchKernelGGL(optim_init_kernel, dim3((n_targets + 63) / 64), dim3(64), 0, stream, d_vp, d_targets, n_targets, op,
+                       (OptState *)ob.d_state, ob.d_act[0], d_pos);
+    const bool fused = optim_use_fused(c, n_targets, n_chunks, op);
+    if (fused_out) *fused_out = fused;
+    int st = fused ? optim_run_fused(c, d_vp, n_targets, d_targets, n_chunks, op, flags, stream)
+                   : optim_run_chained(c, d_vp, n_targets, d_targets, op, flags, stream);
+    if (st != CELESTE_OK) return st;
+    hipLaunchKernelGGL(optim_finalize_kernel, dim3((n_targets + 63) / 64), dim3(64), 0, stream, (const OptState *)ob.d_state,
+                       d_targets, n_targets, d_vp, fb.d_saved, d_iterations, d_f_evals, d_elbo, d_status,
+                       fused ? fb.d_q_ctl : nullptr);
+    HIP_TRY(hipGetLastError());
+    return CELESTE_OK;
+}
+
+// did the last fused launch on this context give up?  (after the stream has been synchronised)
+static int fused_abort_status(celeste_ctx_t *c) {
+    const int code = c->fused.h_ctl ? c->fused.h_ctl[FQC_ABORT] : 0;
+    if (code == 0) return CELESTE_OK;
+    fprintf(stderr, "celeste_mi355x: the fused optimiser launch gave up (%s)\n",
+            code == 1 ? "a workgroup waited longer than CELESTE_FUSED_TIMEOUT_S for work" : "queue capacity exceeded");
+    return CELESTE_ERR_HIP;
+}
+
+extern "C" int celeste_maximize_batch_device(celeste_ctx_t *c, double *d_vp, const double *d_vp_neighbors,
+                                             const double *d_pos_centers, int32_t n_targets, const int32_t *d_targets,
+                                             const celeste_optim_config_t *cfg_in, int32_t *d_iterations, int32_t *d_f_evals,
+                                             double *d_elbo, int32_t *d_status, void *stream_) {
+    if (!c || !d_vp || !d_targets || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
+    if (n_targets == 0) return CELESTE_OK;
+    OptParams op;
+    uint32_t flags;
+    int st = optim_config(cfg_in, &op, &flags);
+    if (st != CELESTE_OK) return st;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    st = optim_buffers(c, (size_t)n_targets, stream);
+    if (st != CELESTE_OK) return st;
+    st = optim_render(c, d_vp_neighbors ? d_vp_neighbors : d_vp, n_targets, d_targets, -1, stream);
+    if (st != CELESTE_OK) return st;
+    return optim_run(c, d_vp, d_pos_centers, n_targets, d_targets, -1, op, flags, d_iterations, d_f_evals, d_elbo, d_status,
+                     stream, nullptr);
+}
+
+static int check_distinct_targets(celeste_ctx_t *c, int32_t n, const int32_t *targets, std::vector<uint8_t> &seen) {
+    seen.assign((size_t)c->S, 0);   // two optimisations of one source would share its row of vp
+    for (int t = 0; t < n; ++t) {
+        if (targets[t] < 0 || targets[t] >= c->S || seen[targets[t]]) return CELESTE_ERR_INVALID_ARG;
+        seen[targets[t]] = 1;
+    }
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double *vp_neighbors,
+                                      const double *pos_centers, int32_t n_targets, const int32_t *targets,
+                                      const celeste_optim_config_t *cfg_in, int32_t *iterations, int32_t *f_evals,
+                                      double *elbo, int32_t *status) {
+    if (!c || !vp || !targets || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
+    if (n_targets == 0) return CELESTE_OK;
+    std::vector<uint8_t> seen;
+    if (check_distinct_targets(c, n_targets, targets, seen) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
+    OptParams op;
+    uint32_t flags;
+    int rc = optim_config(cfg_in, &op, &flags);
+    if (rc != CELESTE_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)n_targets;
+    const size_t vp_bytes = (size_t)c->S * CEL_P * sizeof(double);
+    auto &ob = c->opt;
+    hipStream_t stream = c->stream;
+    rc = optim_buffers(c, n, stream);
+    if (rc != CELESTE_OK) return rc;
+    int64_t n_chunks = 0;
+    for (int t = 0; t < n_targets; ++t) n_chunks += c->h_src_chunks[targets[t]];
+#define MX_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto cleanup; } } while (0)
+    {
+    double *const d_vp = ob.d_vp;
+    double *const d_pos = pos_centers ? ob.d_pos : nullptr;
+    int32_t *const d_targets = ob.d_targets;
+    double *const h_vp0 = ob.h_vp, *const h_vp1 = ob.h_vp + (size_t)c->S * CEL_P;
     MX_TRY(hipMemcpyAsync(d_targets, targets, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     if (pos_centers) MX_TRY(hipMemcpyAsync(d_pos, pos_centers, n * 2 * sizeof(double), hipMemcpyHostToDevice, stream));
-    {
-        // neighbours are rendered once, from their frozen parameters, before any target moves
-        memcpy(h_vp0, vp_neighbors ? vp_neighbors : vp, vp_bytes);
-        MX_TRY(hipMemcpyAsync(d_vp, h_vp0, vp_bytes, hipMemcpyHostToDevice, stream));
-        int st0 = launch_eval(c, d_vp, n_targets, d_targets, 0, d_v, nullptr, nullptr, nullptr, d_st, stream, true);
-        if (st0 != CELESTE_OK) { rc = st0; goto cleanup; }
-        if (vp_neighbors) {
-            memcpy(h_vp1, vp, vp_bytes);
-            MX_TRY(hipMemcpyAsync(d_vp, h_vp1, vp_bytes, hipMemcpyHostToDevice, stream));
-        }
-        hipLaunchKernelGGL(optim_init_kernel, dim3((n_targets + 63) / 64), dim3(64), 0, stream, d_vp, d_targets,
-                           n_targets, op, d_state, d_act[0], d_pos);
-        MX_TRY(hipMemcpyAsync(d_evt[0], d_targets, n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
-        int32_t n_upper = n_targets;
-        int cur = 0;
-        for (int it = 0; it <= cfg.max_iters + 1; ++it) {
-            if (it >= 2) {   // the count two iterations back: an upper bound of the live targets, 0 = all converged
-                MX_TRY(hipEventSynchronize(ob.ev[(it - 2) % RING]));
-                n_upper = ob.h_count[(it - 2) % RING];
-                if (n_upper <= 0) break;
-            }
-            const int32_t *d_live = it == 0 ? nullptr : d_cnt[cur];
-            int st1 = launch_eval(c, d_vp, n_upper, d_evt[cur], flags, d_v, d_d, d_h, nullptr, d_st, stream, false, nullptr,
-                                  -1, false, d_live);
-            if (st1 != CELESTE_OK) { rc = st1; goto cleanup; }
-            hipLaunchKernelGGL(optim_step_kernel, dim3(n_upper), dim3(64), 0, stream, d_vp, d_targets, d_act[cur],
-                               d_v, d_d, d_h, d_st, op, d_state, d_H, d_act[1 - cur], d_evt[1 - cur], d_cnt[1 - cur],
-                               it == 0 ? nullptr : d_cnt[cur], ob.d_count + 2, &ob.h_count[it % RING]);
-            MX_TRY(hipEventRecord(ob.ev[it % RING], stream));
-            cur = 1 - cur;
-        }
-        OptState *const hs = (OptState *)ob.h_state;
-        MX_TRY(hipMemcpyAsync(hs, d_state, n * sizeof(OptState), hipMemcpyDeviceToHost, stream));
-        MX_TRY(hipMemcpyAsync(h_vp0, d_vp, vp_bytes, hipMemcpyDeviceToHost, stream));
-        MX_TRY(hipStreamSynchronize(stream));
-        for (int t = 0; t < n_targets; ++t) {
-            // a target that failed keeps its input row; the others are unaffected (ParallelRun.jl:582-597)
-            if (hs[t].status == CELESTE_OK)
-                memcpy(vp + (size_t)targets[t] * CEL_P, h_vp0 + (size_t)targets[t] * CEL_P, CEL_P * sizeof(double));
-            if (iterations) iterations[t] = hs[t].iter;
-            if (f_evals) f_evals[t] = hs[t].evals;
-            if (elbo) elbo[t] = -hs[t].f;
-            if (status) status[t] = hs[t].status;
-            if (hs[t].status != CELESTE_OK && rc == CELESTE_OK) rc = hs[t].status;
-        }
+    // neighbours are rendered once, from their frozen parameters, before any target moves
+    memcpy(h_vp0, vp_neighbors ? vp_neighbors : vp, vp_bytes);
+    MX_TRY(hipMemcpyAsync(d_vp, h_vp0, vp_bytes, hipMemcpyHostToDevice, stream));
+    rc = optim_render(c, d_vp, n_targets, d_targets, n_chunks, stream);
+    if (rc != CELESTE_OK) goto cleanup;
+    if (vp_neighbors) {
+        memcpy(h_vp1, vp, vp_bytes);
+        MX_TRY(hipMemcpyAsync(d_vp, h_vp1, vp_bytes, hipMemcpyHostToDevice, stream));
+    }
+    bool fused = false;
+    rc = optim_run(c, d_vp, d_pos, n_targets, d_targets, n_chunks, op, flags, nullptr, nullptr, nullptr, nullptr, stream, &fused);
+    if (rc != CELESTE_OK) goto cleanup;
+    OptState *const hs = (OptState *)ob.h_state;
+    MX_TRY(hipMemcpyAsync(hs, ob.d_state, n * sizeof(OptState), hipMemcpyDeviceToHost, stream));
+    MX_TRY(hipMemcpyAsync(h_vp0, d_vp, vp_bytes, hipMemcpyDeviceToHost, stream));
+    MX_TRY(hipStreamSynchronize(stream));
+    if (fused && (rc = fused_abort_status(c)) != CELESTE_OK) goto cleanup;
+    for (int t = 0; t < n_targets; ++t) {
+        // a target that failed keeps its input row; the others are unaffected (ParallelRun.jl:582-597)
+        if (hs[t].status == CELESTE_OK)
+            memcpy(vp + (size_t)targets[t] * CEL_P, h_vp0 + (size_t)targets[t] * CEL_P, CEL_P * sizeof(double));
+        if (iterations) iterations[t] = hs[t].iter;
+        if (f_evals) f_evals[t] = hs[t].evals;
+        if (elbo) elbo[t] = -hs[t].f;
+        if (status) status[t] = hs[t].status;
+        if (hs[t].status != CELESTE_OK && rc == CELESTE_OK) rc = hs[t].status;
     }
     }
 cleanup:
@@ -1252,6 +1461,96 @@ cleanup:
     return rc;
 }
 
+// ---- joint inference: a schedule of layers against one device-resident parameter table -------------------------
+extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layers, const int64_t *layer_offsets,
+                                   const int32_t *layer_targets, const double *pos_centers,
+                                   const celeste_optim_config_t *cfg_in, int32_t *iterations, int32_t *f_evals,
+                                   double *elbo, int32_t *status) {
+    if (!c || !vp || n_layers < 0 || (n_layers > 0 && (!layer_offsets || !layer_targets))) return CELESTE_ERR_INVALID_ARG;
+    if (n_layers == 0) return CELESTE_OK;
+    if (layer_offsets[0] != 0) return CELESTE_ERR_INVALID_ARG;
+    const int64_t total = layer_offsets[n_layers];
+    size_t widest = 0;
+    std::vector<uint8_t> seen;
+    std::vector<int64_t> layer_chunks((size_t)n_layers, 0);
+    for (int l = 0; l < n_layers; ++l) {
+        const int64_t lo = layer_offsets[l], hi = layer_offsets[l + 1];
+        if (hi < lo || hi - lo > 0x7fffffff) return CELESTE_ERR_INVALID_ARG;
+        if (check_distinct_targets(c, (int32_t)(hi - lo), layer_targets + lo, seen) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
+        // the sources of a layer are optimised simultaneously: none may be another's neighbour
+        for (int64_t e = lo; e < hi; ++e) {
+            const int t = layer_targets[e];
+            for (int64_t q = c->h_nbr_off[t]; q < c->h_nbr_off[t + 1]; ++q) if (seen[c->h_nbr_idx[q]]) return CELESTE_ERR_INVALID_ARG;
+            layer_chunks[l] += c->h_src_chunks[t];
+        }
+        widest = std::max(widest, (size_t)(hi - lo));
+    }
+    if (total == 0) return CELESTE_OK;
+    OptParams op;
+    uint32_t flags;
+    int rc = optim_config(cfg_in, &op, &flags);
+    if (rc != CELESTE_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t stream = c->stream;
+    rc = optim_buffers(c, widest, stream);
+    if (rc != CELESTE_OK) return rc;
+    auto &ob = c->opt;
+    const size_t vp_bytes = (size_t)c->S * CEL_P * sizeof(double);
+    // the whole schedule and the per-entry outputs live on the device for the duration of the call
+    int32_t *d_all = nullptr, *d_it = nullptr, *d_ev = nullptr, *d_stt = nullptr;
+    double *d_pos = nullptr, *d_el = nullptr;
+    std::vector<int32_t> h_it((size_t)total), h_ev((size_t)total), h_st((size_t)total);
+    std::vector<double> h_el((size_t)total);
+    bool any_fused = false;
+    int abort_rc = CELESTE_OK;
+#define JI_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto done; } } while (0)
+    JI_TRY(hipMalloc((void **)&d_all, (size_t)total * sizeof(int32_t)));
+    JI_TRY(hipMalloc((void **)&d_it, (size_t)total * sizeof(int32_t)));
+    JI_TRY(hipMalloc((void **)&d_ev, (size_t)total * sizeof(int32_t)));
+    JI_TRY(hipMalloc((void **)&d_stt, (size_t)total * sizeof(int32_t)));
+    JI_TRY(hipMalloc((void **)&d_el, (size_t)total * sizeof(double)));
+    if (pos_centers) JI_TRY(hipMalloc((void **)&d_pos, (size_t)total * 2 * sizeof(double)));
+    JI_TRY(hipMemcpyAsync(d_all, layer_targets, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    if (pos_centers) JI_TRY(hipMemcpyAsync(d_pos, pos_centers, (size_t)total * 2 * sizeof(double), hipMemcpyHostToDevice, stream));
+    memcpy(ob.h_vp, vp, vp_bytes);
+    JI_TRY(hipMemcpyAsync(ob.d_vp, ob.h_vp, vp_bytes, hipMemcpyHostToDevice, stream));
+    for (int l = 0; l < n_layers; ++l) {
+        const int64_t lo = layer_offsets[l];
+        const int32_t n = (int32_t)(layer_offsets[l + 1] - lo);
+        if (n == 0) continue;
+        // every layer sees the table as the layers before it left it (ParallelRun.jl:372-397)
+        rc = optim_render(c, ob.d_vp, n, d_all + lo, layer_chunks[l], stream);
+        if (rc != CELESTE_OK) goto done;
+        bool fused = false;
+        rc = optim_run(c, ob.d_vp, d_pos ? d_pos + 2 * lo : nullptr, n, d_all + lo, layer_chunks[l], op, flags, d_it + lo,
+                       d_ev + lo, d_el + lo, d_stt + lo, stream, &fused);
+        if (rc != CELESTE_OK) goto done;
+        any_fused |= fused;
+    }
+    JI_TRY(hipMemcpyAsync(ob.h_vp, ob.d_vp, vp_bytes, hipMemcpyDeviceToHost, stream));
+    JI_TRY(hipMemcpyAsync(h_it.data(), d_it, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    JI_TRY(hipMemcpyAsync(h_ev.data(), d_ev, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    JI_TRY(hipMemcpyAsync(h_st.data(), d_stt, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    JI_TRY(hipMemcpyAsync(h_el.data(), d_el, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, stream));
+    JI_TRY(hipStreamSynchronize(stream));
+    if (any_fused) abort_rc = fused_abort_status(c);   // (of the last fused layer; an earlier one shows in the statuses)
+    for (int64_t e = 0; e < total; ++e) {
+        if (h_st[e] == CELESTE_ERR_HIP) abort_rc = CELESTE_ERR_HIP;
+        if (iterations) iterations[e] = h_it[e];
+        if (f_evals) f_evals[e] = h_ev[e];
+        if (elbo) elbo[e] = h_el[e];
+        if (status) status[e] = h_st[e];
+        if (h_st[e] != CELESTE_OK && rc == CELESTE_OK) rc = h_st[e];
+    }
+    if (abort_rc != CELESTE_OK) rc = abort_rc;
+    else memcpy(vp, ob.h_vp, vp_bytes);   // failed targets already hold their pre-layer rows (optim_finalize_kernel)
+done:
+#undef JI_TRY
+    (void)hipStreamSynchronize(stream);
+    void *ptrs[] = {d_all, d_it, d_ev, d_stt, d_el, d_pos};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    return rc;
+}
 
 extern "C" int celeste_optim_stats(int reset, uint64_t out[5]) {
     unsigned long long h[5] = {0, 0, 0, 0, 0};

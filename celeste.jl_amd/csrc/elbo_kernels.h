@@ -66,13 +66,12 @@ __device__ inline void brightness(const double *vs, int i, int b, double &El, do
     El = e; Ell = ee;
 }
 
-// the tables of one (source, image) visit: lane c < NC computes component c, lane 63 the brightness moments
-__device__ __forceinline__ void prep_visit(int c, int s, int n, int sn, const double *__restrict__ vp,
-                                           const DevImage *__restrict__ images, const DevPatch *__restrict__ patches, int K,
-                                           SrcImg *__restrict__ srcimg, Comp *__restrict__ comps) {
+// the tables of one (source, image) visit: lane c < NC computes component c, lane 63 the brightness moments.
+// vs: the source's 44 parameters; p: its patch in the image; b: the image's band, 0-based; the results go to *si_out and
+// comps_out[c] -- the per-visit tables in HBM (prep_kernel) or a workgroup's LDS copy (optim_fused_kernel)
+__device__ __forceinline__ void prep_visit_values(int c, const double *__restrict__ vs, const DevPatch &p, int b, int K,
+                                                  SrcImg *__restrict__ si_out, Comp *__restrict__ comps_out) {
     const int NC = 14 * K;
-    const double *vs = vp + (size_t)s * CEL_P;
-    const DevPatch &p = patches[sn];
     const double d0 = vs[0] - p.wc[0], d1 = vs[1] - p.wc[1];
     const double m1 = p.J[0] * d0 + p.J[2] * d1 + p.pc[0];  // linear_world_to_pix (wcs_utils.jl:14-18)
     const double m2 = p.J[1] * d0 + p.J[3] * d1 + p.pc[1];
@@ -98,10 +97,9 @@ __device__ __forceinline__ void prep_visit(int c, int s, int n, int sn, const do
         o.w0 = z * (i == 0 ? dev : 1.0 - dev);
         o.wd = (i == 0 ? z : -z);
         o.nu = nu;
-        comps[(size_t)sn * NC + c] = o;
+        comps_out[c] = o;
     }
     if (c == 63) {
-        const int b = images[n].band - 1;
         double El0, Ell0, El1, Ell1;
         brightness(vs, 0, b, El0, Ell0);
         brightness(vs, 1, b, El1, Ell1);
@@ -110,8 +108,13 @@ __device__ __forceinline__ void prep_visit(int c, int s, int n, int sn, const do
         o.c0 = vs[26] * El0; o.c1 = vs[27] * El1;
         o.q0 = vs[26] * Ell0; o.q1 = vs[27] * Ell1;
         o.dev = vs[2]; o.pad1 = 0;
-        srcimg[sn] = o;
+        *si_out = o;
     }
+}
+__device__ __forceinline__ void prep_visit(int c, int s, int n, int sn, const double *__restrict__ vp,
+                                           const DevImage *__restrict__ images, const DevPatch *__restrict__ patches, int K,
+                                           SrcImg *__restrict__ srcimg, Comp *__restrict__ comps) {
+    prep_visit_values(c, vp + (size_t)s * CEL_P, patches[sn], images[n].band - 1, K, srcimg + sn, comps + (size_t)sn * (14 * K));
 }
 
 __global__ void __launch_bounds__(64)
@@ -148,8 +151,7 @@ prep_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
 }
 
 // per-source shape derivatives and the finiteness flag of its parameters
-__device__ inline void source_geo(const double *vp, int s, SrcGeo *geo) {
-    const double *vs = vp + (size_t)s * CEL_P;
+__device__ __forceinline__ void source_geo_values(const double *vs, SrcGeo *out) {
     double x11, x12, x22;
     bvn_cov(vs[3], vs[4], vs[5], x11, x12, x22);
         // GalaxySigmaDerivs without nuBar (BivariateNormals.jl:346-397); argument order there is
@@ -180,8 +182,9 @@ __device__ inline void source_geo(const double *vp, int s, SrcGeo *geo) {
         int fin = 1;
         for (int q = 0; q < CEL_P; ++q) fin &= (int)isfinite(vs[q]);
         g.finite = fin; g.pad = 0;
-        geo[s] = g;
+        *out = g;
 }
+__device__ inline void source_geo(const double *vp, int s, SrcGeo *geo) { source_geo_values(vp + (size_t)s * CEL_P, geo + s); }
 
 // ---------------------------------------------------------------------------------------------
 // Parameter-independent terms, once per context.
@@ -1127,98 +1130,51 @@ __device__ __forceinline__ PixelInputs load_pixel_inputs(
 #define PIXEL_WAVES 2  // waves per SIMD the register allocator must allow (256 VGPRs, no scratch; 3 waves with a dozen
                        // loop invariants in scratch measured 3 % slower)
 #endif
-// R: arithmetic type of the galaxy component loop (double; float with CELESTE_FLAG_FP32 -- everything
-// downstream of the 24 component sums, and all accumulation, stays fp64)
-// MULTI: several active sources (celeste_elbo_eval_multi) -- compiled separately so that the production
-// instantiation carries none of its per-neighbour bookkeeping
-template <int MODE, typename R, bool MULTI = false>
-__global__ void __launch_bounds__(64, PIXEL_WAVES)
-pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ patches,
-             const double *__restrict__ coefs, const uint8_t *__restrict__ bitmaps,
-             const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
-             const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
-             const int64_t *__restrict__ val_off, const double2 *__restrict__ val,
-             const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px, int G,
-             double *__restrict__ acc, const int64_t *__restrict__ tile_off, double *__restrict__ rec,
-             const int32_t *__restrict__ active_rank, const int2 *__restrict__ items, int M,
-             const int32_t *__restrict__ work, const int32_t *__restrict__ work_total,
-             const int64_t *__restrict__ nv_base, const int32_t *__restrict__ nbr_vis,
-             const int32_t *__restrict__ rec_off) {
+
+// What one 64-pixel iteration of the pixel loop needs besides its position: the (target, image) patch, the target's
+// per-image tables (in LDS) and the neighbour look-up.  Filled once per work item by pixel_kernel, once per queue item by
+// the fused optimiser kernel (optim_fused_kernel): both run the SAME iteration body, pixel_iter.
+template <typename R>
+struct PixWork {
+    const DevImage *img; const DevPatch *P; const DevPatch *patches; const uint8_t *bitmaps;
+    const int32_t *nbr_idx; const int32_t *nv; int64_t nb0, nb1;
+    const int64_t *val_off; const double2 *val; const int32_t *active_rank;
+    int my_rank, N, n, NC, v;
+    SrcImg si;                       // the target's pixel-space position and brightness moments for this image
+    const Comp *tc;                  // its 14 psf_K components (LDS)
+    const CompR<R> *tcr;             // the same in the arithmetic type of the component loop (LDS)
+    const double *etab;              // 2^(j/64) table (LDS)
+    const double *tcoef;             // star spline coefficients of the patch's stamp
+    const int64_t *tile_off; double *rec;   // split variant only
+};
+
+// One iteration of the pixel loop: lanes = the 64 pixels idx = base + lane < p1 of the patch (h fastest).  MODE 0 adds
+// into a[3]; MODE 1 / 2 add the pixel's record entries into the 16 slots per entry at `slot` (accum_entries) after
+// calling gate() -- a no-op in pixel_kernel, where one wave runs the iterations of a chunk in turn; the fused optimiser
+// kernel gives the four iterations of a chunk to four waves and uses the gate to let them ADD in iteration order, which
+// makes its chunk records bit-identical to pixel_kernel's.
+template <int MODE, typename R, bool MULTI, class Gate>
+__device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1, int lane, double *__restrict__ slot,
+                                           double (&a)[3], Gate &&gate) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
-    __shared__ double etab[64];
-    // work list (work_fill_kernel): groups of up to G chunks that exist, longest first.  The grid is the host's bound on
-    // the list's length: exact when it knows the targets, else the chunk count of the n_targets chunk-richest sources --
-    // which a list with repeated targets can exceed, hence the stride loop (one trip in every other case).
-    const int n_items = *work_total;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    if (item != (int)blockIdx.x) __syncthreads();      // second trip: every lane is done with the LDS tables
-    const int wg0 = work[item];  // record index of the group's first chunk, as the lift kernel expects: ((ti * M + j) * CH + ch)
-    const int tn = wg0 / CH;
-    const int ch0 = wg0 - tn * CH;
-    const int ti = tn / M;                     // tn = ti * M + j: target, j-th image it appears in
-    const int t = targets[ti];
-    int n = tn - ti * M, v = t * N + n;        // items == nullptr: every source is listed in all M = N images, visit = t N + n
-    if (items) { const int2 e = items[tn]; v = e.x; n = e.y; }
-    if (v < 0) continue;
-    const int rec_base = rec_off[tn];
-    const DevPatch &P = patches[v];
+    const DevImage &img = *W.img;
+    const DevPatch &P = *W.P;
+    const SrcImg &si = W.si;
     const int H2 = P.H2, W2 = P.W2;
-    const int npx = H2 * W2;
-    if (ch0 * chunk_px >= npx) continue;  // the lift kernel recomputes this predicate
-    const DevImage &img = images[n];
-    const int lane = threadIdx.x;
-    const SrcImg si = srcimg[v];
-    // Workgroup prologue: the exp table and the target's components (64-byte records) are staged in LDS with
-    // one coalesced read each and a single barrier (the scalar data cache cannot hold 8 waves x 1.8 KB per CU:
-    // 68 % of per-component s_loads missed to L2).
-    __shared__ Comp tc[14 * CEL_MAXK];
-    __shared__ CompR<R> tcr_f[sizeof(R) == 4 ? 14 * CEL_MAXK : 1];
-    {
-        const double *src = reinterpret_cast<const double *>(comps + (size_t)v * NC);
-        double *dst = reinterpret_cast<double *>(tc);
-        R *dstf = reinterpret_cast<R *>(tcr_f);
-        const double tabv = g_exp2_table[lane];
-        for (int i = lane; i < NC * 8; i += 64) {
-            const double v = src[i];
-            dst[i] = v;
-            if (sizeof(R) == 4) dstf[i] = (R)v;
-        }
-        etab[lane] = tabv;
-        __syncthreads();
-    }
-    const CompR<R> *tcr = sizeof(R) == 4 ? tcr_f : reinterpret_cast<const CompR<R> *>(tc);
-    const double *__restrict__ tcoef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
-    const int64_t nb0 = nbr_off[t], nb1 = nbr_off[t + 1];
-    // visit lists: the row of this visit in the table of the neighbours' visits
-    const int32_t *__restrict__ nv = nbr_vis ? nbr_vis + nv_base[t] + (int64_t)(tn - ti * M) * (nb1 - nb0) : nullptr;
-    // several active sources (celeste_elbo_eval_multi): a pixel of two active patches is visited by the earlier
-    // one only (elbo_objective.jl:430-470) -- its value term and inactive-source count are dropped here
-    const int my_rank = MULTI ? active_rank[t] : 0;
     const double c0 = si.c0, c1 = si.c1, q0 = si.q0, q1 = si.q1;
     // index offsets of the star spline: itp[h - m1 + 26, w - m2 + 26]
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
-    // the chunk's record, 16 slots per entry (accum_entries); MODE 0 keeps its three sums in registers
-    __shared__ double sacc[MODE == 0 || MODE == 3 ? 1 : ACC_N * ACC_SLOTS];
-    double *const slot = sacc + (lane & (ACC_SLOTS - 1));
-    for (int ch = ch0; ch < ch0 + G && ch * chunk_px < npx; ++ch) {   // every chunk of the group writes its own record
-    const int p0 = ch * chunk_px;
-    const int p1 = min(npx, p0 + chunk_px);
-    const int wg = rec_base + ch;            // the visit's records are consecutive (rec_off: prefix sum of the chunk counts)
-    if constexpr (MODE == 1 || MODE == 2) {
-#pragma unroll
-        for (int i = 0; i < ACC_N * ACC_SLOTS / 64; ++i) sacc[lane + 64 * i] = 0.0;
-        __syncthreads();
-    }
-    double a[3] = {0.0, 0.0, 0.0};
-
-    for (int base = p0; base < p1; base += 64) {
+    const int NC = W.NC;
+    const double *__restrict__ tcoef = W.tcoef;
+    const double *etab = W.etab;
+    {
         const int idx = min(base + lane, p1 - 1);           // clamped: every lane stays in the loop body
         const bool in_range = base + lane < p1;
         const int w2 = idx / H2, h2 = idx - w2 * H2;        // 0-based patch coordinates, h fastest
         const int h = P.off_h + h2 + 1, w = P.off_w + w2 + 1;  // 1-based image coordinates
         const double hh = (double)h, ww = (double)w;
-#define LOAD_PIXEL_INPUTS() load_pixel_inputs<MULTI>(img, P, patches, bitmaps, nbr_idx, nv, nb0, nb1, val_off, val, active_rank, \
-                                                     my_rank, N, n, H2, h, w, h2, w2, in_range)
+#define LOAD_PIXEL_INPUTS() load_pixel_inputs<MULTI>(img, P, W.patches, W.bitmaps, W.nbr_idx, W.nv, W.nb0, W.nb1, W.val_off, \
+                                                     W.val, W.active_rank, W.my_rank, W.N, W.n, H2, h, w, h2, w2, in_range)
         // ---- the active source ----
         const bool own_geo = in_range && (w2 < W2 - 1);  // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
         if (MODE == 0) {
@@ -1229,7 +1185,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             double f0 = 0, f1 = 0;
             if (own) {
                 f0 = star_value(tcoef, hh + sh0, ww + sw0);
-                f1 = galaxy_value(tc, NC, hh - si.m1, ww - si.m2, etab);
+                f1 = galaxy_value(W.tc, NC, hh - si.m1, ww - si.m2, etab);
             }
             if (valid) {
                 const double A = c0 * f0 + c1 * f1;
@@ -1240,7 +1196,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
                 a[1] += own ? 1.0 : 0.0;
                 a[2] += (double)n_inact;
             }
-            continue;
+            return;
         }
 
         PixelTerms T;
@@ -1257,12 +1213,13 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         // inside the patch costs one wasted evaluation; its record entries are zeroed by the weights below).
         if (own_geo) {
 #endif
-            if constexpr (sizeof(R) == 4) S0 = galaxy_sums_pk<GM>(tcr, NC, (float)(hh - si.m1), (float)(ww - si.m2), T);
-            else S0 = galaxy_sums<GM, R>(tcr, 8 * (NC / 14), NC, (R)(hh - si.m1), (R)(ww - si.m2), (R)si.dev, etab, T);
+            if constexpr (sizeof(R) == 4) S0 = galaxy_sums_pk<GM>(W.tcr, NC, (float)(hh - si.m1), (float)(ww - si.m2), T);
+            else S0 = galaxy_sums<GM, R>(W.tcr, 8 * (NC / 14), NC, (R)(hh - si.m1), (R)(ww - si.m2), (R)si.dev, etab, T);
         }
 #if !PIXEL_LOADS_FIRST
         const PixelInputs I = LOAD_PIXEL_INPUTS();
 #endif
+#undef LOAD_PIXEL_INPUTS
         const bool valid = I.valid, dup = I.dup, own = valid && own_geo;
         const double x = I.x, Ebar = I.Ebar, Vbar = I.Vbar, lgx = I.lgx, iota = I.iota, log_iota = I.log_iota;
         const int n_inact = I.n_inact;
@@ -1338,10 +1295,114 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
             }
         }
         if constexpr (MODE == 3)
-            store_entries<0>(T, rec + (size_t)(tile_off[v] + (base >> 6)) * (ACC_N * 64) + lane);
-        else
+            store_entries<0>(T, W.rec + (size_t)(W.tile_off[W.v] + (base >> 6)) * (ACC_N * 64) + lane);
+        else {
+            gate();
             accum_entries<MODE, 0>(T, slot);
+        }
     }
+}
+
+// lane e sums the 16 slots of entry e (rotated start: 4-way instead of 64-way bank conflicts; the order of the additions
+// is fixed per entry, so the record is reproducible) and hands the sum to store(e, s)
+template <int MODE, class Store>
+__device__ __forceinline__ void fold_record_slots(const double *__restrict__ sacc, int lane, Store &&store) {
+    for (int e = lane; e < ACC_N; e += 64) {
+        if (MODE == 1 && e > ZV && e < ACC_CNT) continue;   // Hessian entries are not produced
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < ACC_SLOTS; ++k) s += sacc[e * ACC_SLOTS + ((k + e) & (ACC_SLOTS - 1))];
+        store(e, s);
+    }
+}
+
+// R: arithmetic type of the galaxy component loop (double; float with CELESTE_FLAG_FP32 -- everything
+// downstream of the 24 component sums, and all accumulation, stays fp64)
+// MULTI: several active sources (celeste_elbo_eval_multi) -- compiled separately so that the production
+// instantiation carries none of its per-neighbour bookkeeping
+template <int MODE, typename R, bool MULTI = false>
+__global__ void __launch_bounds__(64, PIXEL_WAVES)
+pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ patches,
+             const double *__restrict__ coefs, const uint8_t *__restrict__ bitmaps,
+             const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
+             const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
+             const int64_t *__restrict__ val_off, const double2 *__restrict__ val,
+             const int32_t *__restrict__ targets, int N, int NC, int CH, int chunk_px, int G,
+             double *__restrict__ acc, const int64_t *__restrict__ tile_off, double *__restrict__ rec,
+             const int32_t *__restrict__ active_rank, const int2 *__restrict__ items, int M,
+             const int32_t *__restrict__ work, const int32_t *__restrict__ work_total,
+             const int64_t *__restrict__ nv_base, const int32_t *__restrict__ nbr_vis,
+             const int32_t *__restrict__ rec_off) {
+    __shared__ double etab[64];
+    // work list (work_fill_kernel): groups of up to G chunks that exist, longest first.  The grid is the host's bound on
+    // the list's length: exact when it knows the targets, else the chunk count of the n_targets chunk-richest sources --
+    // which a list with repeated targets can exceed, hence the stride loop (one trip in every other case).
+    const int n_items = *work_total;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    if (item != (int)blockIdx.x) __syncthreads();      // second trip: every lane is done with the LDS tables
+    const int wg0 = work[item];  // record index of the group's first chunk, as the lift kernel expects: ((ti * M + j) * CH + ch)
+    const int tn = wg0 / CH;
+    const int ch0 = wg0 - tn * CH;
+    const int ti = tn / M;                     // tn = ti * M + j: target, j-th image it appears in
+    const int t = targets[ti];
+    int n = tn - ti * M, v = t * N + n;        // items == nullptr: every source is listed in all M = N images, visit = t N + n
+    if (items) { const int2 e = items[tn]; v = e.x; n = e.y; }
+    if (v < 0) continue;
+    const int rec_base = rec_off[tn];
+    const DevPatch &P = patches[v];
+    const int H2 = P.H2, W2 = P.W2;
+    const int npx = H2 * W2;
+    if (ch0 * chunk_px >= npx) continue;  // the lift kernel recomputes this predicate
+    const int lane = threadIdx.x;
+    // Workgroup prologue: the exp table and the target's components (64-byte records) are staged in LDS with
+    // one coalesced read each and a single barrier (the scalar data cache cannot hold 8 waves x 1.8 KB per CU:
+    // 68 % of per-component s_loads missed to L2).
+    __shared__ Comp tc[14 * CEL_MAXK];
+    __shared__ CompR<R> tcr_f[sizeof(R) == 4 ? 14 * CEL_MAXK : 1];
+    {
+        const double *src = reinterpret_cast<const double *>(comps + (size_t)v * NC);
+        double *dst = reinterpret_cast<double *>(tc);
+        R *dstf = reinterpret_cast<R *>(tcr_f);
+        const double tabv = g_exp2_table[lane];
+        for (int i = lane; i < NC * 8; i += 64) {
+            const double v = src[i];
+            dst[i] = v;
+            if (sizeof(R) == 4) dstf[i] = (R)v;
+        }
+        etab[lane] = tabv;
+        __syncthreads();
+    }
+    PixWork<R> W;
+    W.img = &images[n]; W.P = &P; W.patches = patches; W.bitmaps = bitmaps; W.nbr_idx = nbr_idx;
+    W.nb0 = nbr_off[t]; W.nb1 = nbr_off[t + 1];
+    // visit lists: the row of this visit in the table of the neighbours' visits
+    W.nv = nbr_vis ? nbr_vis + nv_base[t] + (int64_t)(tn - ti * M) * (W.nb1 - W.nb0) : nullptr;
+    W.val_off = val_off; W.val = val; W.active_rank = active_rank;
+    // several active sources (celeste_elbo_eval_multi): a pixel of two active patches is visited by the earlier
+    // one only (elbo_objective.jl:430-470) -- its value term and inactive-source count are dropped here
+    W.my_rank = MULTI ? active_rank[t] : 0;
+    W.N = N; W.n = n; W.NC = NC; W.v = v;
+    W.si = srcimg[v];
+    W.tc = tc;
+    W.tcr = sizeof(R) == 4 ? tcr_f : reinterpret_cast<const CompR<R> *>(tc);
+    W.etab = etab;
+    W.tcoef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
+    W.tile_off = tile_off; W.rec = rec;
+    // the chunk's record, 16 slots per entry (accum_entries); MODE 0 keeps its three sums in registers
+    __shared__ double sacc[MODE == 0 || MODE == 3 ? 1 : ACC_N * ACC_SLOTS];
+    double *const slot = sacc + (lane & (ACC_SLOTS - 1));
+    for (int ch = ch0; ch < ch0 + G && ch * chunk_px < npx; ++ch) {   // every chunk of the group writes its own record
+    const int p0 = ch * chunk_px;
+    const int p1 = min(npx, p0 + chunk_px);
+    const int wg = rec_base + ch;            // the visit's records are consecutive (rec_off: prefix sum of the chunk counts)
+    if constexpr (MODE == 1 || MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < ACC_N * ACC_SLOTS / 64; ++i) sacc[lane + 64 * i] = 0.0;
+        __syncthreads();
+    }
+    double a[3] = {0.0, 0.0, 0.0};
+
+    for (int base = p0; base < p1; base += 64) pixel_iter<MODE, R, MULTI>(W, base, p1, lane, slot, a, []() {});
     if (MODE == 3) continue;
 
     // ---- one 68-double record per (target, image, chunk) ----
@@ -1351,16 +1412,8 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         if (lane == 0) { out[0] = s0; out[ACC_CNT] = s1; out[ACC_CNT + 1] = s2; }
         continue;
     }
-    // lane e sums the 16 slots of entry e (rotated start: 4-way instead of 64-way bank conflicts; the order of the
-    // additions is fixed per entry, so the record is reproducible)
     __syncthreads();
-    for (int e = lane; e < ACC_N; e += 64) {
-        if (MODE == 1 && e > ZV && e < ACC_CNT) continue;   // Hessian entries are not produced
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < ACC_SLOTS; ++k) s += sacc[e * ACC_SLOTS + ((k + e) & (ACC_SLOTS - 1))];
-        out[e] = s;
-    }
+    fold_record_slots<MODE>(sacc, lane, [&](int e, double s) { out[e] = s; });
     __syncthreads();   // the slots are zeroed again for the next chunk of the group
     }
     }   // work item
@@ -1570,44 +1623,97 @@ __device__ unsigned long long g_lift_clk[16];
 #define LIFT_TICK_DECL do { } while (0)
 #endif
 
-// 8 waves per SIMD (64 VGPRs, a 52-byte spill) and 17.7 KB of LDS: 8 workgroups per CU, so that a 2000-target batch is
-// resident in one round (with 5 per CU it ran in two: 76 -> 65 us)
-__global__ void __launch_bounds__(512, 8)
-lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
-            const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
-            const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
-            const int32_t *__restrict__ targets, const double *__restrict__ acc,
-            const PriorDev *__restrict__ prior, const int32_t *__restrict__ vis_off,
-            const int32_t *__restrict__ vis_img, int N, int M, int CH, int chunk_px, uint32_t flags,
-            double *__restrict__ out_v, double *__restrict__ out_d, double *__restrict__ out_h,
-            int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status, const int32_t *__restrict__ live,
-            const double *__restrict__ lg_sum, const int32_t *__restrict__ rec_off) {
-    // lg_sum (per visit, patch_lgamma_kernel; nullptr: the records already hold the term, several active sources)
-    if (live && (int)blockIdx.x >= *live) return;
-    LIFT_TICK_DECL;
-    __shared__ double sh_h[LIFT_NP * LIFT_NP];         // likelihood Hessian, upper triangle, params < 28
-    __shared__ double sh_d[LIFT_NP];
-    __shared__ double s_vs[CEL_P], s_jsh[9], s_tsh[27];
-    __shared__ double s_rec[LIFT_NT][ACC_N];
-    __shared__ double s_jz[LIFT_NT][LIFT_JZ];          // compact Jacobians of the reduced variables (jz_off)
-    __shared__ double s_kap[LIFT_NT][10], s_lam[LIFT_NT][10], s_El[LIFT_NT][2], s_Ell[LIFT_NT][2];
-    __shared__ KLShared K;
-    __shared__ double sh_v, sh_cnt[2];
-    __shared__ int sh_bad;
+// Loads / stores of data that another workgroup of the SAME launch wrote or will read (optim_fused_kernel hands targets
+// from workgroup to workgroup): COH = true makes them agent-scope relaxed atomics, i.e. `global_load / global_store ...
+// sc1` -- write-through stores and L1-bypassing loads, so that no release / acquire fence is needed around them (guide
+// section 6, Guideline 16, form R1).  COH = false: plain accesses (data crosses kernel boundaries only).
+template <bool COH>
+__device__ __forceinline__ double ldc(const double *p) {
+    if constexpr (COH)
+        return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void stc(double *p, double v) {
+    if constexpr (COH)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ int ldc(const int *p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void stc(int *p, int v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 
-    const int ti = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const int t = targets[ti];
+// LDS of the lift (17.7 KB)
+struct LiftShared {
+    double sh_h[LIFT_NP * LIFT_NP];         // likelihood Hessian, upper triangle, params < 28
+    double sh_d[LIFT_NP];
+    double s_vs[CEL_P], s_jsh[9], s_tsh[27];
+    double s_rec[LIFT_NT][ACC_N];
+    double s_jz[LIFT_NT][LIFT_JZ];          // compact Jacobians of the reduced variables (jz_off)
+    double s_kap[LIFT_NT][10], s_lam[LIFT_NT][10], s_El[LIFT_NT][2], s_Ell[LIFT_NT][2];
+    KLShared K;
+    double sh_v, sh_cnt[2];
+    int sh_bad, own_finite;
+};
+
+// The lift of ONE target by the calling workgroup (>= 256 threads): chunk records -> value, 44-gradient, 44 x 44 Hessian
+// at o_v / o_d / o_h (global memory in lift_kernel, LDS in the fused optimiser kernel), KL and status included.
+// COH: the target's parameters and its chunk records were written by other workgroups of this launch (ldc), and its
+// SrcGeo is formed here from the parameters instead of being read from the per-batch table `geo`.
+template <bool COH>
+__device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti, int t, const double *__restrict__ vp,
+        const DevImage *__restrict__ images, const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
+        const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx, const double *__restrict__ acc,
+        const PriorDev *__restrict__ prior, const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img,
+        int N, int M, int CH, int chunk_px, uint32_t flags, double *__restrict__ o_v, double *__restrict__ o_d,
+        double *__restrict__ o_h, int64_t *__restrict__ o_cnt, int32_t *__restrict__ o_status,
+        const double *__restrict__ lg_sum, const int32_t *__restrict__ rec_off) {
+    // lg_sum (per visit, patch_lgamma_kernel; nullptr: the records already hold the term, several active sources)
+    LIFT_TICK_DECL;
+    double (&sh_h)[LIFT_NP * LIFT_NP] = L.sh_h;
+    double (&sh_d)[LIFT_NP] = L.sh_d;
+    double (&s_vs)[CEL_P] = L.s_vs, (&s_jsh)[9] = L.s_jsh, (&s_tsh)[27] = L.s_tsh;
+    double (&s_rec)[LIFT_NT][ACC_N] = L.s_rec;
+    double (&s_jz)[LIFT_NT][LIFT_JZ] = L.s_jz;
+    double (&s_kap)[LIFT_NT][10] = L.s_kap, (&s_lam)[LIFT_NT][10] = L.s_lam, (&s_El)[LIFT_NT][2] = L.s_El, (&s_Ell)[LIFT_NT][2] = L.s_Ell;
+    KLShared &K = L.K;
+    double &sh_v = L.sh_v;
+    double (&sh_cnt)[2] = L.sh_cnt;
+    int &sh_bad = L.sh_bad;
+
+    const int nthr = blockDim.x;
     const bool want_grad = (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS)) != 0;
     const bool want_hess = (flags & CELESTE_FLAG_HESS) != 0;
     const bool want_kl = (flags & CELESTE_FLAG_KL) != 0;
 
-    if (tid < CEL_P) s_vs[tid] = vp[(size_t)t * CEL_P + tid];
-    else if (tid < CEL_P + 9) s_jsh[tid - CEL_P] = geo[t].jsh[tid - CEL_P];
-    else if (tid < CEL_P + 36) s_tsh[tid - CEL_P - 9] = geo[t].tsh[tid - CEL_P - 9];
+    if (tid < CEL_P) s_vs[tid] = ldc<COH>(vp + (size_t)t * CEL_P + tid);
+    if constexpr (!COH) {
+        if (tid >= CEL_P && tid < CEL_P + 9) s_jsh[tid - CEL_P] = geo[t].jsh[tid - CEL_P];
+        else if (tid >= CEL_P + 9 && tid < CEL_P + 36) s_tsh[tid - CEL_P - 9] = geo[t].tsh[tid - CEL_P - 9];
+    }
     for (int k = tid; k < LIFT_NP * LIFT_NP; k += nthr) sh_h[k] = 0.0;
     if (tid < LIFT_NP) sh_d[tid] = 0.0;
     if (tid == 0) { sh_v = 0.0; sh_cnt[0] = 0.0; sh_cnt[1] = 0.0; sh_bad = 0; }
     __syncthreads();
+    if constexpr (COH) {
+        // the target moved since the batch's tables were made: its shape derivatives from its current parameters
+        // (source_geo_values, the function setup_thread fills the table with)
+        __shared__ SrcGeo own_geo;
+        if (tid == 0) { source_geo_values(s_vs, &own_geo); L.own_finite = own_geo.finite; }
+        __syncthreads();
+        if (tid < 9) s_jsh[tid] = own_geo.jsh[tid];
+        else if (tid < 36) s_tsh[tid - 9] = own_geo.tsh[tid - 9];
+        __syncthreads();
+    }
     const double *vs = s_vs;
 
     // KL per (type, component) terms: 16 threads of the last wave, concurrent with the first lift pass
@@ -1653,7 +1759,7 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const int npx = P.H2 * P.W2;
             double s = 0.0;
             for (int ch = 0; ch < CH; ++ch)
-                if (ch * chunk_px < npx) s += acc[(rec_off ? (size_t)rec_off[ti * M + n0 + i] + ch : (size_t)(ti * M + n0 + i) * CH + ch) * ACC_N + e];
+                if (ch * chunk_px < npx) s += ldc<COH>(acc + (rec_off ? (size_t)rec_off[ti * M + n0 + i] + ch : (size_t)(ti * M + n0 + i) * CH + ch) * ACC_N + e);
             s_rec[i][e] = s;
         }
         if (want_grad) {
@@ -1786,38 +1892,60 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
     // ---- assemble, check finiteness (elbo_objective.jl:487,490), store exactly symmetric ----
     int bad = 0;
     if (tid == 0 && !isfinite(sh_v)) bad = 1;
-    if (want_grad && out_d && tid < CEL_P) {
+    if (want_grad && o_d && tid < CEL_P) {
         double v = tid < LIFT_NP ? sh_d[tid] : 0.0;
         if (want_kl) v += kl_grad(K, prior, vs, tid);
         if (!isfinite(v)) bad = 1;
-        out_d[(size_t)ti * CEL_P + tid] = v;
+        o_d[tid] = v;
     }
-    if (want_hess && out_h) {
+    if (want_hess && o_h) {
         for (int k = tid; k < CEL_P * CEL_P; k += nthr) {
             const int c2 = k / CEL_P, c1 = k - c2 * CEL_P;
             const int p1 = c1 < c2 ? c1 : c2, p2 = c1 < c2 ? c2 : c1;
             double v = (p2 < LIFT_NP) ? sh_h[p1 + LIFT_NP * p2] : 0.0;
             if (want_kl) v += kl_hess(K, prior, vs, p1, p2);
             if (!isfinite(v)) bad = 1;
-            if (!(flags & CELESTE_FLAG_PACKED_HESS)) out_h[(size_t)ti * CEL_P * CEL_P + k] = v;
-            else if (c1 <= c2) out_h[(size_t)ti * CELESTE_HP + c2 * (c2 + 1) / 2 + c1] = v;   // upper triangle, by columns
+            if (!(flags & CELESTE_FLAG_PACKED_HESS)) o_h[k] = v;
+            else if (c1 <= c2) o_h[c2 * (c2 + 1) / 2 + c1] = v;   // upper triangle, by columns
         }
     }
     if (bad) atomicOr(&sh_bad, 1);
     __syncthreads();
     if (tid == 0) {
         int st = sh_bad ? CELESTE_ERR_NONFINITE_RESULT : CELESTE_OK;
-        int fin = geo[t].finite;
+        int fin = COH ? L.own_finite : geo[t].finite;
         for (int64_t q = nbr_off[t]; q < nbr_off[t + 1]; ++q) fin &= geo[nbr_idx[q]].finite;
         if (!fin) st = CELESTE_ERR_NONFINITE_INPUT;
-        out_status[ti] = st;
-        out_v[ti] = sh_v;
-        if (out_cnt) { out_cnt[2 * ti] = (int64_t)(sh_cnt[0] + 0.5); out_cnt[2 * ti + 1] = (int64_t)(sh_cnt[1] + 0.5); }
+        *o_status = st;
+        *o_v = sh_v;
+        if (o_cnt) { o_cnt[0] = (int64_t)(sh_cnt[0] + 0.5); o_cnt[1] = (int64_t)(sh_cnt[1] + 0.5); }
     }
     LIFT_TICK(5);
 #ifdef LIFT_TIMING
     if (tid == 0) atomicAdd(&g_lift_clk[15], 1ull);
 #endif
+}
+
+// 8 waves per SIMD (64 VGPRs, a 52-byte spill) and 17.7 KB of LDS: 8 workgroups per CU, so that a 2000-target batch is
+// resident in one round (with 5 per CU it ran in two: 76 -> 65 us)
+__global__ void __launch_bounds__(512, 8)
+lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
+            const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
+            const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
+            const int32_t *__restrict__ targets, const double *__restrict__ acc,
+            const PriorDev *__restrict__ prior, const int32_t *__restrict__ vis_off,
+            const int32_t *__restrict__ vis_img, int N, int M, int CH, int chunk_px, uint32_t flags,
+            double *__restrict__ out_v, double *__restrict__ out_d, double *__restrict__ out_h,
+            int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status, const int32_t *__restrict__ live,
+            const double *__restrict__ lg_sum, const int32_t *__restrict__ rec_off) {
+    if (live && (int)blockIdx.x >= *live) return;
+    __shared__ LiftShared L;
+    const int ti = blockIdx.x;
+    const size_t HS = (flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;
+    lift_target<false>(L, threadIdx.x, ti, targets[ti], vp, images, patches, geo, nbr_off, nbr_idx, acc, prior, vis_off, vis_img, N, M, CH,
+                       chunk_px, flags, out_v + ti, out_d ? out_d + (size_t)ti * CEL_P : nullptr,
+                       out_h ? out_h + (size_t)ti * HS : nullptr, out_cnt ? out_cnt + 2 * (size_t)ti : nullptr, out_status + ti,
+                       lg_sum, rec_off);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,288 @@
+// fused_kernels.h -- ElboMaximize.maximize! for a batch of targets in ONE persistent launch (optim_fused_kernel).
+//
+// The chained optimiser (celeste_abi.hip: work list -> pixel_kernel -> lift_kernel -> optim_step_kernel per Newton
+// iteration, all targets in lock-step) is bound, for small batches, by the latencies of four dependent launches: a
+// Cyclades layer of 80 targets (ParallelRun.jl:302-397) spent 182 us per iteration for ~60 us of work on its critical
+// path, with 1000 of the chip's 1024 SIMDs idle during the 92 us of the trust-region step.  Here every target runs its
+// own Newton iterations at its own pace inside one launch, as a dataflow over a device-side queue:
+//
+//   queue item r >= 0   "evaluate chunk record r": the 256 pixels of chunk ch of the j-th patch of target ti
+//                       (chunk_desc[r]).  A workgroup (4 wavefronts) forms the target's per-image tables in LDS from its
+//                       current parameters (prep_visit_values), each wavefront runs ONE 64-pixel iteration of the pixel
+//                       loop (pixel_iter, the body pixel_kernel runs four times in a row), the wavefronts add their
+//                       pixels' entries to the chunk's record in iteration order, and the record goes to HBM.
+//   last record of a    The workgroup whose record completes a target's evaluation (arrival counter) runs the rest of the
+//   target's evaluation iteration itself: lift_target (records -> value, 44-gradient, 44 x 44 Hessian, in LDS), optim_step_target
+//                       (chain rule, accept / reject, trust-region sub-problem, next trial point), and queues the target's
+//                       chunk records again -- or retires the target.
+//   item EXIT           pushed once per workgroup when the last target retires.
+//
+// No workgroup ever waits for a particular other workgroup: a workgroup that holds nothing waits for its queue ticket, and
+// tickets are filled by workgroups that are running.  The launch is therefore deadlock-free whatever part of the grid is
+// resident.  Every wait is bounded (wall clock): a time-out sets an abort code that every waiting workgroup sees.
+//
+// Hand-offs between workgroups (guide section 6, Guideline 16, forms R1 / R2): everything one workgroup writes for another
+// -- a target's row of vp, its OptState and saved Hessian, chunk records, queue items -- is stored write-through
+// (agent-scope relaxed atomic stores = `global_store ... sc1`, stc<true>) and loaded past the L1 (ldc<true>); the storing
+// wavefronts drain their stores (s_waitcnt vmcnt(0)) before the flag -- the queue item or the arrival counter -- is
+// published.  No release / acquire fences (1.7-6.5 us each on this chip) are needed.
+//
+// Results are bit-identical to the chained path: same device functions (pixel_iter, prep_visit_values, source_geo_values,
+// lift_target, optim_step_target, the non-inlined tri_tr_solve / eig_tr_solve), same 256-pixel chunk records summed in
+// the same order (tests/test_gpu_fused.py).
+#pragma once
+#include "elbo_kernels.h"
+#include "optim_kernels.h"
+
+#define FQ_EMPTY (-1)      // queue slot not written yet (the array is memset to 0xFF before every launch)
+#define FQ_EXIT (-2)
+#define FQ_DIRECT0 (-3)    // item <= FQ_DIRECT0: target ti = FQ_DIRECT0 - item has no pixel to visit -- straight to its step
+#define FUSED_NT 256
+#define FUSED_WAVES (FUSED_NT / 64)
+
+// q_ctl words
+#define FQC_HEAD 0         // next ticket
+#define FQC_TAIL 1         // next free queue position
+#define FQC_LIVE 2         // targets still running
+#define FQC_ABORT 3        // 0, or why the launch gave up: 1 wait timed out, 2 queue capacity exceeded
+#define FQC_WORDS 8
+
+struct FusedArgs {
+    // the context's tables (immutable during the launch)
+    const DevImage *images; const DevPatch *patches; const double *coefs; const uint8_t *bitmaps;
+    const int64_t *nbr_off; const int32_t *nbr_idx; const int64_t *val_off; const double2 *val;
+    const int64_t *nv_base; const int32_t *nbr_vis; const int2 *items; const SrcGeo *geo; const PriorDev *prior;
+    const int32_t *vis_off; const int32_t *vis_img; const double *lg_sum; const int32_t *rec_off;
+    int N, NC, K, M, CH, chunk_px;
+    // the batch
+    const int32_t *targets; int n_targets;
+    double *vp;                    // n_sources x 44: the targets' rows move, every other row is frozen
+    double *acc;                   // chunk records, 68 doubles each
+    const int2 *chunk_desc;        // per record: {ti * M + j, chunk}
+    const int2 *tgt_rec;           // per target: {first record, number of records}
+    OptState *st; double *Hstate; OptParams op; uint32_t flags;
+    // the queue
+    int32_t *q_items; int32_t *q_ctl; int32_t *arrivals; int q_cap;
+    long long timeout_ticks;       // wall_clock64 ticks (100 MHz) a workgroup waits for its ticket before it gives up
+};
+
+// per batch, once: the targets' record ranges, the description of every record, the first round of queue items
+__global__ void fused_setup_kernel(const int32_t *__restrict__ targets, int n_targets, const DevPatch *__restrict__ patches,
+                                   const int32_t *__restrict__ vis_off, const int2 *__restrict__ items, int N, int M,
+                                   int chunk_px, const int32_t *__restrict__ rec_off, int2 *__restrict__ chunk_desc,
+                                   int2 *__restrict__ tgt_rec, int32_t *__restrict__ q_items, int32_t *__restrict__ q_ctl) {
+    const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= n_targets) return;
+    const int t = targets[ti];
+    int n_rec = 0, first = -1;
+    for (int j = 0; j < M; ++j) {
+        const int tn = ti * M + j;
+        int v = t * N + j;                       // items == nullptr: every source is listed in all M = N images
+        if (items) v = items[tn].x;
+        if (v < 0) continue;
+        const DevPatch &P = patches[v];
+        const int npx = P.H2 * P.W2;
+        if (npx <= 0) continue;
+        const int nch = (npx + chunk_px - 1) / chunk_px, r0 = rec_off[tn];
+        if (first < 0) first = r0;
+        for (int ch = 0; ch < nch; ++ch) chunk_desc[r0 + ch] = make_int2(tn, ch);
+        n_rec += nch;
+    }
+    tgt_rec[ti] = make_int2(first < 0 ? 0 : first, n_rec);
+    const int cnt = n_rec > 0 ? n_rec : 1;
+    const int base = atomicAdd(&q_ctl[FQC_TAIL], cnt);
+    if (n_rec > 0) for (int i = 0; i < n_rec; ++i) q_items[base + i] = first + i;
+    else q_items[base] = FQ_DIRECT0 - ti;
+    if (ti == 0) q_ctl[FQC_LIVE] = n_targets;
+}
+
+// LDS of a workgroup of the fused kernel
+struct FusedShared {
+    // evaluating a chunk record
+    double theta[CEL_P];
+    Comp tc[14 * CEL_MAXK];
+    SrcImg si;
+    double etab[64];
+    double sacc[ACC_N * ACC_SLOTS];
+    int turn;                          // the wavefront whose pixels are added to the record next
+    // hand-over between the phases of one workgroup
+    int item, last, done;
+    // the evaluation of a target, from its lift to its step
+    double ev_v, ev_d[CEL_P], ev_h[CEL_P * CEL_P];
+    int ev_status;
+    LiftShared lift;
+    StepShared step;
+};
+
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// thread 0: the next queue item of this workgroup (FQ_EXIT when the launch is over or has been aborted)
+__device__ __forceinline__ int fused_pop(const FusedArgs &A) {
+    if (ldc<true>(&A.q_ctl[FQC_ABORT]) != 0) return FQ_EXIT;
+    const int ticket = __hip_atomic_fetch_add(&A.q_ctl[FQC_HEAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket >= A.q_cap) {
+        __hip_atomic_store(&A.q_ctl[FQC_ABORT], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return FQ_EXIT;
+    }
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 0;; ++spins) {
+        const int v = ldc<true>(&A.q_items[ticket]);
+        if (v != FQ_EMPTY) return v;
+        __builtin_amdgcn_s_sleep(8);
+        if ((spins & 63u) == 63u) {
+            if (ldc<true>(&A.q_ctl[FQC_ABORT]) != 0) return FQ_EXIT;
+            if (wall_clock64() - t0 > A.timeout_ticks) {
+                __hip_atomic_store(&A.q_ctl[FQC_ABORT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return FQ_EXIT;
+            }
+        }
+    }
+}
+
+// the whole workgroup: append `count` items first, first + 1, ... (count > 0), or the one item `first` (count == 0), or
+// `-count` copies of `first` (count < 0).  Every store of the calling workgroup that the items' consumers depend on must
+// have been drained (drain_stores + __syncthreads) before.
+__device__ __forceinline__ void fused_push(const FusedArgs &A, const int tid, int *s_base, int first, int count) {
+    const int n = count > 0 ? count : (count == 0 ? 1 : -count);
+    if (tid == 0) *s_base = __hip_atomic_fetch_add(&A.q_ctl[FQC_TAIL], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int base = *s_base;
+    if (base + n > A.q_cap) {
+        if (tid == 0) __hip_atomic_store(&A.q_ctl[FQC_ABORT], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else
+        for (int i = tid; i < n; i += FUSED_NT) stc<true>(&A.q_items[base + i], count > 0 ? first + i : first);
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(FUSED_NT, 2)
+optim_fused_kernel(const FusedArgs A) {
+    __shared__ FusedShared F;
+    for (;;) {
+        // The thread index passes through an opaque asm in every trip: otherwise the compiler hoists everything that
+        // depends only on it -- index arithmetic and per-thread tables of the lift and the step, hundreds of values -- out
+        // of this loop and keeps it alive (in scratch) across the pixel code.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
+        if (tid == 0) F.item = fused_pop(A);
+        __syncthreads();
+        const int item = F.item;
+        if (item == FQ_EXIT) break;
+        int ti;
+        bool last;
+        if (item >= 0) {
+            // ---- one chunk record ----
+            const int2 desc = A.chunk_desc[item];
+            const int tn = desc.x, ch = desc.y;
+            ti = tn / A.M;
+            const int j = tn - ti * A.M;
+            const int t = A.targets[ti];
+            int n = j, v = t * A.N + j;
+            if (A.items) { const int2 e = A.items[tn]; v = e.x; n = e.y; }
+            const DevPatch &P = A.patches[v];
+            const int npx = P.H2 * P.W2;
+            const int p0 = ch * A.chunk_px, p1 = min(npx, p0 + A.chunk_px);
+            // the target's current parameters (another workgroup stepped it), then its tables for this image
+            if (tid < CEL_P) F.theta[tid] = ldc<true>(A.vp + (size_t)t * CEL_P + tid);
+            if (wave == 1) F.etab[lane] = g_exp2_table[lane];
+            for (int i = tid; i < ACC_N * ACC_SLOTS; i += FUSED_NT) F.sacc[i] = 0.0;
+            if (tid == 0) F.turn = 0;
+            __syncthreads();
+            if (wave == 0) prep_visit_values(lane, F.theta, P, A.images[n].band - 1, A.K, &F.si, F.tc);
+            __syncthreads();
+            const int base = p0 + 64 * wave;
+            if (base < p1) {
+                PixWork<double> W;
+                W.img = &A.images[n]; W.P = &P; W.patches = A.patches; W.bitmaps = A.bitmaps; W.nbr_idx = A.nbr_idx;
+                W.nb0 = A.nbr_off[t]; W.nb1 = A.nbr_off[t + 1];
+                W.nv = A.nbr_vis ? A.nbr_vis + A.nv_base[t] + (int64_t)j * (W.nb1 - W.nb0) : nullptr;
+                W.val_off = A.val_off; W.val = A.val; W.active_rank = nullptr; W.my_rank = 0;
+                W.N = A.N; W.n = n; W.NC = A.NC; W.v = v;
+                W.si = F.si;
+                W.tc = F.tc; W.tcr = reinterpret_cast<const CompR<double> *>(F.tc);
+                W.etab = F.etab;
+                W.tcoef = A.coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
+                W.tile_off = nullptr; W.rec = nullptr;
+                double a[3] = {0.0, 0.0, 0.0};
+                volatile int *turn = &F.turn;
+                // pixel_kernel's wavefront adds iteration after iteration into the slots; here iteration w belongs to
+                // wavefront w, and the wavefronts take turns in the same order
+                pixel_iter<2, double, false>(W, base, p1, lane, F.sacc + (lane & (ACC_SLOTS - 1)), a, [&]() {
+                    while (*turn != wave) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                });
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the adds have been performed ...
+                if (lane == 0) *turn = wave + 1;                          // ... before the next wavefront starts its own
+            }
+            __syncthreads();
+            if (wave == 0) {
+                double *out = A.acc + (size_t)item * ACC_N;
+                fold_record_slots<2>(F.sacc, lane, [&](int e, double s) { stc<true>(out + e, s); });
+                drain_stores();
+                if (lane == 0) {
+                    const int before = __hip_atomic_fetch_add(&A.arrivals[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    F.last = before == A.tgt_rec[ti].y - 1;
+                }
+            }
+            __syncthreads();
+            last = F.last != 0;
+        } else {
+            ti = FQ_DIRECT0 - item;
+            last = true;
+        }
+        if (!last) continue;
+
+        // ---- the target's evaluation is complete: lift, Newton step ----
+        const int t = A.targets[ti];
+        if (tid == 0) stc<true>(&A.arrivals[ti], 0);
+        lift_target<true>(F.lift, tid, ti, t, A.vp, A.images, A.patches, A.geo, A.nbr_off, A.nbr_idx, A.acc, A.prior, A.vis_off,
+                          A.vis_img, A.N, A.M, A.CH, A.chunk_px, A.flags, &F.ev_v, F.ev_d, F.ev_h, nullptr, &F.ev_status,
+                          A.lg_sum, A.rec_off);
+        __syncthreads();
+        const int done = optim_step_target<true, FUSED_NT>(F.step, tid, A.st[ti], A.Hstate + (size_t)ti * NF * NF,
+                                                           A.vp + (size_t)t * CEL_P, F.ev_h, F.ev_d, -F.ev_v, F.ev_status, A.op);
+        drain_stores();      // the target's row of vp, its state and saved Hessian are in memory ...
+        __syncthreads();     // ... before its next items (or the end of the launch) become visible
+        if (!done) {
+            const int2 tr = A.tgt_rec[ti];
+            if (tr.y > 0) fused_push(A, tid, &F.done, tr.x, tr.y);
+            else fused_push(A, tid, &F.done, FQ_DIRECT0 - ti, 0);
+        } else {
+            if (tid == 0)
+                F.done = __hip_atomic_fetch_add(&A.q_ctl[FQC_LIVE], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
+            __syncthreads();
+            const bool all_done = F.done != 0;
+            __syncthreads();
+            if (all_done) fused_push(A, tid, &F.done, FQ_EXIT, -(int)gridDim.x);
+        }
+    }
+}
+
+// after the launch: per-target outputs from the optimiser states; a target that failed gets its input row back
+// (ParallelRun.jl:582-597: the source is skipped, the others keep their results)
+__global__ void optim_finalize_kernel(const OptState *__restrict__ st, const int32_t *__restrict__ targets, int n_targets,
+                                      double *__restrict__ vp, const double *__restrict__ saved_rows,
+                                      int32_t *__restrict__ iterations, int32_t *__restrict__ f_evals,
+                                      double *__restrict__ elbo, int32_t *__restrict__ status,
+                                      const int32_t *__restrict__ q_ctl) {
+    const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= n_targets) return;
+    const OptState &S = st[ti];
+    // q_ctl (fused launches): the launch gave up -- nothing it left behind is a result
+    const int st1 = (q_ctl && q_ctl[FQC_ABORT] != 0) ? CELESTE_ERR_HIP : S.status;
+    if (st1 != CELESTE_OK && saved_rows)
+        for (int k = 0; k < CEL_P; ++k) vp[(size_t)targets[ti] * CEL_P + k] = saved_rows[(size_t)ti * CEL_P + k];
+    if (iterations) iterations[ti] = S.iter;
+    if (f_evals) f_evals[ti] = S.evals;
+    if (elbo) elbo[ti] = -S.f;
+    if (status) status[ti] = st1;
+}
+
+// rows of the targets before the optimisation (restored by optim_finalize_kernel for targets that fail)
+__global__ void save_rows_kernel(const double *__restrict__ vp, const int32_t *__restrict__ targets, int n_targets,
+                                 double *__restrict__ saved_rows) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_targets * CEL_P) return;
+    const int ti = k / CEL_P, q = k - ti * CEL_P;
+    saved_rows[k] = vp[(size_t)targets[ti] * CEL_P + q];
+}

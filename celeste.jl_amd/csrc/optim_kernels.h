@@ -152,6 +152,17 @@ __global__ void optim_init_kernel(double *__restrict__ vp, const int32_t *__rest
     active[ti] = ti;
 }
 
+// The trust-region solvers below are written for ONE wavefront (lane = row / element): lanes exchange data through LDS
+// and registers of that wavefront only.  Its LDS instructions execute in order, so a hand-over between lanes needs no
+// hardware barrier -- only that the compiler keeps the accesses in program order and does not carry LDS values in
+// registers across the point.  (The callers' workgroups may have more wavefronts -- optim_fused_kernel's have four --
+// which do not take part in the solve: a workgroup barrier in here would wait for them.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ double lane_bcast(double x, int src) { return __shfl(x, src, 64); }
 // the same for a wave-uniform source lane: v_readlane into a scalar register pair instead of an LDS permute
 __device__ __forceinline__ double lane_bcast_u(double x, int src) {
@@ -201,7 +212,7 @@ __device__ inline void tred_wave(double *A, double *hv, double *e, double *q, in
         const double u = (ln == l) ? f - g : x;           // Householder vector (0 beyond l)
         if (act) A[i + LDA * ln] = u;
         e[i] = g; hv[i] = h;
-        __syncthreads();
+        wave_sync();
         double acc0 = 0.0, acc1 = 0.0;                    // two chains: the FMA latency is the critical path here
         if (act) {
             int k = 0;
@@ -216,12 +227,12 @@ __device__ inline void tred_wave(double *A, double *hv, double *e, double *q, in
         const double hh = wave_sum_dpp(p * u) * (0.5 * rh);
         const double qv = p - hh * u;
         if (act) q[ln] = qv;
-        __syncthreads();
+        wave_sync();
         if (act) for (int k = 0; k <= l; ++k) A[ln + LDA * k] -= u * q[k] + qv * A[i + LDA * k];
-        __syncthreads();
+        wave_sync();
     }
     hv[0] = 0.0; e[0] = 0.0;
-    __syncthreads();
+    wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -289,11 +300,11 @@ __device__ __forceinline__ void tred_reg(double *__restrict__ A, double &v, doub
     const int row = ln < NF ? ln : 0;                        // lanes >= NF: never active, any finite values do
 #pragma unroll
     for (int k = 0; k < NF; ++k) a[k] = A[row + LDA * k];
-    __syncthreads();                                         // rows of A are overwritten with the u_i below
+    wave_sync();                                         // rows of A are overwritten with the u_i below
     td = 0.0; ev = 0.0; hvv = 0.0;                           // e[ln], hv[ln]: each lane keeps its own (lane 0: none)
     tred_reg_steps<NF - 1>(a, A, ev, hvv, v, td, ln);
     if (ln == 0) td = a[0];
-    __syncthreads();
+    wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -308,7 +319,7 @@ __device__ inline void eig_sym_wave(double *A, double *w, double *e, double *q, 
         const double h = w[i];
         if (h != 0.0 && ln < i) A[ln + LDA * i] = A[i + LDA * ln] / h;
     }
-    __syncthreads();
+    wave_sync();
     for (int i = 0; i < NF; ++i) {
         const int l = i - 1;
         const double hi = w[i];
@@ -317,21 +328,21 @@ __device__ inline void eig_sym_wave(double *A, double *w, double *e, double *q, 
             for (int k = 0; k <= l; ++k) g += A[i + LDA * k] * A[k + LDA * ln];
             for (int k = 0; k <= l; ++k) A[k + LDA * ln] -= g * A[k + LDA * i];
         }
-        __syncthreads();
+        wave_sync();
         const double dii = A[i + LDA * i];
-        __syncthreads();
+        wave_sync();
         w[i] = dii;
         if (ln == 0) A[i + LDA * i] = 1.0;
         if (ln <= l) { A[ln + LDA * i] = 0.0; A[i + LDA * ln] = 0.0; }
-        __syncthreads();
+        wave_sync();
     }
     // implicit-shift QL on (w, e); rotations are applied to row ln of the eigenvector matrix
     {
         const double ev = (ln >= 1 && ln < NF) ? e[ln] : 0.0;
-        __syncthreads();
+        wave_sync();
         if (ln >= 1 && ln < NF) e[ln - 1] = ev;
         if (ln == 0) e[NF - 1] = 0.0;
-        __syncthreads();
+        wave_sync();
     }
     const bool row = ln < NF;
     for (int l = 0; l < NF; ++l) {
@@ -374,7 +385,7 @@ __device__ inline void eig_sym_wave(double *A, double *w, double *e, double *q, 
             w[l] -= p; e[l] = g; e[m] = 0.0;
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -534,11 +545,19 @@ __device__ double *g_dbg_T;   // debug builds: (td, te, Q'g, hv) of every sub-pr
 #define TRI_MAXC 4   // largest cluster of lowest eigenvalues the hard-case test handles in the tridiagonal basis
 struct TriLds { double *A, *hv, *td, *te, *te2, *q; };   // hv, te, q: tred_wave's (OPTIM_TRED_LDS builds only)
 
+// Result of a sub-problem solve, per lane: element ln of the step, the model decrease, the interior flag, and whether the
+// tridiagonal-space solver solved it (false: the hard case it hands to the eigen-decomposition).
+struct TrResult { double p, m; int interior, solved; };
+
 // Trust-region step in the tridiagonal basis.  In: L.A = H (destroyed), g (lane register), delta.
-// Out: step p (lane register), model decrease m, interior flag.  Returns false in the hard case (caller falls
+// Out: step p (lane register), model decrease m, interior flag; solved = 0 in the hard case (caller falls
 // back to the eigen-decomposition).
-__device__ __forceinline__ bool tri_tr_solve(const TriLds &L, double g, double delta, int ln, int secular_iters, double &p_out,
-                                    double &m_out, int &interior_out) {
+// NOT inlined: the function is 22 k instructions long and its register allocation (248 VGPRs at the edge of the two-waves-
+// per-SIMD budget) should not depend on the kernel around it -- optim_step_kernel, tr_solve_kernel and optim_fused_kernel
+// call the same code, so their steps agree bit for bit by construction.
+__device__ __noinline__ TrResult tri_tr_solve(TriLds L, double g, double delta, int ln, int secular_iters) {
+    double p_out = 0.0, m_out = 0.0;
+    int interior_out = 0;
     const bool fr = ln < NF;
     OPT_TICK_DECL;
     // T = Q' H Q and gt = Q' g (reflections n-1 ... 2 in turn) in one pass
@@ -561,7 +580,7 @@ __device__ __forceinline__ bool tri_tr_solve(const TriLds &L, double g, double d
     if (fr && g_dbg_T) { double *o = g_dbg_T + (size_t)blockIdx.x * 4 * NF; o[ln] = td_l; o[NF + ln] = te_l; o[2 * NF + ln] = gt_l; o[3 * NF + ln] = hv_l; }
 #endif
     if (fr) { L.td[ln] = td_l; L.te2[ln] = te2_l; }   // the Sturm passes read T from LDS (hoisted: loop invariant)
-    __syncthreads();
+    wave_sync();
     OPT_TICK(4);
     // Gershgorin interval, extreme eigenvalues
     double wmin, wmax, wmin_lower, norm_bound;
@@ -608,7 +627,7 @@ __device__ __forceinline__ bool tri_tr_solve(const TriLds &L, double g, double d
             // T - shift I is positive definite) and Gram-Schmidt.
             int mc = sturm_count(L.td, L.te2, wmin + 1e-10, wide);
             if (mc < 1) mc = 1;
-            if (mc > TRI_MAXC) { if (ln == 0) atomicAdd(&g_optim_stats[2], 1ull); return false; }
+            if (mc > TRI_MAXC) { if (ln == 0) atomicAdd(&g_optim_stats[2], 1ull); return TrResult{0.0, 0.0, 0, 0}; }
             const double shift = wmin_lower - 4.440892098500626e-16 * norm_bound;
             double ips, mks;
             tri_factor(td_l, te_l, te2_l, -shift, wide, ln, ips, mks);
@@ -690,15 +709,17 @@ __device__ __forceinline__ bool tri_tr_solve(const TriLds &L, double g, double d
     if (interior && ln == 0) atomicAdd(&g_optim_stats[0], 1ull);
     p_out = y;
     interior_out = interior;
-    return true;
+    return TrResult{p_out, m_out, interior_out, 1};
 }
 
 // The same sub-problem through the full eigen-decomposition (Optim.jl's own route): the hard-case fallback of
 // tri_tr_solve, and OptParams.solver = 1.  In: A = H (LDS, destroyed), g, delta.  w, e, q, cv: NF doubles of LDS each.
-__device__ __forceinline__ void eig_tr_solve(double *A, double *w, double *e, double *q, double *cvs, double g, double delta_in,
-                                    int tid, int secular_iters, double &step, double &m, int &interior) {
+__device__ __noinline__ TrResult eig_tr_solve(double *A, double *w, double *e, double *q, double *cvs, double g, double delta_in,
+                                              int tid, int secular_iters) {
+    double step, m;
+    int interior;
     const bool fr = tid < NF;
-    __shared__ double s_g[NF];
+    double *const s_g = cvs;   // g until its projections are formed, the step's coefficients afterwards
     if (fr) s_g[tid] = g;
     eig_sym_wave(A, w, e, q, tid);
     double qg = 0.0;
@@ -749,32 +770,262 @@ __device__ __forceinline__ void eig_tr_solve(double *A, double *w, double *e, do
         }
     }
     m = wave_sum(fr ? qg * cv + 0.5 * wi * cv * cv : 0.0);
+    wave_sync();
     if (fr) cvs[tid] = cv;
-    __syncthreads();
+    wave_sync();
     step = 0.0;
     if (fr) for (int i = 0; i < NF; ++i) step += A[tid + LDA * i] * cvs[i];
+    return TrResult{step, m, interior, 1};
 }
 
-// to_bound! by one wavefront: x (41, LDS) -> vs (44)
+// to_bound! by one wavefront: x (41, LDS) -> vs (44).  COH: vs is read by other workgroups of the same launch (stc)
+template <bool COH = false>
 __device__ inline void to_bound_wave(const double *x, const double *pos0, const OptParams &op, double *vs, int ln) {
     if (ln < 26) {
         double lo, hi, sc;
         box_bounds(ln, pos0, op, lo, hi, sc);
-        vs[ln] = (1.0 / (1.0 + exp(-x[ln] / sc))) * (hi - lo) + lo;
+        stc<COH>(vs + ln, (1.0 / (1.0 + exp(-x[ln] / sc))) * (hi - lo) + lo);
     } else if (ln < 29) {
         const int g = ln - 26;
         double p[8];
         simplex_probs(x, g, p);
         const int n = c_simplex_n[g];
         const double lo = c_simplex_lo[g];
-        for (int i = 0; i < n; ++i) vs[c_simplex_b0[g] + i] = (1 - n * lo) * p[i] + lo;
+        for (int i = 0; i < n; ++i) stc<COH>(vs + c_simplex_b0[g] + i, (1 - n * lo) * p[i] + lo);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One Newton trust-region iteration of ONE target by the calling workgroup of NTHR threads: optim_step_kernel (NTHR = 64:
+// a workgroup is a wavefront) and optim_fused_kernel (NTHR = 256) run the same body.  With several wavefronts the chain
+// rule and the copies are shared out -- every entry is still computed by one thread with the same arithmetic, so the
+// result does not depend on NTHR -- and the trust-region sub-problem stays with wavefront 0.
+// COH: the optimiser state, the saved Hessian and the target's row of vp move between workgroups inside one launch
+// (ldc / stc).  In: h = 44 x 44 bound-space Hessian, ev_d = 44-gradient, ft_in = -elbo, st_in = status of the
+// evaluation at the trial point S.xt.  Returns 1 when the target is finished (its row of vp holds the result), else 0
+// (its row holds the next trial point).
+// ---------------------------------------------------------------------------------------------------------
+struct StepShared {
+    // LDS budget of optim_step_kernel: 19.7 KB per workgroup so that 8 workgroups (2 waves per SIMD, the VGPR limit) fit a
+    // CU and a batch of 2000 targets is resident in one round.
+    double sA[LDA * NF];       // rows 0..43: H J (44 x 41) -> J'HJ (41 x 41, negated) -> solver; rows 41..44 spare
+    double sx[NF], sg[NF], sw[NF], se[NF], scv[NF];
+    double sgt_q[NF];          // trial gradient during the chain rule, Householder scratch afterwards
+    double sU[9 * NF];         // chain-rule tables, then the solver's vectors (disjoint lifetimes)
+    int s_flag[2];             // 0: accept, 1: done
+    double s_delta;            // trust-region radius after the update
+};
+
+template <bool COH, int NTHR>
+__device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, OptState &S, double *__restrict__ Hs, double *__restrict__ vp_row,
+                                                 const double *__restrict__ h, const double *__restrict__ ev_d, double ft_in,
+                                                 int st_in, const OptParams &op) {
+    constexpr int PARTS = NTHR / 64;
+    double *const sA = Z.sA, *const sx = Z.sx, *const sg = Z.sg, *const sw = Z.sw, *const se = Z.se, *const scv = Z.scv;
+    double *const sU = Z.sU;
+    double *const sgt = Z.sgt_q, *const sq = Z.sgt_q;
+    double *const sd = sU, *const sJb = sU + 44, *const sHb = sU + 70;                   // 44 + 26 + 26
+    double (*const sp)[8] = reinterpret_cast<double (*)[8]>(sU + 96);                    // 3 x 8
+    double (*const sJs)[8][7] = reinterpret_cast<double (*)[8][7]>(sU + 120);            // 3 x 8 x 7 (ends at 288)
+    double *const std_ = sU, *const ste2 = sU + NF;
+    int *const s_flag = Z.s_flag;
+
+    OPT_TICK_DECL;
+    const int ln = PARTS == 1 ? tid : (tid & 63), part = PARTS == 1 ? 0 : (tid >> 6);
+
+    // scalars of the optimiser state, loaded now so that their latency hides behind the chain rule below
+    const double S_f = ldc<COH>(&S.f), S_m = ldc<COH>(&S.m), S_delta = ldc<COH>(&S.delta);
+    const int S_iter = ldc<COH>(&S.iter), S_interior = ldc<COH>(&S.interior), S_evals = ldc<COH>(&S.evals);
+
+    // ---- chain rule to the free parameters at the evaluated point xt (propagate_derivatives!) ----
+    if (tid < CEL_P) sd[tid] = ev_d[tid];
+    if (tid < NF) sx[tid] = ldc<COH>(&S.xt[tid]);
+    __syncthreads();
+    if (tid < 26) {
+        double lo, hi, sc;
+        box_bounds(tid, S.pos0, op, lo, hi, sc);
+        const double s = 1.0 / (1.0 + exp(-sx[tid] / sc)), w = hi - lo;
+        sJb[tid] = w * s * (1 - s) / sc;
+        sHb[tid] = w * s * (1 - s) * (1 - 2 * s) / (sc * sc);
+    } else if (tid < 29) simplex_probs(sx, tid - 26, sp[tid - 26]);
+    __syncthreads();
+    OPT_TICK(9);
+    // simplex Jacobians d bound_{b0+a} / d free_{f0+j} = (1 - n lo) p_a ((a == j) - p_j)
+    for (int k = tid; k < 3 * 56; k += NTHR) {
+        const int g = k / 56, r = k - g * 56, a = r / 7, j = r - a * 7;
+        const int n = c_simplex_n[g];
+        sJs[g][a][j] = (a < n && j < n - 1) ? (1 - n * c_simplex_lo[g]) * sp[g][a] * ((a == j) - sp[g][j]) : 0.0;
+    }
+    __syncthreads();
+    if (tid < NF) {   // gradient: J' d
+        double s;
+        if (tid < 26) s = sJb[tid] * sd[tid];
+        else {
+            const int g = tid < 27 ? 0 : (tid < 34 ? 1 : 2), j = tid - c_simplex_f0[g];
+            s = 0;
+            for (int a = 0; a < c_simplex_n[g]; ++a) s += sJs[g][a][j] * sd[c_simplex_b0[g] + a];
+        }
+        sgt[tid] = -s;  // minimise -elbo
+    }
+    OPT_TICK(10);
+    // J' H J, J block diagonal (26 scalars + simplex blocks 2x1, 8x7, 8x7): rows first (lane = row; the columns are
+    // shared out over the wavefronts) ...
+    if (ln < CEL_P) {   // row `ln` of the bound-space Hessian (lanes read consecutive addresses)
+        for (int i = part; i < 26; i += PARTS) sA[ln + LDA * i] = h[ln + CEL_P * i] * sJb[i];
+        for (int g = 0; g < 3; ++g) {
+            const int n = c_simplex_n[g], b0 = c_simplex_b0[g], f0 = c_simplex_f0[g];
+            double hv[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) hv[b] = b < n ? h[ln + CEL_P * (b0 + b)] : 0.0;
+            for (int j = part; j < n - 1; j += PARTS) {
+                double o = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) o += hv[b] * sJs[g][b][j];
+                sA[ln + LDA * (f0 + j)] = o;
+            }
+        }
+    }
+    __syncthreads();
+    OPT_TICK(11);
+    // ... then columns (lane = column; the rows are shared out over the wavefronts), plus the second derivatives of the
+    // transform contracted with the bound gradient, negated (minimise -elbo)
+    {
+        // the lane's column is fetched in one batch of independent LDS reads and worked on in registers (entry by
+        // entry through LDS, with loop bounds the compiler could not see, this pass was a chain of ~300 exposed LDS
+        // latencies: 7.2 us of the kernel's 95)
+        double *col = sA + LDA * (ln < NF ? ln : 0);
+        double cv[CEL_P];
+        auto fetch = [&]() {
+#pragma unroll
+            for (int i = 0; i < CEL_P; ++i) cv[i] = col[i];
+        };
+        auto columns = [&]() {
+#pragma unroll
+            for (int i = 0; i < 26; ++i) {
+                if (PARTS > 1 && i % PARTS != part) continue;
+                double o = -(cv[i] * sJb[i]);
+                if (i == ln) o -= sd[i] * sHb[i];
+                col[i] = o;
+            }
+            constexpr int GN[3] = {2, 8, 8}, GB0[3] = {26, 28, 36}, GF0[3] = {26, 27, 34};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                constexpr double lo_[3] = {0.005, 0.01 / 8, 0.01 / 8};
+                const int n = GN[g], b0 = GB0[g], f0 = GF0[g];
+                const int kk = ln - f0;
+                const bool own = kk >= 0 && kk < n - 1;
+                const double *pp = sp[g];
+                const double scl = 1 - n * lo_[g];
+#pragma unroll
+                for (int jj = 0; jj < 7; ++jj) {
+                    if (jj >= n - 1) break;
+                    if (PARTS > 1 && (f0 + jj) % PARTS != part) continue;
+                    double o = 0;
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) if (a < n) o += sJs[g][a][jj] * cv[b0 + a];
+                    if (own) {
+                        for (int a = 0; a < n; ++a) {
+                            const double d2 = pp[a] * (((a == jj) - pp[jj]) * ((a == kk) - pp[kk]) - pp[jj] * ((jj == kk) - pp[kk]));
+                            o += sd[b0 + a] * scl * d2;
+                        }
+                    }
+                    col[f0 + jj] = -o;
+                }
+            }
+        };
+        if constexpr (PARTS == 1) {
+            if (ln < NF) { fetch(); columns(); }
+        } else {
+            fetch();
+            __syncthreads();   // every wavefront has its copy of the column before any entry of it is replaced
+            if (ln < NF) columns();
+        }
+    }
+    __syncthreads();
+    OPT_TICK(12);
+    if (ln < NF) for (int i = part; i < ln; i += PARTS) sA[ln + LDA * i] = sA[i + LDA * ln];   // exactly symmetric
+    __syncthreads();
+
+    OPT_TICK(0);
+    // ---- accept / reject, radius update, convergence (N&W Alg. 4.1 as in Optim.jl's NewtonTrustRegion) ----
+    if (part == 0) {
+        const double dxl = tid < NF ? fabs(sx[tid] - ldc<COH>(&S.x[tid])) : 0.0, gl = tid < NF ? fabs(sgt[tid]) : 0.0;
+        double dx = dxl, gmax = gl;
+        for (int o = 32; o >= 1; o >>= 1) { dx = fmax(dx, __shfl_xor(dx, o, 64)); gmax = fmax(gmax, __shfl_xor(gmax, o, 64)); }
+        if (tid == 0) {
+            const double ft = ft_in;
+            int accept = 1, done = 0;
+            double delta = S_delta;
+            stc<COH>(&S.evals, S_evals + 1);
+            if (st_in != CELESTE_OK) { stc<COH>(&S.status, st_in); accept = 0; done = 1; }
+            else if (S_iter >= 0) {
+                const double m = S_m;
+                double rho;
+                if (fabs(m) <= 2.220446049250313e-16) rho = 1.0;
+                else if (m > 0) rho = 0.25 - 1.0;
+                else rho = (S_f - ft) / (0 - m);
+                if (rho < 0.25) delta *= 0.25;
+                else if (rho > 0.75 && !S_interior) delta = fmin(2 * delta, op.delta_hat);
+                accept = rho > 0.1;
+                if (accept && (dx <= op.xtol_abs || fabs(ft - S_f) <= op.ftol_rel * fabs(ft) || gmax <= op.gtol)) done = 1;
+            } else if (gmax <= op.gtol) done = 1;   // already stationary at the starting point: no iteration at all
+            if (accept) stc<COH>(&S.f, ft);
+            stc<COH>(&S.delta, delta); Z.s_delta = delta;
+            stc<COH>(&S.iter, S_iter + 1);
+            if (S_iter + 1 >= op.max_iters) done = 1;
+            s_flag[0] = accept; s_flag[1] = done;
+        }
+    }
+    __syncthreads();
+    const int accept = s_flag[0], done = s_flag[1];
+    if (accept) {
+        if (tid < NF) { stc<COH>(&S.x[tid], sx[tid]); stc<COH>(&S.g[tid], sgt[tid]); sg[tid] = sgt[tid]; }
+        if (!done) for (int k = tid; k < NF * NF; k += NTHR) { const int j = k / NF; stc<COH>(&Hs[k], sA[(k - j * NF) + LDA * j]); }
+    } else {
+        if (tid < NF) { sx[tid] = ldc<COH>(&S.x[tid]); sg[tid] = ldc<COH>(&S.g[tid]); }
+        if (!done) for (int k = tid; k < NF * NF; k += NTHR) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = ldc<COH>(&Hs[k]); }
+    }
+    __syncthreads();
+    OPT_TICK(1);
+    if (done) {
+        if (tid == 0) stc<COH>(&S.done, 1);
+        to_bound_wave<COH>(sx, S.pos0, op, vp_row, tid);
+        return 1;
+    }
+
+    // ---- trust-region sub-problem at the accepted point (N&W section 4.3): wavefront 0 ----
+    if (part == 0) {
+        const bool fr = tid < NF;
+        TrResult R = {0.0, 0.0, 0, 0};
+        if (op.solver != 1) {
+            const TriLds L = {sA, sw, std_, se, ste2, sq};
+            R = tri_tr_solve(L, fr ? sg[tid] : 0.0, Z.s_delta, tid, op.secular_iters);
+            if (!R.solved) {   // hard case: restore H and diagonalise it
+                for (int k = tid; k < NF * NF; k += 64) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = ldc<COH>(&Hs[k]); }
+                wave_sync();
+            }
+        }
+        if (!R.solved) R = eig_tr_solve(sA, sw, se, sq, scv, fr ? sg[tid] : 0.0, Z.s_delta, tid, op.secular_iters);
+        OPT_TICK(2);   // the whole sub-problem (sections 3-7 are its parts)
+        if (tid == 0) { stc<COH>(&S.m, R.m); stc<COH>(&S.interior, R.interior); }
+        if (fr) {
+            const double xn = sx[tid] + R.p;
+            stc<COH>(&S.xt[tid], xn); sx[tid] = xn;
+        }
+    }
+    __syncthreads();
+    to_bound_wave<COH>(sx, S.pos0, op, vp_row, tid);   // next evaluation point
+    OPT_TICK(8);
+#ifdef OPTIM_TIMING
+    if (tid == 0) atomicAdd(&g_optim_clk[15], 1ull);
+#endif
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // optim_step_kernel
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64, 2)   // 2 waves per SIMD: 8 workgroups per CU (see the LDS budget below)
+__global__ void __launch_bounds__(64, 2)   // 2 waves per SIMD: 8 workgroups per CU (see the LDS budget of StepShared)
 optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, const int32_t *__restrict__ active,
                   const double *__restrict__ ev_v, const double *__restrict__ ev_d, const double *__restrict__ ev_h,
                   const int32_t *__restrict__ ev_status, OptParams op, OptState *__restrict__ st,
@@ -795,208 +1046,18 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
         }
     };
     if (live && (int)blockIdx.x >= *live) { finish(); return; }   // the grid is sized by an older, larger count
-    // LDS budget: 19.7 KB per workgroup so that 8 workgroups (2 waves per SIMD, the VGPR limit) fit a CU and a batch
-    // of 2000 targets is resident in one round.
-    __shared__ double sA[LDA * NF];       // rows 0..43: H J (44 x 41) -> J'HJ (41 x 41, negated) -> solver; rows 41..44 spare
-    __shared__ double sx[NF], sg[NF], sw[NF], se[NF], scv[NF];
-    __shared__ double sgt_q[NF];          // trial gradient during the chain rule, Householder scratch afterwards
-    __shared__ double sU[9 * NF];         // chain-rule tables, then the solver's vectors (disjoint lifetimes)
-    double *const sgt = sgt_q, *const sq = sgt_q;
-    double *const sd = sU, *const sJb = sU + 44, *const sHb = sU + 70;                   // 44 + 26 + 26
-    double (*const sp)[8] = reinterpret_cast<double (*)[8]>(sU + 96);                    // 3 x 8
-    double (*const sJs)[8][7] = reinterpret_cast<double (*)[8][7]>(sU + 120);            // 3 x 8 x 7 (ends at 288)
-    double *const std_ = sU, *const ste2 = sU + NF;
-    __shared__ int s_flag[2];             // 0: accept, 1: done
-    __shared__ double s_delta;            // trust-region radius after the update
-
-    OPT_TICK_DECL;
-    const int li = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    __shared__ StepShared Z;
+    const int li = blockIdx.x;
     const int slot = active[li];
-    OptState &S = st[slot];
     const int t = targets[slot];
-    double *Hs = Hstate + (size_t)slot * NF * NF;
-    const double *h = ev_h + (size_t)li * CEL_P * CEL_P;
-
-    // scalars of the optimiser state, loaded now so that their latency hides behind the chain rule below
-    const double S_f = S.f, S_m = S.m, S_delta = S.delta;
-    const int S_iter = S.iter, S_interior = S.interior, S_evals = S.evals;
-    const double ft_in = -ev_v[li];
-    const int st_in = ev_status[li];
-
-    // ---- chain rule to the free parameters at the evaluated point xt (propagate_derivatives!) ----
-    if (tid < CEL_P) sd[tid] = ev_d[(size_t)li * CEL_P + tid];
-    if (tid < NF) sx[tid] = S.xt[tid];
-    __syncthreads();
-    if (tid < 26) {
-        double lo, hi, sc;
-        box_bounds(tid, S.pos0, op, lo, hi, sc);
-        const double s = 1.0 / (1.0 + exp(-sx[tid] / sc)), w = hi - lo;
-        sJb[tid] = w * s * (1 - s) / sc;
-        sHb[tid] = w * s * (1 - s) * (1 - 2 * s) / (sc * sc);
-    } else if (tid < 29) simplex_probs(sx, tid - 26, sp[tid - 26]);
-    __syncthreads();
-    OPT_TICK(9);
-    // simplex Jacobians d bound_{b0+a} / d free_{f0+j} = (1 - n lo) p_a ((a == j) - p_j)
-    for (int k = tid; k < 3 * 56; k += nthr) {
-        const int g = k / 56, r = k - g * 56, a = r / 7, j = r - a * 7;
-        const int n = c_simplex_n[g];
-        sJs[g][a][j] = (a < n && j < n - 1) ? (1 - n * c_simplex_lo[g]) * sp[g][a] * ((a == j) - sp[g][j]) : 0.0;
-    }
-    __syncthreads();
-    if (tid < NF) {   // gradient: J' d
-        double s;
-        if (tid < 26) s = sJb[tid] * sd[tid];
-        else {
-            const int g = tid < 27 ? 0 : (tid < 34 ? 1 : 2), j = tid - c_simplex_f0[g];
-            s = 0;
-            for (int a = 0; a < c_simplex_n[g]; ++a) s += sJs[g][a][j] * sd[c_simplex_b0[g] + a];
-        }
-        sgt[tid] = -s;  // minimise -elbo
-    }
-    OPT_TICK(10);
-    // J' H J, J block diagonal (26 scalars + simplex blocks 2x1, 8x7, 8x7): rows first (lane = row) ...
-    if (tid < CEL_P) {   // row `tid` of the bound-space Hessian straight from HBM (lanes read consecutive addresses)
-        for (int i = 0; i < 26; ++i) sA[tid + LDA * i] = h[tid + CEL_P * i] * sJb[i];
-        for (int g = 0; g < 3; ++g) {
-            const int n = c_simplex_n[g], b0 = c_simplex_b0[g], f0 = c_simplex_f0[g];
-            double hv[8];
-#pragma unroll
-            for (int b = 0; b < 8; ++b) hv[b] = b < n ? h[tid + CEL_P * (b0 + b)] : 0.0;
-            for (int j = 0; j < n - 1; ++j) {
-                double o = 0;
-#pragma unroll
-                for (int b = 0; b < 8; ++b) o += hv[b] * sJs[g][b][j];
-                sA[tid + LDA * (f0 + j)] = o;
-            }
-        }
-    }
-    __syncthreads();
-    OPT_TICK(11);
-    // ... then columns (lane = column), plus the second derivatives of the transform contracted with the bound
-    // gradient, negated (minimise -elbo)
-    if (tid < NF) {
-        // the lane's column is fetched in one batch of independent LDS reads and worked on in registers (entry by
-        // entry through LDS, with loop bounds the compiler could not see, this pass was a chain of ~300 exposed LDS
-        // latencies: 7.2 us of the kernel's 95)
-        double *col = sA + LDA * tid;
-        double cv[CEL_P];
-#pragma unroll
-        for (int i = 0; i < CEL_P; ++i) cv[i] = col[i];
-#pragma unroll
-        for (int i = 0; i < 26; ++i) {
-            double o = -(cv[i] * sJb[i]);
-            if (i == tid) o -= sd[i] * sHb[i];
-            col[i] = o;
-        }
-        constexpr int GN[3] = {2, 8, 8}, GB0[3] = {26, 28, 36}, GF0[3] = {26, 27, 34};
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            constexpr double lo_[3] = {0.005, 0.01 / 8, 0.01 / 8};
-            const int n = GN[g], b0 = GB0[g], f0 = GF0[g];
-            const int kk = tid - f0;
-            const bool own = kk >= 0 && kk < n - 1;
-            const double *pp = sp[g];
-            const double scl = 1 - n * lo_[g];
-#pragma unroll
-            for (int jj = 0; jj < 7; ++jj) {
-                if (jj >= n - 1) break;
-                double o = 0;
-#pragma unroll
-                for (int a = 0; a < 8; ++a) if (a < n) o += sJs[g][a][jj] * cv[b0 + a];
-                if (own) {
-                    for (int a = 0; a < n; ++a) {
-                        const double d2 = pp[a] * (((a == jj) - pp[jj]) * ((a == kk) - pp[kk]) - pp[jj] * ((jj == kk) - pp[kk]));
-                        o += sd[b0 + a] * scl * d2;
-                    }
-                }
-                col[f0 + jj] = -o;
-            }
-        }
-    }
-    __syncthreads();
-    OPT_TICK(12);
-    if (tid < NF) for (int i = 0; i < tid; ++i) sA[tid + LDA * i] = sA[i + LDA * tid];   // exactly symmetric
-    __syncthreads();
-
-    OPT_TICK(0);
-    // ---- accept / reject, radius update, convergence (N&W Alg. 4.1 as in Optim.jl's NewtonTrustRegion) ----
-    {
-        const double dxl = tid < NF ? fabs(sx[tid] - S.x[tid]) : 0.0, gl = tid < NF ? fabs(sgt[tid]) : 0.0;
-        double dx = dxl, gmax = gl;
-        for (int o = 32; o >= 1; o >>= 1) { dx = fmax(dx, __shfl_xor(dx, o, 64)); gmax = fmax(gmax, __shfl_xor(gmax, o, 64)); }
-        if (tid == 0) {
-            const double ft = ft_in;
-            int accept = 1, done = 0;
-            double delta = S_delta;
-            S.evals = S_evals + 1;
-            if (st_in != CELESTE_OK) { S.status = st_in; accept = 0; done = 1; }
-            else if (S_iter >= 0) {
-                const double m = S_m;
-                double rho;
-                if (fabs(m) <= 2.220446049250313e-16) rho = 1.0;
-                else if (m > 0) rho = 0.25 - 1.0;
-                else rho = (S_f - ft) / (0 - m);
-                if (rho < 0.25) delta *= 0.25;
-                else if (rho > 0.75 && !S_interior) delta = fmin(2 * delta, op.delta_hat);
-                accept = rho > 0.1;
-                if (accept && (dx <= op.xtol_abs || fabs(ft - S_f) <= op.ftol_rel * fabs(ft) || gmax <= op.gtol)) done = 1;
-            } else if (gmax <= op.gtol) done = 1;   // already stationary at the starting point: no iteration at all
-            if (accept) S.f = ft;
-            S.delta = delta; s_delta = delta;
-            S.iter = S_iter + 1;
-            if (S_iter + 1 >= op.max_iters) done = 1;
-            s_flag[0] = accept; s_flag[1] = done;
-        }
-    }
-    __syncthreads();
-    const int accept = s_flag[0], done = s_flag[1];
-    if (accept) {
-        if (tid < NF) { S.x[tid] = sx[tid]; S.g[tid] = sgt[tid]; sg[tid] = sgt[tid]; }
-        if (!done) for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; Hs[k] = sA[(k - j * NF) + LDA * j]; }
-    } else {
-        if (tid < NF) { sx[tid] = S.x[tid]; sg[tid] = S.g[tid]; }
-        if (!done) for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hs[k]; }
-    }
-    __syncthreads();
-    OPT_TICK(1);
-    if (done) {
-        if (tid == 0) S.done = 1;
-        to_bound_wave(sx, S.pos0, op, vp + (size_t)t * CEL_P, tid);
-        finish();
-        return;
-    }
-
-    // ---- trust-region sub-problem at the accepted point (N&W section 4.3) ----
-    const bool fr = tid < NF;
-    double step = 0.0, m = 0.0;
-    int interior = 0;
-    bool solved = false;
-    if (op.solver != 1) {
-        const TriLds L = {sA, sw, std_, se, ste2, sq};
-        solved = tri_tr_solve(L, fr ? sg[tid] : 0.0, s_delta, tid, op.secular_iters, step, m, interior);
-        if (!solved) {   // hard case: restore H and diagonalise it
-            for (int k = tid; k < NF * NF; k += nthr) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hs[k]; }
-            __syncthreads();
-        }
-    }
-    if (!solved) eig_tr_solve(sA, sw, se, sq, scv, fr ? sg[tid] : 0.0, s_delta, tid, op.secular_iters, step, m, interior);
-    OPT_TICK(2);   // the whole sub-problem (sections 3-7 are its parts)
-    if (tid == 0) { S.m = m; S.interior = interior; }
-    if (fr) {
-        const double xn = sx[tid] + step;
-        S.xt[tid] = xn; sx[tid] = xn;
-    }
-    __syncthreads();
-    to_bound_wave(sx, S.pos0, op, vp + (size_t)t * CEL_P, tid);   // next evaluation point
-    if (tid == 0) {
+    const int done = optim_step_target<false, 64>(Z, threadIdx.x, st[slot], Hstate + (size_t)slot * NF * NF, vp + (size_t)t * CEL_P,
+                                                  ev_h + (size_t)li * CEL_P * CEL_P, ev_d + (size_t)li * CEL_P, -ev_v[li],
+                                                  ev_status[li], op);
+    if (!done && threadIdx.x == 0) {
         const int pos = atomicAdd(next_count, 1);
         next_active[pos] = slot; next_targets[pos] = t;
     }
     finish();
-    OPT_TICK(8);
-#ifdef OPTIM_TIMING
-    if (tid == 0) atomicAdd(&g_optim_clk[15], 1ull);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1019,19 +1080,17 @@ tr_solve_kernel(const double *__restrict__ H, const double *__restrict__ g, cons
     const double gl = fr ? g[(size_t)b * NF + tid] : 0.0;
     const double dl = delta[b];
     __syncthreads();
-    double step = 0.0, m = 0.0;
-    int interior = 0;
-    bool solved = false;
+    TrResult R = {0.0, 0.0, 0, 0};
     if (solver != 1) {
         const TriLds L = {sA, sw, sU, se, sU + NF, sq};
-        solved = tri_tr_solve(L, gl, dl, tid, secular_iters, step, m, interior);
-        if (!solved && solver == 0) {
+        R = tri_tr_solve(L, gl, dl, tid, secular_iters);
+        if (!R.solved && solver == 0) {
             for (int k = tid; k < NF * NF; k += 64) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = Hb[k]; }
             __syncthreads();
         }
     }
-    if (tid == 0) fallback_out[b] = !solved && solver != 1;
-    if (!solved && solver != 2) eig_tr_solve(sA, sw, se, sq, scv, gl, dl, tid, secular_iters, step, m, interior);
-    if (fr) p[(size_t)b * NF + tid] = step;
-    if (tid == 0) { m_out[b] = m; interior_out[b] = interior; }
+    if (tid == 0) fallback_out[b] = !R.solved && solver != 1;
+    if (!R.solved && solver != 2) R = eig_tr_solve(sA, sw, se, sq, scv, gl, dl, tid, secular_iters);
+    if (fr) p[(size_t)b * NF + tid] = R.solved ? R.p : 0.0;
+    if (tid == 0) { m_out[b] = R.m; interior_out[b] = R.interior; }
 }

@@ -183,6 +183,47 @@ class FieldContext:
             cabi.check(st, self.lib)
         return vp, its, evals, el, status
 
+    def maximize_batch_device(self, d_vp: int, n_targets: int, d_targets: int, cfg: Optional["ElboConfig"] = None,
+                              include_kl: bool = True, d_vp_neighbors: int = 0, d_pos_centers: int = 0, d_iterations: int = 0,
+                              d_f_evals: int = 0, d_elbo: int = 0, d_status: int = 0, stream: int = 0):
+        """celeste_maximize_batch_device: maximize! of the targets against the parameter table at device pointer `d_vp`
+        (n_sources x 44 doubles, optimised in place for the targets); every other argument a device pointer (0 = NULL) as
+        in include/celeste_mi355x.h.  Asynchronous on `stream` for batches of up to 1024 targets."""
+        ccfg = (cfg or ElboConfig()).to_c(include_kl)
+        cabi.check(self.lib.celeste_maximize_batch_device(self.handle, d_vp, d_vp_neighbors or None, d_pos_centers or None,
+                                                          n_targets, d_targets, C.byref(ccfg), d_iterations or None,
+                                                          d_f_evals or None, d_elbo or None, d_status or None, stream or None),
+                   self.lib)
+
+    def joint_infer(self, vp, layers: Sequence[Sequence[int]], cfg: Optional["ElboConfig"] = None, include_kl: bool = True,
+                    pos_centers=None):
+        """celeste_joint_infer: the layers (lists of mutually non-neighbouring sources) are optimised one after another
+        against ONE device-resident parameter table.  pos_centers: one [len(layer), 2] array per layer (or None).
+        Returns (vp_new[S,44], iterations, f_evals, elbo, status) with the per-entry outputs concatenated over the layers
+        in order; vp is not modified.  Sources that fail keep the row they had before their layer (status != 0)."""
+        cfg = cfg or ElboConfig()
+        vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(self.S, P)).copy()
+        off = np.zeros(len(layers) + 1, dtype=np.int64)
+        for l, layer in enumerate(layers):
+            off[l + 1] = off[l] + len(layer)
+        total = int(off[-1])
+        tg = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32) for l in layers]) if total else np.zeros(0, np.int32))
+        pc = None
+        if pos_centers is not None:
+            pc = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.float64).reshape(-1, 2) for c in pos_centers]))
+            assert pc.shape == (total, 2)
+        its = np.zeros(total, dtype=np.int32); evals = np.zeros(total, dtype=np.int32)
+        el = np.zeros(total); status = np.zeros(total, dtype=np.int32)
+        ccfg = cfg.to_c(include_kl)
+        st = self.lib.celeste_joint_infer(self.handle, vp.ctypes.data_as(cabi.c_double_p), len(layers),
+                                          off.ctypes.data_as(cabi.c_int64_p), tg.ctypes.data_as(cabi.c_int32_p),
+                                          pc.ctypes.data_as(cabi.c_double_p) if pc is not None else None, C.byref(ccfg),
+                                          its.ctypes.data_as(cabi.c_int32_p), evals.ctypes.data_as(cabi.c_int32_p),
+                                          el.ctypes.data_as(cabi.c_double_p), status.ctypes.data_as(cabi.c_int32_p))
+        if st not in (cabi.ERR_NONFINITE_INPUT, cabi.ERR_NONFINITE_RESULT):
+            cabi.check(st, self.lib)
+        return vp, its, evals, el, status
+
     def render_expected(self, vp, image: int) -> np.ndarray:
         """sum_s E[G_s] in nanomaggies on image `image` (bin/write_celeste_expectation.jl:112-156); H x W array."""
         vp = np.ascontiguousarray(np.asarray(vp, dtype=np.float64).reshape(self.S, P))

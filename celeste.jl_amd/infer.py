@@ -31,6 +31,15 @@ NUM_JOINT_VI_ITERS = 3   # Config.num_joint_vi_iters (src/config.jl:17-25)
 log = logging.getLogger("celeste_jl_amd.infer")
 
 
+def default_infer_config() -> ElboConfig:
+    """The optimiser settings of the node-level loops when the caller gives none: ElboConfig's defaults with the
+    trust-region multiplier iteration capped at 5 steps, as Optim.jl's solve_tr_subproblem! does (converged or not) --
+    the reference's production behaviour (ElboMaximize.jl:228-242 -> Optim.optimize).  ElboConfig() itself keeps
+    tr_secular_iters = 0 (run to convergence, <= 20 steps), the setting the optimiser tests pin against a 60-digit
+    solution of the sub-problem; the two differ only on boundary steps whose multiplier needs more than 5 Newton steps."""
+    return ElboConfig(tr_secular_iters=5)
+
+
 def _report_failures(targets, status, where: str, failed: Optional[set]):
     """A source whose ELBO turned non-finite is logged and skipped -- the reference's production / multi-thread
     behaviour (Log.exception in process_sources_kernel! and one_node_single_infer, ParallelRun.jl:389-396, 582-597):
@@ -50,6 +59,7 @@ def one_node_single_infer(ctx: FieldContext, catalog, target_sources: Sequence[i
     vp = vp_nbr.copy()
     for t in target_sources:
         vp[t] = generic_init_source(catalog[t].pos)
+    cfg = cfg or default_infer_config()
     new, _, _, _, st = ctx.maximize_batch(vp, list(target_sources), cfg, vp_neighbors=vp_nbr, raise_on_error=False)
     _report_failures(target_sources, st, "one_node_single_infer", failed)
     return new[list(target_sources)]
@@ -73,8 +83,28 @@ def joint_infer_sweeps(maximize_layer: Callable, vp: np.ndarray, targets: Sequen
     whole table, optimises its cost-balanced shard of each layer and the updated rows are all-gathered (352 B per
     target and layer: SURVEY.md 8(e)) -- the only exchange of the path.  vp is updated in place and returned."""
     targets = list(targets)
-    tset = set(targets)
     centers = {t: vp[t, 0:2].copy() for t in targets}        # boxes stay at the initial positions
+    for layer in joint_layers(targets, neighbors, batch_size, n_iters, rng, schedule):
+
+        def run(local):
+            pc = np.stack([centers[t] for t in local])
+            return maximize_layer(vp, list(local), pc)
+        if world == 1:
+            vp[layer] = run(layer)
+        else:
+            lc = [1.0 if costs is None else costs[t] for t in layer]
+            vp[layer] = sharded_maximize(run, layer, lc, rank, world, all_gather, device)
+    return vp
+
+
+def joint_layers(targets: Sequence[int], neighbors: List[List[int]], batch_size: int = 400,
+                 n_iters: int = NUM_JOINT_VI_ITERS, rng: Optional[np.random.Generator] = None,
+                 schedule: str = "cyclades") -> List[List[int]]:
+    """The joint-inference schedule as a flat list of layers (lists of source ids no two of which are neighbours), in the
+    order they are optimised: for every sweep, for every batch, the j-th sources of all its connected components
+    (j = 0, 1, ...).  This is what celeste_joint_infer consumes."""
+    targets = list(targets)
+    tset = set(targets)
     nmap = {t: [n for n in neighbors[t] if n in tset] for t in targets}
     if schedule == "coloring":
         batches = [[[i] for i in cls] for cls in color_classes(targets, nmap)]   # one layer per colour
@@ -82,21 +112,13 @@ def joint_infer_sweeps(maximize_layer: Callable, vp: np.ndarray, targets: Sequen
         assert schedule == "cyclades"
         batches = partition_cyclades_dynamic(targets, nmap, batch_size=batch_size,
                                              rng=rng or np.random.default_rng(42))   # srand(42), ParallelRun.jl:143
+    layers = []
     for _ in range(n_iters):
         for components in batches:
             depth = max(len(c) for c in components)
             for j in range(depth):
-                layer = [targets[c[j]] for c in components if len(c) > j]
-
-                def run(local):
-                    pc = np.stack([centers[t] for t in local])
-                    return maximize_layer(vp, list(local), pc)
-                if world == 1:
-                    vp[layer] = run(layer)
-                else:
-                    lc = [1.0 if costs is None else costs[t] for t in layer]
-                    vp[layer] = sharded_maximize(run, layer, lc, rank, world, all_gather, device)
-    return vp
+                layers.append([targets[c[j]] for c in components if len(c) > j])
+    return layers
 
 
 def one_node_joint_infer(ctx: FieldContext, catalog, target_sources: Sequence[int], neighbors: List[List[int]],
@@ -111,6 +133,25 @@ def one_node_joint_infer(ctx: FieldContext, catalog, target_sources: Sequence[in
     vp = np.stack([catalog_init_source(ce) for ce in catalog])
     for t in targets:
         vp[t] = generic_init_source(catalog[t].pos)
+    cfg = cfg or default_infer_config()
+    if world == 1:
+        # the whole schedule in one call: the parameter table stays in HBM across all layers (celeste_joint_infer)
+        layers = joint_layers(targets, neighbors, batch_size, n_iters, rng, schedule)
+        centers = [vp[layer, 0:2].copy() for layer in layers]      # boxes stay at the initial positions
+        vp, _, _, _, st = ctx.joint_infer(vp, layers, cfg, pos_centers=centers)
+        _report_failures([t for layer in layers for t in layer], st, "one_node_joint_infer", failed)
+        return vp[targets]
+    if all_gather is None:
+        # one process per GPU: every rank optimises its shard of each layer against its own device-resident table and
+        # the optimised rows (+ status) are all-gathered on the device after every layer (RCCL; gloo: through the host)
+        from .parallel import DeviceJointInfer
+        dj = DeviceJointInfer(ctx, vp, rank, world, cfg)
+        centers = {t: vp[t, 0:2].copy() for t in targets}
+        for layer in joint_layers(targets, neighbors, batch_size, n_iters, rng, schedule):
+            lc = [1.0 if costs is None else costs[t] for t in layer]
+            st = dj.layer(layer, lc, np.stack([centers[t] for t in layer]))
+            _report_failures(layer, st, "one_node_joint_infer", failed)
+        return dj.table()[targets]
 
     def maximize_layer(table, layer, pc):
         new, _, _, _, st = ctx.maximize_batch(table, layer, cfg, pos_centers=pc, raise_on_error=False)

@@ -91,6 +91,27 @@ def sharded_maximize(maximize: Callable[[Sequence[int]], np.ndarray], targets: S
     return out
 
 
+def gather_status(local_status: Sequence[int], n_targets: int, costs: Sequence[float], rank: int, world: int,
+                  all_gather: Optional[Callable] = None, device: Optional[int] = None) -> np.ndarray:
+    """The per-target status codes of a sharded optimisation on EVERY rank (each rank only knows its shard's): the same
+    partition as sharded_maximize, one more all-gather of one column.  Without it `failed` sets and warnings differ
+    between ranks although the parameter tables agree."""
+    shards = shard_targets(costs, world)
+    width = max(len(s) for s in shards)
+    block = np.zeros((width, 1))
+    block[:len(shards[rank]), 0] = np.asarray(local_status, dtype=np.float64)
+    if world == 1:
+        blocks = [block]
+    elif all_gather is not None:
+        blocks = all_gather(block)
+    else:
+        blocks = _default_all_gather(block, world, device)
+    out = np.zeros(n_targets, dtype=np.int32)
+    for r in range(world):
+        out[shards[r]] = np.rint(blocks[r][:len(shards[r]), 0]).astype(np.int32)
+    return out
+
+
 class DeviceShardedSweep:
     """BASELINE.json configs[3]: ONE field, its targets sharded by source across `world` ranks, on the device.
 
@@ -209,3 +230,67 @@ class DeviceShardedSweep:
         """[n_local, 44, 44] Hessians of this rank's shard (targets `self.mine`)."""
         self.wait()
         return None if self.d_h is None else self.d_h[:self.n].cpu().numpy()
+
+
+class DeviceJointInfer:
+    """Joint inference across ranks with the parameter table resident in HBM on every rank (ParallelRun.jl:135-196 on
+    N GPUs): for every layer of the schedule each rank optimises its cost-balanced shard of the layer in place
+    (`celeste_maximize_batch_device`: no table H2D / D2H), then the optimised rows -- 44 doubles + the status, padded to
+    the widest shard -- are all-gathered with ONE `all_gather_into_tensor` on device blocks (RCCL over xGMI; 360 B per
+    target and layer) and scattered into every rank's table.  With the gloo backend the blocks are
+    staged through the host (two ranks sharing one GPU in the tests)."""
+
+    def __init__(self, ctx, vp: np.ndarray, rank: int, world: int, cfg=None, backend: Optional[str] = None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.ctx, self.rank, self.world, self.cfg = ctx, rank, world, cfg
+        self.backend = backend or (dist.get_backend() if world > 1 else "none")
+        self.dev = torch.device("cuda", ctx.device)
+        with torch.cuda.device(self.dev):
+            self.d_vp = torch.tensor(np.ascontiguousarray(vp, dtype=np.float64).reshape(ctx.S, P), device=self.dev)
+
+    def layer(self, layer: Sequence[int], costs: Sequence[float], pos_centers: np.ndarray) -> np.ndarray:
+        """Optimise the sources of `layer` (mutually non-neighbouring) against the shared table; returns their status
+        codes, identical on every rank."""
+        torch = self.torch
+        layer = np.asarray(layer, dtype=np.int64)
+        shards = shard_targets(costs, self.world)
+        mine = shards[self.rank]
+        W = max(1, max(len(s) for s in shards))
+        with torch.cuda.device(self.dev):
+            stream = torch.cuda.current_stream(self.dev)
+            block = torch.zeros(W, P + 1, dtype=torch.float64, device=self.dev)
+            if len(mine):
+                d_tg = torch.tensor(layer[mine], dtype=torch.int32, device=self.dev)
+                d_pc = torch.tensor(np.ascontiguousarray(pos_centers[mine], dtype=np.float64), device=self.dev)
+                d_st = torch.zeros(len(mine), dtype=torch.int32, device=self.dev)
+                self.ctx.maximize_batch_device(self.d_vp.data_ptr(), len(mine), d_tg.data_ptr(), self.cfg,
+                                               d_pos_centers=d_pc.data_ptr(), d_status=d_st.data_ptr(),
+                                               stream=stream.cuda_stream)
+                block[:len(mine), :P] = self.d_vp[d_tg.long()]
+                block[:len(mine), P] = d_st.double()
+            if self.world == 1:
+                gathered = block.unsqueeze(0)
+            elif self.backend == "nccl":
+                gathered = torch.empty(self.world, W, P + 1, dtype=torch.float64, device=self.dev)
+                self.dist.all_gather_into_tensor(gathered, block)
+            else:   # gloo: through the host
+                h = block.cpu()
+                outs = [torch.empty_like(h) for _ in range(self.world)]
+                self.dist.all_gather(outs, h)
+                gathered = torch.stack(outs).to(self.dev)
+            status = np.zeros(len(layer), dtype=np.int32)
+            for r in range(self.world):
+                idx = shards[r]
+                if not len(idx):
+                    continue
+                rows = torch.tensor(layer[idx], dtype=torch.int64, device=self.dev)
+                if r != self.rank:
+                    self.d_vp[rows] = gathered[r, :len(idx), :P]
+                status[idx] = gathered[r, :len(idx), P].round().to(torch.int32).cpu().numpy()
+        return status
+
+    def table(self) -> np.ndarray:
+        self.torch.cuda.synchronize(self.dev)
+        return self.d_vp.cpu().numpy()

@@ -162,6 +162,10 @@ typedef struct celeste_work_stats_t {
     int64_t record_tiles;           /* split variant: 64-pixel record tiles actually stored / re-read */
 } celeste_work_stats_t;
 
+/* ABI version: major * 100 + minor.  200: celeste_optim_config_t carries tr_secular_iters (round 2 grew the struct by 8
+ * bytes without bumping the version); celeste_maximize_batch_device and celeste_joint_infer exist.  Bindings check it
+ * (cabi.load_library, shim/CelesteMI355X.jl): a caller built against another major version must not pass structs. */
+#define CELESTE_ABI_VERSION 200
 int celeste_version(void);
 const char *celeste_strerror(int status);
 
@@ -295,6 +299,36 @@ typedef struct celeste_optim_config_t {
 int celeste_maximize_batch(celeste_ctx_t *ctx, double *vp, const double *vp_neighbors, const double *pos_centers,
                            int32_t n_targets, const int32_t *targets, const celeste_optim_config_t *cfg,
                            int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status);
+
+/* celeste_maximize_batch with every pointer already in HBM, on `stream` (a hipStream_t, NULL = default stream): d_vp
+ * (n_sources x 44) is optimised in place for the targets -- the parameter table never leaves the device, which is what
+ * lets a multi-GPU driver all-gather the optimised rows over RCCL straight from it (parallel.sharded_maximize).
+ * d_vp_neighbors (may be NULL = d_vp) and d_pos_centers (n_targets x 2, may be NULL) as above; the per-target outputs
+ * d_iterations / d_f_evals / d_elbo / d_status (device, may be NULL) are written when the batch is done.  Targets must be
+ * distinct (not checked here: they live on the device).  Batches of up to 1024 targets run as ONE persistent launch
+ * (every target iterates at its own pace) and the call is asynchronous; larger batches run the lock-step driver,
+ * which blocks the host until the batch has converged.  A failing target gets its input row back and its status set
+ * (CELESTE_ERR_HIP for every target if the launch itself gave up). */
+int celeste_maximize_batch_device(celeste_ctx_t *ctx, double *d_vp, const double *d_vp_neighbors,
+                                  const double *d_pos_centers, int32_t n_targets, const int32_t *d_targets,
+                                  const celeste_optim_config_t *cfg, int32_t *d_iterations, int32_t *d_f_evals,
+                                  double *d_elbo, int32_t *d_status, void *stream);
+
+/* ParallelRun.one_node_joint_infer's inner loop (ParallelRun.jl:135-196, 302-397) for a schedule the caller has laid
+ * out: `n_layers` layers, layer l = layer_targets[layer_offsets[l] .. layer_offsets[l + 1]).  The sources of a layer are
+ * optimised simultaneously (celeste_maximize_batch semantics: neighbours frozen), so no two of them may be neighbours
+ * (CELESTE_ERR_INVALID_ARG otherwise) -- the j-th sources of the connected components of a Cyclades batch
+ * (partition.jl:173-236) are such a layer; every layer sees the parameter table as the layers before it left it, which
+ * reproduces the reference's sequential-within-component schedule.  Repeat the layers for num_joint_vi_iters sweeps.
+ * vp (n_sources x 44, host) is uploaded once, stays in HBM across all layers and is written back at the end.
+ * pos_centers (2 doubles per entry of layer_targets, may be NULL = the position at the start of that layer): the
+ * centres of the position boxes, which the reference pins at the initial positions (ParallelRun.jl:96-100).  The
+ * per-entry outputs (may be NULL) are indexed like layer_targets.  A source that fails in some layer keeps the row it
+ * had before that layer (status set, the rest of the schedule goes on: ParallelRun.jl:389-396); the return value is the
+ * first such status. */
+int celeste_joint_infer(celeste_ctx_t *ctx, double *vp, int32_t n_layers, const int64_t *layer_offsets,
+                        const int32_t *layer_targets, const double *pos_centers, const celeste_optim_config_t *cfg,
+                        int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status);
 
 /* Diagnostics of the trust-region sub-problems solved since the last reset, summed over all contexts of the
  * process: out[0] interior Newton steps, out[1] boundary solutions, out[2] hard cases, out[3] total and out[4]

@@ -16,7 +16,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(cabi.EXPORTED_SYMBOLS), declared ^ set(cabi.EXPORTED_SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.celeste_version() >= 101
+    assert lib.celeste_version() == cabi.ABI_VERSION
     assert lib.celeste_strerror(0) == b"ok" and b"CPU fallback" in lib.celeste_strerror(cabi.ERR_NO_DEVICE)
 
 

@@ -1,0 +1,238 @@
+"""-m gpu: the fused optimiser launch (optim_fused_kernel: every target iterates at its own pace inside ONE persistent
+launch, csrc/fused_kernels.h) against the chained driver (work list -> pixel -> lift -> step per Newton iteration).
+
+Both drivers run the same device functions on the same 256-pixel chunk records, so everything they return must agree
+BIT FOR BIT -- parameters, iteration counts, evaluation counts, ELBO values, status codes -- whatever the batch, and the
+chained driver is in turn held to the CPU restatement by tests/test_gpu_optimizer.py.  Also here: the entry points built
+on the fused launch (celeste_maximize_batch_device, celeste_joint_infer)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _both(ctx, vp, targets, cfg, **kw):
+    """(chained, fused) results of the same call"""
+    out = []
+    for mode in (0, 1):
+        with _env(CELESTE_OPT_FUSED=mode):
+            out.append(ctx.maximize_batch(vp, targets, cfg, raise_on_error=False, **kw))
+    return out
+
+
+def _assert_identical(a, b, what):
+    names = ("vp", "iterations", "f_evals", "elbo", "status")
+    for x, y, n in zip(a, b, names):
+        assert np.array_equal(x, y), "%s: %s differs (max |diff| %.3e)" % (
+            what, n, np.abs(np.asarray(x, dtype=np.float64) - np.asarray(y, dtype=np.float64)).max())
+
+
+@pytest.fixture(scope="module")
+def crowded():
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(220, 240, 40, seed=23, margin=30)
+    return f, cel.FieldContext(f.images, f.patches, f.neighbors)
+
+
+def test_fused_launch_equals_chained_driver_bit_for_bit(crowded):
+    import celeste_jl_amd as cel
+    f, ctx = crowded
+    S = len(f.catalog)
+    rng = np.random.default_rng(5)
+    cases = [
+        ("one target", [3], cel.ElboConfig(max_iters=7), {}),
+        ("five targets, to convergence", [0, 9, 17, 25, 33], cel.ElboConfig(), {}),
+        ("every source", list(range(S)), cel.ElboConfig(max_iters=12), {}),
+        ("every source, shuffled, Optim's secular cap, no KL", [int(t) for t in rng.permutation(S)],
+         cel.ElboConfig(max_iters=9, tr_secular_iters=5), {"include_kl": False}),
+        ("wide position boxes, pinned centres", list(range(0, S, 2)), cel.ElboConfig(max_iters=10, loc_width=0.5),
+         {"pos_centers": f.vp[0:S:2, 0:2] + 0.01}),
+        ("frozen neighbours from another table", list(range(1, S, 3)), cel.ElboConfig(max_iters=8),
+         {"vp_neighbors": f.vp * (1.0 + 1e-3 * rng.standard_normal(f.vp.shape) * (np.arange(44) >= 6))}),
+    ]
+    for what, tg, cfg, kw in cases:
+        a, b = _both(ctx, f.vp, tg, cfg, **kw)
+        assert (a[4] == 0).all(), what
+        assert a[1].max() >= min(cfg.max_iters, 5), (what, a[1])       # the optimiser really iterated
+        assert not np.array_equal(a[0][tg], f.vp[tg])
+        _assert_identical(a, b, what)
+        print("%-55s %3d targets, iterations %d..%d: identical" % (what, len(tg), a[1].min(), a[1].max()))
+
+
+def test_fused_launch_with_visit_lists_and_eigen_solver(crowded):
+    """the sparse-patch-list code path (visit items instead of the dense s * N + n tables) and the eigen-decomposition
+    route of the sub-problem"""
+    import celeste_jl_amd as cel
+    f, _ = crowded
+    with _env(CELESTE_FORCE_VISIT_LISTS=1):
+        ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    tg = list(range(0, len(f.catalog), 2))
+    a, b = _both(ctx, f.vp, tg, cel.ElboConfig(max_iters=8))
+    _assert_identical(a, b, "visit lists")
+    with _env(CELESTE_TR_SOLVER="eig"):
+        c, d = _both(ctx, f.vp, tg, cel.ElboConfig(max_iters=8))
+    _assert_identical(c, d, "eigen solver")
+    assert np.abs(c[0] - a[0]).max() < 1e-6          # (two routes to the same step)
+
+
+def test_fused_launch_survives_a_failing_target_and_refuses_duplicates(crowded):
+    """ParallelRun.jl:582-597: the failing source keeps its row and gets its status, the others are optimised as if it
+    were not there -- in both drivers, identically"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import cabi
+    f, ctx = crowded
+    vp = f.vp.copy()
+    bad = 6
+    vp[bad, 8] = np.nan                                   # a non-finite flux variance
+    tg = [2, bad, 11, 20]
+    tg = [t for t in tg if bad not in f.neighbors[t] or t == bad]      # the bad source's neighbours would fail with it
+    assert len(tg) >= 3
+    a, b = _both(ctx, vp, tg, cel.ElboConfig(max_iters=6))
+    _assert_identical(a, b, "failing target")
+    k = tg.index(bad)
+    assert a[4][k] == cabi.ERR_NONFINITE_INPUT and (np.delete(a[4], k) == 0).all()
+    assert np.array_equal(a[0][bad], vp[bad], equal_nan=True)
+    ok = [t for t in tg if t != bad]
+    clean, _ = _both(ctx, f.vp, ok, cel.ElboConfig(max_iters=6))
+    assert np.array_equal(clean[0][ok], a[0][ok])
+    with _env(CELESTE_OPT_FUSED=1), pytest.raises(cabi.CelesteError):
+        ctx.maximize_batch(f.vp, [3, 5, 3], cel.ElboConfig(max_iters=2))
+
+
+def test_a_fused_launch_that_cannot_make_progress_gives_up_instead_of_hanging(crowded):
+    """every wait inside the launch is bounded: with a time-out shorter than one Newton step the workgroups that wait for
+    work abort the launch, the call fails loudly (CELESTE_ERR_HIP) and vp is untouched"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import cabi
+    f, ctx = crowded
+    with _env(CELESTE_OPT_FUSED=1, CELESTE_FUSED_TIMEOUT_S=1e-6):
+        with pytest.raises(cabi.CelesteError) as e:
+            ctx.maximize_batch(f.vp, list(range(10)), cel.ElboConfig(max_iters=20))
+    assert e.value.status == cabi.ERR_HIP
+    a, b = _both(ctx, f.vp, list(range(10)), cel.ElboConfig(max_iters=5))     # the context is still usable
+    _assert_identical(a, b, "after an aborted launch")
+
+
+def test_maximize_batch_device_equals_the_host_pointer_call(crowded):
+    """celeste_maximize_batch_device: the table is optimised in place in HBM; same rows, same per-target outputs"""
+    import torch
+    import celeste_jl_amd as cel
+    f, ctx = crowded
+    dev = torch.device("cuda", ctx.device)
+    tg = np.arange(0, len(f.catalog), 3, dtype=np.int32)
+    cfg = cel.ElboConfig(max_iters=9)
+    pc = f.vp[tg, 0:2] - 0.02
+    ref = ctx.maximize_batch(f.vp, tg, cfg, pos_centers=pc)
+    for mode in (0, 1):
+        d_vp = torch.tensor(f.vp, dtype=torch.float64, device=dev)
+        d_tg = torch.tensor(tg, device=dev)
+        d_pc = torch.tensor(pc, dtype=torch.float64, device=dev)
+        d_it = torch.zeros(len(tg), dtype=torch.int32, device=dev)
+        d_ev = torch.zeros_like(d_it)
+        d_st = torch.zeros_like(d_it)
+        d_el = torch.zeros(len(tg), dtype=torch.float64, device=dev)
+        with _env(CELESTE_OPT_FUSED=mode):
+            ctx.maximize_batch_device(d_vp.data_ptr(), len(tg), d_tg.data_ptr(), cfg, d_pos_centers=d_pc.data_ptr(),
+                                      d_iterations=d_it.data_ptr(), d_f_evals=d_ev.data_ptr(), d_elbo=d_el.data_ptr(),
+                                      d_status=d_st.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        got = (d_vp.cpu().numpy(), d_it.cpu().numpy(), d_ev.cpu().numpy(), d_el.cpu().numpy(), d_st.cpu().numpy())
+        _assert_identical(ref, got, "device-pointer call, fused=%d" % mode)
+
+
+def test_joint_infer_entry_equals_layer_by_layer_calls(crowded):
+    """celeste_joint_infer keeps the table in HBM across all layers of the schedule; the same schedule driven from the
+    host, one celeste_maximize_batch per layer with the table going up and down, must leave the same table"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd.infer import joint_infer_sweeps, joint_layers
+    from celeste_jl_amd.params import catalog_init_source, generic_init_source
+    f, ctx = crowded
+    S = len(f.catalog)
+    targets = [s for s in range(S) if s % 7 != 3]                    # a few sources stay frozen neighbours
+    vp0 = np.stack([catalog_init_source(ce) for ce in f.catalog])
+    for t in targets:
+        vp0[t] = generic_init_source(f.catalog[t].pos)
+    cfg = cel.ElboConfig(max_iters=6)
+    for schedule, bs in (("cyclades", 12), ("coloring", 0)):
+        layers = joint_layers(targets, f.neighbors, batch_size=bs, n_iters=2, rng=np.random.default_rng(3), schedule=schedule)
+        assert len(layers) >= 4 and sorted(t for l in layers for t in l) == sorted(targets + targets)
+        centers = [vp0[l, 0:2].copy() for l in layers]
+        new, its, evals, el, st = ctx.joint_infer(vp0, layers, cfg, pos_centers=centers)
+        assert (st == 0).all() and its.max() == 6
+
+        def layer_host(vp, layer, pc):
+            out, _, _, _, s = ctx.maximize_batch(vp, layer, cfg, pos_centers=pc)
+            assert (s == 0).all()
+            return out[layer]
+        for mode in (0, 1):
+            with _env(CELESTE_OPT_FUSED=mode):
+                ref = joint_infer_sweeps(layer_host, vp0.copy(), targets, f.neighbors, batch_size=bs, n_iters=2,
+                                         rng=np.random.default_rng(3), schedule=schedule)
+            assert np.array_equal(ref, new), (schedule, mode, np.abs(ref - new).max())
+        frozen = [s for s in range(S) if s not in targets]
+        assert np.array_equal(new[frozen], vp0[frozen]) and not np.array_equal(new[targets], vp0[targets])
+        print("joint inference, %s: %d layers of %d..%d sources: one call == layer-by-layer calls" %
+              (schedule, len(layers), min(map(len, layers)), max(map(len, layers))))
+    # a layer with two neighbouring sources is refused
+    a = next(s for s in range(S) if f.neighbors[s])
+    from celeste_jl_amd import cabi
+    with pytest.raises(cabi.CelesteError):
+        ctx.joint_infer(vp0, [[a, f.neighbors[a][0]]], cfg)
+
+
+def test_one_node_joint_infer_uses_the_entry_and_reports_failures(crowded):
+    import celeste_jl_amd as cel
+    from celeste_jl_amd.infer import one_node_joint_infer
+    f, ctx = crowded
+    S = len(f.catalog)
+    failed = set()
+    vs = one_node_joint_infer(ctx, f.catalog, list(range(S)), f.neighbors, cel.ElboConfig(max_iters=4), batch_size=10,
+                              n_iters=1, failed=failed)
+    assert vs.shape == (S, 44) and np.isfinite(vs).all() and not failed
+
+
+def test_fused_launch_on_the_bench_field():
+    """config 3 (2048 x 1489 x 5, 2000 sources): a Cyclades-sized layer, a rank's N = 8 shard and the whole field"""
+    import time
+    import bench
+    import celeste_jl_amd as cel
+    fld = bench.build_field(2048, 1489, 2000, 3)
+    ctx = cel.FieldContext(fld.images, fld.patches, fld.neighbors)
+    rng = np.random.default_rng(11)
+    for n, iters in ((80, 50), (250, 50), (2000, 50)):
+        tg = np.sort(rng.choice(2000, n, replace=False)).astype(np.int32)
+        res, dt = [], []
+        for mode in (0, 1):
+            with _env(CELESTE_OPT_FUSED=mode):
+                ctx.maximize_batch(fld.vp, tg, cel.ElboConfig(max_iters=2))
+                t0 = time.perf_counter()
+                res.append(ctx.maximize_batch(fld.vp, tg, cel.ElboConfig(max_iters=iters)))
+                dt.append(time.perf_counter() - t0)
+        _assert_identical(res[0], res[1], "%d targets" % n)
+        its = res[0][1]
+        print("%4d targets, %d..%d Newton iterations (mean %.1f): chained %.2f ms (%.0f us per iteration of the slowest target), "
+              "fused %.2f ms (%.0f us)" % (n, its.min(), its.max(), its.mean(), dt[0] * 1e3, dt[0] * 1e6 / (its.max() + 1),
+                                           dt[1] * 1e3, dt[1] * 1e6 / (its.max() + 1)))
