@@ -140,7 +140,8 @@ struct celeste_ctx {
     // buffers of the fused optimiser launch (optim_fused_kernel), kept between calls (grown on demand)
     struct FusedBuffers {
         size_t cap_t = 0, cap_rec = 0, cap_q = 0, cap_saved = 0;
-        int2 *d_chunk_desc = nullptr, *d_tgt_rec = nullptr;
+        int4 *d_chunk_desc = nullptr;
+        int2 *d_tgt_rec = nullptr;
         int32_t *d_q_items = nullptr, *d_q_ctl = nullptr, *d_arrivals = nullptr;
         double *d_saved = nullptr;          // the targets' rows before the optimisation
         int32_t *h_ctl = nullptr;           // page-locked copy of the queue control words of the last launch
@@ -722,7 +723,9 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         HIP_TRY(hipMemsetAsync(c->d_needed, 0, (size_t)c->S * sizeof(int32_t), stream));
         c->stamp = 1;
     }
-    const size_t setup_threads = std::max<size_t>((size_t)c->S, (size_t)n_targets * (c->dense ? 1 : c->M));
+    // SrcGeo: of every source when the neighbours are (re)rendered, else of the targets only (setup_thread)
+    const int geo_S = render_neighbors ? c->S : -1;
+    const size_t setup_threads = std::max<size_t>(render_neighbors ? (size_t)c->S : 0, (size_t)n_targets * (c->dense ? 1 : c->M));
     // the sources whose tables this launch fills are marked by the setup kernel (targets + neighbours)
     int32_t *const prep_mark = render_neighbors && !tables_current && !prep_all ? c->d_prep_mark : nullptr;
     bool prep_fused = false;
@@ -732,13 +735,13 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         prep_fused = !render_neighbors && !getenv("CELESTE_NO_FUSED_PREP");
         const unsigned prep_blocks = prep_fused ? (unsigned)((n_visits + WORK1_NT / 64 - 1) / (WORK1_NT / 64)) : 0u;
         hipLaunchKernelGGL(setup_worklist_kernel, dim3(1 + setup_blocks + prep_blocks), dim3(WORK1_NT),
-                           0, stream, d_vp, c->S, c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M,
+                           0, stream, d_vp, geo_S, c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M,
                            c->dense ? nullptr : c->d_items, render_neighbors ? c->d_needed : nullptr, c->stamp, c->d_patches,
                            c->N, c->CH, c->chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live, prep_mark,
                            c->d_nbr_off, c->d_nbr_idx, c->d_rec_off, (int)setup_blocks, c->d_images, c->K, c->d_srcimg,
                            c->d_comps);
     } else {
-        hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 63) / 64)), dim3(64), 0, stream, d_vp, c->S,
+        hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 63) / 64)), dim3(64), 0, stream, d_vp, geo_S,
                            c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
                            render_neighbors ? c->d_needed : nullptr, c->stamp, prep_mark, c->d_nbr_off, c->d_nbr_idx);
         hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
@@ -1257,7 +1260,7 @@ static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, co
         HIP_TRY(hipStreamSynchronize(stream));
         if (fb.d_chunk_desc) { (void)hipFree(fb.d_chunk_desc); fb.d_chunk_desc = nullptr; }
         fb.cap_rec = 0;
-        HIP_TRY(hipMalloc((void **)&fb.d_chunk_desc, std::max<size_t>(rec, 1) * sizeof(int2)));
+        HIP_TRY(hipMalloc((void **)&fb.d_chunk_desc, std::max<size_t>(rec, 1) * 2 * sizeof(int4)));
         fb.cap_rec = rec;
     }
     if (q_cap > fb.cap_q) {
@@ -1621,6 +1624,15 @@ extern "C" int celeste_lift_clocks(int reset, uint64_t out[16]) {   // debug bui
     HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lift_clk), sizeof h));
     for (int i = 0; i < 16; ++i) out[i] = h[i];
     if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lift_clk), z, sizeof z)); }
+    return CELESTE_OK;
+}
+#endif
+#ifdef FUSED_TIMING
+extern "C" int celeste_fused_clocks(int reset, uint64_t out[16]) {   // debug builds only (tools/variants)
+    unsigned long long h[16] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fused_clk), sizeof h));
+    for (int i = 0; i < 16; ++i) out[i] = h[i];
+    if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_fused_clk), z, sizeof z)); }
     return CELESTE_OK;
 }
 #endif

@@ -69,12 +69,20 @@ __device__ inline void brightness(const double *vs, int i, int b, double &El, do
 // the tables of one (source, image) visit: lane c < NC computes component c, lane 63 the brightness moments.
 // vs: the source's 44 parameters; p: its patch in the image; b: the image's band, 0-based; the results go to *si_out and
 // comps_out[c] -- the per-visit tables in HBM (prep_kernel) or a workgroup's LDS copy (optim_fused_kernel)
+// linear_world_to_pix (wcs_utils.jl:14-18)
+__device__ __forceinline__ void world_to_pix(const double *__restrict__ vs, const DevPatch &p, double &m1, double &m2) {
+    const double d0 = vs[0] - p.wc[0], d1 = vs[1] - p.wc[1];
+    m1 = p.J[0] * d0 + p.J[2] * d1 + p.pc[0];
+    m2 = p.J[1] * d0 + p.J[3] * d1 + p.pc[1];
+}
+// MOMENTS = false: the components only (the fused optimiser kernel forms the brightness moments on other lanes,
+// brightness_moments_wave)
+template <bool MOMENTS = true>
 __device__ __forceinline__ void prep_visit_values(int c, const double *__restrict__ vs, const DevPatch &p, int b, int K,
                                                   SrcImg *__restrict__ si_out, Comp *__restrict__ comps_out) {
     const int NC = 14 * K;
-    const double d0 = vs[0] - p.wc[0], d1 = vs[1] - p.wc[1];
-    const double m1 = p.J[0] * d0 + p.J[2] * d1 + p.pc[0];  // linear_world_to_pix (wcs_utils.jl:14-18)
-    const double m2 = p.J[1] * d0 + p.J[3] * d1 + p.pc[1];
+    double m1, m2;
+    world_to_pix(vs, p, m1, m2);
     double x11, x12, x22;
     bvn_cov(vs[3], vs[4], vs[5], x11, x12, x22);
     if (c < NC) {
@@ -99,12 +107,51 @@ __device__ __forceinline__ void prep_visit_values(int c, const double *__restric
         o.nu = nu;
         comps_out[c] = o;
     }
-    if (c == 63) {
+    if (MOMENTS && c == 63) {
         double El0, Ell0, El1, Ell1;
         brightness(vs, 0, b, El0, Ell0);
         brightness(vs, 1, b, El1, Ell1);
         SrcImg o;
         o.m1 = m1; o.m2 = m2;
+        o.c0 = vs[26] * El0; o.c1 = vs[27] * El1;
+        o.q0 = vs[26] * Ell0; o.q1 = vs[27] * Ell1;
+        o.dev = vs[2]; o.pad1 = 0;
+        *si_out = o;
+    }
+}
+
+// The SrcImg of a visit by one whole wavefront: brightness() evaluates up to ten exponentials per type one after the
+// other on a single lane (1.3 us on the critical path of every chunk item of the fused optimiser kernel); here lane
+// 10 i + 5 w + f evaluates factor f (0: flux, 1..4: colours 3, 4, 2, 1 -- brightness()'s order) of E_l_a (w = 0) or
+// E_ll_a (w = 1) of type i, and lanes 0..3 form the four products in brightness()'s order.  Every factor's argument is a
+// sum of two terms scaled by powers of two, i.e. rounded once however it is contracted: the results are brightness()'s, bit
+// for bit.
+__device__ __forceinline__ void brightness_moments_wave(int lane, const double *__restrict__ vs, const DevPatch &p, int b,
+                                                        SrcImg *__restrict__ si_out) {
+    double fac = 1.0;
+    if (lane < 20) {
+        const int i = lane / 10, w = (lane / 5) & 1, f = lane % 5;
+        const double r = vs[6 + i], v = vs[8 + i];
+        const double *cm = vs + 10 + 4 * i, *cv = vs + 18 + 4 * i;
+        const int col = f == 1 ? 2 : (f == 2 ? 3 : (f == 3 ? 1 : 0));            // colour index of factors 1..4
+        const double sgn = f >= 3 ? -1.0 : 1.0;                                     // colours 1, 2 enter with a minus sign
+        double arg;
+        if (f == 0) arg = w ? 2 * r + 2 * v : r + 0.5 * v;
+        else arg = w ? 2 * (sgn * cm[col]) + 2 * cv[col] : sgn * cm[col] + .5 * cv[col];
+        fac = exp(arg);
+    }
+    const int base = lane < 4 ? 5 * lane : 0;                                       // lane q < 4: type q / 2, moment q % 2
+    double prod = __shfl(fac, base, 64);
+    const double f1 = __shfl(fac, base + 1, 64), f2 = __shfl(fac, base + 2, 64), f3 = __shfl(fac, base + 3, 64),
+                 f4 = __shfl(fac, base + 4, 64);
+    if (b >= 3) prod *= f1;
+    if (b >= 4) prod *= f2;
+    if (b <= 1) prod *= f3;
+    if (b <= 0) prod *= f4;
+    const double El0 = __shfl(prod, 0, 64), Ell0 = __shfl(prod, 1, 64), El1 = __shfl(prod, 2, 64), Ell1 = __shfl(prod, 3, 64);
+    if (lane == 0) {
+        SrcImg o;
+        world_to_pix(vs, p, o.m1, o.m2);
         o.c0 = vs[26] * El0; o.c1 = vs[27] * El1;
         o.q0 = vs[26] * Ell0; o.q1 = vs[27] * Ell1;
         o.dev = vs[2]; o.pad1 = 0;
@@ -353,7 +400,11 @@ __device__ inline void setup_thread(int k, const double *__restrict__ vp, int S,
                                     const int32_t *__restrict__ vis_img, int M, int2 *__restrict__ items,
                                     int32_t *__restrict__ is_target, int32_t stamp, int32_t *__restrict__ prep_mark,
                                     const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx) {
-    if (k < S) source_geo(vp, k, geo);
+    // S < 0: the neighbours are frozen (an optimiser iteration) -- only the targets have moved since the batch's SrcGeo
+    // table was made, and the neighbours' entries (their finiteness flags) keep describing the parameters they were
+    // rendered with
+    if (S < 0) { if (k < n_targets) source_geo(vp, targets[k], geo); }
+    else if (k < S) source_geo(vp, k, geo);
     if (prep_mark && k < n_targets) {   // the sources whose per-image tables this batch reads
         const int t = targets[k];
         prep_mark[t] = stamp;
@@ -832,6 +883,22 @@ __device__ __forceinline__ void accum_entries(const PixelTerms &T, double *__res
     if constexpr (E + 1 < ACC_N) accum_entries<MODE, E + 1>(T, slot);
 }
 
+// the same in two steps: the values (pinned in registers by an empty asm, so that they are formed where this is called),
+// then the adds
+template <int MODE, int E>
+__device__ __forceinline__ void form_entries(const PixelTerms &T, double (&ent)[ACC_N]) {
+    constexpr bool hess_only = E > ZV && E < ACC_CNT;
+    if constexpr (!(MODE == 1 && hess_only) && !entry_is_zero<E>()) { ent[E] = record_entry<E>(T); asm volatile("" : "+v"(ent[E])); }
+    if constexpr (E + 1 < ACC_N) form_entries<MODE, E + 1>(T, ent);
+}
+template <int MODE, int E>
+__device__ __forceinline__ void add_entries(const double (&ent)[ACC_N], double *__restrict__ slot) {
+    constexpr bool hess_only = E > ZV && E < ACC_CNT;
+    if constexpr (!(MODE == 1 && hess_only) && !entry_is_zero<E>())
+        __hip_atomic_fetch_add(slot + ACC_SLOTS * E, ent[E], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if constexpr (E + 1 < ACC_N) add_entries<MODE, E + 1>(ent, slot);
+}
+
 // Split variant (CELESTE_FLAG_SPLIT): instead of folding, every pixel's 68-entry record goes to HBM, entry-major
 // inside a 64-pixel tile (rec[e * 64 + lane]) so that each store instruction writes one contiguous 512-byte row.
 template <int E>
@@ -1153,7 +1220,7 @@ struct PixWork {
 // calling gate() -- a no-op in pixel_kernel, where one wave runs the iterations of a chunk in turn; the fused optimiser
 // kernel gives the four iterations of a chunk to four waves and uses the gate to let them ADD in iteration order, which
 // makes its chunk records bit-identical to pixel_kernel's.
-template <int MODE, typename R, bool MULTI, class Gate>
+template <int MODE, typename R, bool MULTI, bool GATED = false, class Gate>
 __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1, int lane, double *__restrict__ slot,
                                            double (&a)[3], Gate &&gate) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
@@ -1296,7 +1363,15 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
         }
         if constexpr (MODE == 3)
             store_entries<0>(T, W.rec + (size_t)(W.tile_off[W.v] + (base >> 6)) * (ACC_N * 64) + lane);
-        else {
+        else if constexpr (GATED) {
+            // several wavefronts share the slots and add in turn: the entries are formed BEFORE a wavefront waits for its
+            // turn (they fit the registers the component loop no longer needs), so a turn is 65 LDS adds long, not 600 VALU
+            // instructions + 65 adds
+            double ent[ACC_N];
+            form_entries<MODE, 0>(T, ent);
+            gate();
+            add_entries<MODE, 0>(ent, slot);
+        } else {
             gate();
             accum_entries<MODE, 0>(T, slot);
         }
@@ -1758,8 +1833,20 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
             const DevPatch &P = patches[vo + n0 + i];   // tables are indexed by visit
             const int npx = P.H2 * P.W2;
             double s = 0.0;
-            for (int ch = 0; ch < CH; ++ch)
-                if (ch * chunk_px < npx) s += ldc<COH>(acc + (rec_off ? (size_t)rec_off[ti * M + n0 + i] + ch : (size_t)(ti * M + n0 + i) * CH + ch) * ACC_N + e);
+            const double *const r0 = acc + (rec_off ? (size_t)rec_off[ti * M + n0 + i] : (size_t)(ti * M + n0 + i) * CH) * ACC_N + e;
+            if constexpr (COH) {
+                // L1-bypassing loads, four in flight at a time; added in chunk order like the plain loop below
+                for (int c0 = 0; c0 * chunk_px < npx && c0 < CH; c0 += 4) {
+                    double v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (c0 + q < CH && (c0 + q) * chunk_px < npx) ? ldc<true>(r0 + (size_t)(c0 + q) * ACC_N) : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (c0 + q < CH && (c0 + q) * chunk_px < npx) s += v[q];
+                }
+            } else {
+                for (int ch = 0; ch < CH; ++ch)
+                    if (ch * chunk_px < npx) s += r0[(size_t)ch * ACC_N];
+            }
             s_rec[i][e] = s;
         }
         if (want_grad) {
@@ -1898,7 +1985,22 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
         if (!isfinite(v)) bad = 1;
         o_d[tid] = v;
     }
-    if (want_hess && o_h) {
+    if (want_hess && o_h && COH) {
+        // (the fused optimiser: o_h is in LDS) every entry (p1 <= p2) of the upper triangle is formed once and stored at
+        // (p1, p2) and (p2, p1): half the kl_hess evaluations of the loop below, same values
+        for (int k = tid; k < CELESTE_HP; k += nthr) {
+            int p2 = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
+            while ((p2 + 1) * (p2 + 2) / 2 <= k) ++p2;
+            while (p2 * (p2 + 1) / 2 > k) --p2;
+            const int p1 = k - p2 * (p2 + 1) / 2;
+            double v = (p2 < LIFT_NP) ? sh_h[p1 + LIFT_NP * p2] : 0.0;
+            if (want_kl) v += kl_hess(K, prior, vs, p1, p2);
+            if (!isfinite(v)) bad = 1;
+            if (!(flags & CELESTE_FLAG_PACKED_HESS)) { o_h[p1 + CEL_P * p2] = v; o_h[p2 + CEL_P * p1] = v; }
+            else o_h[k] = v;   // upper triangle, by columns: (p1, p2) at p2 (p2 + 1) / 2 + p1
+        }
+    } else if (want_hess && o_h) {
+        // (o_h in HBM: consecutive threads store consecutive entries)
         for (int k = tid; k < CEL_P * CEL_P; k += nthr) {
             const int c2 = k / CEL_P, c1 = k - c2 * CEL_P;
             const int p1 = c1 < c2 ? c1 : c2, p2 = c1 < c2 ? c2 : c1;

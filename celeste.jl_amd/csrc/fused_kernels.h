@@ -38,6 +38,9 @@
 #define FQ_EXIT (-2)
 #define FQ_DIRECT0 (-3)    // item <= FQ_DIRECT0: target ti = FQ_DIRECT0 - item has no pixel to visit -- straight to its step
 #define FUSED_NT 256
+#ifndef FUSED_GATED
+#define FUSED_GATED 1      // 1: a wavefront forms its pixels' record entries before it waits for its turn to add them (pixel_iter)
+#endif
 #define FUSED_WAVES (FUSED_NT / 64)
 
 // q_ctl words
@@ -58,7 +61,7 @@ struct FusedArgs {
     const int32_t *targets; int n_targets;
     double *vp;                    // n_sources x 44: the targets' rows move, every other row is frozen
     double *acc;                   // chunk records, 68 doubles each
-    const int2 *chunk_desc;        // per record: {ti * M + j, chunk}
+    const int4 *chunk_desc;        // per record, two entries: {ti, j, chunk, target} {visit, image, 0, 0}
     const int2 *tgt_rec;           // per target: {first record, number of records}
     OptState *st; double *Hstate; OptParams op; uint32_t flags;
     // the queue
@@ -69,7 +72,7 @@ struct FusedArgs {
 // per batch, once: the targets' record ranges, the description of every record, the first round of queue items
 __global__ void fused_setup_kernel(const int32_t *__restrict__ targets, int n_targets, const DevPatch *__restrict__ patches,
                                    const int32_t *__restrict__ vis_off, const int2 *__restrict__ items, int N, int M,
-                                   int chunk_px, const int32_t *__restrict__ rec_off, int2 *__restrict__ chunk_desc,
+                                   int chunk_px, const int32_t *__restrict__ rec_off, int4 *__restrict__ chunk_desc,
                                    int2 *__restrict__ tgt_rec, int32_t *__restrict__ q_items, int32_t *__restrict__ q_ctl) {
     const int ti = blockIdx.x * blockDim.x + threadIdx.x;
     if (ti >= n_targets) return;
@@ -77,15 +80,18 @@ __global__ void fused_setup_kernel(const int32_t *__restrict__ targets, int n_ta
     int n_rec = 0, first = -1;
     for (int j = 0; j < M; ++j) {
         const int tn = ti * M + j;
-        int v = t * N + j;                       // items == nullptr: every source is listed in all M = N images
-        if (items) v = items[tn].x;
+        int v = t * N + j, n = j;                // items == nullptr: every source is listed in all M = N images
+        if (items) { v = items[tn].x; n = items[tn].y; }
         if (v < 0) continue;
         const DevPatch &P = patches[v];
         const int npx = P.H2 * P.W2;
         if (npx <= 0) continue;
         const int nch = (npx + chunk_px - 1) / chunk_px, r0 = rec_off[tn];
         if (first < 0) first = r0;
-        for (int ch = 0; ch < nch; ++ch) chunk_desc[r0 + ch] = make_int2(tn, ch);
+        for (int ch = 0; ch < nch; ++ch) {      // everything a workgroup needs to start on the record, in one 32-byte read
+            chunk_desc[2 * (r0 + ch)] = make_int4(ti, j, ch, t);
+            chunk_desc[2 * (r0 + ch) + 1] = make_int4(v, n, 0, 0);
+        }
         n_rec += nch;
     }
     tgt_rec[ti] = make_int2(first < 0 ? 0 : first, n_rec);
@@ -113,6 +119,17 @@ struct FusedShared {
     LiftShared lift;
     StepShared step;
 };
+
+#ifdef FUSED_TIMING   // debug builds (tools/variants): shader clocks per phase of the fused kernel, thread 0 of every workgroup
+__device__ unsigned long long g_fused_clk[16];
+#define FT_DECL long long ft__ = clock64()
+#define FT(k) do { const long long now__ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_fused_clk[k], (unsigned long long)(now__ - ft__)); ft__ = clock64(); } while (0)
+#define FT_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_fused_clk[k], 1ull); } while (0)
+#else
+#define FT_DECL do { } while (0)
+#define FT(k) do { } while (0)
+#define FT_COUNT(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -164,32 +181,32 @@ optim_fused_kernel(const FusedArgs A) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6;
+        FT_DECL;
         if (tid == 0) F.item = fused_pop(A);
         __syncthreads();
         const int item = F.item;
         if (item == FQ_EXIT) break;
+        FT(0);
         int ti;
         bool last;
         if (item >= 0) {
             // ---- one chunk record ----
-            const int2 desc = A.chunk_desc[item];
-            const int tn = desc.x, ch = desc.y;
-            ti = tn / A.M;
-            const int j = tn - ti * A.M;
-            const int t = A.targets[ti];
-            int n = j, v = t * A.N + j;
-            if (A.items) { const int2 e = A.items[tn]; v = e.x; n = e.y; }
+            const int4 d0 = A.chunk_desc[2 * item], d1 = A.chunk_desc[2 * item + 1];
+            ti = d0.x;
+            const int j = d0.y, ch = d0.z, t = d0.w, v = d1.x, n = d1.y;
             const DevPatch &P = A.patches[v];
             const int npx = P.H2 * P.W2;
             const int p0 = ch * A.chunk_px, p1 = min(npx, p0 + A.chunk_px);
             // the target's current parameters (another workgroup stepped it), then its tables for this image
             if (tid < CEL_P) F.theta[tid] = ldc<true>(A.vp + (size_t)t * CEL_P + tid);
-            if (wave == 1) F.etab[lane] = g_exp2_table[lane];
+            if (wave == 2) F.etab[lane] = g_exp2_table[lane];
             for (int i = tid; i < ACC_N * ACC_SLOTS; i += FUSED_NT) F.sacc[i] = 0.0;
             if (tid == 0) F.turn = 0;
             __syncthreads();
-            if (wave == 0) prep_visit_values(lane, F.theta, P, A.images[n].band - 1, A.K, &F.si, F.tc);
+            if (wave == 0) prep_visit_values<false>(lane, F.theta, P, A.images[n].band - 1, A.K, &F.si, F.tc);
+            else if (wave == 1) brightness_moments_wave(lane, F.theta, P, A.images[n].band - 1, &F.si);
             __syncthreads();
+            FT(1);
             const int base = p0 + 64 * wave;
             if (base < p1) {
                 PixWork<double> W;
@@ -207,7 +224,7 @@ optim_fused_kernel(const FusedArgs A) {
                 volatile int *turn = &F.turn;
                 // pixel_kernel's wavefront adds iteration after iteration into the slots; here iteration w belongs to
                 // wavefront w, and the wavefronts take turns in the same order
-                pixel_iter<2, double, false>(W, base, p1, lane, F.sacc + (lane & (ACC_SLOTS - 1)), a, [&]() {
+                pixel_iter<2, double, false, FUSED_GATED != 0>(W, base, p1, lane, F.sacc + (lane & (ACC_SLOTS - 1)), a, [&]() {
                     while (*turn != wave) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 });
@@ -215,6 +232,7 @@ optim_fused_kernel(const FusedArgs A) {
                 if (lane == 0) *turn = wave + 1;                          // ... before the next wavefront starts its own
             }
             __syncthreads();
+            FT(2);
             if (wave == 0) {
                 double *out = A.acc + (size_t)item * ACC_N;
                 fold_record_slots<2>(F.sacc, lane, [&](int e, double s) { stc<true>(out + e, s); });
@@ -226,6 +244,7 @@ optim_fused_kernel(const FusedArgs A) {
             }
             __syncthreads();
             last = F.last != 0;
+            FT(3); FT_COUNT(14);
         } else {
             ti = FQ_DIRECT0 - item;
             last = true;
@@ -239,8 +258,10 @@ optim_fused_kernel(const FusedArgs A) {
                           A.vis_img, A.N, A.M, A.CH, A.chunk_px, A.flags, &F.ev_v, F.ev_d, F.ev_h, nullptr, &F.ev_status,
                           A.lg_sum, A.rec_off);
         __syncthreads();
+        FT(4);
         const int done = optim_step_target<true, FUSED_NT>(F.step, tid, A.st[ti], A.Hstate + (size_t)ti * NF * NF,
                                                            A.vp + (size_t)t * CEL_P, F.ev_h, F.ev_d, -F.ev_v, F.ev_status, A.op);
+        FT(5);
         drain_stores();      // the target's row of vp, its state and saved Hessian are in memory ...
         __syncthreads();     // ... before its next items (or the end of the launch) become visible
         if (!done) {
@@ -255,6 +276,7 @@ optim_fused_kernel(const FusedArgs A) {
             __syncthreads();
             if (all_done) fused_push(A, tid, &F.done, FQ_EXIT, -(int)gridDim.x);
         }
+        FT(6); FT_COUNT(15);
     }
 }
 

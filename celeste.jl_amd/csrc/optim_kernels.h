@@ -276,8 +276,12 @@ __device__ __forceinline__ void tred_reg_steps(double (&a)[NF], double *__restri
                     if (k & 1) acc1 = __builtin_fma(a[k], uk, acc1);
                     else acc0 = __builtin_fma(a[k], uk, acc0);
                 }
-                v -= (vu / h) * u;
-                const double rh = 1.0 / h;
+                // 1 / h once per step (h > 0): hardware reciprocal + two Newton steps -- half the dependent instructions of
+                // an IEEE division, and the step used to hold two of those
+                double rh = __builtin_amdgcn_rcp(h);
+                rh = __builtin_fma(__builtin_fma(-h, rh, 1.0), rh, rh);
+                rh = __builtin_fma(__builtin_fma(-h, rh, 1.0), rh, rh);
+                v -= (vu * rh) * u;
                 const double p = act ? (acc0 + acc1) * rh : 0.0;
                 const double hh = wave_sum_dpp(p * u) * (0.5 * rh);
                 const double qv = p - hh * u;
@@ -527,6 +531,107 @@ __device__ inline double tri_extreme(const double *__restrict__ td, const double
     return 0.5 * (a + b);
 }
 
+// Both extreme eigenvalues in one go, several shifts per lane.  A Sturm pass is a chain of 41 dependent steps whose
+// latency (~70 cycles a step: multiply -> FMA -> every few steps a rescale) leaves the SIMD idle more than half of the time,
+// and whose T(k, k), T(k - 1, k)^2 operands the compiler would not keep out of the chain (one exposed LDS read per two
+// steps: 24 us for the 12 + 3 passes of tri_extreme, measured; holding the 82 operands in registers instead made the
+// function spill inside the loop: 35 us).  Here T stays one element per lane and reaches the chains through scalar registers
+// (v_readlane, four per step shared by all chains: no memory access and no register array), and every lane runs
+// SEVERAL independent recurrences side by side: STURM_M shifts of the smallest eigenvalue's bracket and, during the first
+// WMAX_PASSES passes, one shift of the largest's -- whose three passes so cost next to nothing.  (STURM_M = 2, a 129-way
+// multisection in 11 passes, issues more instructions per step than the chain's latency hides: 1 is the measured optimum
+// of the estimate 3 x 98 vs 2 x 70 cycles per step.)  Shift i of a bracket sits in lane i / M, chain i % M; x_i = a +
+// (b - a) (i + 1) / (64 M + 1) is evaluated by the lanes and by the bracket update with the same expression.  narrow: |T|
+// within 2^+-60 of one -- the pair (P_{k-1}, P_k) then needs its exact power-of-two rescaling only every 16th step.
+#ifndef STURM_IMPL
+#define STURM_IMPL 1       // 0: tri_extreme (one chain, T read from LDS), 1: tri_extremes
+#endif
+#ifndef STURM_M
+#define STURM_M 1
+#endif
+#define WMIN_PASSES (STURM_M == 1 ? 12 : 11)
+#define WMAX_PASSES 3
+template <int NCH, int PERIOD>
+__device__ __forceinline__ bool sturm_counts(const double td_l, const double e2_l, const double (&x)[NCH], int (&c)[NCH]) {
+    // Per chain and step: subtract, multiply, FMA for the recurrence; the sign changes are collected as bits -- the XOR of
+    // the sign bits of P_k and P_{k-1}, shifted into an accumulator by one v_alignbit -- and counted by two popcounts at
+    // the end; |P_k| is folded into a running minimum whose being zero sends the whole pass to the careful loop (an exact
+    // zero of a P_k needs its sign convention, and two in a row would break the rescaling).  Comparing and adding booleans
+    // cost twice the instructions (34 VALU per two-chain step, issue-bound at 148 cycles: measured).
+    double pm[NCH], pc[NCH], tiny[NCH];
+    unsigned hp[NCH], acc0[NCH], acc1[NCH];
+    const double td0 = lane_bcast_u(td_l, 0);
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        pm[m] = 1.0; pc[m] = td0 - x[m]; tiny[m] = fabs(pc[m]);
+        hp[m] = (unsigned)__double2hiint(pc[m]);
+        acc0[m] = hp[m] >> 31; acc1[m] = 0u;          // P_0 = 1 is positive
+    }
+#pragma unroll
+    for (int k = 1; k < NF; ++k) {
+        const double tdk = lane_bcast_u(td_l, k), e2k = lane_bcast_u(e2_l, k);
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            const double pn = __builtin_fma(tdk - x[m], pc[m], -e2k * pm[m]);
+            tiny[m] = fmin(tiny[m], fabs(pn));
+            const unsigned h = (unsigned)__double2hiint(pn);
+            if (k < 32) acc0[m] = __builtin_amdgcn_alignbit(acc0[m], h ^ hp[m], 31);
+            else acc1[m] = __builtin_amdgcn_alignbit(acc1[m], h ^ hp[m], 31);
+            hp[m] = h;
+            pm[m] = pc[m]; pc[m] = pn;
+            if (k % PERIOD == 0) poly_rescale(pm[m], pc[m]);
+        }
+    }
+    bool zero = false;
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) { c[m] = __popc(acc0[m]) + __popc(acc1[m]); zero |= tiny[m] == 0.0; }
+    return zero;
+}
+__device__ __forceinline__ double sturm_shift(double a, double b, int i, int ways) { return a + (b - a) * ((double)(i + 1) * (1.0 / (double)(ways + 1))); }
+// bracket update: i0 = first shift (in index order) whose count reached the threshold, -1: none
+__device__ __forceinline__ void sturm_narrow(double &a, double &b, int i0, int ways) {
+    if (i0 < 0) a = sturm_shift(a, b, ways - 1, ways);
+    else { const double nb = sturm_shift(a, b, i0, ways), na = i0 > 0 ? sturm_shift(a, b, i0 - 1, ways) : a; a = na; b = nb; }
+}
+__device__ __forceinline__ void tri_extremes(const double *__restrict__ td, const double *__restrict__ te2, double lo, double hi,
+                                             int ln, bool wide, bool narrow, double &wmin, double &wmin_lower, double &wmax) {
+    const double td_l = td[ln < NF ? ln : 0], e2_l = te2[ln < NF ? ln : 0];
+    double a = lo, b = hi, a2 = lo, b2 = hi;        // brackets of the smallest / the largest eigenvalue
+    constexpr int W1 = 64 * STURM_M, W2 = 64;
+    bool done1 = false;
+    for (int pass = 0; pass < WMIN_PASSES && !done1; ++pass) {
+        const bool with_max = pass < WMAX_PASSES;
+        double x[STURM_M + 1];
+        int c[STURM_M + 1];
+#pragma unroll
+        for (int m = 0; m < STURM_M; ++m) x[m] = sturm_shift(a, b, ln * STURM_M + m, W1);
+        x[STURM_M] = sturm_shift(a2, b2, ln, W2);   // (idle after WMAX_PASSES: the chain is still cheaper than a second code path)
+        bool zero;
+        if (wide) zero = true;
+        else if (narrow) zero = sturm_counts<STURM_M + 1, 16>(td_l, e2_l, x, c);
+        else zero = sturm_counts<STURM_M + 1, POLY_PERIOD>(td_l, e2_l, x, c);
+        if (wide || __ballot(zero) != 0ull) {       // an exact zero of some P_k, or entries far from one: the careful loop
+#pragma unroll
+            for (int m = 0; m <= STURM_M; ++m) c[m] = sturm_count_careful(td, te2, x[m]);
+        }
+        int i0 = -1;
+#pragma unroll
+        for (int m = STURM_M - 1; m >= 0; --m) {
+            const unsigned long long mask = __ballot(c[m] >= 1);
+            if (mask) { const int i = (__ffsll((long long)mask) - 1) * STURM_M + m; if (i0 < 0 || i < i0) i0 = i; }
+        }
+        sturm_narrow(a, b, i0, W1);
+        if (with_max) {
+            const unsigned long long mask = __ballot(c[STURM_M] >= NF);
+            sturm_narrow(a2, b2, mask ? __ffsll((long long)mask) - 1 : -1, W2);
+        }
+        done1 = b - a <= 8.881784197001252e-16 * fmax(fabs(a), fabs(b)) && !with_max;
+    }
+    wmin_lower = a;
+    wmin = 0.5 * (a + b);
+    wmax = 0.5 * (a2 + b2);
+}
+
 // diagnostics: sub-problems solved as interior Newton steps / on the boundary / hard case, total and maximum
 // number of secular-equation iterations (celeste_optim_stats)
 __device__ unsigned long long g_optim_stats[5];
@@ -592,11 +697,17 @@ __device__ __noinline__ TrResult tri_tr_solve(TriLds L, double g, double delta, 
         for (int o = 32; o >= 1; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
         const double pad = 4.440892098500626e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300;
         lo -= pad; hi += pad;
-        double unused;
         norm_bound = fmax(fabs(lo), fabs(hi));
         wide = poly_wide_range(norm_bound);
+        const bool narrow = norm_bound > 8.673617379884035e-19 && norm_bound < 1.152921504606847e18;   // 2^-60 .. 2^60
+#if STURM_IMPL == 0
+        double unused;
         wmin = tri_extreme(L.td, L.te2, lo, hi, 1, 12, ln, wide, wmin_lower);
         wmax = tri_extreme(L.td, L.te2, lo, hi, NF, 3, ln, wide, unused);
+        (void)narrow;
+#else
+        tri_extremes(L.td, L.te2, lo, hi, ln, wide, narrow, wmin, wmin_lower, wmax);
+#endif
     }
     const double d2 = delta * delta;
     int interior = 0;
@@ -699,10 +810,11 @@ __device__ __noinline__ TrResult tri_tr_solve(TriLds L, double g, double delta, 
         double uu[NF];
 #pragma unroll
         for (int i = 2; i < NF; ++i) uu[i] = ln < i ? L.A[i + LDA * ln] : 0.0;
+        const double rhv_l = hv_l != 0.0 ? 1.0 / hv_l : 0.0;   // one division per lane, in parallel, instead of one in every link of the chain
 #pragma unroll
         for (int i = 2; i < NF; ++i) {
-            const double h = lane_bcast_u(hv_l, i);
-            if (h != 0.0) y -= (wave_sum_dpp(uu[i] * y) / h) * uu[i];
+            const double rh = lane_bcast_u(rhv_l, i);
+            if (rh != 0.0) y -= (wave_sum_dpp(uu[i] * y) * rh) * uu[i];
         }
     }
     OPT_TICK(7);

@@ -99,27 +99,43 @@ def test_fused_launch_with_visit_lists_and_eigen_solver(crowded):
 
 
 def test_fused_launch_survives_a_failing_target_and_refuses_duplicates(crowded):
-    """ParallelRun.jl:582-597: the failing source keeps its row and gets its status, the others are optimised as if it
-    were not there -- in both drivers, identically"""
+    """ParallelRun.jl:582-597: a source whose ELBO is not finite (here: a neighbour with a non-finite parameter) keeps its
+    row and gets its status, the others are optimised as if it were not there -- in both drivers, identically"""
     import celeste_jl_amd as cel
     from celeste_jl_amd import cabi
     f, ctx = crowded
-    vp = f.vp.copy()
-    bad = 6
-    vp[bad, 8] = np.nan                                   # a non-finite flux variance
-    tg = [2, bad, 11, 20]
-    tg = [t for t in tg if bad not in f.neighbors[t] or t == bad]      # the bad source's neighbours would fail with it
-    assert len(tg) >= 3
-    a, b = _both(ctx, vp, tg, cel.ElboConfig(max_iters=6))
-    _assert_identical(a, b, "failing target")
-    k = tg.index(bad)
-    assert a[4][k] == cabi.ERR_NONFINITE_INPUT and (np.delete(a[4], k) == 0).all()
-    assert np.array_equal(a[0][bad], vp[bad], equal_nan=True)
-    ok = [t for t in tg if t != bad]
-    clean, _ = _both(ctx, f.vp, ok, cel.ElboConfig(max_iters=6))
-    assert np.array_equal(clean[0][ok], a[0][ok])
+    S = len(f.catalog)
+    bad = int(np.argmax([len(n) for n in f.neighbors]))
+    hit = set(f.neighbors[bad])
+    targets = [t for t in range(S) if t != bad]
+    nb = f.vp.copy()
+    nb[bad, 7] = np.nan
+    cfg = cel.ElboConfig(max_iters=6)
+    a, b = _both(ctx, f.vp, targets, cfg, vp_neighbors=nb)
+    _assert_identical(a, b, "failing targets")
+    ok = [k for k, t in enumerate(targets) if t not in hit]
+    ko = [k for k, t in enumerate(targets) if t in hit]
+    assert len(ko) > 0 and len(ok) > 0
+    assert np.isin(a[4][ko], (cabi.ERR_NONFINITE_INPUT, cabi.ERR_NONFINITE_RESULT)).all() and (a[4][ok] == 0).all()
+    for k in ko:
+        assert np.array_equal(a[0][targets[k]], f.vp[targets[k]]), "a failed target keeps its input row"
+    good = [targets[k] for k in ok]
+    clean, _ = _both(ctx, f.vp, good, cfg)
+    assert np.array_equal(clean[0][good], a[0][good]) and np.array_equal(clean[3], a[3][ok])
     with _env(CELESTE_OPT_FUSED=1), pytest.raises(cabi.CelesteError):
         ctx.maximize_batch(f.vp, [3, 5, 3], cel.ElboConfig(max_iters=2))
+    # the same through the joint-inference entry: the failed sources keep the rows they had before their layer
+    from celeste_jl_amd.infer import joint_layers
+    layers = joint_layers(targets, f.neighbors, batch_size=10, n_iters=1, rng=np.random.default_rng(1))
+    vpb = f.vp.copy()
+    vpb[bad, 7] = np.nan
+    new, its, evals, el, st = ctx.joint_infer(vpb, layers, cfg)
+    flat = [t for l in layers for t in l]
+    for t, s1 in zip(flat, st):
+        assert (s1 != 0) == (t in hit), (t, s1)
+        if t in hit:
+            assert np.array_equal(new[t], f.vp[t])
+    assert np.isnan(new[bad, 7]) and np.isfinite(np.delete(new, bad, axis=0)).all()
 
 
 def test_a_fused_launch_that_cannot_make_progress_gives_up_instead_of_hanging(crowded):

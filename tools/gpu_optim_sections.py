@@ -37,16 +37,36 @@ def lift_clocks():
     return np.array(out[:], dtype=np.float64)
 
 
+has_fused = hasattr(lib, "celeste_fused_clocks")
+FUSED_NAMES = ["wait for a queue item", "chunk: descriptor, parameters, tables", "chunk: pixels + ordered adds", "chunk: fold, store, arrival",
+               "step: lift", "step: chain rule + accept + sub-problem", "step: drain + queue"]
+
+
+def fused_clocks():
+    if not has_fused:
+        return None
+    out = (C.c_uint64 * 16)()
+    lib.celeste_fused_clocks(1, out)
+    return np.array(out[:], dtype=np.float64)
+
+
 def run(tg, label, reps=3):
     cfg = cel.ElboConfig(max_iters=50)
     ctx.maximize_batch(fld.vp, tg, cfg)
-    clocks(); lift_clocks()
+    clocks(); lift_clocks(); fused_clocks()
     t0 = time.time()
     for _ in range(reps):
         vp, its, evals, elbo, st = ctx.maximize_batch(fld.vp, tg, cfg)
     dt = (time.time() - t0) / reps
     print("%s: %d targets, %.3f ms per call, max iters %d, mean %.1f -> %.1f us per Newton iteration of the longest target"
           % (label, len(tg), dt * 1e3, its.max(), its.mean(), dt * 1e6 / (its.max() + 1)))
+    c = fused_clocks()
+    if c is not None and c[15] > 0:
+        for k, name in enumerate(FUSED_NAMES):
+            n = c[14] if 1 <= k <= 3 else (c[15] if k >= 4 else c[14] + 0.0)
+            print("    fused %-42s %8.0f cycles per %s (%.1f us at 2.4 GHz); total %.3g" %
+                  (name, c[k] / max(n, 1), "chunk item" if k <= 3 else "step", c[k] / max(n, 1) / 2400, c[k]))
+        print("    fused: %d chunk items, %d steps" % (c[14], c[15]))
     c = lift_clocks()
     if c is not None and c[15] > 0:
         for k, name in enumerate(LIFT_NAMES):
