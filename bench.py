@@ -49,23 +49,26 @@ def profile_facts():
         return None
 
 
-def live_pmc(args, timeout_s=60):
-    """HBM traffic and VALU issue utilisation of pixel_kernel<2, double> measured in THIS run: three rocprofv3 --pmc
-    passes (FETCH_SIZE, WRITE_SIZE, SQ counters -- separate passes with --kernel-trace only, as the guide's HBM
-    section prescribes) over a few sweeps of the same field in a child process.  None when rocprofv3 is absent, fails
-    or times out; the line then falls back to the committed figures of profiles/hbm_traffic.json and says so."""
+def live_pmc(args, timeout_s=60, split=False):
+    """HBM traffic and VALU issue utilisation of pixel_kernel<2, double> (split=True: HBM traffic of record_sum_kernel,
+    the split variant's streaming sum) measured in THIS run: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ
+    counters -- separate passes with --kernel-trace only, as the guide's HBM section prescribes) over a few sweeps of
+    the same field in a child process.  None when rocprofv3 is absent, fails or times out; the line then falls back
+    to the committed figures of profiles/hbm_traffic.json and says so."""
     import csv, glob, shutil, subprocess, tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
     out = {}
-    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "3", "--warmup", "1", "--height", str(args.height),
-             "--width", str(args.width), "--sources", str(args.sources), "--seed", str(args.seed)]
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "split" if split else "fused", "--steps", "3", "--warmup", "1",
+             "--height", str(args.height), "--width", str(args.width), "--sources", str(args.sources), "--seed", str(args.seed)]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    kernel = "record_sum_kernel" if split else "pixel_kernel<2, double"
+    passes = (("FETCH_SIZE",), ("WRITE_SIZE",)) if split else (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"))
     try:
-        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")):
+        for counters in passes:
             with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
                 cmd = [exe, "--pmc"] + list(counters) + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--"] + child
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
@@ -73,7 +76,7 @@ def live_pmc(args, timeout_s=60):
                 if r.returncode != 0 or not files:
                     return None
                 rows = [row for f in files for row in csv.DictReader(open(f))
-                        if row["Kernel_Name"].replace("void ", "").startswith("pixel_kernel<2, double")]
+                        if row["Kernel_Name"].replace("void ", "").startswith(kernel)]
                 if not rows:
                     return None
                 gmax = max(int(row["Grid_Size"]) for row in rows)
@@ -84,6 +87,12 @@ def live_pmc(args, timeout_s=60):
                     out[c] = sum(vals) / len(vals)
     except Exception:
         return None
+    if split:
+        # 16 B/lane streaming loads: FETCH_SIZE counts half the bytes on gfx950 (guide, HBM section) -> doubled
+        return {"record_sum_bytes_per_launch": (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0,
+                "record_sum_source": "measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over 3 split "
+                                     "sweeps in a child process; KiB x 1024, FETCH_SIZE x 2 (the gfx950 correction for 16 B/lane "
+                                     "streaming reads)"}
     return {"pixel_kernel_bytes_per_launch": (out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0,
             "fetch_bytes": out["FETCH_SIZE"] * 1024.0, "write_bytes": out["WRITE_SIZE"] * 1024.0,
             "pixel_kernel_valu_utilization": out["SQ_ACTIVE_INST_VALU"] * 4.0 / (out["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
@@ -193,7 +202,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the timed sweep and the roofline")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not run the rocprofv3 counter passes; report the committed profiles/hbm_traffic.json figures")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the profiled child of live_pmc
+    ap.add_argument("--pmc-child", default=None, choices=("fused", "split"), help=argparse.SUPPRESS)   # the profiled child of live_pmc
+    ap.add_argument("--no-config5", action="store_true",
+                    help="config 3, one GPU: do not append the config5 sub-record (a short full-size --config 5 --dtype f32 run)")
     ap.add_argument("--check-dir", default=None,
                     help="every rank writes its gathered (v, d) of the last sweep to <dir>/rank<r>.npz (tests)")
     args = ap.parse_args()
@@ -284,6 +295,15 @@ def main():
         sweep.step(d_vp.data_ptr())
     sync()
     dt = time.perf_counter() - t0
+    if args.pmc_child == "split":   # the profiled child of live_pmc(split=True): a few sweeps of the split variant
+        d_v0 = torch.zeros(S, dtype=torch.float64, device=dev)
+        d_d0 = torch.zeros(S, 44, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            ctx.eval_batch_device(d_vp.data_ptr(), S, sweep.d_tg.data_ptr(), FLAGS_ALL | cabi.FLAG_SPLIT, d_v0.data_ptr(),
+                                  d_d0.data_ptr(), sweep.d_h.data_ptr(), sweep.d_cnt.data_ptr(), sweep.d_st.data_ptr(),
+                                  torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        return
     if args.pmc_child:     # the profiled child of live_pmc(): the sweeps are all rocprofv3 needs
         return
     if use_dist:
@@ -348,6 +368,17 @@ def main():
         eh = float(((h32 - d_h64).abs().amax(dim=(1, 2)) / d_h64.abs().amax(dim=(1, 2))).max().item())
         assert max(ev, ed, eh) <= 1e-4, (ev, ed, eh)
         out_extra["fp32_vs_fp64_device"] = {"v": ev, "d": ed, "h": eh, "tolerance": 1e-4, "sources_checked": S}
+        # the same sweep with the fp64 component loop: what the precision mode buys
+        ctx.enable_timing(True)
+        k64 = []
+        for _ in range(3):
+            ctx.eval_batch_device(d_vp.data_ptr(), S, d_tg.data_ptr(), FLAGS_ALL, d_v.data_ptr(), d_d.data_ptr(),
+                                  d_h64.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), stream)
+            torch.cuda.synchronize(dev)
+            k64.append(ctx.last_kernel_ms()[1])
+        ctx.enable_timing(False)
+        out_extra["fp64_pixel_kernel_ms"] = float(np.mean(k64[1:]))
+        out_extra["fp32_speedup_over_fp64_pixel_kernel"] = float(np.mean(k64[1:]) / kms[1])
         del d_h64
 
     # split variant: per-pixel records to HBM, then the streaming per-patch sum -- the one
@@ -356,11 +387,14 @@ def main():
     facts = profile_facts() or {}
     # HBM bytes and VALU utilisation of the dominant kernel: measured now when rocprofv3 can run here, else the
     # committed figures (the flop count per pixel visit always comes from the ISA of the tree, tools/count_flops.py)
-    pmc_live = None
+    pmc_live = pmc_split = None
     if world == 1 and rank == 0 and args.config == 3 and args.dtype == "f64" and extras and not args.no_live_pmc:
         pmc_live = live_pmc(args)
         if pmc_live:
             facts = dict(facts, **pmc_live)
+        pmc_split = live_pmc(args, split=True)
+        if pmc_split:
+            facts = dict(facts, **pmc_split)
     if extras and args.config == 3:
         d_h = sweep.d_h
 
@@ -381,7 +415,8 @@ def main():
                  "algorithmic_bytes_per_launch": rb, "achieved": rb / (sm[3] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": rb / (sm[3] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "stored_record_bytes": stats["record_tiles"] * 68 * 64 * 8,
-                 "traffic": facts.get("record_sum_bytes_per_launch"),
+                 "traffic": facts.get("record_sum_bytes_per_launch"), "traffic_measured_in_this_run": bool(pmc_split),
+                 "traffic_source": facts.get("record_sum_source", facts.get("source")),
                  "record_write_kernel_ms": float(sm[1]), "lift_ms": float(sm[2]),
                  "note": "544 B (68 f64) per visited pixel + one 544 B result per patch; fused kernel stays the "
                          "throughput configuration"}
@@ -447,16 +482,21 @@ def main():
             "pixel_visits_per_sec_rank0": pixel_visits_local / (kms[1] * 1e-3),
         }
         if fpp:
-            fl = fpp * stats["active_pixel_visits"] / (kms[1] * 1e-3) / 1e12
+            # executed flops: the compiled ISA's count per visit x the (pixel, active source) pairs the kernel counted --
+            # not the patches' areas, which include the last-column pixels that skip the component loop
+            fl = fpp * pixel_visits_local / (kms[1] * 1e-3) / 1e12
             out["roofline"]["valu"] = {"achieved": fl, "peak": peak_fl, "unit": "TFLOP/s", "frac": fl / peak_fl,
-                                       "flops_per_pixel_visit": fpp, "dtype": args.dtype}
+                                       "flops_per_pixel_visit": fpp, "pixel_visits": pixel_visits_local, "dtype": args.dtype,
+                                       "instruction_mix": facts.get("instruction_mix_f32" if args.dtype == "f32" else "instruction_mix")}
             if args.dtype == "f64":
                 out["roofline"]["fp64"] = out["roofline"]["valu"]
         out.update(out_extra)
         if split is not None:
             out["split_variant"] = split
         if extras:
-            out.update(secondary_figures(ctx, fld, targets, args))
+            out.update(secondary_figures(ctx, fld, targets, args, costs))
+        if extras and args.config == 3 and not args.no_config5 and args.height >= 2048:
+            out["config5"] = config5_record(args)
         if not args.no_cpu_baseline and world == 1:
             tg_cpu = targets if args.config == 3 else targets[:: max(1, S // 2000)]
             out["cpu_baseline"] = cpu_baseline(ctx.problem, fld.vp, tg_cpu)
@@ -470,10 +510,14 @@ def main():
         dist.destroy_process_group()
 
 
-def secondary_figures(ctx, fld, targets, args):
-    """End-to-end figures next to the headline (rank 0, one GPU): the host-pointer API the Julia shim calls, and
-    ElboMaximize.maximize! for every source."""
+def secondary_figures(ctx, fld, targets, args, costs):
+    """Figures next to the headline (rank 0, one GPU) that say how the engine behaves where the reference actually calls
+    it: the host-pointer API the Julia shim binds, one elbo() per call (the literal drop-in of ElboMaximize.jl:166),
+    maximize! for every source and for a Cyclades-sized layer, joint inference, and the sweep time of rank 0's shard for
+    N = 2, 4, 8 ranks (what strong scaling can reach when the catalog gather hides under the next sweep)."""
+    import torch
     import celeste_jl_amd as cel
+    from celeste_jl_amd.partition import shard_targets
     out = {}
     S = len(targets)
     # host-pointer API (celeste_elbo_eval_batch): vp H2D, kernels, D2H of v / d / h / counters / status
@@ -485,17 +529,124 @@ def secondary_figures(ctx, fld, targets, args):
         for _ in range(reps):
             ctx.eval_batch(fld.vp, targets, fl)
         out["host_api_sources_per_sec" + ("_packed_hessian" if packed else "")] = S * reps / (time.perf_counter() - t1)
-    if args.config == 3:
-        # ElboMaximize.maximize! (Newton trust region, <= 50 iterations, KL on) for every source of the field,
-        # neighbours frozen; wall time includes H2D/D2H
-        ctx.maximize_batch(fld.vp, targets, cel.ElboConfig(max_iters=1))  # warm-up: the call's buffers at full size
+    if args.config != 3:
+        return out
+    # celeste_elbo_eval: ONE target per call (value + gradient + Hessian + KL), host pointers
+    lat = []
+    for k in range(210):
+        t = int(targets[(k * 97) % S])
         t1 = time.perf_counter()
-        _, its, evals, _, ost = ctx.maximize_batch(fld.vp, targets, cel.ElboConfig())
-        dt_opt = time.perf_counter() - t1
-        out["optimizer"] = {"optimized_sources_per_sec": S / dt_opt, "seconds": dt_opt,
-                            "mean_newton_iterations": float(its.mean()), "elbo_evaluations": int(evals.sum()),
-                            "failed": int((ost != 0).sum())}
+        ctx.eval_batch(fld.vp, [t], FLAGS_ALL, pinned=False)
+        lat.append(time.perf_counter() - t1)
+    lat = np.sort(np.array(lat[10:]))
+    out["single_call_latency_us"] = {"median": float(np.median(lat) * 1e6), "p90": float(lat[int(0.9 * len(lat))] * 1e6),
+                                     "calls": int(len(lat)), "what": "celeste_elbo_eval for one target (value + gradient + Hessian "
+                                     "+ KL), vp up and results down included"}
+    # ElboMaximize.maximize! (Newton trust region, <= 50 iterations, KL on) for every source of the field,
+    # neighbours frozen; wall time includes H2D/D2H
+    ctx.maximize_batch(fld.vp, targets, cel.ElboConfig(max_iters=1))  # warm-up: the call's buffers at full size
+    t1 = time.perf_counter()
+    _, its, evals, _, ost = ctx.maximize_batch(fld.vp, targets, cel.ElboConfig())
+    dt_opt = time.perf_counter() - t1
+    out["optimizer"] = {"optimized_sources_per_sec": S / dt_opt, "seconds": dt_opt,
+                        "mean_newton_iterations": float(its.mean()), "elbo_evaluations": int(evals.sum()),
+                        "failed": int((ost != 0).sum())}
+    # a Cyclades-sized layer: 80 conflict-free targets in one call (the fused optimiser launch)
+    rng = np.random.default_rng(5)
+    nb = [set(map(int, x)) for x in fld.neighbors]
+    chosen, blocked = [], set()
+    for t in rng.permutation(S):
+        if int(t) in blocked:
+            continue
+        chosen.append(int(t)); blocked |= nb[int(t)]; blocked.add(int(t))
+        if len(chosen) == min(80, S):
+            break
+    layer = np.array(chosen, dtype=np.int32)
+    ctx.maximize_batch(fld.vp, layer, cel.ElboConfig(max_iters=2))
+    t1 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        _, lits, _, _, lst = ctx.maximize_batch(fld.vp, layer, cel.ElboConfig())
+    dt_layer = (time.perf_counter() - t1) / reps
+    out["optimizer"]["cyclades_layer"] = {"targets": int(layer.size), "seconds": dt_layer, "max_newton_iterations": int(lits.max()),
+                                          "us_per_newton_iteration_of_the_slowest_target": dt_layer * 1e6 / (int(lits.max()) + 1),
+                                          "driver": "fused" if os.environ.get("CELESTE_OPT_FUSED", "") != "0" else "chained",
+                                          "failed": int((lst != 0).sum())}
+    # ParallelRun.one_node_joint_infer: the reference's schedule (Cyclades batches of 400, 3 sweeps), one C call
+    from celeste_jl_amd.infer import joint_layers, one_node_joint_infer
+    tg = [int(t) for t in targets]
+    layers = joint_layers(tg, fld.neighbors)
+    one_node_joint_infer(ctx, fld.catalog, tg, fld.neighbors)
+    t1 = time.perf_counter()
+    failed = set()
+    one_node_joint_infer(ctx, fld.catalog, tg, fld.neighbors, failed=failed)
+    dt_joint = time.perf_counter() - t1
+    out["joint_infer"] = {"seconds": dt_joint, "sources_per_sec": S / dt_joint, "schedule": "Cyclades batches of 400, 3 sweeps "
+                          "(ParallelRun.jl:135-196), celeste_joint_infer: the table stays in HBM across all layers",
+                          "layers": len(layers), "largest_layer": max(map(len, layers)), "failed": len(failed)}
+    # rank 0's cost-balanced shard of THIS field for N ranks, swept on this GPU (device-pointer API, HIP events)
+    dev = torch.device("cuda", ctx.device)
+    d_vp = torch.tensor(fld.vp, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    proj = {}
+    for world in (1, 2, 4, 8):
+        mine = np.asarray(shard_targets(costs, world)[0], dtype=np.int32)
+        n = int(mine.size)
+        d_tg = torch.tensor(mine, device=dev)
+        blk = torch.zeros(n * 45, dtype=torch.float64, device=dev)
+        d_h = torch.zeros(n, 44, 44, dtype=torch.float64, device=dev)
+        d_cnt = torch.zeros(n, 2, dtype=torch.int64, device=dev)
+        d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+
+        def sweep():
+            ctx.eval_batch_device(d_vp.data_ptr(), n, d_tg.data_ptr(), FLAGS_ALL, blk.data_ptr(), blk.data_ptr() + 8 * n,
+                                  d_h.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), stream.cuda_stream)
+        for _ in range(3):
+            sweep()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        K = 20
+        e0.record(stream)
+        for _ in range(K):
+            sweep()
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        proj[str(world)] = {"targets_rank0": n, "ms_per_sweep": e0.elapsed_time(e1) / K}
+    for world in (2, 4, 8):
+        proj[str(world)]["compute_bound_efficiency"] = proj["1"]["ms_per_sweep"] / (world * proj[str(world)]["ms_per_sweep"])
+    out["shard_projection"] = dict(proj, note="rank 0's shard of this field for N ranks, swept on ONE GPU: the strong-scaling "
+                                   "efficiency the kernels allow if the catalog gather hides under the next sweep; not a "
+                                   "multi-GPU measurement")
     return out
+
+
+def config5_record(args):
+    """BASELINE configs[4] on this one GPU, as a child run of this script (`--config 5 --dtype f32`, full size: 16 fields,
+    80 images, 30 000 sources): throughput, the fp32-vs-fp64 check on every source, the fp32 kernel's VALU roofline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "5", "--dtype", "f32", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras", "--height", str(args.height), "--width", str(args.width)]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": "child run failed (rc %d): %s" % (r.returncode, r.stderr[-300:])}
+        d = json.loads(line[-1])
+    except Exception as e:   # (the headline does not depend on it)
+        return {"error": repr(e)}
+    keep = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "kernels_ms", "fp32_vs_fp64_device",
+                              "pixel_visits_per_sec_rank0", "fp64_pixel_kernel_ms", "fp32_speedup_over_fp64_pixel_kernel") if k in d}
+    keep["workload"] = d["config"]["workload"]
+    keep["sources_per_step"] = d["config"]["sources_per_step"]
+    keep["pixel_visits_per_sweep"] = d["config"]["pixel_visits_per_sweep"]
+    keep["roofline_valu"] = d["roofline"].get("valu")
+    keep["roofline_hbm_frac"] = d["roofline"]["frac"]
+    keep["wall_s_including_field_generation"] = time.time() - t0
+    return keep
 
 
 if __name__ == "__main__":

@@ -916,6 +916,17 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
     double *const o_d = want_d ? (pin_d ? d : c->p_d) : nullptr;
     double *const o_h = want_h ? (pin_h ? h : c->p_h) : nullptr;
     int64_t *const o_c = counters ? (pin_c ? counters : c->p_cnt) : nullptr;
+    // From here on copies into the CALLER's buffers may be in flight on the copy stream: an error return first waits for
+    // both streams, so that no DMA writes into memory the caller believes is his again (page-locked blocks are recycled)
+#define EB_TRY(expr)                                                                                             \
+    do {                                                                                                         \
+        hipError_t e__ = (expr);                                                                                 \
+        if (e__ != hipSuccess) {                                                                                 \
+            fprintf(stderr, "celeste_mi355x: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy_stream);                   \
+            return CELESTE_ERR_HIP;                                                                              \
+        }                                                                                                        \
+    } while (0)
     int part_lo[celeste_ctx::MAX_PARTS + 1];
     for (int k = 0; k <= n_parts; ++k) part_lo[k] = (int)((int64_t)n_targets * k / n_parts);
     for (int k = 0; k < n_parts; ++k) {
@@ -926,28 +937,29 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
                              c->d_h + (size_t)lo * HS, c->d_cnt + 2 * (size_t)lo, c->d_status + lo, c->stream, true,
                              nullptr, n_chunks, k > 0, nullptr, n_parts > 1);
         if (st != CELESTE_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy_stream); return st; }
-        HIP_TRY(hipEventRecord(c->part_done[k], c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->part_done[k], 0));
-        if (o_h) HIP_TRY(hipMemcpyAsync(o_h + (size_t)lo * HS, c->d_h + (size_t)lo * HS, (size_t)cnt * HS * sizeof(double),
+        EB_TRY(hipEventRecord(c->part_done[k], c->stream));
+        EB_TRY(hipStreamWaitEvent(c->copy_stream, c->part_done[k], 0));
+        if (o_h) EB_TRY(hipMemcpyAsync(o_h + (size_t)lo * HS, c->d_h + (size_t)lo * HS, (size_t)cnt * HS * sizeof(double),
                                         hipMemcpyDeviceToHost, c->copy_stream));
-        if (o_d) HIP_TRY(hipMemcpyAsync(o_d + (size_t)lo * CEL_P, c->d_d + (size_t)lo * CEL_P,
+        if (o_d) EB_TRY(hipMemcpyAsync(o_d + (size_t)lo * CEL_P, c->d_d + (size_t)lo * CEL_P,
                                         (size_t)cnt * CEL_P * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipMemcpyAsync(o_v + lo, c->d_v + lo, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
-        if (o_c) HIP_TRY(hipMemcpyAsync(o_c + 2 * (size_t)lo, c->d_cnt + 2 * (size_t)lo, (size_t)cnt * 2 * sizeof(int64_t),
+        EB_TRY(hipMemcpyAsync(o_v + lo, c->d_v + lo, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
+        if (o_c) EB_TRY(hipMemcpyAsync(o_c + 2 * (size_t)lo, c->d_cnt + 2 * (size_t)lo, (size_t)cnt * 2 * sizeof(int64_t),
                                         hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipMemcpyAsync(c->p_status + lo, c->d_status + lo, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost,
+        EB_TRY(hipMemcpyAsync(c->p_status + lo, c->d_status + lo, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost,
                                c->copy_stream));
-        HIP_TRY(hipEventRecord(c->part_copied[k], c->copy_stream));
+        EB_TRY(hipEventRecord(c->part_copied[k], c->copy_stream));
     }
     for (int k = 0; k < n_parts; ++k) {   // staged outputs: host copy of part k while later parts are still in flight
         const int lo = part_lo[k], cnt = part_lo[k + 1] - lo;
-        HIP_TRY(hipEventSynchronize(c->part_copied[k]));
+        EB_TRY(hipEventSynchronize(c->part_copied[k]));
         if (v && !pin_v) memcpy(v + lo, c->p_v + lo, (size_t)cnt * sizeof(double));
         if (want_d && !pin_d) memcpy(d + (size_t)lo * CEL_P, c->p_d + (size_t)lo * CEL_P, (size_t)cnt * CEL_P * sizeof(double));
         if (want_h && !pin_h) memcpy(h + (size_t)lo * HS, c->p_h + (size_t)lo * HS, (size_t)cnt * HS * sizeof(double));
         if (counters && !pin_c) memcpy(counters + 2 * (size_t)lo, c->p_cnt + 2 * (size_t)lo, (size_t)cnt * 2 * sizeof(int64_t));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    EB_TRY(hipStreamSynchronize(c->stream));
+#undef EB_TRY
     int worst = CELESTE_OK;
     for (int t = 0; t < n_targets; ++t) {
         const int32_t s1 = c->p_status[t];

@@ -119,6 +119,12 @@ class FieldContext:
         if st in (cabi.ERR_NONFINITE_INPUT, cabi.ERR_NONFINITE_RESULT):
             if raise_on_error:
                 raise AssertionError(self.lib.celeste_strerror(st).decode())
+            # targets that failed carry no result (the pooled page-locked blocks are not cleared between calls)
+            bad = status != 0
+            if d is not None:
+                d[bad] = np.nan
+            if h is not None:
+                h[bad] = np.nan
         else:
             cabi.check(st, self.lib)
         # h is symmetric, so column-major == row-major

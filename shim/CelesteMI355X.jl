@@ -26,6 +26,13 @@ end
 
 check(st) = st == 0 || error(unsafe_string(ccall((:celeste_strerror, libceleste), Cstring, (Cint,), st)))
 
+# the struct layouts below (COptimConfig ...) are those of ABI version 2xx (CELESTE_ABI_VERSION in the header)
+const CELESTE_ABI_MAJOR = 2
+function check_abi()
+    v = ccall((:celeste_version, libceleste), Cint, ())
+    div(v, 100) == CELESTE_ABI_MAJOR || error("libceleste_mi355x has ABI version $v, this shim was written against $(CELESTE_ABI_MAJOR)xx")
+end
+
 # ---- the images of a box, uploaded ONCE (celeste_images_create) ------------------------------------------------
 # process_source builds one ElboArgs per source over the same `images` (ParallelRun.jl:468-488); every per-source
 # context below is created on this handle and costs a patch-table upload, not a copy of the planes.
@@ -34,6 +41,7 @@ mutable struct MI355XImages
     images::Vector{Image}
 end
 function MI355XImages(images::Vector{Image}; device::Int = 0)
+    check_abi()
     keep = Any[]
     cimgs = map(images) do img
         sky = convert(Matrix{Float32}, img.sky)          # SDSSBackground / Fill materialised: img.sky[h, w]
@@ -81,8 +89,13 @@ function MI355XContext(ea::ElboArgs, imgs::MI355XImages)
     prob = CProblem(ea.N, ea.S, ea.psf_K, length(stamp_id), C_NULL, pointer(patches), pointer(stamps),
                     pointer(off), pointer(idx), C_NULL, 0, C_NULL, C_NULL)
     h = Ref{Ptr{Void}}(C_NULL)
-    check(ccall((:celeste_ctx_create_on, libceleste), Cint, (Ptr{Void}, Ref{CProblem}, Ref{Ptr{Void}}),
-                imgs.handle, prob, h))
+    # every array CProblem points into is referenced AFTER the call (the library copies what it needs during it): the
+    # collector must not free `patches`, `stamps`, `off`, `idx`, the PSF vectors or the bitmaps while the ccall runs
+    roots = Any[keep, patches, stamps, off, idx]
+    st = ccall((:celeste_ctx_create_on, libceleste), Cint, (Ptr{Void}, Ref{CProblem}, Ref{Ptr{Void}}),
+               imgs.handle, prob, h)
+    length(roots) == 5 || error("unreachable")           # (keeps `roots` live until here on Julia 0.6; GC.@preserve on >= 0.7)
+    check(st)
     ctx = MI355XContext(h[], imgs)
     finalizer(ctx, c -> ccall((:celeste_ctx_destroy, libceleste), Void, (Ptr{Void},), c.handle))
     ctx
@@ -113,14 +126,25 @@ end
 
 """Page-locked output buffers (celeste_host_alloc): the library DMAs results straight into them, overlapped with the
 kernels of the next part of the batch.  Allocate once per box and reuse."""
-struct PinnedOutputs
+mutable struct PinnedOutputs       # (mutable: a finalizer returns the page-locked blocks to the library)
     v::Vector{Float64}; d::Matrix{Float64}; h::Matrix{Float64}; counters::Matrix{Int64}; status::Vector{Int32}
+    blocks::Vector{Ptr{Void}}
 end
 function PinnedOutputs(n::Int; packed::Bool = true)
     hs = packed ? 990 : 44 * 44                          # CELESTE_FLAG_PACKED_HESS: upper triangle by columns
-    pin(T, dims...) = unsafe_wrap(Array, convert(Ptr{T}, ccall((:celeste_host_alloc, libceleste), Ptr{Void},
-                                                               (Csize_t,), sizeof(T) * prod(dims))), dims)
-    PinnedOutputs(pin(Float64, n), pin(Float64, 44, n), pin(Float64, hs, n), pin(Int64, 2, n), pin(Int32, n))
+    blocks = Ptr{Void}[]
+    function pin(T, dims...)
+        ptr = ccall((:celeste_host_alloc, libceleste), Ptr{Void}, (Csize_t,), sizeof(T) * prod(dims))
+        if ptr == C_NULL                                 # (hipHostMalloc failed: give back what we have, fail loudly)
+            foreach(b -> ccall((:celeste_host_free, libceleste), Void, (Ptr{Void},), b), blocks)
+            error("celeste_host_alloc: out of page-locked memory")
+        end
+        push!(blocks, ptr)
+        unsafe_wrap(Array, convert(Ptr{T}, ptr), dims)    # own = false: freed by the finalizer below, not by Julia
+    end
+    out = PinnedOutputs(pin(Float64, n), pin(Float64, 44, n), pin(Float64, hs, n), pin(Int64, 2, n), pin(Int32, n), blocks)
+    finalizer(out, o -> foreach(b -> ccall((:celeste_host_free, libceleste), Void, (Ptr{Void},), b), o.blocks))
+    out
 end
 
 """elbo() for a conflict-free batch of targets; `targets0` are 0-based source ids.  flags: 1 gradient, 2 Hessian,
@@ -143,15 +167,41 @@ end
 """ElboMaximize.maximize! for a conflict-free batch; vp_all (44 x S) is updated in place for the targets whose status
 is 0 (a failing target keeps its column and is logged by the caller, ParallelRun.jl:389-396)."""
 function maximize_batch!(ctx::MI355XContext, vp_all::Matrix{Float64}, targets0::Vector{Int32};
-                         vp_frozen_neighbors = C_NULL, box_centres = C_NULL, include_kl::Bool = true)
+                         vp_frozen_neighbors = C_NULL, box_centres = C_NULL, include_kl::Bool = true,
+                         tr_secular_iters::Int = 5)
+    # tr_secular_iters = 5: Optim.jl's solve_tr_subproblem! stops the multiplier iteration after 5 steps -- what a run of the
+    # reference does; 0 runs it to convergence (the library's own default)
     n = length(targets0)
     iterations = zeros(Int32, n); f_calls = zeros(Int32, n); max_values = zeros(n); status = zeros(Int32, n)
-    cfgc = Ref(COptimConfig(1e-4, 1.0, 50, include_kl, 1e-7, 1e-6, 1e-8, 1.0, 1e9, 0, 0))   # ElboConfig defaults
+    cfgc = Ref(COptimConfig(1e-4, 1.0, 50, include_kl, 1e-7, 1e-6, 1e-8, 1.0, 1e9, tr_secular_iters, 0))   # ElboConfig defaults
     st = ccall((:celeste_maximize_batch, libceleste), Cint,
                (Ptr{Void}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Int32}, Ref{COptimConfig},
                 Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}),
                ctx.handle, vp_all, vp_frozen_neighbors #= or C_NULL =#, box_centres #= or C_NULL =#,
                n, targets0, cfgc, iterations, f_calls, max_values, status)
+    return st, iterations, f_calls, max_values, status
+end
+
+"""
+ParallelRun.one_node_joint_infer's inner loop (ParallelRun.jl:302-397) in ONE call: `layers` is the schedule -- each layer a
+vector of 0-based source ids no two of which are neighbours (the j-th sources of the connected components of a Cyclades
+batch), repeated for every sweep; vp_all (44 x S) goes up once, stays in HBM across all layers and comes back at the end.
+box_centres[k] (2 x length(layers[k])) pins the position boxes (ParallelRun.jl:96-100).  Returns the first non-zero
+per-source status (those sources keep the column they had before their layer) and the per-entry outputs.
+"""
+function joint_infer!(ctx::MI355XContext, vp_all::Matrix{Float64}, layers::Vector{Vector{Int32}};
+                      box_centres::Vector{Matrix{Float64}} = Matrix{Float64}[], include_kl::Bool = true,
+                      tr_secular_iters::Int = 5)
+    offsets = Int64[0; cumsum(map(length, layers))]
+    flat = vcat(layers...)
+    total = length(flat)
+    centres = isempty(box_centres) ? C_NULL : hcat(box_centres...)      # 2 x total, column per entry
+    iterations = zeros(Int32, total); f_calls = zeros(Int32, total); max_values = zeros(total); status = zeros(Int32, total)
+    cfgc = Ref(COptimConfig(1e-4, 1.0, 50, include_kl, 1e-7, 1e-6, 1e-8, 1.0, 1e9, tr_secular_iters, 0))
+    st = ccall((:celeste_joint_infer, libceleste), Cint,
+               (Ptr{Void}, Ptr{Float64}, Int32, Ptr{Int64}, Ptr{Int32}, Ptr{Float64}, Ref{COptimConfig},
+                Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}),
+               ctx.handle, vp_all, length(layers), offsets, flat, centres, cfgc, iterations, f_calls, max_values, status)
     return st, iterations, f_calls, max_values, status
 end
 

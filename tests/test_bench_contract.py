@@ -31,6 +31,17 @@ def test_bench_json_line():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 0 and d["split_variant"]["kernel"] == "record_sum_kernel" and d["optimizer"]["failed"] == 0
+    # what the engine does where the reference calls it: one elbo() per call, a Cyclades-sized layer, the
+    # joint-inference schedule through celeste_joint_infer, rank 0's shard for N ranks
+    assert d["single_call_latency_us"]["median"] > 0 and d["single_call_latency_us"]["calls"] == 200
+    lay = d["optimizer"]["cyclades_layer"]
+    assert lay["failed"] == 0 and lay["us_per_newton_iteration_of_the_slowest_target"] > 0 and lay["driver"] == "fused"
+    assert d["joint_infer"]["seconds"] > 0 and d["joint_infer"]["layers"] >= 3 and d["joint_infer"]["failed"] == 0
+    sp = d["shard_projection"]
+    assert sp["1"]["targets_rank0"] == 60 and sp["8"]["targets_rank0"] < sp["2"]["targets_rank0"] and sp["8"]["ms_per_sweep"] > 0
+    v = r["valu"]
+    assert v["pixel_visits"] == d["config"]["pixel_visits_per_sweep"] and 0 < v["frac"] < 1 and v["instruction_mix"]["fma_class"] > 0
+    assert "config5" not in d          # (appended to full-size config-3 runs only: it generates 16 SDSS-size fields)
 
 
 def test_bench_refuses_to_run_without_a_gpu():

@@ -252,3 +252,51 @@ def test_fused_launch_on_the_bench_field():
         print("%4d targets, %d..%d Newton iterations (mean %.1f): chained %.2f ms (%.0f us per iteration of the slowest target), "
               "fused %.2f ms (%.0f us)" % (n, its.min(), its.max(), its.mean(), dt[0] * 1e3, dt[0] * 1e6 / (its.max() + 1),
                                            dt[1] * 1e3, dt[1] * 1e6 / (its.max() + 1)))
+
+
+JOINT_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import celeste_jl_amd as cel
+from celeste_jl_amd import synthetic
+from celeste_jl_amd.infer import one_node_joint_infer
+from celeste_jl_amd.partition import estimate_time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                       # both ranks share the one GPU: gloo, blocks staged through the host
+dist.init_process_group("gloo", rank=rank, world_size=world)
+f = synthetic.make_field(220, 240, 40, seed=23, margin=30)
+ctx = cel.FieldContext(f.images, f.patches, f.neighbors, device=0)
+costs = [float(estimate_time(row)) for row in f.patches]
+failed = set()
+vs = one_node_joint_infer(ctx, f.catalog, list(range(40)), f.neighbors, cel.ElboConfig(max_iters=5), batch_size=12, n_iters=2,
+                          rank=rank, world=world, costs=costs, failed=failed)
+assert not failed
+np.save(os.path.join(%(out)r, "joint_rank%%d.npy" %% rank), vs)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_joint_inference_two_ranks_on_one_gpu_equals_one_rank(crowded, tmp_path):
+    """one_node_joint_infer with world = 2 (parallel.DeviceJointInfer: every layer sharded by cost, each rank optimises its
+    shard in place in its device-resident table with celeste_maximize_batch_device, the optimised rows + status are
+    all-gathered -- here over gloo, two processes sharing the one GPU; over RCCL in tests/test_gpu_multi_rccl.py) leaves
+    every rank with the one-rank table, bit for bit"""
+    import subprocess
+    import sys
+    import celeste_jl_amd as cel
+    from celeste_jl_amd.infer import one_node_joint_infer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(str(tmp_path), "joint_worker.py")
+    with open(script, "w") as fh:
+        fh.write(JOINT_WORKER % {"root": root, "out": str(tmp_path)})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 200), script]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    f, ctx = crowded
+    ref = one_node_joint_infer(ctx, f.catalog, list(range(40)), f.neighbors, cel.ElboConfig(max_iters=5), batch_size=12, n_iters=2)
+    for r in range(2):
+        got = np.load(os.path.join(str(tmp_path), "joint_rank%d.npy" % r))
+        assert np.array_equal(got, ref), "rank %d: max |diff| %.3e" % (r, np.abs(got - ref).max())
