@@ -17,6 +17,13 @@
 #include "optim_kernels.h"
 #include "fused_kernels.h"
 
+// Evaluation batches of up to this many targets run eval_fused_kernel (launch_eval): a batch whose chunk records fit the
+// chip in one round of 256-thread workgroups is latency-bound, and four wavefronts per record + the lift in the same
+// launch shorten its critical path.  Beyond that the chip is full and pixel_kernel's one wavefront per record (its
+// prologue paid once per four iterations, no turn-taking) has 2-3 x the throughput: a rank's N = 8 shard of the bench
+// field (250 targets) takes 0.168 ms with pixel_kernel + lift_kernel, 0.287 ms with eval_fused_kernel (measured).
+#define EVAL_FUSED_MAX 32
+
 #define HIP_TRY(expr)                                                                    \
     do {                                                                                 \
         hipError_t e__ = (expr);                                                         \
@@ -140,6 +147,7 @@ struct celeste_ctx {
     // buffers of the fused optimiser launch (optim_fused_kernel), kept between calls (grown on demand)
     struct FusedBuffers {
         size_t cap_t = 0, cap_rec = 0, cap_q = 0, cap_saved = 0;
+        bool arrivals_dirty = true;        // the arrival counters may hold anything (fresh allocation, an aborted launch)
         int4 *d_chunk_desc = nullptr;
         int2 *d_tgt_rec = nullptr;
         int32_t *d_q_items = nullptr, *d_q_ctl = nullptr, *d_arrivals = nullptr;
@@ -634,6 +642,40 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
     return launch_eval(c, d_vp, n_targets, d_targets, flags, d_v, d_d, d_h, d_counters, d_status, stream_, true);
 }
 
+// the context's tables, as the fused kernels take them
+static void fused_args_tables(celeste_ctx_t *c, FusedArgs &A) {
+    A.images = c->d_images; A.patches = c->d_patches; A.coefs = c->d_coefs; A.bitmaps = c->d_bitmaps;
+    A.nbr_off = c->d_nbr_off; A.nbr_idx = c->d_nbr_idx; A.val_off = c->d_val_off; A.val = c->d_val;
+    A.nv_base = c->d_nv_base; A.nbr_vis = c->d_nbr_vis; A.items = c->dense ? nullptr : c->d_items; A.geo = c->d_geo;
+    A.prior = c->d_prior; A.vis_off = c->d_vis_off; A.vis_img = c->d_vis_img; A.lg_sum = c->d_lg_sum; A.rec_off = c->d_rec_off;
+    A.N = c->N; A.NC = c->NC; A.K = c->K; A.M = c->M; A.CH = c->CH; A.chunk_px = c->chunk_px;
+    A.acc = c->d_acc;
+    A.st = nullptr; A.Hstate = nullptr; A.q_items = nullptr; A.q_ctl = nullptr; A.q_cap = 0; A.timeout_ticks = 0;
+}
+
+// per-target / per-record buffers of the fused kernels at capacity >= (n, rec)
+static int fused_buffers(celeste_ctx_t *c, size_t n, size_t rec, hipStream_t stream) {
+    auto &fb = c->fused;
+    if (n > fb.cap_t) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        void **ps[] = {(void **)&fb.d_tgt_rec, (void **)&fb.d_arrivals};
+        for (void **q : ps) if (*q) { (void)hipFree(*q); *q = nullptr; }
+        fb.cap_t = 0;
+        HIP_TRY(hipMalloc((void **)&fb.d_tgt_rec, n * sizeof(int2)));
+        HIP_TRY(hipMalloc((void **)&fb.d_arrivals, n * sizeof(int32_t)));
+        fb.cap_t = n;
+        fb.arrivals_dirty = true;
+    }
+    if (rec > fb.cap_rec) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (fb.d_chunk_desc) { (void)hipFree(fb.d_chunk_desc); fb.d_chunk_desc = nullptr; }
+        fb.cap_rec = 0;
+        HIP_TRY(hipMalloc((void **)&fb.d_chunk_desc, std::max<size_t>(rec, 1) * 2 * sizeof(int4)));
+        fb.cap_rec = rec;
+    }
+    return CELESTE_OK;
+}
+
 // render_neighbors = false keeps the neighbours' pre-rendered light of an earlier call (frozen neighbours
 // during an optimisation, ParallelRun.jl:474-488)
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
@@ -695,6 +737,15 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     // visit_chunks): 4 for large sweeps, 1 for small batches whose critical path is one patch
     int G = n_targets >= 1536 ? 4 : n_targets >= 768 ? 2 : 1;   // (measured on the bench field's shards: 1000 targets 0.287 ms with 2, 0.315 with 4)
     if (const char *e = getenv("CELESTE_CHUNK_GROUP")) if (atoi(e) >= 1 && atoi(e) <= 16) G = atoi(e);
+    // small Hessian-mode fp64 batches: eval_fused_kernel instead of pixel_kernel + lift_kernel (below)
+    bool eval_fused = !render_only && (flags & CELESTE_FLAG_HESS) && !(flags & (CELESTE_FLAG_FP32 | CELESTE_FLAG_SPLIT)) &&
+                      !d_active_rank && !d_live && d_d && d_h && n_targets <= EVAL_FUSED_MAX;
+    if (const char *e = getenv("CELESTE_EVAL_FUSED")) {
+        if (atoi(e) == 0) eval_fused = false;
+        else if (atoi(e) == 1) eval_fused = !render_only && (flags & CELESTE_FLAG_HESS) && !(flags & (CELESTE_FLAG_FP32 | CELESTE_FLAG_SPLIT)) &&
+                                          !d_active_rank && !d_live && d_d && d_h;
+    }
+    if (eval_fused) G = 1;        // one record per work item: the work-list total is the batch's number of records
     const int n_classes = WORK_CLASSES;   // work-list classes: full groups, then the patches' last groups by length
     if ((size_t)n_wblk * (n_classes + 1) > c->work_blk_cap) {   // + the row of chunk counts (rec_off)
         if (c->d_work_blk) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_work_blk)); c->d_work_blk = nullptr; }
@@ -771,6 +822,30 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     }
     if (render_only) { HIP_TRY(hipGetLastError()); return CELESTE_OK; }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
+    if (eval_fused) {
+        // small batch: one workgroup per chunk record (four wavefronts, one 64-pixel iteration each), the lift by the
+        // workgroup that completes a target -- eval_fused_kernel; same records, same results as pixel_kernel + lift_kernel
+        auto &fb = c->fused;
+        { int stb = fused_buffers(c, (size_t)n_targets, rec_cap, stream); if (stb != CELESTE_OK) return stb; }
+        if (fb.arrivals_dirty) {
+            HIP_TRY(hipMemsetAsync(fb.d_arrivals, 0, fb.cap_t * sizeof(int32_t), stream));
+            fb.arrivals_dirty = false;
+        }
+        hipLaunchKernelGGL(fused_setup_kernel, dim3((unsigned)((n_targets + 63) / 64)), dim3(64), 0, stream, d_targets, n_targets,
+                           c->d_patches, c->d_vis_off, c->dense ? nullptr : c->d_items, c->N, c->M, c->chunk_px, c->d_rec_off,
+                           fb.d_chunk_desc, fb.d_tgt_rec, (int32_t *)nullptr, (int32_t *)nullptr);
+        FusedArgs A;
+        fused_args_tables(c, A);
+        A.targets = d_targets; A.n_targets = n_targets; A.vp = const_cast<double *>(d_vp);
+        A.chunk_desc = fb.d_chunk_desc; A.tgt_rec = fb.d_tgt_rec; A.arrivals = fb.d_arrivals; A.flags = flags;
+        memset(&A.op, 0, sizeof A.op);
+        const unsigned rec_bound = (unsigned)std::max<size_t>(grid_need, 1);
+        hipLaunchKernelGGL(eval_fused_kernel, dim3(rec_bound + (unsigned)n_targets), dim3(FUSED_NT), 0, stream, A, c->d_srcimg,
+                           c->d_comps, c->d_work_total, (int)rec_bound, d_v, d_d, d_h, d_counters, d_status);
+        if (c->timing) { HIP_TRY(hipEventRecord(c->ev[2], stream)); HIP_TRY(hipEventRecord(c->ev[3], stream)); c->ev_valid = 1; c->ev_split = 0; }
+        HIP_TRY(hipGetLastError());
+        return CELESTE_OK;
+    }
     const dim3 grid((unsigned)std::max<size_t>(grid_need, 1));
 #define PIXEL_ARGS                                                                                                \
     c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx,       \
@@ -1259,22 +1334,7 @@ static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, co
     }
     const int G = (int)std::max<size_t>(1, std::min<size_t>((size_t)fb.max_resident, rec + n));
     const size_t q_cap = (rec + n) * ((size_t)op.max_iters + 2) + (size_t)G + 64;
-    if (n > fb.cap_t) {
-        HIP_TRY(hipStreamSynchronize(stream));
-        void **ps[] = {(void **)&fb.d_tgt_rec, (void **)&fb.d_arrivals};
-        for (void **q : ps) if (*q) { (void)hipFree(*q); *q = nullptr; }
-        fb.cap_t = 0;
-        HIP_TRY(hipMalloc((void **)&fb.d_tgt_rec, n * sizeof(int2)));
-        HIP_TRY(hipMalloc((void **)&fb.d_arrivals, n * sizeof(int32_t)));
-        fb.cap_t = n;
-    }
-    if (rec > fb.cap_rec) {
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (fb.d_chunk_desc) { (void)hipFree(fb.d_chunk_desc); fb.d_chunk_desc = nullptr; }
-        fb.cap_rec = 0;
-        HIP_TRY(hipMalloc((void **)&fb.d_chunk_desc, std::max<size_t>(rec, 1) * 2 * sizeof(int4)));
-        fb.cap_rec = rec;
-    }
+    { int stb = fused_buffers(c, n, rec, stream); if (stb != CELESTE_OK) return stb; }
     if (q_cap > fb.cap_q) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (fb.d_q_items) { (void)hipFree(fb.d_q_items); fb.d_q_items = nullptr; }
@@ -1288,16 +1348,13 @@ static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, co
     HIP_TRY(hipMemsetAsync(fb.d_q_items, 0xFF, q_cap * sizeof(int32_t), stream));
     HIP_TRY(hipMemsetAsync(fb.d_q_ctl, 0, FQC_WORDS * sizeof(int32_t), stream));
     HIP_TRY(hipMemsetAsync(fb.d_arrivals, 0, n * sizeof(int32_t), stream));
+    fb.arrivals_dirty = true;      // (clean again only if the launch runs to its end: eval_fused re-checks)
     hipLaunchKernelGGL(fused_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_targets, n_targets,
                        c->d_patches, c->d_vis_off, c->dense ? nullptr : c->d_items, c->N, c->M, c->chunk_px, c->d_rec_off,
                        fb.d_chunk_desc, fb.d_tgt_rec, fb.d_q_items, fb.d_q_ctl);
     FusedArgs A;
-    A.images = c->d_images; A.patches = c->d_patches; A.coefs = c->d_coefs; A.bitmaps = c->d_bitmaps;
-    A.nbr_off = c->d_nbr_off; A.nbr_idx = c->d_nbr_idx; A.val_off = c->d_val_off; A.val = c->d_val;
-    A.nv_base = c->d_nv_base; A.nbr_vis = c->d_nbr_vis; A.items = c->dense ? nullptr : c->d_items; A.geo = c->d_geo;
-    A.prior = c->d_prior; A.vis_off = c->d_vis_off; A.vis_img = c->d_vis_img; A.lg_sum = c->d_lg_sum; A.rec_off = c->d_rec_off;
-    A.N = c->N; A.NC = c->NC; A.K = c->K; A.M = c->M; A.CH = c->CH; A.chunk_px = c->chunk_px;
-    A.targets = d_targets; A.n_targets = n_targets; A.vp = d_vp; A.acc = c->d_acc;
+    fused_args_tables(c, A);
+    A.targets = d_targets; A.n_targets = n_targets; A.vp = d_vp;
     A.chunk_desc = fb.d_chunk_desc; A.tgt_rec = fb.d_tgt_rec;
     A.st = (OptState *)ob.d_state; A.Hstate = ob.d_H; A.op = op; A.flags = flags;
     A.q_items = fb.d_q_items; A.q_ctl = fb.d_q_ctl; A.arrivals = fb.d_arrivals; A.q_cap = (int)std::min<size_t>(q_cap, 0x7fffffff);

@@ -927,16 +927,25 @@ template <> __device__ __forceinline__ float fma_r<float>(float a, float b, floa
 // nu, nu^2.  (dx, dy) = pixel - m_pos.  Returns sum f; fills the S* members of T.
 // ---- explicit LDS reads of a component record (PIXEL_LDS_PINGPONG) -------------------------------------------
 typedef double dbl2 __attribute__((ext_vector_type(2)));
-struct LdsComp { dbl2 a, b, c; };   // {p11, p12} {p22, w0} {wd, nu}
+struct LdsComp { dbl2 a, b, c, d, e; };   // {p11, p12} {p22, w0} {wd, nu} | {-2 p12, -3 p11} {-3 p12, -3 p22}
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
-__device__ __forceinline__ void lds_issue_comp(LdsComp &r, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32"
-                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c) : "v"(addr) : "memory");
+__device__ __forceinline__ void lds_issue_comp(LdsComp &r, unsigned addr, unsigned addrx) {
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
+                 "ds_read_b128 %3, %6\n\tds_read_b128 %4, %6 offset:16"
+                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d), "=&v"(r.e) : "v"(addr), "v"(addrx) : "memory");
 }
 __device__ __forceinline__ void lds_wait_comp(LdsComp &r) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e));
+}
+// The multiples of a component's precision matrix that the third- and fourth-order Hermite polynomials need, formed once
+// per workgroup next to the staged record (COMPX doubles per component in LDS): with them u^2 v - p11 v - 2 p12 u =
+// fma(v, ha, u * (-2 p12)) etc. are one multiply and one FMA, where -2 u, -3 ha, -3 hc, -2 hb each cost an instruction of
+// their own -- 5 of the loop's 72 VALU instructions per component.
+#define COMPX 4
+__device__ __forceinline__ void comp_extra(const Comp &k, double *__restrict__ x) {
+    x[0] = -2.0 * k.p12; x[1] = -3.0 * k.p11; x[2] = -3.0 * k.p12; x[3] = -3.0 * k.p22;
 }
 #ifndef PIXEL_LDS_PINGPONG
 #define PIXEL_LDS_PINGPONG 1
@@ -947,7 +956,7 @@ __device__ __forceinline__ void lds_wait_comp(LdsComp &r) {
 
 template <int MODE, typename R>
 __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int nc, R dx, R dy, R dev, const double *etab,
-                                              PixelTerms &T) {
+                                              PixelTerms &T, const double *tcx = nullptr) {
     if constexpr (MODE == 2) {
         // The six sums that exist in an f-weighted (w0 = z theta_i) and a d-weighted (wd = +-z) version -- order 0, order
         // 1 (x, y) and the nu-weighted order 2 (xx, xy, yy) -- are accumulated ONCE, d-weighted, per profile type: the
@@ -956,7 +965,8 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
         // 18 accumulations per component instead of 24.
         R U0[6] = {0, 0, 0, 0, 0, 0}, U1[6] = {0, 0, 0, 0, 0, 0};
         R S2a = 0, S2b = 0, S2c = 0, S3a = 0, S3b = 0, S3c = 0, S3d = 0, S4a = 0, S4b = 0, S4c = 0, S4d = 0, S4e = 0;
-        auto body_regs = [&](R p11, R p12, R p22, R w0, R wd, R nu, R (&U)[6], R d1, R d2, auto &&after_exp_issue) {
+        auto body_regs = [&](R p11, R p12, R p22, R w0, R wd, R nu, R m2p12, R m3p11, R m3p12, R m3p22, R (&U)[6], R d1, R d2,
+                             auto &&after_exp_issue) {
             struct { R p11, p12, p22, w0, wd, nu; } k = {p11, p12, p22, w0, wd, nu};
             const R u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
             // exp_nonpos in two halves: the table entry is requested as soon as its index is known, the Hermite
@@ -974,18 +984,16 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             after_exp_issue();
             const R ha = fma_r<R>(u, u, -k.p11), hb = fma_r<R>(u, v, -k.p12), hc = fma_r<R>(v, v, -k.p22);
             // third order: u^3 - 3 p11 u, u^2 v - p11 v - 2 p12 u, u v^2 - p22 u - 2 p12 v, v^3 - 3 p22 v
-            const R tu = (R)-2.0 * u, tv = (R)-2.0 * v;
             const R h3a = u * fma_r<R>((R)-2.0, k.p11, ha);
-            const R h3b = fma_r<R>(v, ha, tu * k.p12);
-            const R h3c = fma_r<R>(u, hc, tv * k.p12);
+            const R h3b = fma_r<R>(v, ha, u * m2p12);
+            const R h3c = fma_r<R>(u, hc, v * m2p12);
             const R h3d = v * fma_r<R>((R)-2.0, k.p22, hc);
             // fourth order
-            const R m3a = (R)-3.0 * ha, m3c = (R)-3.0 * hc;
-            const R h4a = fma_r<R>(u, h3a, m3a * k.p11);
-            const R h4b = fma_r<R>(v, h3a, m3a * k.p12);
-            const R h4c = fma_r<R>(u, h3c, fma_r<R>((R)-2.0 * hb, k.p12, -hc * k.p11));
-            const R h4d = fma_r<R>(u, h3d, m3c * k.p12);
-            const R h4e = fma_r<R>(v, h3d, m3c * k.p22);
+            const R h4a = fma_r<R>(u, h3a, ha * m3p11);
+            const R h4b = fma_r<R>(v, h3a, ha * m3p12);
+            const R h4c = fma_r<R>(u, h3c, fma_r<R>(hb, m2p12, -hc * k.p11));
+            const R h4d = fma_r<R>(u, h3d, hc * m3p12);
+            const R h4e = fma_r<R>(v, h3d, hc * m3p22);
             R e;
             if constexpr (sizeof(R) == 8) {
                 pe = exp_poly(xr);
@@ -1006,7 +1014,8 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
         };
         auto body = [&](int c, R (&U)[6], R d1, R d2) {
             const CompR<R> k = tc[c];
-            body_regs(k.p11, k.p12, k.p22, k.w0, k.wd, k.nu, U, d1, d2, []() {});
+            body_regs(k.p11, k.p12, k.p22, k.w0, k.wd, k.nu, (R)tcx[COMPX * c], (R)tcx[COMPX * c + 1], (R)tcx[COMPX * c + 2],
+                      (R)tcx[COMPX * c + 3], U, d1, d2, []() {});
         };
         // runs of 8 (de Vaucouleurs) / 6 (exponential) prototypes share a PSF component, i.e. the offset xiBar_k
 #if PIXEL_LDS_PINGPONG
@@ -1015,13 +1024,15 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             // unrolled by two): the compiler neither rotates the loop nor leaves a hand-hoisted load where it is put,
             // so the reads are volatile asm, and every set passes through the "+v" operands of an explicit s_waitcnt
             // before it is used (free when the data has already arrived under the exponential's table read).
-            const unsigned base = lds_addr(tc);
+            const unsigned base = lds_addr(tc), basex = lds_addr(tcx);
             LdsComp ra, rb;
-            lds_issue_comp(ra, base);
+            lds_issue_comp(ra, base, basex);
             auto half = [&](LdsComp &k, LdsComp &nxt, int c_next, R (&U)[6], R d1, R d2) {
                 lds_wait_comp(k);
-                body_regs(k.a.x, k.a.y, k.b.x, k.b.y, k.c.x, k.c.y, U, d1, d2,
-                          [&]() { lds_issue_comp(nxt, base + 64u * (unsigned)(c_next < nc ? c_next : nc - 1)); });
+                body_regs(k.a.x, k.a.y, k.b.x, k.b.y, k.c.x, k.c.y, k.d.x, k.d.y, k.e.x, k.e.y, U, d1, d2, [&]() {
+                    const unsigned cn = (unsigned)(c_next < nc ? c_next : nc - 1);
+                    lds_issue_comp(nxt, base + 64u * cn, basex + (unsigned)(COMPX * 8) * cn);
+                });
             };
             for (int c0 = 0; c0 < n_dev; c0 += 8) {
                 const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
@@ -1157,6 +1168,9 @@ __device__ __forceinline__ PixelInputs load_pixel_inputs(
     bool dup = false;
 
     // ---- neighbours: gather their pre-rendered (E_G_s.v, var_G_s.v) ----
+#ifdef PIXEL_EXP_NO_NEIGHBORS   // (timing experiment, wrong results: what the gather costs)
+    nb1 = nb0;
+#endif
     for (int64_t q = nb0; q < nb1; ++q) {
         const int s2 = nbr_idx[q];
         const int v2 = nv ? nv[q - nb0] : s2 * N + n;    // the neighbour's table entry for this image (visit lists: -1 = none)
@@ -1209,6 +1223,7 @@ struct PixWork {
     int my_rank, N, n, NC, v;
     SrcImg si;                       // the target's pixel-space position and brightness moments for this image
     const Comp *tc;                  // its 14 psf_K components (LDS)
+    const double *tcx;               // comp_extra of each (LDS; Hessian mode, fp64 loop)
     const CompR<R> *tcr;             // the same in the arithmetic type of the component loop (LDS)
     const double *etab;              // 2^(j/64) table (LDS)
     const double *tcoef;             // star spline coefficients of the patch's stamp
@@ -1281,7 +1296,7 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
         if (own_geo) {
 #endif
             if constexpr (sizeof(R) == 4) S0 = galaxy_sums_pk<GM>(W.tcr, NC, (float)(hh - si.m1), (float)(ww - si.m2), T);
-            else S0 = galaxy_sums<GM, R>(W.tcr, 8 * (NC / 14), NC, (R)(hh - si.m1), (R)(ww - si.m2), (R)si.dev, etab, T);
+            else S0 = galaxy_sums<GM, R>(W.tcr, 8 * (NC / 14), NC, (R)(hh - si.m1), (R)(ww - si.m2), (R)si.dev, etab, T, W.tcx);
         }
 #if !PIXEL_LOADS_FIRST
         const PixelInputs I = LOAD_PIXEL_INPUTS();
@@ -1294,7 +1309,11 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
 
         // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
         T.f0 = 0; T.f0g0 = 0; T.f0g1 = 0; T.f0h0 = 0; T.f0h1 = 0; T.f0h2 = 0;
+#ifdef PIXEL_EXP_NO_STAR        // (timing experiment, wrong results: what the star spline costs)
+        if (own && hh < -1e30) {
+#else
         if (own) {
+#endif
             const double xh = hh + sh0, xw = ww + sw0;
             int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
             int iy = (int)floor(xw); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
@@ -1447,6 +1466,11 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         etab[lane] = tabv;
         __syncthreads();
     }
+    __shared__ double tcx[(MODE == 2 || MODE == 3) && sizeof(R) == 8 ? COMPX * 14 * CEL_MAXK : 1];
+    if constexpr ((MODE == 2 || MODE == 3) && sizeof(R) == 8) {
+        if (lane < NC) comp_extra(tc[lane], tcx + COMPX * lane);
+        __syncthreads();
+    }
     PixWork<R> W;
     W.img = &images[n]; W.P = &P; W.patches = patches; W.bitmaps = bitmaps; W.nbr_idx = nbr_idx;
     W.nb0 = nbr_off[t]; W.nb1 = nbr_off[t + 1];
@@ -1458,7 +1482,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     W.my_rank = MULTI ? active_rank[t] : 0;
     W.N = N; W.n = n; W.NC = NC; W.v = v;
     W.si = srcimg[v];
-    W.tc = tc;
+    W.tc = tc; W.tcx = tcx;
     W.tcr = sizeof(R) == 4 ? tcr_f : reinterpret_cast<const CompR<R> *>(tc);
     W.etab = etab;
     W.tcoef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
@@ -1742,9 +1766,10 @@ struct LiftShared {
 
 // The lift of ONE target by the calling workgroup (>= 256 threads): chunk records -> value, 44-gradient, 44 x 44 Hessian
 // at o_v / o_d / o_h (global memory in lift_kernel, LDS in the fused optimiser kernel), KL and status included.
-// COH: the target's parameters and its chunk records were written by other workgroups of this launch (ldc), and its
-// SrcGeo is formed here from the parameters instead of being read from the per-batch table `geo`.
-template <bool COH>
+// COH: the target's parameters were written by another workgroup of this launch (ldc), and its SrcGeo is formed here
+// from the parameters instead of being read from the per-batch table `geo`.  COH_ACC: so were its chunk records
+// (eval_fused_kernel: records from this launch, parameters from before it).
+template <bool COH, bool COH_ACC = COH>
 __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti, int t, const double *__restrict__ vp,
         const DevImage *__restrict__ images, const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
         const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx, const double *__restrict__ acc,
@@ -1834,7 +1859,7 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
             const int npx = P.H2 * P.W2;
             double s = 0.0;
             const double *const r0 = acc + (rec_off ? (size_t)rec_off[ti * M + n0 + i] : (size_t)(ti * M + n0 + i) * CH) * ACC_N + e;
-            if constexpr (COH) {
+            if constexpr (COH_ACC) {
                 // L1-bypassing loads, four in flight at a time; added in chunk order like the plain loop below
                 for (int c0 = 0; c0 * chunk_px < npx && c0 < CH; c0 += 4) {
                     double v[4];

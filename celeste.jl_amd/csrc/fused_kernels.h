@@ -70,6 +70,7 @@ struct FusedArgs {
 };
 
 // per batch, once: the targets' record ranges, the description of every record, the first round of queue items
+// (q_items == nullptr: no queue -- eval_fused_kernel)
 __global__ void fused_setup_kernel(const int32_t *__restrict__ targets, int n_targets, const DevPatch *__restrict__ patches,
                                    const int32_t *__restrict__ vis_off, const int2 *__restrict__ items, int N, int M,
                                    int chunk_px, const int32_t *__restrict__ rec_off, int4 *__restrict__ chunk_desc,
@@ -95,6 +96,7 @@ __global__ void fused_setup_kernel(const int32_t *__restrict__ targets, int n_ta
         n_rec += nch;
     }
     tgt_rec[ti] = make_int2(first < 0 ? 0 : first, n_rec);
+    if (!q_items) return;
     const int cnt = n_rec > 0 ? n_rec : 1;
     const int base = atomicAdd(&q_ctl[FQC_TAIL], cnt);
     if (n_rec > 0) for (int i = 0; i < n_rec; ++i) q_items[base + i] = first + i;
@@ -107,6 +109,7 @@ struct FusedShared {
     // evaluating a chunk record
     double theta[CEL_P];
     Comp tc[14 * CEL_MAXK];
+    double tcx[COMPX * 14 * CEL_MAXK];
     SrcImg si;
     double etab[64];
     double sacc[ACC_N * ACC_SLOTS];
@@ -203,8 +206,10 @@ optim_fused_kernel(const FusedArgs A) {
             for (int i = tid; i < ACC_N * ACC_SLOTS; i += FUSED_NT) F.sacc[i] = 0.0;
             if (tid == 0) F.turn = 0;
             __syncthreads();
-            if (wave == 0) prep_visit_values<false>(lane, F.theta, P, A.images[n].band - 1, A.K, &F.si, F.tc);
-            else if (wave == 1) brightness_moments_wave(lane, F.theta, P, A.images[n].band - 1, &F.si);
+            if (wave == 0) {
+                prep_visit_values<false>(lane, F.theta, P, A.images[n].band - 1, A.K, &F.si, F.tc);
+                if (lane < A.NC) comp_extra(F.tc[lane], F.tcx + COMPX * lane);
+            } else if (wave == 1) brightness_moments_wave(lane, F.theta, P, A.images[n].band - 1, &F.si);
             __syncthreads();
             FT(1);
             const int base = p0 + 64 * wave;
@@ -216,7 +221,7 @@ optim_fused_kernel(const FusedArgs A) {
                 W.val_off = A.val_off; W.val = A.val; W.active_rank = nullptr; W.my_rank = 0;
                 W.N = A.N; W.n = n; W.NC = A.NC; W.v = v;
                 W.si = F.si;
-                W.tc = F.tc; W.tcr = reinterpret_cast<const CompR<double> *>(F.tc);
+                W.tc = F.tc; W.tcx = F.tcx; W.tcr = reinterpret_cast<const CompR<double> *>(F.tc);
                 W.etab = F.etab;
                 W.tcoef = A.coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
                 W.tile_off = nullptr; W.rec = nullptr;
@@ -278,6 +283,100 @@ optim_fused_kernel(const FusedArgs A) {
         }
         FT(6); FT_COUNT(15);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// eval_fused_kernel: one elbo() sweep of a SMALL batch (a rank's shard at N >= 4, a single call) with the fused kernel's
+// chunk evaluation -- one workgroup per chunk record, its four 64-pixel iterations on four wavefronts adding in
+// iteration order -- and the lift done by whichever workgroup completes a target (arrival counter), instead of
+// pixel_kernel (one wavefront per record, four iterations in a row: the critical path of a batch that cannot fill the
+// chip) followed by a lift launch.  Records and results are bit-identical to that pair's.  No queue and no waiting:
+// every workgroup does its record, and at most one lift.  The per-image tables come from prep_kernel (HBM).
+// ---------------------------------------------------------------------------------------------------------
+struct EvalFusedShared {
+    Comp tc[14 * CEL_MAXK];
+    double tcx[COMPX * 14 * CEL_MAXK];
+    double etab[64];
+    double sacc[ACC_N * ACC_SLOTS];
+    int turn, last;
+    LiftShared lift;
+};
+
+__global__ void __launch_bounds__(FUSED_NT, 2)
+eval_fused_kernel(const FusedArgs A, const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
+                  const int32_t *__restrict__ n_records, int rec_bound, double *__restrict__ out_v, double *__restrict__ out_d,
+                  double *__restrict__ out_h, int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status) {
+    __shared__ EvalFusedShared F;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int item = blockIdx.x;
+    if (item >= rec_bound) {
+        // the last n_targets blocks: targets that visit no pixel at all (off every image) have no record to complete them
+        const int te = item - rec_bound;
+        if (A.tgt_rec[te].y > 0) return;
+        const size_t HSe = (A.flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;
+        lift_target<false, true>(F.lift, tid, te, A.targets[te], A.vp, A.images, A.patches, A.geo, A.nbr_off, A.nbr_idx, A.acc,
+                                 A.prior, A.vis_off, A.vis_img, A.N, A.M, A.CH, A.chunk_px, A.flags, out_v + te,
+                                 out_d + (size_t)te * CEL_P, out_h + (size_t)te * HSe, out_cnt ? out_cnt + 2 * (size_t)te : nullptr,
+                                 out_status + te, A.lg_sum, A.rec_off);
+        return;
+    }
+    if (item >= *n_records) return;              // rec_bound is the host's bound on the number of records
+    const int4 d0 = A.chunk_desc[2 * item], d1 = A.chunk_desc[2 * item + 1];
+    const int ti = d0.x, j = d0.y, ch = d0.z, t = d0.w, v = d1.x, n = d1.y;
+    const DevPatch &P = A.patches[v];
+    const int npx = P.H2 * P.W2;
+    const int p0 = ch * A.chunk_px, p1 = min(npx, p0 + A.chunk_px);
+    {
+        const double *src = reinterpret_cast<const double *>(comps + (size_t)v * A.NC);
+        double *dst = reinterpret_cast<double *>(F.tc);
+        for (int i = tid; i < A.NC * 8; i += FUSED_NT) dst[i] = src[i];
+        if (wave == 2) F.etab[lane] = g_exp2_table[lane];
+        for (int i = tid; i < ACC_N * ACC_SLOTS; i += FUSED_NT) F.sacc[i] = 0.0;
+        if (tid == 0) F.turn = 0;
+        __syncthreads();
+        if (tid < A.NC) comp_extra(F.tc[tid], F.tcx + COMPX * tid);
+        __syncthreads();
+    }
+    const int base = p0 + 64 * wave;
+    if (base < p1) {
+        PixWork<double> W;
+        W.img = &A.images[n]; W.P = &P; W.patches = A.patches; W.bitmaps = A.bitmaps; W.nbr_idx = A.nbr_idx;
+        W.nb0 = A.nbr_off[t]; W.nb1 = A.nbr_off[t + 1];
+        W.nv = A.nbr_vis ? A.nbr_vis + A.nv_base[t] + (int64_t)j * (W.nb1 - W.nb0) : nullptr;
+        W.val_off = A.val_off; W.val = A.val; W.active_rank = nullptr; W.my_rank = 0;
+        W.N = A.N; W.n = n; W.NC = A.NC; W.v = v;
+        W.si = srcimg[v];
+        W.tc = F.tc; W.tcx = F.tcx; W.tcr = reinterpret_cast<const CompR<double> *>(F.tc);
+        W.etab = F.etab;
+        W.tcoef = A.coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
+        W.tile_off = nullptr; W.rec = nullptr;
+        double a[3] = {0.0, 0.0, 0.0};
+        volatile int *turn = &F.turn;
+        pixel_iter<2, double, false, FUSED_GATED != 0>(W, base, p1, lane, F.sacc + (lane & (ACC_SLOTS - 1)), a, [&]() {
+            while (*turn != wave) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) *turn = wave + 1;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double *out = A.acc + (size_t)item * ACC_N;
+        fold_record_slots<2>(F.sacc, lane, [&](int e, double s) { stc<true>(out + e, s); });
+        drain_stores();
+        if (lane == 0) {
+            const int before = __hip_atomic_fetch_add(&A.arrivals[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            F.last = before == A.tgt_rec[ti].y - 1;
+            if (F.last) stc<true>(&A.arrivals[ti], 0);        // re-armed for the next launch
+        }
+    }
+    __syncthreads();
+    if (!F.last) return;
+    const size_t HS = (A.flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;
+    lift_target<false, true>(F.lift, tid, ti, t, A.vp, A.images, A.patches, A.geo, A.nbr_off, A.nbr_idx, A.acc, A.prior, A.vis_off,
+                             A.vis_img, A.N, A.M, A.CH, A.chunk_px, A.flags, out_v + ti, out_d + (size_t)ti * CEL_P,
+                             out_h + (size_t)ti * HS, out_cnt ? out_cnt + 2 * (size_t)ti : nullptr, out_status + ti, A.lg_sum,
+                             A.rec_off);
 }
 
 // after the launch: per-target outputs from the optimiser states; a target that failed gets its input row back

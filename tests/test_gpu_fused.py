@@ -300,3 +300,39 @@ def test_joint_inference_two_ranks_on_one_gpu_equals_one_rank(crowded, tmp_path)
     for r in range(2):
         got = np.load(os.path.join(str(tmp_path), "joint_rank%d.npy" % r))
         assert np.array_equal(got, ref), "rank %d: max |diff| %.3e" % (r, np.abs(got - ref).max())
+
+
+def test_eval_fused_kernel_equals_pixel_and_lift_kernels(crowded):
+    """small evaluation batches (a rank's shard at N >= 4, one elbo() per call) run eval_fused_kernel -- one workgroup per
+    chunk record, four wavefronts adding in iteration order, the lift by the workgroup that completes a target; everything
+    it returns is pixel_kernel + lift_kernel's, bit for bit"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import cabi, synthetic
+    f, ctx = crowded
+    S = len(f.catalog)
+    rng = np.random.default_rng(2)
+    with _env(CELESTE_FORCE_VISIT_LISTS=1):
+        ctx_lists = cel.FieldContext(f.images, f.patches, f.neighbors)
+    mf = synthetic.make_multifield(grid=(2, 2), H=150, W=160, n_sources=60, seed=8, sparse=True)   # sources in 1..4 of 20 images
+    ctx_mf = cel.FieldContext(mf.images, mf.patches, mf.neighbors)
+    cases = [("one target", ctx, f.vp, [7], 7), ("every source", ctx, f.vp, list(range(S)), 7),
+             ("repeated targets, no KL", ctx, f.vp, [3, 3, 9, 3, 11], 3),
+             ("packed Hessians", ctx, f.vp, [int(t) for t in rng.permutation(S)[:17]], 7 | cabi.FLAG_PACKED_HESS),
+             ("visit lists", ctx_lists, f.vp, list(range(0, S, 2)), 7),
+             ("overlapping fields, sparse patch list", ctx_mf, mf.vp, list(range(60)), 7)]
+    for what, cx, vp, tg, flags in cases:
+        res = []
+        for mode in (0, 1):
+            with _env(CELESTE_EVAL_FUSED=mode):
+                res.append(cx.eval_batch(vp, tg, flags))
+        assert (res[0][4] == 0).all(), what
+        for a, b, name in zip(res[0], res[1], ("v", "d", "h", "counters", "status")):
+            assert np.array_equal(a, b), "%s: %s differs (max |diff| %.3e)" % (what, name, np.abs(a - b).max())
+    # a non-finite parameter: same status, same (non-finite) outputs
+    bad = f.vp.copy()
+    bad[4, 7] = np.inf
+    out = []
+    for mode in (0, 1):
+        with _env(CELESTE_EVAL_FUSED=mode):
+            out.append(ctx.eval_batch(bad, [4, 5], 7, raise_on_error=False))
+    assert np.array_equal(out[0][4], out[1][4]) and out[0][4][0] == cabi.ERR_NONFINITE_INPUT
