@@ -274,16 +274,23 @@ patch_lgamma_kernel(const DevImage *__restrict__ images, const DevPatch *__restr
 // ---------------------------------------------------------------------------------------------
 // pixel_kernel
 // ---------------------------------------------------------------------------------------------
-__device__ inline void bspline_w(double f, double w[4]) {
-    const double o = 1.0 - f;
-    w[0] = o * o * o * (1.0 / 6); w[1] = 2.0 / 3 - f * f + f * f * f * 0.5;
-    w[2] = 2.0 / 3 - o * o + o * o * o * 0.5; w[3] = f * f * f * (1.0 / 6);
+template <typename S>
+__device__ inline void bspline_w(S f, S w[4]) {
+    const S o = (S)1.0 - f;
+    w[0] = o * o * o * (S)(1.0 / 6); w[1] = (S)(2.0 / 3) - f * f + f * f * f * (S)0.5;
+    w[2] = (S)(2.0 / 3) - o * o + o * o * o * (S)0.5; w[3] = f * f * f * (S)(1.0 / 6);
 }
-__device__ inline void bspline_dw(double f, double dw[4], double ddw[4]) {
-    const double o = 1.0 - f;
-    dw[0] = -0.5 * o * o; dw[1] = -2 * f + 1.5 * f * f; dw[2] = 2 * o - 1.5 * o * o; dw[3] = 0.5 * f * f;
-    ddw[0] = o; ddw[1] = -2 + 3 * f; ddw[2] = -2 + 3 * o; ddw[3] = f;
+template <typename S>
+__device__ inline void bspline_dw(S f, S dw[4], S ddw[4]) {
+    const S o = (S)1.0 - f;
+    dw[0] = (S)-0.5 * o * o; dw[1] = (S)-2 * f + (S)1.5 * f * f; dw[2] = (S)2 * o - (S)1.5 * o * o; dw[3] = (S)0.5 * f * f;
+    ddw[0] = o; ddw[1] = (S)-2 + (S)3 * f; ddw[2] = (S)-2 + (S)3 * o; ddw[3] = f;
 }
+// exp / log in the arithmetic type of the per-pixel terms
+__device__ __forceinline__ double exp_s(double x) { return exp(x); }
+__device__ __forceinline__ float exp_s(float x) { return __expf(x); }
+__device__ __forceinline__ double log_s(double x) { return log(x); }
+__device__ __forceinline__ float log_s(float x) { return __logf(x); }
 
 // exp(x) for x <= 0 in fp64.  x = (64 m + j) ln2/64 + r with |r| <= ln2/128, so
 // exp(x) = 2^m * 2^(j/64) * exp(r): a 64-entry table in LDS (filled by exp_table_init), a degree-4
@@ -751,64 +758,72 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
 // ---------------------------------------------------------------------------------------------
 // pixel_kernel
 // ---------------------------------------------------------------------------------------------
-// Per-pixel quantities from which every entry of the 68-double record is formed.
-struct PixelTerms {
-    double vterm, cnt_act, cnt_inact;
-    double f0, f1;
-    double alpha, beta, w2, w12;
-    double k0, k1;
-    double f0g0, f0g1, f0h0, f0h1, f0h2;
+// Per-pixel quantities from which every entry of the 68-double record is formed.  S: double; float in the single-precision
+// mode (CELESTE_FLAG_FP32), where everything per pixel -- the terms below, the record entries, the chunk's slots in LDS --
+// is fp32 and only the chunk records leave the kernel as doubles.
+template <typename S>
+struct PixelTermsT {
+    typedef S scalar;
+    S vterm, cnt_act, cnt_inact;
+    S f0, f1;
+    S alpha, beta, w2, w12;
+    S k0, k1;
+    S f0g0, f0g1, f0h0, f0h1, f0h2;
     // With dA = c0 ds + c1 dg and dB = 2 q0 f0 ds + 2 q1 f1 dg (ds / dg = gradients of the star / galaxy density) every
     // derivative entry is a combination of ds, dg and their second derivatives with per-pixel scalar weights:
-    double C0s, C0g, C1s, C1g;   // rows (c0, geo), (c1, geo):  C.s ds + C.g dg
-    double Q0s, Q0g, Q1s, Q1g;   // rows (q0, geo), (q1, geo)
-    double Wgg, Wsg, Wss;        // (geo, geo): Wgg dg dg' + Wsg (ds dg' + dg ds') + Wss ds ds' + k1 d2g + k0 d2s
+    S C0s, C0g, C1s, C1g;   // rows (c0, geo), (c1, geo):  C.s ds + C.g dg
+    S Q0s, Q0g, Q1s, Q1g;   // rows (q0, geo), (q1, geo)
+    S Wgg, Wsg, Wss;        // (geo, geo): Wgg dg dg' + Wsg (ds dg' + dg ds') + Wss ds ds' + k1 d2g + k0 d2s
     // galaxy component sums (see pixel_kernel)
-    double S0d, S1x, S1y, S1xd, S1yd, S2a, S2b, S2c, S2an, S2bn, S2cn, S2ad, S2bd, S2cd;
-    double S3a, S3b, S3c, S3d, S4a, S4b, S4c, S4d, S4e;
+    S S0d, S1x, S1y, S1xd, S1yd, S2a, S2b, S2c, S2an, S2bn, S2cn, S2ad, S2bd, S2cd;
+    S S3a, S3b, S3c, S3d, S4a, S4b, S4c, S4d, S4e;
 };
+typedef PixelTermsT<double> PixelTerms;
 
 // d f1 / d(m1 m2 dev Xi11 Xi12 Xi22)
-template <int G>
-__device__ __forceinline__ double gal_g(const PixelTerms &T) {
+template <int G, class TT>
+__device__ __forceinline__ typename TT::scalar gal_g(const TT &T) {
+    typedef typename TT::scalar S;
     if constexpr (G == 0) return T.S1x;
     else if constexpr (G == 1) return T.S1y;
     else if constexpr (G == 2) return T.S0d;
-    else if constexpr (G == 3) return 0.5 * T.S2an;
+    else if constexpr (G == 3) return (S)0.5 * T.S2an;
     else if constexpr (G == 4) return T.S2bn;
-    else return 0.5 * T.S2cn;
+    else return (S)0.5 * T.S2cn;
 }
 // d2 f1 (upper triangle, G <= G2): Gaussian derivatives d/dm = -d/dx, d/dXi = (nu/2) d2/dx2
-template <int G, int G2>
-__device__ __forceinline__ double gal_h(const PixelTerms &T) {
+template <int G, int G2, class TT>
+__device__ __forceinline__ typename TT::scalar gal_h(const TT &T) {
+    typedef typename TT::scalar S;
     constexpr int k = G * 6 + G2;
     if constexpr (k == 0) return T.S2a;                 // m1 m1
     else if constexpr (k == 1) return T.S2b;            // m1 m2
     else if constexpr (k == 2) return T.S1xd;           // m1 dev
-    else if constexpr (k == 3) return 0.5 * T.S3a;      // m1 Xi11
+    else if constexpr (k == 3) return (S)0.5 * T.S3a;      // m1 Xi11
     else if constexpr (k == 4) return T.S3b;            // m1 Xi12
-    else if constexpr (k == 5) return 0.5 * T.S3c;      // m1 Xi22
+    else if constexpr (k == 5) return (S)0.5 * T.S3c;      // m1 Xi22
     else if constexpr (k == 7) return T.S2c;            // m2 m2
     else if constexpr (k == 8) return T.S1yd;
-    else if constexpr (k == 9) return 0.5 * T.S3b;
+    else if constexpr (k == 9) return (S)0.5 * T.S3b;
     else if constexpr (k == 10) return T.S3c;
-    else if constexpr (k == 11) return 0.5 * T.S3d;
-    else if constexpr (k == 14) return 0.0;             // dev dev
-    else if constexpr (k == 15) return 0.5 * T.S2ad;
+    else if constexpr (k == 11) return (S)0.5 * T.S3d;
+    else if constexpr (k == 14) return (S)0.0;             // dev dev
+    else if constexpr (k == 15) return (S)0.5 * T.S2ad;
     else if constexpr (k == 16) return T.S2bd;
-    else if constexpr (k == 17) return 0.5 * T.S2cd;
-    else if constexpr (k == 21) return 0.25 * T.S4a;    // Xi11 Xi11
-    else if constexpr (k == 22) return 0.5 * T.S4b;
-    else if constexpr (k == 23) return 0.25 * T.S4c;
+    else if constexpr (k == 17) return (S)0.5 * T.S2cd;
+    else if constexpr (k == 21) return (S)0.25 * T.S4a;    // Xi11 Xi11
+    else if constexpr (k == 22) return (S)0.5 * T.S4b;
+    else if constexpr (k == 23) return (S)0.25 * T.S4c;
     else if constexpr (k == 28) return T.S4c;           // Xi12 Xi12
-    else if constexpr (k == 29) return 0.5 * T.S4d;
-    else { static_assert(k == 35, "upper triangle only"); return 0.25 * T.S4e; }  // Xi22 Xi22
+    else if constexpr (k == 29) return (S)0.5 * T.S4d;
+    else { static_assert(k == 35, "upper triangle only"); return (S)0.25 * T.S4e; }  // Xi22 Xi22
 }
-template <int G>
-__device__ __forceinline__ double star_g(const PixelTerms &T) {
+template <int G, class TT>
+__device__ __forceinline__ typename TT::scalar star_g(const TT &T) {
+    typedef typename TT::scalar S;
     if constexpr (G == 0) return T.f0g0;
     else if constexpr (G == 1) return T.f0g1;
-    else return 0.0;
+    else return (S)0.0;
 }
 constexpr int hess_row(int e) {  // packed upper-triangle index (e - ACC_H0) -> row
     int i = 0, k = e - ACC_H0;
@@ -822,8 +837,9 @@ constexpr int hess_col(int e) {
 }
 
 // entry E of the 68-double record for this pixel
-template <int E>
-__device__ __forceinline__ double record_entry(const PixelTerms &T) {
+template <int E, class TT>
+__device__ __forceinline__ typename TT::scalar record_entry(const TT &T) {
+    typedef typename TT::scalar S;
     if constexpr (E == 0) return T.vterm;
     else if constexpr (E == ACC_CNT) return T.cnt_act;
     else if constexpr (E == ACC_CNT + 1) return T.cnt_inact;
@@ -839,22 +855,22 @@ __device__ __forceinline__ double record_entry(const PixelTerms &T) {
         constexpr int i = hess_row(E), j = hess_col(E);
         if constexpr (j < 2) return T.beta * (i == 0 ? T.f0 : T.f1) * (j == 0 ? T.f0 : T.f1);      // (c, c)
         else if constexpr (i < 2 && j < 4) {                                                         // (c, q)
-            const double fi = i == 0 ? T.f0 : T.f1, fj = j == 2 ? T.f0 : T.f1;
+            const S fi = i == 0 ? T.f0 : T.f1, fj = j == 2 ? T.f0 : T.f1;
             return T.w12 * fi * (fj * fj);
-        } else if constexpr (j < 4) return 0.0;                                                      // (q, q)
+        } else if constexpr (j < 4) return (S)0.0;                                                      // (q, q)
         else if constexpr (i < 4) {                                                                   // (c / q, geo)
             constexpr int g2 = j - 4;
-            const double xs = i == 0 ? T.C0s : (i == 1 ? T.C1s : (i == 2 ? T.Q0s : T.Q1s));
-            const double xg = i == 0 ? T.C0g : (i == 1 ? T.C1g : (i == 2 ? T.Q0g : T.Q1g));
+            const S xs = i == 0 ? T.C0s : (i == 1 ? T.C1s : (i == 2 ? T.Q0s : T.Q1s));
+            const S xg = i == 0 ? T.C0g : (i == 1 ? T.C1g : (i == 2 ? T.Q0g : T.Q1g));
             if constexpr (g2 < 2) return xs * star_g<g2>(T) + xg * gal_g<g2>(T);
             else return xg * gal_g<g2>(T);
         } else {                                                                                      // (geo, geo)
             constexpr int g = i - 4, g2 = j - 4;
-            double a = T.Wgg * gal_g<g>(T);
+            S a = T.Wgg * gal_g<g>(T);
             if constexpr (g < 2) a += T.Wsg * star_g<g>(T);
-            double v = T.k1 * gal_h<g, g2>(T) + a * gal_g<g2>(T);
+            S v = T.k1 * gal_h<g, g2>(T) + a * gal_g<g2>(T);
             if constexpr (g2 < 2) {   // then g < 2 as well (upper triangle)
-                const double f0h = (g + g2 == 0) ? T.f0h0 : ((g + g2 == 1) ? T.f0h1 : T.f0h2);
+                const S f0h = (g + g2 == 0) ? T.f0h0 : ((g + g2 == 1) ? T.f0h1 : T.f0h2);
                 v += T.k0 * f0h + (T.Wsg * gal_g<g>(T) + T.Wss * star_g<g>(T)) * star_g<g2>(T);
             }
             return v;
@@ -875,35 +891,38 @@ constexpr bool entry_is_zero() {
     if (E > ZV && E < ACC_CNT) { const int i = hess_row(E), j = hess_col(E); return i >= 2 && i < 4 && j < 4; }
     return false;
 }
-template <int MODE, int E>
-__device__ __forceinline__ void accum_entries(const PixelTerms &T, double *__restrict__ slot) {
+// (The slots are fp64 in the single-precision mode too -- the entry is widened for the add: ds_add_f32 turned out four
+// times slower than ds_add_f64 on gfx950 in this access pattern, 35.9 against 8.2 ms for the config-5 sweep, and its
+// sums differed between two launches.)
+template <int MODE, int E, class TT>
+__device__ __forceinline__ void accum_entries(const TT &T, double *__restrict__ slot) {
     constexpr bool hess_only = E > ZV && E < ACC_CNT;
     if constexpr (!(MODE == 1 && hess_only) && !entry_is_zero<E>())
-        __hip_atomic_fetch_add(slot + ACC_SLOTS * E, record_entry<E>(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(slot + ACC_SLOTS * E, (double)record_entry<E>(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if constexpr (E + 1 < ACC_N) accum_entries<MODE, E + 1>(T, slot);
 }
 
 // the same in two steps: the values (pinned in registers by an empty asm, so that they are formed where this is called),
 // then the adds
-template <int MODE, int E>
-__device__ __forceinline__ void form_entries(const PixelTerms &T, double (&ent)[ACC_N]) {
+template <int MODE, int E, class TT>
+__device__ __forceinline__ void form_entries(const TT &T, typename TT::scalar (&ent)[ACC_N]) {
     constexpr bool hess_only = E > ZV && E < ACC_CNT;
     if constexpr (!(MODE == 1 && hess_only) && !entry_is_zero<E>()) { ent[E] = record_entry<E>(T); asm volatile("" : "+v"(ent[E])); }
     if constexpr (E + 1 < ACC_N) form_entries<MODE, E + 1>(T, ent);
 }
-template <int MODE, int E>
-__device__ __forceinline__ void add_entries(const double (&ent)[ACC_N], double *__restrict__ slot) {
+template <int MODE, int E, typename S>
+__device__ __forceinline__ void add_entries(const S (&ent)[ACC_N], double *__restrict__ slot) {
     constexpr bool hess_only = E > ZV && E < ACC_CNT;
     if constexpr (!(MODE == 1 && hess_only) && !entry_is_zero<E>())
-        __hip_atomic_fetch_add(slot + ACC_SLOTS * E, ent[E], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(slot + ACC_SLOTS * E, (double)ent[E], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if constexpr (E + 1 < ACC_N) add_entries<MODE, E + 1>(ent, slot);
 }
 
 // Split variant (CELESTE_FLAG_SPLIT): instead of folding, every pixel's 68-entry record goes to HBM, entry-major
 // inside a 64-pixel tile (rec[e * 64 + lane]) so that each store instruction writes one contiguous 512-byte row.
-template <int E>
-__device__ __forceinline__ void store_entries(const PixelTerms &T, double *__restrict__ tile_lane) {
-    __builtin_nontemporal_store(record_entry<E>(T), tile_lane + E * 64);
+template <int E, class TT>
+__device__ __forceinline__ void store_entries(const TT &T, double *__restrict__ tile_lane) {
+    __builtin_nontemporal_store((double)record_entry<E>(T), tile_lane + E * 64);
     if constexpr (E + 1 < ACC_N) store_entries<E + 1>(T, tile_lane);
 }
 
@@ -1087,17 +1106,20 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
 // v_pk_mul_f32 (NC = 14 psf_K is even); only the exponential is evaluated per half.  The two halves of every sum are
 // added at the end.  Same arithmetic per component as galaxy_sums<MODE, float>.
 typedef float f2v __attribute__((ext_vector_type(2)));
-template <int MODE>
-__device__ __forceinline__ double galaxy_sums_pk(const CompR<float> *tc, int nc, float dx, float dy, PixelTerms &T) {
+template <int MODE, class TT>
+__device__ __forceinline__ typename TT::scalar galaxy_sums_pk(const CompR<float> *tc, int nc, float dx, float dy, TT &T) {
+    typedef typename TT::scalar S;
     const f2v z = (f2v)(0.0f);
     f2v S0 = z, S0d = z, S1x = z, S1y = z, S1xd = z, S1yd = z;
     f2v S2a = z, S2b = z, S2c = z, S2an = z, S2bn = z, S2cn = z, S2ad = z, S2bd = z, S2cd = z;
     f2v S3a = z, S3b = z, S3c = z, S3d = z, S4a = z, S4b = z, S4c = z, S4d = z, S4e = z;
     const f2v dxx = (f2v)(dx), dyy = (f2v)(dy);
+    // the records are staged pair-interleaved (pixel_kernel's prologue): field i of components c, c + 1 sits in the two
+    // halves of one 8-byte slot, so the packed operands come out of the LDS reads as they are (13 v_mov per trip saved)
+    const f2v *tp = reinterpret_cast<const f2v *>(tc);
     for (int c = 0; c < nc; c += 2) {
-        const CompR<float> a = tc[c], b = tc[c + 1];
-        const f2v p11 = {a.p11, b.p11}, p12 = {a.p12, b.p12}, p22 = {a.p22, b.p22};
-        const f2v xi1 = {a.xi1, b.xi1}, xi2 = {a.xi2, b.xi2}, w0 = {a.w0, b.w0}, wd = {a.wd, b.wd}, nu = {a.nu, b.nu};
+        const f2v *k = tp + 4 * c;      // 8 slots per pair of components
+        const f2v p11 = k[0], p12 = k[1], p22 = k[2], w0 = k[3], wd = k[4], nu = k[5], xi1 = k[6], xi2 = k[7];
         const f2v d1 = dxx - xi1, d2 = dyy - xi2;
         const f2v u = p11 * d1 + p12 * d2, v = p12 * d1 + p22 * d2;
         const f2v q = -0.5f * (d1 * u + d2 * v);
@@ -1121,12 +1143,12 @@ __device__ __forceinline__ double galaxy_sums_pk(const CompR<float> *tc, int nc,
             S4a += h4a * fnn; S4b += h4b * fnn; S4c += h4c * fnn; S4d += h4d * fnn; S4e += h4e * fnn;
         }
     }
-#define PKSUM(name) T.name = (double)name.x + (double)name.y
+#define PKSUM(name) T.name = (S)name.x + (S)name.y
     PKSUM(S0d); PKSUM(S1x); PKSUM(S1y); PKSUM(S1xd); PKSUM(S1yd);
     PKSUM(S2a); PKSUM(S2b); PKSUM(S2c); PKSUM(S2an); PKSUM(S2bn); PKSUM(S2cn); PKSUM(S2ad); PKSUM(S2bd); PKSUM(S2cd);
     PKSUM(S3a); PKSUM(S3b); PKSUM(S3c); PKSUM(S3d); PKSUM(S4a); PKSUM(S4b); PKSUM(S4c); PKSUM(S4d); PKSUM(S4e);
 #undef PKSUM
-    return (double)S0.x + (double)S0.y;
+    return (S)S0.x + (S)S0.y;
 }
 
 
@@ -1243,7 +1265,6 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
     const DevPatch &P = *W.P;
     const SrcImg &si = W.si;
     const int H2 = P.H2, W2 = P.W2;
-    const double c0 = si.c0, c1 = si.c1, q0 = si.q0, q1 = si.q1;
     // index offsets of the star spline: itp[h - m1 + 26, w - m2 + 26]
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
     const int NC = W.NC;
@@ -1270,6 +1291,7 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
                 f1 = galaxy_value(W.tc, NC, hh - si.m1, ww - si.m2, etab);
             }
             if (valid) {
+                const double c0 = si.c0, c1 = si.c1, q0 = si.q0, q1 = si.q1;
                 const double A = c0 * f0 + c1 * f1;
                 const double E = Ebar + A;
                 const double V = Vbar + ((q0 * (f0 * f0) + q1 * (f1 * f1)) - A * A);
@@ -1281,8 +1303,11 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
             return;
         }
 
-        PixelTerms T;
-        double S0 = 0;
+        // S: the arithmetic type of everything per pixel outside the component loop -- double, or float in the
+        // single-precision mode (the loop's type R)
+        typedef R S;
+        PixelTermsT<S> T;
+        S S0 = 0;
         T.S0d = 0; T.S1x = 0; T.S1y = 0; T.S1xd = 0; T.S1yd = 0;
         T.S2a = 0; T.S2b = 0; T.S2c = 0; T.S2an = 0; T.S2bn = 0; T.S2cn = 0; T.S2ad = 0; T.S2bd = 0; T.S2cd = 0;
         T.S3a = 0; T.S3b = 0; T.S3c = 0; T.S3d = 0; T.S4a = 0; T.S4b = 0; T.S4c = 0; T.S4d = 0; T.S4e = 0;
@@ -1303,9 +1328,10 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
 #endif
 #undef LOAD_PIXEL_INPUTS
         const bool valid = I.valid, dup = I.dup, own = valid && own_geo;
-        const double x = I.x, Ebar = I.Ebar, Vbar = I.Vbar, lgx = I.lgx, iota = I.iota, log_iota = I.log_iota;
+        const S x = (S)I.x, Ebar = (S)I.Ebar, Vbar = (S)I.Vbar, lgx = (S)I.lgx, iota = (S)I.iota, log_iota = (S)I.log_iota;
         const int n_inact = I.n_inact;
-        T.f1 = own ? S0 : 0.0;
+        const S c0 = (S)si.c0, c1 = (S)si.c1, q0 = (S)si.q0, q1 = (S)si.q1;
+        T.f1 = own ? S0 : (S)0.0;
 
         // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
         T.f0 = 0; T.f0g0 = 0; T.f0g1 = 0; T.f0h0 = 0; T.f0h1 = 0; T.f0h2 = 0;
@@ -1314,31 +1340,31 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
 #else
         if (own) {
 #endif
-            const double xh = hh + sh0, xw = ww + sw0;
+            const double xh = hh + sh0, xw = ww + sw0;     // (the cell index and the offset inside the cell from fp64 coordinates)
             int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
             int iy = (int)floor(xw); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
             const double *cc = tcoef + (ix - 1) + CEL_COEF * (iy - 1);
-            const double fx = xh - ix, fy = xw - iy;
-            double wx[4], wy[4], dwx[4], ddwx[4], dwy[4], ddwy[4];
+            const S fx = (S)(xh - ix), fy = (S)(xw - iy);
+            S wx[4], wy[4], dwx[4], ddwx[4], dwy[4], ddwy[4];
             bspline_w(fx, wx); bspline_w(fy, wy);
             bspline_dw(fx, dwx, ddwx); bspline_dw(fy, dwy, ddwy);
-            double y = 0, yx = 0, yy = 0, yxx = 0, yxy = 0, yyy = 0;
+            S y = 0, yx = 0, yy = 0, yxx = 0, yxy = 0, yyy = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const double *cb = cc + CEL_COEF * b;
-                const double k0 = cb[0], k1 = cb[1], k2 = cb[2], k3 = cb[3];
-                const double r = k0 * wx[0] + k1 * wx[1] + k2 * wx[2] + k3 * wx[3];
-                const double rx = k0 * dwx[0] + k1 * dwx[1] + k2 * dwx[2] + k3 * dwx[3];
-                const double rxx = k0 * ddwx[0] + k1 * ddwx[1] + k2 * ddwx[2] + k3 * ddwx[3];
+                const S k0 = (S)cb[0], k1 = (S)cb[1], k2 = (S)cb[2], k3 = (S)cb[3];
+                const S r = k0 * wx[0] + k1 * wx[1] + k2 * wx[2] + k3 * wx[3];
+                const S rx = k0 * dwx[0] + k1 * dwx[1] + k2 * dwx[2] + k3 * dwx[3];
+                const S rxx = k0 * ddwx[0] + k1 * ddwx[1] + k2 * ddwx[2] + k3 * ddwx[3];
                 y += r * wy[b]; yx += rx * wy[b]; yxx += rxx * wy[b];
                 yy += r * dwy[b]; yxy += rx * dwy[b]; yyy += r * ddwy[b];
             }
             // softpluslikeinv and its derivatives; not C2 at 0, branch exactly (fsm_util.jl:222)
-            double gv, gp, gpp;
-            if (y < 0) { gv = 1e-3 * exp(y); gp = gv; gpp = gv; }
-            else { gv = 1e-3 * (y + 1.0); gp = 1e-3; gpp = 0.0; }
+            S gv, gp, gpp;
+            if (y < 0) { gv = (S)1e-3 * exp_s(y); gp = gv; gpp = gv; }
+            else { gv = (S)1e-3 * (y + (S)1.0); gp = (S)1e-3; gpp = (S)0.0; }
             T.f0 = gv;
-            const double ym1 = -yx, ym2 = -yy;  // d(index)/dm = -1
+            const S ym1 = -yx, ym2 = -yy;  // d(index)/dm = -1
             T.f0g0 = gp * ym1; T.f0g1 = gp * ym2;
             T.f0h0 = gpp * ym1 * ym1 + gp * yxx;
             T.f0h1 = gpp * ym1 * ym2 + gp * yxy;
@@ -1347,65 +1373,66 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
 
         // ---- per-pixel term (add_pixel_term!, add_elbo_log_term!) ----
         {
-            const double A = c0 * T.f0 + c1 * T.f1;                       // E_G_s.v
-            const double B = q0 * (T.f0 * T.f0) + q1 * (T.f1 * T.f1);     // E_G2_s.v
-            const double E = valid ? Ebar + A : 1.0;                      // E_G.v
-            const double V = Vbar + (B - A * A);                          // var_G.v
-            const double iE = 1.0 / E;
-            const double iE2 = iE * iE, iE3 = iE2 * iE;
-            T.vterm = (valid && !(MULTI && dup)) ? x * (log_iota + (log(E) - V * (0.5 * iE2))) - iota * E - lgx : 0.0;
-            T.cnt_act = own ? 1.0 : 0.0;
-            T.cnt_inact = (double)n_inact;
+            const S A = c0 * T.f0 + c1 * T.f1;                       // E_G_s.v
+            const S B = q0 * (T.f0 * T.f0) + q1 * (T.f1 * T.f1);     // E_G2_s.v
+            const S E = valid ? Ebar + A : (S)1.0;                   // E_G.v
+            const S V = Vbar + (B - A * A);                          // var_G.v
+            const S iE = (S)1.0 / E;
+            const S iE2 = iE * iE, iE3 = iE2 * iE;
+            T.vterm = (valid && !(MULTI && dup)) ? x * (log_iota + (log_s(E) - V * ((S)0.5 * iE2))) - iota * E - lgx : (S)0.0;
+            T.cnt_act = own ? (S)1.0 : (S)0.0;
+            T.cnt_inact = (S)n_inact;
             // derivative weights are zero unless the active source covers the pixel, which zeroes every
             // derivative entry of the record (all lanes take part in the cross-lane exchange below)
-            const double xo = own ? x : 0.0, io = own ? iota : 0.0;
-            const double w1 = xo * (iE + V * iE3) - io;            // dT/dE
-            T.w2 = -0.5 * xo * iE2;                                // dT/dVar
-            const double w11 = -xo * (iE2 + 3.0 * V * iE2 * iE2);  // d2T/dE2
-            T.w12 = xo * iE3;                                      // d2T/dE dVar
-            T.alpha = w1 - 2.0 * A * T.w2;
-            T.beta = w11 - 2.0 * T.w2 - 4.0 * A * T.w12;
-            T.k1 = T.alpha * c1 + 2.0 * T.w2 * q1 * T.f1;          // multiplies d2 f1
-            T.k0 = T.alpha * c0 + 2.0 * T.w2 * q0 * T.f0;          // multiplies d2 f0
+            const S xo = own ? x : (S)0.0, io = own ? iota : (S)0.0;
+            const S w1 = xo * (iE + V * iE3) - io;                   // dT/dE
+            T.w2 = (S)-0.5 * xo * iE2;                               // dT/dVar
+            const S w11 = -xo * (iE2 + (S)3.0 * V * iE2 * iE2);      // d2T/dE2
+            T.w12 = xo * iE3;                                        // d2T/dE dVar
+            T.alpha = w1 - (S)2.0 * A * T.w2;
+            T.beta = w11 - (S)2.0 * T.w2 - (S)4.0 * A * T.w12;
+            T.k1 = T.alpha * c1 + (S)2.0 * T.w2 * q1 * T.f1;         // multiplies d2 f1
+            T.k0 = T.alpha * c0 + (S)2.0 * T.w2 * q0 * T.f0;         // multiplies d2 f0
             {
-                const double t0 = 2.0 * T.w12 * q0 * T.f0, t1 = 2.0 * T.w12 * q1 * T.f1;
-                const double P0 = T.beta * c0 + t0, P1 = T.beta * c1 + t1;      // beta dA + w12 dB = P0 ds + P1 dg
+                const S t0 = (S)2.0 * T.w12 * q0 * T.f0, t1 = (S)2.0 * T.w12 * q1 * T.f1;
+                const S P0 = T.beta * c0 + t0, P1 = T.beta * c1 + t1;      // beta dA + w12 dB = P0 ds + P1 dg
                 T.C0s = T.alpha + T.f0 * P0; T.C0g = T.f0 * P1;
                 T.C1s = T.f1 * P0; T.C1g = T.alpha + T.f1 * P1;
-                const double v0 = T.w12 * (T.f0 * T.f0), v1 = T.w12 * (T.f1 * T.f1), u0 = 2.0 * T.w2 * T.f0, u1 = 2.0 * T.w2 * T.f1;
+                const S v0 = T.w12 * (T.f0 * T.f0), v1 = T.w12 * (T.f1 * T.f1), u0 = (S)2.0 * T.w2 * T.f0, u1 = (S)2.0 * T.w2 * T.f1;
                 T.Q0s = u0 + v0 * c0; T.Q0g = v0 * c1;                          // 2 w2 f0 ds + w12 f0^2 dA
                 T.Q1s = v1 * c0; T.Q1g = u1 + v1 * c1;
-                T.Wgg = 2.0 * T.w2 * q1 + c1 * (P1 + t1);
-                T.Wss = 2.0 * T.w2 * q0 + c0 * (P0 + t0);
+                T.Wgg = (S)2.0 * T.w2 * q1 + c1 * (P1 + t1);
+                T.Wss = (S)2.0 * T.w2 * q0 + c0 * (P0 + t0);
                 T.Wsg = c0 * P1 + c1 * t0;
             }
         }
+        double *const slot_s = slot;
         if constexpr (MODE == 3)
             store_entries<0>(T, W.rec + (size_t)(W.tile_off[W.v] + (base >> 6)) * (ACC_N * 64) + lane);
         else if constexpr (GATED) {
             // several wavefronts share the slots and add in turn: the entries are formed BEFORE a wavefront waits for its
             // turn (they fit the registers the component loop no longer needs), so a turn is 65 LDS adds long, not 600 VALU
             // instructions + 65 adds
-            double ent[ACC_N];
+            S ent[ACC_N];
             form_entries<MODE, 0>(T, ent);
             gate();
-            add_entries<MODE, 0>(ent, slot);
+            add_entries<MODE, 0>(ent, slot_s);
         } else {
             gate();
-            accum_entries<MODE, 0>(T, slot);
+            accum_entries<MODE, 0>(T, slot_s);
         }
     }
 }
 
 // lane e sums the 16 slots of entry e (rotated start: 4-way instead of 64-way bank conflicts; the order of the additions
 // is fixed per entry, so the record is reproducible) and hands the sum to store(e, s)
-template <int MODE, class Store>
-__device__ __forceinline__ void fold_record_slots(const double *__restrict__ sacc, int lane, Store &&store) {
+template <int MODE, typename S, class Store>
+__device__ __forceinline__ void fold_record_slots(const S *__restrict__ sacc, int lane, Store &&store) {
     for (int e = lane; e < ACC_N; e += 64) {
         if (MODE == 1 && e > ZV && e < ACC_CNT) continue;   // Hessian entries are not produced
-        double s = 0.0;
+        double s = 0.0;                                      // (fp32 slots are widened here: the record is fp64)
 #pragma unroll
-        for (int k = 0; k < ACC_SLOTS; ++k) s += sacc[e * ACC_SLOTS + ((k + e) & (ACC_SLOTS - 1))];
+        for (int k = 0; k < ACC_SLOTS; ++k) s += (double)sacc[e * ACC_SLOTS + ((k + e) & (ACC_SLOTS - 1))];
         store(e, s);
     }
 }
@@ -1451,7 +1478,10 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     // Workgroup prologue: the exp table and the target's components (64-byte records) are staged in LDS with
     // one coalesced read each and a single barrier (the scalar data cache cannot hold 8 waves x 1.8 KB per CU:
     // 68 % of per-component s_loads missed to L2).
-    __shared__ Comp tc[14 * CEL_MAXK];
+    // (the fp64 copy is what the value-only mode and the fp64 loop read: the single-precision instantiations with
+    // derivatives do not keep it -- 3.5 KB of LDS less per workgroup, which is what lets a third wavefront per SIMD in)
+    constexpr bool keep_tc = sizeof(R) == 8 || MODE == 0;
+    __shared__ Comp tc[keep_tc ? 14 * CEL_MAXK : 1];
     __shared__ CompR<R> tcr_f[sizeof(R) == 4 ? 14 * CEL_MAXK : 1];
     {
         const double *src = reinterpret_cast<const double *>(comps + (size_t)v * NC);
@@ -1460,8 +1490,9 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         const double tabv = g_exp2_table[lane];
         for (int i = lane; i < NC * 8; i += 64) {
             const double v = src[i];
-            dst[i] = v;
-            if (sizeof(R) == 4) dstf[i] = (R)v;
+            if (keep_tc) dst[i] = v;
+            // fp32 loop: pair-interleaved -- field f of component c at slot (c / 2) * 8 + f, half c & 1 (galaxy_sums_pk)
+            if (sizeof(R) == 4) { const int c = i >> 3, f = i & 7; dstf[((c >> 1) * 8 + f) * 2 + (c & 1)] = (R)v; }
         }
         etab[lane] = tabv;
         __syncthreads();
