@@ -1106,49 +1106,75 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
 // v_pk_mul_f32 (NC = 14 psf_K is even); only the exponential is evaluated per half.  The two halves of every sum are
 // added at the end.  Same arithmetic per component as galaxy_sums<MODE, float>.
 typedef float f2v __attribute__((ext_vector_type(2)));
+#define PKSLOTS 12   // 8-byte slots per PAIR of components in the fp32 record table: the eight fields of Comp, then -2 p12, -3 p11, -3 p12, -3 p22
 template <int MODE, class TT>
-__device__ __forceinline__ typename TT::scalar galaxy_sums_pk(const CompR<float> *tc, int nc, float dx, float dy, TT &T) {
+__device__ __forceinline__ typename TT::scalar galaxy_sums_pk(const CompR<float> *tc, int n_dev, int nc, float dx, float dy,
+                                                              float dev, TT &T) {
     typedef typename TT::scalar S;
     const f2v z = (f2v)(0.0f);
-    f2v S0 = z, S0d = z, S1x = z, S1y = z, S1xd = z, S1yd = z;
-    f2v S2a = z, S2b = z, S2c = z, S2an = z, S2bn = z, S2cn = z, S2ad = z, S2bd = z, S2cd = z;
-    f2v S3a = z, S3b = z, S3c = z, S3d = z, S4a = z, S4b = z, S4c = z, S4d = z, S4e = z;
     const f2v dxx = (f2v)(dx), dyy = (f2v)(dy);
     // the records are staged pair-interleaved (pixel_kernel's prologue): field i of components c, c + 1 sits in the two
     // halves of one 8-byte slot, so the packed operands come out of the LDS reads as they are (13 v_mov per trip saved)
     const f2v *tp = reinterpret_cast<const f2v *>(tc);
-    for (int c = 0; c < nc; c += 2) {
-        const f2v *k = tp + 4 * c;      // 8 slots per pair of components
-        const f2v p11 = k[0], p12 = k[1], p22 = k[2], w0 = k[3], wd = k[4], nu = k[5], xi1 = k[6], xi2 = k[7];
-        const f2v d1 = dxx - xi1, d2 = dyy - xi2;
-        const f2v u = p11 * d1 + p12 * d2, v = p12 * d1 + p22 * d2;
-        const f2v q = -0.5f * (d1 * u + d2 * v);
-        const f2v e = {__expf(q.x), __expf(q.y)};
-        const f2v f = w0 * e, fd = wd * e, fn = f * nu;
-        const f2v ha = u * u - p11, hb = u * v - p12, hc = v * v - p22;
-        S0 += f; S0d += fd;
-        S1x += u * f; S1y += v * f;
-        S2an += ha * fn; S2bn += hb * fn; S2cn += hc * fn;
-        if (MODE == 2) {
-            const f2v fdn = fd * nu, fnn = fn * nu;
-            S1xd += u * fd; S1yd += v * fd;
+    if constexpr (MODE == 2) {
+        // as in galaxy_sums: the six sums that exist f-weighted and d-weighted are accumulated once, d-weighted, per profile
+        // type (U0: de Vaucouleurs, U1: exponential, carrying wd's minus sign); pairs never straddle the types (8 psf_K and
+        // 6 psf_K are even).  18 packed accumulations per pair instead of 24, and the Hermite polynomials take their
+        // multiples of the precision matrix from the record (comp_extra's constants).
+        f2v U0[6] = {z, z, z, z, z, z}, U1[6] = {z, z, z, z, z, z};
+        f2v S2a = z, S2b = z, S2c = z, S3a = z, S3b = z, S3c = z, S3d = z, S4a = z, S4b = z, S4c = z, S4d = z, S4e = z;
+        auto pair = [&](int c, f2v (&U)[6]) {
+            const f2v *k = tp + (PKSLOTS / 2) * c;
+            const f2v p11 = k[0], p12 = k[1], p22 = k[2], w0 = k[3], wd = k[4], nu = k[5], xi1 = k[6], xi2 = k[7];
+            const f2v m2p12 = k[8], m3p11 = k[9], m3p12 = k[10], m3p22 = k[11];
+            const f2v d1 = dxx - xi1, d2 = dyy - xi2;
+            const f2v u = p11 * d1 + p12 * d2, v = p12 * d1 + p22 * d2;
+            const f2v q = -0.5f * (d1 * u + d2 * v);
+            const f2v e = {__expf(q.x), __expf(q.y)};
+            const f2v f = w0 * e, g = wd * e, fn = f * nu, gn = g * nu, fnn = fn * nu;
+            const f2v ha = u * u - p11, hb = u * v - p12, hc = v * v - p22;
+            U[0] += g; U[1] += u * g; U[2] += v * g;
+            U[3] += ha * gn; U[4] += hb * gn; U[5] += hc * gn;
             S2a += ha * f; S2b += hb * f; S2c += hc * f;
-            S2ad += ha * fdn; S2bd += hb * fdn; S2cd += hc * fdn;
-            const f2v h3a = u * (ha - 2.0f * p11), h3b = v * ha - 2.0f * u * p12, h3c = u * hc - 2.0f * v * p12,
-                      h3d = v * (hc - 2.0f * p22);
+            const f2v h3a = u * (ha - 2.0f * p11), h3b = v * ha + u * m2p12, h3c = u * hc + v * m2p12, h3d = v * (hc - 2.0f * p22);
             S3a += h3a * fn; S3b += h3b * fn; S3c += h3c * fn; S3d += h3d * fn;
-            const f2v h4a = u * h3a - 3.0f * ha * p11, h4b = v * h3a - 3.0f * ha * p12,
-                      h4c = u * h3c - 2.0f * hb * p12 - hc * p11, h4d = u * h3d - 3.0f * hc * p12,
-                      h4e = v * h3d - 3.0f * hc * p22;
+            const f2v h4a = u * h3a + ha * m3p11, h4b = v * h3a + ha * m3p12, h4c = u * h3c + (hb * m2p12 - hc * p11),
+                      h4d = u * h3d + hc * m3p12, h4e = v * h3d + hc * m3p22;
             S4a += h4a * fnn; S4b += h4b * fnn; S4c += h4c * fnn; S4d += h4d * fnn; S4e += h4e * fnn;
+        };
+        for (int c = 0; c < n_dev; c += 2) pair(c, U0);
+        for (int c = n_dev; c < nc; c += 2) pair(c, U1);
+        const S th0 = (S)dev, th1 = (S)1.0 - (S)dev;
+#define PKH(v) ((S)(v).x + (S)(v).y)
+        const S u0[6] = {PKH(U0[0]), PKH(U0[1]), PKH(U0[2]), PKH(U0[3]), PKH(U0[4]), PKH(U0[5])};
+        const S u1[6] = {PKH(U1[0]), PKH(U1[1]), PKH(U1[2]), PKH(U1[3]), PKH(U1[4]), PKH(U1[5])};
+        T.S0d = u0[0] + u1[0]; T.S1xd = u0[1] + u1[1]; T.S1yd = u0[2] + u1[2];
+        T.S2ad = u0[3] + u1[3]; T.S2bd = u0[4] + u1[4]; T.S2cd = u0[5] + u1[5];
+        T.S1x = th0 * u0[1] - th1 * u1[1]; T.S1y = th0 * u0[2] - th1 * u1[2];
+        T.S2an = th0 * u0[3] - th1 * u1[3]; T.S2bn = th0 * u0[4] - th1 * u1[4]; T.S2cn = th0 * u0[5] - th1 * u1[5];
+        T.S2a = PKH(S2a); T.S2b = PKH(S2b); T.S2c = PKH(S2c);
+        T.S3a = PKH(S3a); T.S3b = PKH(S3b); T.S3c = PKH(S3c); T.S3d = PKH(S3d);
+        T.S4a = PKH(S4a); T.S4b = PKH(S4b); T.S4c = PKH(S4c); T.S4d = PKH(S4d); T.S4e = PKH(S4e);
+        return th0 * u0[0] - th1 * u1[0];
+    } else {
+        f2v S0 = z, S0d = z, S1x = z, S1y = z, S2an = z, S2bn = z, S2cn = z;
+        for (int c = 0; c < nc; c += 2) {
+            const f2v *k = tp + (PKSLOTS / 2) * c;
+            const f2v p11 = k[0], p12 = k[1], p22 = k[2], w0 = k[3], wd = k[4], nu = k[5], xi1 = k[6], xi2 = k[7];
+            const f2v d1 = dxx - xi1, d2 = dyy - xi2;
+            const f2v u = p11 * d1 + p12 * d2, v = p12 * d1 + p22 * d2;
+            const f2v q = -0.5f * (d1 * u + d2 * v);
+            const f2v e = {__expf(q.x), __expf(q.y)};
+            const f2v f = w0 * e, fd = wd * e, fn = f * nu;
+            const f2v ha = u * u - p11, hb = u * v - p12, hc = v * v - p22;
+            S0 += f; S0d += fd;
+            S1x += u * f; S1y += v * f;
+            S2an += ha * fn; S2bn += hb * fn; S2cn += hc * fn;
         }
+        T.S0d = PKH(S0d); T.S1x = PKH(S1x); T.S1y = PKH(S1y); T.S2an = PKH(S2an); T.S2bn = PKH(S2bn); T.S2cn = PKH(S2cn);
+        return PKH(S0);
+#undef PKH
     }
-#define PKSUM(name) T.name = (S)name.x + (S)name.y
-    PKSUM(S0d); PKSUM(S1x); PKSUM(S1y); PKSUM(S1xd); PKSUM(S1yd);
-    PKSUM(S2a); PKSUM(S2b); PKSUM(S2c); PKSUM(S2an); PKSUM(S2bn); PKSUM(S2cn); PKSUM(S2ad); PKSUM(S2bd); PKSUM(S2cd);
-    PKSUM(S3a); PKSUM(S3b); PKSUM(S3c); PKSUM(S3d); PKSUM(S4a); PKSUM(S4b); PKSUM(S4c); PKSUM(S4d); PKSUM(S4e);
-#undef PKSUM
-    return (S)S0.x + (S)S0.y;
 }
 
 
@@ -1320,7 +1346,7 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
         // inside the patch costs one wasted evaluation; its record entries are zeroed by the weights below).
         if (own_geo) {
 #endif
-            if constexpr (sizeof(R) == 4) S0 = galaxy_sums_pk<GM>(W.tcr, NC, (float)(hh - si.m1), (float)(ww - si.m2), T);
+            if constexpr (sizeof(R) == 4) S0 = galaxy_sums_pk<GM>(W.tcr, 8 * (NC / 14), NC, (float)(hh - si.m1), (float)(ww - si.m2), (float)si.dev, T);
             else S0 = galaxy_sums<GM, R>(W.tcr, 8 * (NC / 14), NC, (R)(hh - si.m1), (R)(ww - si.m2), (R)si.dev, etab, T, W.tcx);
         }
 #if !PIXEL_LOADS_FIRST
@@ -1442,7 +1468,7 @@ __device__ __forceinline__ void fold_record_slots(const S *__restrict__ sacc, in
 // MULTI: several active sources (celeste_elbo_eval_multi) -- compiled separately so that the production
 // instantiation carries none of its per-neighbour bookkeeping
 template <int MODE, typename R, bool MULTI = false>
-__global__ void __launch_bounds__(64, PIXEL_WAVES)
+__global__ void __launch_bounds__(64, sizeof(R) == 4 ? 3 : PIXEL_WAVES)   // the single-precision kernels fit three waves per SIMD
 pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ patches,
              const double *__restrict__ coefs, const uint8_t *__restrict__ bitmaps,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
@@ -1482,7 +1508,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     // derivatives do not keep it -- 3.5 KB of LDS less per workgroup, which is what lets a third wavefront per SIMD in)
     constexpr bool keep_tc = sizeof(R) == 8 || MODE == 0;
     __shared__ Comp tc[keep_tc ? 14 * CEL_MAXK : 1];
-    __shared__ CompR<R> tcr_f[sizeof(R) == 4 ? 14 * CEL_MAXK : 1];
+    __shared__ float tcr_f[sizeof(R) == 4 ? PKSLOTS * 14 * CEL_MAXK : 1];   // PKSLOTS slots of two floats per pair of components
     {
         const double *src = reinterpret_cast<const double *>(comps + (size_t)v * NC);
         double *dst = reinterpret_cast<double *>(tc);
@@ -1491,8 +1517,16 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         for (int i = lane; i < NC * 8; i += 64) {
             const double v = src[i];
             if (keep_tc) dst[i] = v;
-            // fp32 loop: pair-interleaved -- field f of component c at slot (c / 2) * 8 + f, half c & 1 (galaxy_sums_pk)
-            if (sizeof(R) == 4) { const int c = i >> 3, f = i & 7; dstf[((c >> 1) * 8 + f) * 2 + (c & 1)] = (R)v; }
+            // fp32 loop: pair-interleaved -- field f of component c at slot (c / 2) PKSLOTS + f, half c & 1, followed by
+            // comp_extra's multiples of the precision matrix (galaxy_sums_pk)
+            if (sizeof(R) == 4) {
+                const int c = i >> 3, f = i & 7;
+                R *const rec = dstf + (c >> 1) * (2 * PKSLOTS) + (c & 1);
+                rec[2 * f] = (R)v;
+                if (f == 0) rec[2 * 9] = (R)(-3.0 * v);
+                if (f == 1) { rec[2 * 8] = (R)(-2.0 * v); rec[2 * 10] = (R)(-3.0 * v); }
+                if (f == 2) rec[2 * 11] = (R)(-3.0 * v);
+            }
         }
         etab[lane] = tabv;
         __syncthreads();
@@ -1514,7 +1548,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     W.N = N; W.n = n; W.NC = NC; W.v = v;
     W.si = srcimg[v];
     W.tc = tc; W.tcx = tcx;
-    W.tcr = sizeof(R) == 4 ? tcr_f : reinterpret_cast<const CompR<R> *>(tc);
+    W.tcr = sizeof(R) == 4 ? reinterpret_cast<const CompR<R> *>(tcr_f) : reinterpret_cast<const CompR<R> *>(tc);
     W.etab = etab;
     W.tcoef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
     W.tile_off = tile_off; W.rec = rec;

@@ -66,8 +66,10 @@ enum {
     CELESTE_FLAG_GRAD = 1u,
     CELESTE_FLAG_HESS = 2u,
     CELESTE_FLAG_KL = 4u,
-    /* single-precision galaxy component loop (BASELINE config 5, tolerance 1e-4 against the fp64 result);
-     * per-pixel terms, accumulation, the lift and the KL stay fp64.  No reference counterpart. */
+    /* single-precision pixel arithmetic (BASELINE config 5, tolerance 1e-4 against the fp64 result): the galaxy
+     * component loop (packed, two components per instruction), the star spline, the per-pixel term and the record
+     * entries are fp32; the chunk records they are summed into, the lift and the KL stay fp64.  Measured against the
+     * fp64 path on all 30 000 sources of config 5: 6e-6 / 5e-7 / 1.2e-6 on v / d / h.  No reference counterpart. */
     CELESTE_FLAG_FP32 = 8u,
     /* split variant of the pixel sum (measurement aid): the pixel kernel writes one
      * 68-double record per visited pixel to HBM and a separate streaming kernel forms the per-patch sums
