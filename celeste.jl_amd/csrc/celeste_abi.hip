@@ -87,6 +87,9 @@ struct celeste_ctx {
     std::vector<int32_t> h_vis_off, h_vis_img, h_vis_src;
     int32_t *d_vis_off = nullptr, *d_vis_img = nullptr, *d_vis_src = nullptr;
     int4 *d_value_items = nullptr;  // value_kernel work items: {neighbour's table entry, target's, chunk, target}
+    int4 *d_vitems_src = nullptr;   // the same, grouped by target
+    int32_t *d_vitem_off = nullptr; // S + 1 offsets into d_vitems_src
+    std::vector<int32_t> h_vitem_off;
     int64_t n_value_items = 0;
     int32_t *d_prep_mark = nullptr; // per source: stamp of the last batch that read its per-image tables
     double *d_lg_sum = nullptr;     // per visit: sum of lgamma(pixel + 1) over the patch's visited pixels
@@ -550,6 +553,17 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
             }
         c->n_value_items = (int64_t)desc.size();
         CTX_TRY(dev_upload(&c->d_value_items, desc.data(), desc.size()));
+        // the same items grouped by target (joint dataflow launch: an entry renders its own source's neighbours)
+        c->h_vitem_off.assign((size_t)c->S + 1, 0);
+        for (auto &d : desc) c->h_vitem_off[(size_t)d.w + 1]++;
+        for (int s = 0; s < c->S; ++s) c->h_vitem_off[s + 1] += c->h_vitem_off[s];
+        {
+            std::vector<int4> by_src(desc.size());
+            std::vector<int32_t> fill(c->h_vitem_off.begin(), c->h_vitem_off.end() - 1);
+            for (auto &d : desc) by_src[(size_t)fill[d.w]++] = d;
+            CTX_TRY(dev_upload(&c->d_vitems_src, by_src.data(), by_src.size()));
+            CTX_TRY(dev_upload(&c->d_vitem_off, c->h_vitem_off.data(), c->h_vitem_off.size()));
+        }
         CTX_TRY(dev_upload<int32_t>(&c->d_prep_mark, nullptr, (size_t)c->S));
         if (hipMemset(c->d_prep_mark, 0, (size_t)c->S * sizeof(int32_t)) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
     }
@@ -584,7 +598,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *ptrs[] = {c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
-                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_prep_mark, c->d_rec_off, c->d_lg_sum, c->d_nv_base, c->d_nbr_vis, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
+                    c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_vitems_src, c->d_vitem_off, c->d_prep_mark, c->d_rec_off, c->d_lg_sum, c->d_nv_base, c->d_nbr_vis, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     {
@@ -651,6 +665,9 @@ static void fused_args_tables(celeste_ctx_t *c, FusedArgs &A) {
     A.N = c->N; A.NC = c->NC; A.K = c->K; A.M = c->M; A.CH = c->CH; A.chunk_px = c->chunk_px;
     A.acc = c->d_acc;
     A.st = nullptr; A.Hstate = nullptr; A.q_items = nullptr; A.q_ctl = nullptr; A.q_cap = 0; A.timeout_ticks = 0;
+    A.j_R = 0; A.j_gshift = 0; A.j_dep = nullptr; A.j_succ_off = nullptr; A.j_succ = nullptr; A.j_vitem_off = nullptr;
+    A.j_vitems = nullptr; A.j_render_arr = nullptr; A.j_saved = nullptr; A.j_pos = nullptr; A.j_srcimg = nullptr;
+    A.j_comps = nullptr; A.j_geo = nullptr;
 }
 
 // per-target / per-record buffers of the fused kernels at capacity >= (n, rec)
@@ -1305,21 +1322,26 @@ static int optim_render(celeste_ctx_t *c, const double *d_table, int32_t n_targe
 }
 
 // how the batch is optimised: 1 = fused launch, 0 = chained
-static bool optim_use_fused(celeste_ctx_t *c, int32_t n_targets, int64_t n_chunks, const OptParams &op) {
+static bool optim_use_fused(celeste_ctx_t *c, int32_t n_targets, int64_t n_chunks, const OptParams &op, bool any_size = false) {
     int mode = -1;
     if (const char *e = getenv("CELESTE_OPT_FUSED")) mode = atoi(e);
     if (mode == 0) return false;
     const int64_t rec = n_chunks >= 0 ? n_chunks : std::min<int64_t>((int64_t)n_targets * c->max_src_chunks, (int64_t)n_targets * c->M * c->CH);
     const int64_t q = (rec + n_targets) * ((int64_t)op.max_iters + 2) + 4096;
     if (q > (int64_t)1 << 28) return false;   // a queue of more than 1 GiB of tickets: lock-step is the better tool
-    if (mode == 1) return true;
+    if (mode == 1 || any_size) return true;
     return n_targets <= FUSED_AUTO_MAX;
 }
 
 // The fused launch.  The targets have been initialised (optim_init_kernel) and rendered (optim_render) on `stream`;
 // asynchronous.  c->fused.h_ctl[FQC_ABORT] != 0 after the stream has drained: the launch gave up (see fused_kernels.h).
+// joint mode (celeste_joint_infer): the entries' dependency counters and successor lists, per-entry scratch
+struct JointLaunch {
+    int32_t *d_dep; const int32_t *d_succ_off, *d_succ; int32_t *d_render_arr; double *d_saved; const double *d_pos;
+    int gshift; size_t render_groups;   // bits of a render-group index; groups of the whole schedule
+};
 static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, const int32_t *d_targets, int64_t n_chunks,
-                           const OptParams &op, uint32_t flags, hipStream_t stream) {
+                           const OptParams &op, uint32_t flags, hipStream_t stream, const JointLaunch *J = nullptr) {
     auto &fb = c->fused;
     auto &ob = c->opt;
     const size_t n = (size_t)n_targets;
@@ -1327,13 +1349,14 @@ static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, co
                                               : std::min<int64_t>((int64_t)n_targets * c->max_src_chunks, (int64_t)n_targets * c->M * c->CH));
     if (!fb.max_resident) {
         int per_cu = 0, cus = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, optim_fused_kernel, FUSED_NT, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, optim_fused_kernel<true>, FUSED_NT, 0));
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
         fb.max_resident = std::max(1, std::min(per_cu, 2) * cus);
         if (const char *e = getenv("CELESTE_FUSED_GRID")) if (atoi(e) > 0) fb.max_resident = atoi(e);
     }
     const int G = (int)std::max<size_t>(1, std::min<size_t>((size_t)fb.max_resident, rec + n));
-    const size_t q_cap = (rec + n) * ((size_t)op.max_iters + 2) + (size_t)G + 64;
+    const size_t q_cap = (rec + n) * ((size_t)op.max_iters + 2) + (J ? n + J->render_groups : 0) + (size_t)G + 64;
+    if (q_cap > 0x7fffffffull) return CELESTE_ERR_INVALID_ARG;
     { int stb = fused_buffers(c, n, rec, stream); if (stb != CELESTE_OK) return stb; }
     if (q_cap > fb.cap_q) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1351,17 +1374,23 @@ static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, co
     fb.arrivals_dirty = true;      // (clean again only if the launch runs to its end: eval_fused re-checks)
     hipLaunchKernelGGL(fused_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_targets, n_targets,
                        c->d_patches, c->d_vis_off, c->dense ? nullptr : c->d_items, c->N, c->M, c->chunk_px, c->d_rec_off,
-                       fb.d_chunk_desc, fb.d_tgt_rec, fb.d_q_items, fb.d_q_ctl);
+                       fb.d_chunk_desc, fb.d_tgt_rec, fb.d_q_items, fb.d_q_ctl, J ? J->d_dep : nullptr, (int)rec);
     FusedArgs A;
     fused_args_tables(c, A);
     A.targets = d_targets; A.n_targets = n_targets; A.vp = d_vp;
     A.chunk_desc = fb.d_chunk_desc; A.tgt_rec = fb.d_tgt_rec;
     A.st = (OptState *)ob.d_state; A.Hstate = ob.d_H; A.op = op; A.flags = flags;
+    if (J) {
+        A.j_R = (int)rec; A.j_gshift = J->gshift; A.j_dep = J->d_dep; A.j_succ_off = J->d_succ_off; A.j_succ = J->d_succ;
+        A.j_vitem_off = c->d_vitem_off; A.j_vitems = c->d_vitems_src; A.j_render_arr = J->d_render_arr; A.j_saved = J->d_saved;
+        A.j_pos = J->d_pos; A.j_srcimg = c->d_srcimg; A.j_comps = c->d_comps; A.j_geo = c->d_geo;
+    }
     A.q_items = fb.d_q_items; A.q_ctl = fb.d_q_ctl; A.arrivals = fb.d_arrivals; A.q_cap = (int)std::min<size_t>(q_cap, 0x7fffffff);
     double tmo_s = 10.0;
     if (const char *e = getenv("CELESTE_FUSED_TIMEOUT_S")) if (atof(e) > 0) tmo_s = atof(e);
     A.timeout_ticks = (long long)(tmo_s * 1e8);   // wall_clock64: 100 MHz
-    hipLaunchKernelGGL(optim_fused_kernel, dim3((unsigned)G), dim3(FUSED_NT), 0, stream, A);
+    if (J) hipLaunchKernelGGL(optim_fused_kernel<true>, dim3((unsigned)G), dim3(FUSED_NT), 0, stream, A);
+    else hipLaunchKernelGGL(optim_fused_kernel<false>, dim3((unsigned)G), dim3(FUSED_NT), 0, stream, A);
     HIP_TRY(hipMemcpyAsync(fb.h_ctl, fb.d_q_ctl, FQC_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipGetLastError());
     return CELESTE_OK;
@@ -1533,6 +1562,95 @@ cleanup:
     return rc;
 }
 
+
+// ---- joint inference as ONE launch: the schedule's entries as a dataflow (fused_kernels.h, joint mode) ----------------
+#define JOINT_DATAFLOW_MAX 65536
+// *ran = false (and CELESTE_OK): the schedule does not fit the launch's encodings -- the caller runs it layer by layer
+static int joint_dataflow(celeste_ctx_t *c, int64_t total, const int32_t *targets, const int32_t *d_all, const double *d_pos,
+                          const OptParams &op, uint32_t flags, int32_t *d_it, int32_t *d_ev, double *d_el, int32_t *d_stt,
+                          hipStream_t stream, bool *ran) {
+    *ran = false;
+    const int E = (int)total;
+    auto &ob = c->opt;
+    auto &fb = c->fused;
+    // An entry waits for the last earlier entry that wrote a row it reads -- its source's, its neighbours' -- and for
+    // the earlier entries that read the row it writes: the order the layer-by-layer schedule enforces with barriers.
+    std::vector<int32_t> last((size_t)c->S, -1), dep((size_t)E, 0), deps;
+    std::vector<std::vector<int32_t>> readers((size_t)c->S), succ((size_t)E);
+    int64_t n_chunks = 0;
+    size_t groups = 0, gmax = 1;
+    for (int e = 0; e < E; ++e) {
+        const int t = targets[e];
+        deps.clear();
+        if (last[t] >= 0) deps.push_back(last[t]);
+        for (int64_t q = c->h_nbr_off[t]; q < c->h_nbr_off[t + 1]; ++q) if (last[c->h_nbr_idx[q]] >= 0) deps.push_back(last[c->h_nbr_idx[q]]);
+        deps.insert(deps.end(), readers[t].begin(), readers[t].end());
+        std::sort(deps.begin(), deps.end());
+        deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
+        for (int32_t d : deps) succ[(size_t)d].push_back(e);
+        dep[(size_t)e] = (int32_t)deps.size();
+        last[t] = e;
+        readers[t].clear();
+        for (int64_t q = c->h_nbr_off[t]; q < c->h_nbr_off[t + 1]; ++q) readers[c->h_nbr_idx[q]].push_back(e);
+        n_chunks += c->h_src_chunks[t];
+        const size_t g = ((size_t)(c->h_vitem_off[t + 1] - c->h_vitem_off[t]) + FUSED_WAVES - 1) / FUSED_WAVES;
+        groups += g; gmax = std::max(gmax, g);
+    }
+    std::vector<int32_t> succ_off((size_t)E + 1, 0), succ_flat;
+    size_t most = 0;
+    for (int e = 0; e < E; ++e) {
+        succ_off[(size_t)e + 1] = succ_off[(size_t)e] + (int32_t)succ[(size_t)e].size();
+        succ_flat.insert(succ_flat.end(), succ[(size_t)e].begin(), succ[(size_t)e].end());
+        most = std::max(most, succ[(size_t)e].size());
+    }
+    int gshift = 1;
+    while (((size_t)1 << gshift) < gmax) ++gshift;
+    // item codes are int32: records, then one START per entry, then (entry, render group); the ready list of an ending
+    // entry is staged in 2048 LDS words
+    if (most > 2048 || (uint64_t)n_chunks + (uint64_t)E + ((uint64_t)E << gshift) >= 0x7fffffffull) return CELESTE_OK;
+    if (!optim_use_fused(c, E, n_chunks, op, /*any_size=*/true)) return CELESTE_OK;
+    int32_t *d_dep = nullptr, *d_succ_off = nullptr, *d_succ = nullptr, *d_rarr = nullptr;
+    int rc = CELESTE_OK;
+#define JD_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto out; } } while (0)
+    JD_TRY(hipMalloc((void **)&d_dep, (size_t)E * sizeof(int32_t)));
+    JD_TRY(hipMalloc((void **)&d_succ_off, ((size_t)E + 1) * sizeof(int32_t)));
+    JD_TRY(hipMalloc((void **)&d_succ, std::max<size_t>(succ_flat.size(), 1) * sizeof(int32_t)));
+    JD_TRY(hipMalloc((void **)&d_rarr, (size_t)E * sizeof(int32_t)));
+    if ((size_t)E * CEL_P > fb.cap_saved) {
+        JD_TRY(hipStreamSynchronize(stream));
+        if (fb.d_saved) { (void)hipFree(fb.d_saved); fb.d_saved = nullptr; }
+        fb.cap_saved = 0;
+        JD_TRY(hipMalloc((void **)&fb.d_saved, (size_t)E * CEL_P * sizeof(double)));
+        fb.cap_saved = (size_t)E * CEL_P;
+    }
+    JD_TRY(hipMemcpyAsync(d_dep, dep.data(), (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    JD_TRY(hipMemcpyAsync(d_succ_off, succ_off.data(), ((size_t)E + 1) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    if (!succ_flat.empty())
+        JD_TRY(hipMemcpyAsync(d_succ, succ_flat.data(), succ_flat.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    JD_TRY(hipMemsetAsync(d_rarr, 0, (size_t)E * sizeof(int32_t), stream));
+    // the batch's bookkeeping for all entries (visit items, record offsets), every source's tables and shape derivatives
+    // from the input table; the entries refresh them as they end
+    rc = optim_render(c, ob.d_vp, E, d_all, n_chunks, stream);
+    if (rc != CELESTE_OK) goto out;
+    {
+        JointLaunch J = {d_dep, d_succ_off, d_succ, d_rarr, fb.d_saved, d_pos, gshift, groups};
+        rc = optim_run_fused(c, ob.d_vp, E, d_all, n_chunks, op, flags, stream, &J);
+        if (rc != CELESTE_OK) goto out;
+        // (failed entries gave their rows back in flight: no saved rows here)
+        hipLaunchKernelGGL(optim_finalize_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, stream, (const OptState *)ob.d_state,
+                           d_all, E, ob.d_vp, (const double *)nullptr, d_it, d_ev, d_el, d_stt, fb.d_q_ctl);
+        JD_TRY(hipGetLastError());
+        JD_TRY(hipStreamSynchronize(stream));      // (the host vectors above are in flight until here)
+        *ran = true;
+    }
+out:
+#undef JD_TRY
+    if (rc != CELESTE_OK) (void)hipStreamSynchronize(stream);
+    void *ptrs[] = {d_dep, d_succ_off, d_succ, d_rarr};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    return rc;
+}
+
 // ---- joint inference: a schedule of layers against one device-resident parameter table -------------------------
 extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layers, const int64_t *layer_offsets,
                                    const int32_t *layer_targets, const double *pos_centers,
@@ -1564,7 +1682,10 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
     if (rc != CELESTE_OK) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t stream = c->stream;
-    rc = optim_buffers(c, widest, stream);
+    // CELESTE_JOINT_DATAFLOW=0: layer by layer (one fused or chained optimisation per layer)
+    bool dataflow = total <= JOINT_DATAFLOW_MAX && optim_use_fused(c, 1, 1, op);
+    if (const char *e = getenv("CELESTE_JOINT_DATAFLOW")) if (atoi(e) == 0) dataflow = false;
+    rc = optim_buffers(c, dataflow ? (size_t)total : widest, stream);
     if (rc != CELESTE_OK) return rc;
     auto &ob = c->opt;
     const size_t vp_bytes = (size_t)c->S * CEL_P * sizeof(double);
@@ -1586,6 +1707,13 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
     if (pos_centers) JI_TRY(hipMemcpyAsync(d_pos, pos_centers, (size_t)total * 2 * sizeof(double), hipMemcpyHostToDevice, stream));
     memcpy(ob.h_vp, vp, vp_bytes);
     JI_TRY(hipMemcpyAsync(ob.d_vp, ob.h_vp, vp_bytes, hipMemcpyHostToDevice, stream));
+    if (dataflow) {
+        // one launch for the whole schedule (fused_kernels.h, joint mode)
+        rc = joint_dataflow(c, total, layer_targets, d_all, d_pos, op, flags, d_it, d_ev, d_el, d_stt, stream, &dataflow);
+        if (rc != CELESTE_OK) goto done;
+        any_fused = dataflow;
+    }
+    if (!dataflow)
     for (int l = 0; l < n_layers; ++l) {
         const int64_t lo = layer_offsets[l];
         const int32_t n = (int32_t)(layer_offsets[l + 1] - lo);

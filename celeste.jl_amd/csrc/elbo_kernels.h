@@ -378,6 +378,35 @@ __device__ inline double wave_sum(double x) {
     return x;
 }
 
+// Loads / stores of data that another workgroup of the SAME launch wrote or will read (optim_fused_kernel hands targets
+// from workgroup to workgroup): COH = true makes them agent-scope relaxed atomics, i.e. `global_load / global_store ...
+// sc1` -- write-through stores and L1-bypassing loads, so that no release / acquire fence is needed around them (guide
+// section 6, Guideline 16, form R1).  COH = false: plain accesses (data crosses kernel boundaries only).
+template <bool COH>
+__device__ __forceinline__ double ldc(const double *p) {
+    if constexpr (COH)
+        return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void stc(double *p, double v) {
+    if constexpr (COH)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ int ldc(const int *p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void stc(int *p, int v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // mark_kernel / value_kernel: value-only light of every source that is some target's neighbour
 // (is_active_source == false branch of add_pixel_term!, elbo_objective.jl:254-257), rendered once
@@ -684,6 +713,30 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
     }
 }
 
+// the light of one neighbour on pixels [p0, p1) of an overlap rectangle (h fastest, RH rows, corner (h_lo, w_lo) in 0-based
+// image coordinates), into the neighbour's own patch buffer `out`: value_kernel's loop, one wavefront.  COH: the values
+// are for workgroups of the same launch (write-through stores).
+template <bool COH>
+__device__ __forceinline__ void value_pixels(int lane, const DevPatch &P, const SrcImg &si, const Comp *__restrict__ tc, int NC,
+                                             const double *__restrict__ coefs, const double *__restrict__ etab, int h_lo,
+                                             int w_lo, int RH, int p0, int p1, double2 *__restrict__ out) {
+    const double *__restrict__ coef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
+    const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
+    for (int idx = p0 + lane; idx < p1; idx += 64) {
+        const int rw = idx / RH, rh = idx - rw * RH;
+        const int h0 = h_lo + rh, w0 = w_lo + rw;  // 0-based image coordinates
+        const double hh = (double)(h0 + 1), ww = (double)(w0 + 1);
+        const double f0 = star_value(coef, hh + sh0, ww + sw0);
+        const double f1 = galaxy_value(tc, NC, hh - si.m1, ww - si.m2, etab);
+        const double En = si.c0 * f0 + si.c1 * f1;                      // E_G_s.v  (elbo_objective.jl:62-65)
+        const double E2n = si.q0 * (f0 * f0) + si.q1 * (f1 * f1);
+        double2 *const o = out + ((h0 - P.off_h) + (int64_t)P.H2 * (w0 - P.off_w));
+        const double var = E2n - En * En;                               // var_G_s.v (:204)
+        if constexpr (COH) { stc<true>(&o->x, En); stc<true>(&o->y, var); }
+        else *o = make_double2(En, var);
+    }
+}
+
 // One wavefront per work item (neighbour link t -> s2, image, chunk of the overlap): renders s2's value-only
 // light on the rectangle where s2's patch (minus its last column, elbo_objective.jl:349) overlaps target t's
 // patch, into s2's own patch buffer.  The items with a non-empty overlap are listed once per context
@@ -732,19 +785,7 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
         __syncthreads();
     }
     VT(1);
-    const double *__restrict__ coef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
-    double2 *__restrict__ out = val + val_off[sn];
-    const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
-    for (int idx = p0 + (int)threadIdx.x; idx < p1; idx += 64) {
-        const int rw = idx / RH, rh = idx - rw * RH;
-        const int h0 = h_lo + rh, w0 = w_lo + rw;  // 0-based image coordinates
-        const double hh = (double)(h0 + 1), ww = (double)(w0 + 1);
-        const double f0 = star_value(coef, hh + sh0, ww + sw0);
-        const double f1 = galaxy_value(tc, NC, hh - si.m1, ww - si.m2, etab);
-        const double En = si.c0 * f0 + si.c1 * f1;                      // E_G_s.v  (elbo_objective.jl:62-65)
-        const double E2n = si.q0 * (f0 * f0) + si.q1 * (f1 * f1);
-        out[(h0 - P.off_h) + (int64_t)P.H2 * (w0 - P.off_w)] = make_double2(En, E2n - En * En);  // var_G_s.v (:204)
-    }
+    value_pixels<false>(threadIdx.x, P, si, tc, NC, coefs, etab, h_lo, w_lo, RH, p0, p1, val + val_off[sn]);
     VT(2);
 #ifdef VALUE_TIMING
     if (threadIdx.x == 0) {
@@ -1185,7 +1226,9 @@ struct PixelInputs {
     int n_inact;
     bool valid, dup;
 };
-template <bool MULTI>
+// COHV: the neighbours' light was rendered by other workgroups of the SAME launch (joint dataflow, fused_kernels.h): its
+// loads go past the non-coherent caches
+template <bool MULTI, bool COHV = false>
 __device__ __forceinline__ PixelInputs load_pixel_inputs(
         const DevImage &img, const DevPatch &P, const DevPatch *__restrict__ patches, const uint8_t *__restrict__ bitmaps,
         const int32_t *__restrict__ nbr_idx, const int32_t *__restrict__ nv, int64_t nb0, int64_t nb1,
@@ -1237,7 +1280,8 @@ __device__ __forceinline__ PixelInputs load_pixel_inputs(
             }
         }
         if (in) {
-            const double2 ev = val[val_off[v2] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1)];
+            const double2 *const pv = val + (val_off[v2] + (ph2 - 1) + (int64_t)Q.H2 * (pw2 - 1));
+            const double2 ev = COHV ? make_double2(ldc<true>(&pv->x), ldc<true>(&pv->y)) : *pv;
             Ebar += ev.x;
             Vbar += ev.y;
             n_inact += MULTI ? (r2 < 0) : 1;
@@ -1283,7 +1327,7 @@ struct PixWork {
 // calling gate() -- a no-op in pixel_kernel, where one wave runs the iterations of a chunk in turn; the fused optimiser
 // kernel gives the four iterations of a chunk to four waves and uses the gate to let them ADD in iteration order, which
 // makes its chunk records bit-identical to pixel_kernel's.
-template <int MODE, typename R, bool MULTI, bool GATED = false, class Gate>
+template <int MODE, typename R, bool MULTI, bool GATED = false, bool COHV = false, class Gate>
 __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1, int lane, double *__restrict__ slot,
                                            double (&a)[3], Gate &&gate) {
     constexpr int GM = MODE == 3 ? 2 : MODE;  // MODE 3 = MODE 2 sums, per-pixel records stored instead of folded
@@ -1302,7 +1346,7 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
         const int w2 = idx / H2, h2 = idx - w2 * H2;        // 0-based patch coordinates, h fastest
         const int h = P.off_h + h2 + 1, w = P.off_w + w2 + 1;  // 1-based image coordinates
         const double hh = (double)h, ww = (double)w;
-#define LOAD_PIXEL_INPUTS() load_pixel_inputs<MULTI>(img, P, W.patches, W.bitmaps, W.nbr_idx, W.nv, W.nb0, W.nb1, W.val_off, \
+#define LOAD_PIXEL_INPUTS() load_pixel_inputs<MULTI, COHV>(img, P, W.patches, W.bitmaps, W.nbr_idx, W.nv, W.nb0, W.nb1, W.val_off, \
                                                      W.val, W.active_rank, W.my_rank, W.N, W.n, H2, h, w, h2, w2, in_range)
         // ---- the active source ----
         const bool own_geo = in_range && (w2 < W2 - 1);  // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
@@ -1787,35 +1831,6 @@ __device__ unsigned long long g_lift_clk[16];
 #define LIFT_TICK_DECL do { } while (0)
 #endif
 
-// Loads / stores of data that another workgroup of the SAME launch wrote or will read (optim_fused_kernel hands targets
-// from workgroup to workgroup): COH = true makes them agent-scope relaxed atomics, i.e. `global_load / global_store ...
-// sc1` -- write-through stores and L1-bypassing loads, so that no release / acquire fence is needed around them (guide
-// section 6, Guideline 16, form R1).  COH = false: plain accesses (data crosses kernel boundaries only).
-template <bool COH>
-__device__ __forceinline__ double ldc(const double *p) {
-    if constexpr (COH)
-        return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT));
-    else return *p;
-}
-template <bool COH>
-__device__ __forceinline__ void stc(double *p, double v) {
-    if constexpr (COH)
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-template <bool COH>
-__device__ __forceinline__ int ldc(const int *p) {
-    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-template <bool COH>
-__device__ __forceinline__ void stc(int *p, int v) {
-    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
 // LDS of the lift (17.7 KB)
 struct LiftShared {
     double sh_h[LIFT_NP * LIFT_NP];         // likelihood Hessian, upper triangle, params < 28
@@ -2106,7 +2121,7 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
     if (tid == 0) {
         int st = sh_bad ? CELESTE_ERR_NONFINITE_RESULT : CELESTE_OK;
         int fin = COH ? L.own_finite : geo[t].finite;
-        for (int64_t q = nbr_off[t]; q < nbr_off[t + 1]; ++q) fin &= geo[nbr_idx[q]].finite;
+        for (int64_t q = nbr_off[t]; q < nbr_off[t + 1]; ++q) fin &= ldc<COH>(&geo[nbr_idx[q]].finite);
         if (!fin) st = CELESTE_ERR_NONFINITE_INPUT;
         *o_status = st;
         *o_v = sh_v;

@@ -27,6 +27,21 @@
 // wavefronts drain their stores (s_waitcnt vmcnt(0)) before the flag -- the queue item or the arrival counter -- is
 // published.  No release / acquire fences (1.7-6.5 us each on this chip) are needed.
 //
+// Joint mode (optim_fused_kernel<true>, celeste_joint_infer): the whole schedule of one_node_joint_infer -- every
+// (sweep, Cyclades batch, layer, source) entry, ParallelRun.jl:302-397 -- in ONE launch, as a dataflow over the entries:
+// an entry may start when every earlier entry that wrote a row it reads (its own source's, its neighbours') or read the
+// row it writes has finished.  That is exactly the order the layer-by-layer schedule guarantees, without its barriers: a
+// layer no longer waits for its slowest source, a batch no longer waits for its longest chain.  Three more item kinds:
+//   START e             the entry's dependencies are met: save the source's row, start its optimiser state
+//                       (optim_init_values), queue the rendering of its neighbours
+//   RENDER (e, g)       four of the value-kernel items of the entry's source, one per wavefront (value_pixels): the
+//                       neighbours' light on the overlaps with the source's patches, from the neighbours' CURRENT rows;
+//                       the last group queues the entry's first chunk records
+//   (end of an entry)   the workgroup that ran the entry's last step restores the row if the entry failed, refreshes the
+//                       source's per-image tables and shape derivatives (what prep_kernel / setup_kernel do between
+//                       layers), then counts the entry off its successors and queues those that become ready.
+// Every entry sees the parameter table the layered schedule shows it, so the results are bit-identical to it.
+//
 // Results are bit-identical to the chained path: same device functions (pixel_iter, prep_visit_values, source_geo_values,
 // lift_target, optim_step_target, the non-inlined tri_tr_solve / eig_tr_solve), same 256-pixel chunk records summed in
 // the same order (tests/test_gpu_fused.py).
@@ -67,6 +82,16 @@ struct FusedArgs {
     // the queue
     int32_t *q_items; int32_t *q_ctl; int32_t *arrivals; int q_cap;
     long long timeout_ticks;       // wall_clock64 ticks (100 MHz) a workgroup waits for its ticket before it gives up
+    // joint mode (optim_fused_kernel<true>): `targets` lists the entries of the schedule (sources repeat)
+    int j_R;                       // number of chunk records = first START item; START e = j_R + e
+    int j_gshift;                  // RENDER (e, g) = j_R + n_targets + (e << j_gshift | g)
+    int32_t *j_dep;                // per entry: predecessors still running
+    const int32_t *j_succ_off; const int32_t *j_succ;   // per entry: the entries that wait for it
+    const int32_t *j_vitem_off; const int4 *j_vitems;   // per source: its value-kernel items (celeste_ctx_create)
+    int32_t *j_render_arr;         // per entry: render groups done
+    double *j_saved;               // per entry: the source's row before the entry
+    const double *j_pos;           // per entry: centre of the position box (nullptr: the position at its start)
+    SrcImg *j_srcimg; Comp *j_comps; SrcGeo *j_geo;     // the context's per-visit / per-source tables, refreshed in flight
 };
 
 // per batch, once: the targets' record ranges, the description of every record, the first round of queue items
@@ -74,7 +99,8 @@ struct FusedArgs {
 __global__ void fused_setup_kernel(const int32_t *__restrict__ targets, int n_targets, const DevPatch *__restrict__ patches,
                                    const int32_t *__restrict__ vis_off, const int2 *__restrict__ items, int N, int M,
                                    int chunk_px, const int32_t *__restrict__ rec_off, int4 *__restrict__ chunk_desc,
-                                   int2 *__restrict__ tgt_rec, int32_t *__restrict__ q_items, int32_t *__restrict__ q_ctl) {
+                                   int2 *__restrict__ tgt_rec, int32_t *__restrict__ q_items, int32_t *__restrict__ q_ctl,
+                                   const int32_t *__restrict__ j_dep = nullptr, int j_R = 0) {
     const int ti = blockIdx.x * blockDim.x + threadIdx.x;
     if (ti >= n_targets) return;
     const int t = targets[ti];
@@ -97,6 +123,11 @@ __global__ void fused_setup_kernel(const int32_t *__restrict__ targets, int n_ta
     }
     tgt_rec[ti] = make_int2(first < 0 ? 0 : first, n_rec);
     if (!q_items) return;
+    if (j_dep) {     // joint mode: the entries without predecessors start
+        if (j_dep[ti] == 0) q_items[atomicAdd(&q_ctl[FQC_TAIL], 1)] = j_R + ti;
+        if (ti == 0) q_ctl[FQC_LIVE] = n_targets;
+        return;
+    }
     const int cnt = n_rec > 0 ? n_rec : 1;
     const int base = atomicAdd(&q_ctl[FQC_TAIL], cnt);
     if (n_rec > 0) for (int i = 0; i < n_rec; ++i) q_items[base + i] = first + i;
@@ -174,6 +205,155 @@ __device__ __forceinline__ void fused_push(const FusedArgs &A, const int tid, in
     __syncthreads();
 }
 
+// the entry's evaluation items: its chunk records, or the direct item of a source that visits no pixel
+__device__ __forceinline__ void fused_push_eval(const FusedArgs &A, const int tid, int *s_base, int ti) {
+    const int2 tr = A.tgt_rec[ti];
+    if (tr.y > 0) fused_push(A, tid, s_base, tr.x, tr.y);
+    else fused_push(A, tid, s_base, FQ_DIRECT0 - ti, 0);
+}
+
+// ---- joint mode: the start of an entry ----
+__device__ __forceinline__ void joint_start(const FusedArgs &A, FusedShared &F, const int tid, const int e) {
+    const int t = A.targets[e];
+    double *const row = A.vp + (size_t)t * CEL_P;
+    OptState *const js = reinterpret_cast<OptState *>(F.ev_h);          // (LDS scratch: no evaluation is in flight here)
+    if (tid < CEL_P) {
+        const double v = ldc<true>(row + tid);
+        F.theta[tid] = v;
+        stc<true>(A.j_saved + (size_t)e * CEL_P + tid, v);
+    }
+    __syncthreads();
+    if (tid == 0) optim_init_values(F.theta, A.op, A.j_pos ? A.j_pos + 2 * (size_t)e : nullptr, *js);
+    __syncthreads();
+    if (tid < CEL_P) stc<true>(row + tid, F.theta[tid]);
+    {
+        double *dst = reinterpret_cast<double *>(&A.st[e]);
+        const double *src = reinterpret_cast<const double *>(js);
+        static_assert(sizeof(OptState) % sizeof(double) == 0, "OptState is copied in 8-byte words");
+        for (int i = tid; i < (int)(sizeof(OptState) / sizeof(double)); i += FUSED_NT) stc<true>(dst + i, src[i]);
+    }
+    drain_stores();
+    __syncthreads();
+    const int n_it = A.j_vitem_off[t + 1] - A.j_vitem_off[t];
+    if (n_it > 0) fused_push(A, tid, &F.done, A.j_R + A.n_targets + (e << A.j_gshift), (n_it + FUSED_WAVES - 1) / FUSED_WAVES);
+    else fused_push_eval(A, tid, &F.done, e);
+}
+
+// ---- joint mode: one group of value-kernel items of an entry's source, one item per wavefront ----
+__device__ __forceinline__ void joint_render(const FusedArgs &A, FusedShared &F, const int tid, const int code) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int e = code >> A.j_gshift, g = code & ((1 << A.j_gshift) - 1);
+    const int t = A.targets[e];
+    const int i0 = A.j_vitem_off[t], i1 = A.j_vitem_off[t + 1];
+    if (wave == 0) F.etab[lane] = g_exp2_table[lane];
+    __syncthreads();
+    const int idx = i0 + g * FUSED_WAVES + wave;
+    if (idx < i1) {
+        const int4 it = A.j_vitems[idx];
+        const int sn = it.x, ch = it.z;
+        const DevPatch &P = A.patches[sn];
+        const DevPatch &T = A.patches[it.y];
+        // (value_kernel's item: the overlap of the neighbour's patch, minus its last column, with the target's)
+        const int h_lo = max(P.off_h, T.off_h), h_hi = min(P.off_h + P.H2, T.off_h + T.H2);
+        const int w_lo = max(P.off_w, T.off_w), w_hi = min(P.off_w + P.W2 - 1, T.off_w + T.W2);
+        const int RH = h_hi - h_lo, RW = w_hi - w_lo;
+        const int npx = RH * RW, p0 = ch * A.chunk_px;
+        if (RH > 0 && RW > 0 && p0 < npx) {
+            // the neighbour's tables: another workgroup refreshed them when the neighbour's last entry ended
+            Comp *const tc = reinterpret_cast<Comp *>(F.ev_h) + wave * (14 * CEL_MAXK);
+            SrcImg *const siw = reinterpret_cast<SrcImg *>(F.sacc) + wave;
+            {
+                const double *src = reinterpret_cast<const double *>(A.j_comps + (size_t)sn * A.NC);
+                double *dst = reinterpret_cast<double *>(tc);
+                for (int i = lane; i < A.NC * 8; i += 64) dst[i] = ldc<true>(src + i);
+                static_assert(sizeof(SrcImg) % sizeof(double) == 0 && sizeof(SrcImg) / sizeof(double) <= 64, "SrcImg is copied in 8-byte words");
+                if (lane < (int)(sizeof(SrcImg) / sizeof(double)))
+                    reinterpret_cast<double *>(siw)[lane] = ldc<true>(reinterpret_cast<const double *>(A.j_srcimg + sn) + lane);
+            }
+            wave_sync();
+            const SrcImg si = *siw;
+            value_pixels<true>(lane, P, si, tc, A.NC, A.coefs, F.etab, h_lo, w_lo, RH, p0, min(npx, p0 + A.chunk_px),
+                               const_cast<double2 *>(A.val) + A.val_off[sn]);
+        }
+    }
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) {
+        const int ng = (i1 - i0 + FUSED_WAVES - 1) / FUSED_WAVES;
+        F.last = __hip_atomic_fetch_add(&A.j_render_arr[e], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1;
+    }
+    __syncthreads();
+    const bool last = F.last != 0;
+    __syncthreads();
+    if (last) fused_push_eval(A, tid, &F.done, e);
+}
+
+// ---- joint mode: the end of an entry (its last step has been stored and drained) ----
+__device__ __forceinline__ void joint_end(const FusedArgs &A, FusedShared &F, const int tid, const int e) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int t = A.targets[e];
+    double *const row = A.vp + (size_t)t * CEL_P;
+    // a source that failed keeps the row it had before the entry (ParallelRun.jl:582-597)
+    const bool failed = ldc<true>(&A.st[e].status) != CELESTE_OK;
+    if (tid < CEL_P) {
+        const double v = failed ? ldc<true>(A.j_saved + (size_t)e * CEL_P + tid) : ldc<true>(row + tid);
+        if (failed) stc<true>(row + tid, v);
+        F.theta[tid] = v;
+    }
+    __syncthreads();
+    // the source's per-image tables and shape derivatives from its final row: what the next layer's prep_kernel and
+    // setup kernel would compute for it as somebody's neighbour
+    for (int j = wave; j < A.M; j += FUSED_WAVES) {
+        int v = t * A.N + j, n = j;
+        if (A.items) { v = A.items[e * A.M + j].x; n = A.items[e * A.M + j].y; }
+        if (v < 0) continue;
+        const DevPatch &P = A.patches[v];
+        if (P.H2 * P.W2 <= 0) continue;
+        Comp *const tc = reinterpret_cast<Comp *>(F.ev_h) + wave * (14 * CEL_MAXK);
+        SrcImg *const siw = reinterpret_cast<SrcImg *>(F.sacc) + wave;
+        prep_visit_values<true>(lane, F.theta, P, A.images[n].band - 1, A.K, siw, tc);
+        wave_sync();
+        double *dst = reinterpret_cast<double *>(A.j_comps + (size_t)v * A.NC);
+        const double *src = reinterpret_cast<const double *>(tc);
+        for (int i = lane; i < A.NC * 8; i += 64) stc<true>(dst + i, src[i]);
+        if (lane < (int)(sizeof(SrcImg) / sizeof(double)))
+            stc<true>(reinterpret_cast<double *>(A.j_srcimg + v) + lane, reinterpret_cast<const double *>(siw)[lane]);
+        wave_sync();
+    }
+    SrcGeo *const gl = reinterpret_cast<SrcGeo *>(F.etab);
+    static_assert(sizeof(SrcGeo) <= 64 * sizeof(double) && sizeof(SrcGeo) % sizeof(double) == 0, "SrcGeo staged in the exp table's LDS");
+    __syncthreads();
+    if (tid == 0) { source_geo_values(F.theta, gl); gl->pad = 0; }
+    __syncthreads();
+    if (tid < (int)(sizeof(SrcGeo) / sizeof(double)))
+        stc<true>(reinterpret_cast<double *>(A.j_geo + t) + tid, reinterpret_cast<const double *>(gl)[tid]);
+    drain_stores();
+    __syncthreads();
+    // count the entry off its successors; those that become ready start
+    int *const ready = reinterpret_cast<int *>(F.sacc);
+    if (tid == 0) F.turn = 0;
+    __syncthreads();
+    const int s0 = A.j_succ_off[e], ns = A.j_succ_off[e + 1] - s0;
+    for (int i = tid; i < ns; i += FUSED_NT) {
+        const int s = A.j_succ[s0 + i];
+        if (__hip_atomic_fetch_add(&A.j_dep[s], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)
+            ready[atomicAdd(&F.turn, 1)] = s;
+    }
+    __syncthreads();
+    const int nready = F.turn;
+    if (nready > 0) {
+        if (tid == 0) F.done = __hip_atomic_fetch_add(&A.q_ctl[FQC_TAIL], nready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int base = F.done;
+        if (base + nready > A.q_cap) {
+            if (tid == 0) __hip_atomic_store(&A.q_ctl[FQC_ABORT], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else
+            for (int i = tid; i < nready; i += FUSED_NT) stc<true>(&A.q_items[base + i], A.j_R + ready[i]);
+    }
+    __syncthreads();
+}
+
+template <bool JOINT>
 __global__ void __launch_bounds__(FUSED_NT, 2)
 optim_fused_kernel(const FusedArgs A) {
     __shared__ FusedShared F;
@@ -192,6 +372,11 @@ optim_fused_kernel(const FusedArgs A) {
         FT(0);
         int ti;
         bool last;
+        if (JOINT && item >= A.j_R) {
+            if (item < A.j_R + A.n_targets) joint_start(A, F, tid, item - A.j_R);
+            else joint_render(A, F, tid, item - A.j_R - A.n_targets);
+            continue;
+        }
         if (item >= 0) {
             // ---- one chunk record ----
             const int4 d0 = A.chunk_desc[2 * item], d1 = A.chunk_desc[2 * item + 1];
@@ -229,7 +414,7 @@ optim_fused_kernel(const FusedArgs A) {
                 volatile int *turn = &F.turn;
                 // pixel_kernel's wavefront adds iteration after iteration into the slots; here iteration w belongs to
                 // wavefront w, and the wavefronts take turns in the same order
-                pixel_iter<2, double, false, FUSED_GATED != 0>(W, base, p1, lane, F.sacc + (lane & (ACC_SLOTS - 1)), a, [&]() {
+                pixel_iter<2, double, false, FUSED_GATED != 0, JOINT>(W, base, p1, lane, F.sacc + (lane & (ACC_SLOTS - 1)), a, [&]() {
                     while (*turn != wave) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 });
@@ -269,11 +454,9 @@ optim_fused_kernel(const FusedArgs A) {
         FT(5);
         drain_stores();      // the target's row of vp, its state and saved Hessian are in memory ...
         __syncthreads();     // ... before its next items (or the end of the launch) become visible
-        if (!done) {
-            const int2 tr = A.tgt_rec[ti];
-            if (tr.y > 0) fused_push(A, tid, &F.done, tr.x, tr.y);
-            else fused_push(A, tid, &F.done, FQ_DIRECT0 - ti, 0);
-        } else {
+        if (!done) fused_push_eval(A, tid, &F.done, ti);
+        else {
+            if (JOINT) joint_end(A, F, tid, ti);
             if (tid == 0)
                 F.done = __hip_atomic_fetch_add(&A.q_ctl[FQC_LIVE], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
             __syncthreads();

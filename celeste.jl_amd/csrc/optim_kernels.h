@@ -112,16 +112,12 @@ __device__ inline void to_bound_dev(const double *x, const double *pos0, const O
 }
 
 // enforce! + to_free! + first trial point; one thread per target
-__global__ void optim_init_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, int n_targets,
-                                  OptParams op, OptState *__restrict__ st, int32_t *__restrict__ active,
-                                  const double *__restrict__ pos_centers) {
-    const int ti = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ti >= n_targets) return;
-    double *vs = vp + (size_t)targets[ti] * CEL_P;
-    OptState &S = st[ti];
+// One thread: the start of maximize! for one target -- vs: its 44 parameters (enforced in place, then set to the first
+// evaluation point), S: its optimiser state, pos: the centre of its position box (nullptr: its current position)
+__device__ inline void optim_init_values(double *__restrict__ vs, const OptParams &op, const double *__restrict__ pos, OptState &S) {
     // the position box stays where the first ElboConfig put it (ParallelRun.jl:96-100); default: current position
-    S.pos0[0] = pos_centers ? pos_centers[2 * ti] : vs[0];
-    S.pos0[1] = pos_centers ? pos_centers[2 * ti + 1] : vs[1];
+    S.pos0[0] = pos ? pos[0] : vs[0];
+    S.pos0[1] = pos ? pos[1] : vs[1];
     for (int i = 0; i < 26; ++i) {
         double lo, hi, sc;
         box_bounds(i, S.pos0, op, lo, hi, sc);
@@ -149,6 +145,14 @@ __global__ void optim_init_kernel(double *__restrict__ vp, const int32_t *__rest
     for (int i = 0; i < NF; ++i) S.xt[i] = S.x[i];
     S.f = 0; S.delta = op.initial_delta; S.m = 0; S.iter = -1; S.done = 0; S.interior = 0; S.evals = 0; S.status = 0;
     to_bound_dev(S.xt, S.pos0, op, vs);  // the evaluation point, as evaluate! does (ElboMaximize.jl:163-166)
+}
+
+__global__ void optim_init_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, int n_targets,
+                                  OptParams op, OptState *__restrict__ st, int32_t *__restrict__ active,
+                                  const double *__restrict__ pos_centers) {
+    const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= n_targets) return;
+    optim_init_values(vp + (size_t)targets[ti] * CEL_P, op, pos_centers ? pos_centers + 2 * ti : nullptr, st[ti]);
     active[ti] = ti;
 }
 

@@ -219,6 +219,66 @@ def test_joint_infer_entry_equals_layer_by_layer_calls(crowded):
         ctx.joint_infer(vp0, [[a, f.neighbors[a][0]]], cfg)
 
 
+def test_joint_dataflow_launch_equals_the_layered_schedule(crowded):
+    """celeste_joint_infer runs the whole schedule as one dataflow launch (entries start when the entries they depend on
+    have ended); CELESTE_JOINT_DATAFLOW=0 runs it layer by layer.  Same table, same per-entry iterations, evaluations,
+    ELBO values and statuses, bit for bit -- also when entries fail, and on the bench field's full schedule."""
+    import time
+    import celeste_jl_amd as cel
+    from celeste_jl_amd.infer import joint_layers, default_infer_config
+    from celeste_jl_amd.params import catalog_init_source, generic_init_source
+    f, ctx = crowded
+    S = len(f.catalog)
+    targets = list(range(S))
+    vp0 = np.stack([catalog_init_source(ce) for ce in f.catalog])
+    for t in targets:
+        vp0[t] = generic_init_source(f.catalog[t].pos)
+    bad = int(np.argmax([len(n) for n in f.neighbors]))
+    for case, cfg in (("clean", cel.ElboConfig(max_iters=8)), ("failing", cel.ElboConfig(max_iters=5)), ("eig", cel.ElboConfig(max_iters=4))):
+        vp = vp0.copy()
+        tg = targets
+        if case == "failing":
+            vp[bad, 7] = np.nan
+            tg = [t for t in targets if t != bad]
+        layers = joint_layers(tg, f.neighbors, batch_size=12, n_iters=3, rng=np.random.default_rng(7))
+        centers = [vp[l, 0:2].copy() for l in layers]
+        with _env(CELESTE_TR_SOLVER="eig" if case == "eig" else None):
+            with _env(CELESTE_JOINT_DATAFLOW=0):
+                ref = ctx.joint_infer(vp, layers, cfg, pos_centers=centers)
+            got = ctx.joint_infer(vp, layers, cfg, pos_centers=centers)
+        for a, b, what in zip(ref, got, ("table", "iterations", "evaluations", "elbo", "status")):
+            assert np.array_equal(a, b, equal_nan=True), (case, what)
+        if case == "failing":
+            assert (ref[4] != 0).any() and (ref[4] == 0).any()
+        else:
+            assert (ref[4] == 0).all()
+    # the bench field: 2000 sources, Cyclades batches of 400, 3 sweeps
+    import bench
+    fld = bench.build_field(2048, 1489, 2000, 3)
+    ctx2 = cel.FieldContext(fld.images, fld.patches, fld.neighbors)
+    tg = list(range(len(fld.catalog)))
+    vp = np.stack([catalog_init_source(ce) for ce in fld.catalog])
+    for t in tg:
+        vp[t] = generic_init_source(fld.catalog[t].pos)
+    layers = joint_layers(tg, fld.neighbors)
+    centers = [vp[l, 0:2].copy() for l in layers]
+    cfg = default_infer_config()
+    out = {}
+    for mode in (0, 1):
+        with _env(CELESTE_JOINT_DATAFLOW=mode):
+            ctx2.joint_infer(vp, layers[:2], cfg, pos_centers=centers[:2])
+            t0 = time.perf_counter()
+            out[mode] = ctx2.joint_infer(vp, layers, cfg, pos_centers=centers)
+            dt = time.perf_counter() - t0
+        print("bench field, %d layers, %d entries, %s: %.3f s" % (len(layers), sum(map(len, layers)),
+                                                                 "one dataflow launch" if mode else "layer by layer", dt))
+    for a, b, what in zip(out[0], out[1], ("table", "iterations", "evaluations", "elbo", "status")):
+        assert np.array_equal(a, b), what
+    assert (out[1][4] == 0).all()
+    ctx2.close()
+
+
+
 def test_one_node_joint_infer_uses_the_entry_and_reports_failures(crowded):
     import celeste_jl_amd as cel
     from celeste_jl_amd.infer import one_node_joint_infer
