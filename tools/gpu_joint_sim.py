@@ -47,3 +47,20 @@ print(json.dumps({"layers": len(layers), "entries": int(off[-1]), "mean_evals": 
                   "critical_path_evals_layered": layered, "critical_path_evals_chained_per_batch": chained,
                   "evals_by_sweep": [float(np.mean([evals[off[l]:off[l + 1]].mean() for l, t in enumerate(tags) if t[0] == sw])) for sw in range(3)],
                   "layer_max_by_sweep": [int(sum(evals[off[l]:off[l + 1]].max() for l, t in enumerate(tags) if t[0] == sw)) for sw in range(3)]}))
+
+# how the trust-region sub-problems of this schedule were solved
+import ctypes as C
+from celeste_jl_amd import cabi
+st5 = (C.c_uint64 * 5)()
+lib = cabi.load_library()
+lib.celeste_optim_stats(1, st5)
+ctx.joint_infer(vp, layers, default_infer_config(), pos_centers=centers)
+lib.celeste_optim_stats(0, st5)
+print(json.dumps({"tr_interior": int(st5[0]), "tr_boundary": int(st5[1]), "tr_hard": int(st5[2]), "secular_iters_total": int(st5[3]),
+                  "secular_iters_max": int(st5[4])}))
+import time
+for mode in ("0", "1"):
+    os.environ["CELESTE_JOINT_DATAFLOW"] = mode
+    for rep in range(2):
+        t0 = time.perf_counter(); ctx.joint_infer(vp, layers, default_infer_config(), pos_centers=centers); dt = time.perf_counter() - t0
+    print("joint_infer dataflow=%s: %.4f s" % (mode, dt))
