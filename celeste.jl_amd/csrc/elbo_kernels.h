@@ -1752,6 +1752,95 @@ __device__ inline void bright_coef(int q, int b, double &kap, double &lam) {
 #endif
 #define LIFT_NP 28   // parameters with likelihood derivatives (the k block, 28..43, only enters the KL)
 
+// Static tables of the lift (built at compile time): which record entries and Jacobian slots every gradient / Hessian
+// entry combines, so that the passes below are straight-line code per entry instead of un-ranking k with a square root
+// and walking param_rows / hidx per term.
+#define LIFT_JZP (3 * LIFT_NP)          // padded Jacobian: 3 slots per parameter, unused ones hold 0
+#define LIFT_REC_ZERO ACC_N             // index of the zero entry appended to every per-image record (padding terms)
+struct LiftTables {
+    unsigned char p1[LIFT_NP * (LIFT_NP + 1) / 2], p2[LIFT_NP * (LIFT_NP + 1) / 2];   // pair k = p2 (p2 + 1) / 2 + p1
+    unsigned char rec[LIFT_NP * (LIFT_NP + 1) / 2][9];   // record entry (Hessian of the reduced variables) of (row a of p1, row c of p2)
+    unsigned char code[LIFT_NP * (LIFT_NP + 1) / 2];     // second-derivative term: 0 none, 1 shape x shape, 2 brightness of one type
+    unsigned short order[CELESTE_HP];                    // assembly order of the 990 upper-triangle entries: no KL term first, then by KL branch
+    unsigned char ap1[CELESTE_HP], ap2[CELESTE_HP], akl[CELESTE_HP];   // entry k = p2 (p2 + 1) / 2 + p1: its parameters, KL branch id (0 = no KL term)
+    // the same, one load per entry: pair k -> {rec 0..3, rec 4..7, rec 8 | p1 << 8 | p2 << 16 | code << 24, 0};
+    // assembly position kk -> k | p1 << 10 | p2 << 16 | KL branch << 22
+    unsigned int pdesc[LIFT_NP * (LIFT_NP + 1) / 2][4];
+    unsigned int adesc[CELESTE_HP];
+};
+constexpr void lift_param_rows(int p, int &start, int &cnt, int &stride, int &cls) {
+    if (p < 2) { start = 4; cnt = 2; stride = 1; cls = 0; }
+    else if (p == 2) { start = 6; cnt = 1; stride = 1; cls = 1; }
+    else if (p < 6) { start = 7; cnt = 3; stride = 1; cls = 2; }
+    else if (p < 28) {
+        int i = 0;
+        if (p < 10) i = (p - 6) & 1;
+        else if (p < 26) i = ((p - 10) >> 2) & 1;
+        else i = p - 26;
+        start = i; cnt = 2; stride = 2; cls = 3 + i;
+    } else { start = 0; cnt = 0; stride = 1; cls = 5; }
+}
+constexpr int lift_kl_branch(int p1, int p2) {   // which return statement of kl_hess (p1 <= p2) is taken; 0: the entry has no KL term
+    if (p1 == 5 && p2 == 5) return 1;
+    if (p1 < 6 || p2 < 6) return 0;
+    auto type_of = [](int p) { return p < 10 ? ((p - 6) & 1) : (p < 26 ? (((p - 10) >> 2) & 1) : (p < 28 ? p - 26 : ((p - 28) >> 3))); };
+    auto cls = [](int p) { return p < 8 ? 0 : (p < 10 ? 1 : (p < 18 ? 2 : (p < 26 ? 3 : (p < 28 ? 4 : 5)))); };
+    if (type_of(p1) != type_of(p2)) return 0;
+    const int c1 = cls(p1), c2 = cls(p2);
+    const int q1 = (c1 == 2 || c1 == 3) ? ((p1 - 10) & 3) : (c1 == 5 ? ((p1 - 28) & 7) : 0);
+    const int q2 = (c2 == 2 || c2 == 3) ? ((p2 - 10) & 3) : (c2 == 5 ? ((p2 - 28) & 7) : 0);
+    if (c2 == 4) return c1 == 4 ? 2 : (c1 == 0 ? 3 : (c1 == 1 ? 4 : 5));
+    if (c2 == 5) return c1 == 5 ? (q1 == q2 ? 6 : 0) : (c1 == 4 ? 7 : (c1 == 2 ? 8 : (c1 == 3 ? 9 : 0)));
+    if (c1 == 0 && c2 == 0) return 10;
+    if (c1 == 1 && c2 == 1) return 11;
+    if (c1 == 3 && c2 == 3) return q1 == q2 ? 12 : 0;
+    if (c1 == 2 && c2 == 2) return 13;
+    return 0;
+}
+constexpr LiftTables make_lift_tables() {
+    LiftTables T = {};
+    for (int p2 = 0; p2 < LIFT_NP; ++p2)
+        for (int p1 = 0; p1 <= p2; ++p1) {
+            const int k = p2 * (p2 + 1) / 2 + p1;
+            T.p1[k] = (unsigned char)p1; T.p2[k] = (unsigned char)p2;
+            int st1 = 0, cn1 = 0, sd1 = 0, cls1 = 0, st2 = 0, cn2 = 0, sd2 = 0, cls2 = 0;
+            lift_param_rows(p1, st1, cn1, sd1, cls1);
+            lift_param_rows(p2, st2, cn2, sd2, cls2);
+            for (int a = 0; a < 3; ++a)
+                for (int c = 0; c < 3; ++c) {
+                    int idx = LIFT_REC_ZERO;
+                    if (a < cn1 && c < cn2) {
+                        const int r1 = st1 + a * sd1, r2 = st2 + c * sd2;
+                        idx = hidx(r1 < r2 ? r1 : r2, r1 < r2 ? r2 : r1);
+                    }
+                    T.rec[k][3 * a + c] = (unsigned char)idx;
+                }
+            T.code[k] = (cls1 == 2 && cls2 == 2) ? 1 : ((cls1 == cls2 && cls1 >= 3 && cls1 <= 4) ? 2 : 0);
+        }
+    int n = 0;
+    for (int br = 0; br <= 13; ++br)
+        for (int p2 = 0; p2 < CEL_P; ++p2)
+            for (int p1 = 0; p1 <= p2; ++p1)
+                if (lift_kl_branch(p1, p2) == br) T.order[n++] = (unsigned short)(p2 * (p2 + 1) / 2 + p1);
+    for (int p2 = 0; p2 < CEL_P; ++p2)
+        for (int p1 = 0; p1 <= p2; ++p1) {
+            const int k = p2 * (p2 + 1) / 2 + p1;
+            T.ap1[k] = (unsigned char)p1; T.ap2[k] = (unsigned char)p2; T.akl[k] = (unsigned char)lift_kl_branch(p1, p2);
+        }
+    for (int k = 0; k < LIFT_NP * (LIFT_NP + 1) / 2; ++k) {
+        T.pdesc[k][0] = T.rec[k][0] | (T.rec[k][1] << 8) | (T.rec[k][2] << 16) | ((unsigned)T.rec[k][3] << 24);
+        T.pdesc[k][1] = T.rec[k][4] | (T.rec[k][5] << 8) | (T.rec[k][6] << 16) | ((unsigned)T.rec[k][7] << 24);
+        T.pdesc[k][2] = T.rec[k][8] | (T.p1[k] << 8) | (T.p2[k] << 16) | ((unsigned)T.code[k] << 24);
+        T.pdesc[k][3] = 0;
+    }
+    for (int kk = 0; kk < CELESTE_HP; ++kk) {
+        const int k = T.order[kk];
+        T.adesc[kk] = (unsigned)k | ((unsigned)T.ap1[k] << 10) | ((unsigned)T.ap2[k] << 16) | ((unsigned)T.akl[k] << 22);
+    }
+    return T;
+}
+__device__ const __attribute__((aligned(16))) LiftTables c_lift = make_lift_tables();
+
 // Shared state of the analytic KL term (subtract_kl, elbo_kl.jl:94-154)
 struct KLShared {
     double t[16], m[16], Ld[16][4], ml[16][4];  // per (type, colour component)
@@ -1836,8 +1925,10 @@ struct LiftShared {
     double sh_h[LIFT_NP * LIFT_NP];         // likelihood Hessian, upper triangle, params < 28
     double sh_d[LIFT_NP];
     double s_vs[CEL_P], s_jsh[9], s_tsh[27];
-    double s_rec[LIFT_NT][ACC_N];
-    double s_jz[LIFT_NT][LIFT_JZ];          // compact Jacobians of the reduced variables (jz_off)
+    double s_rec[LIFT_NT][ACC_N + 1];       // per-image records; entry ACC_N = 0 (LIFT_REC_ZERO)
+    double s_jz[LIFT_NT][LIFT_JZP];         // Jacobians of the reduced variables, 3 slots per parameter (unused: 0)
+    double s_J[LIFT_NT][4];                 // the patches' pixel-per-world Jacobians
+    double klv;                             // the KL value
     double s_kap[LIFT_NT][10], s_lam[LIFT_NT][10], s_El[LIFT_NT][2], s_Ell[LIFT_NT][2];
     KLShared K;
     double sh_v, sh_cnt[2];
@@ -1862,8 +1953,8 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
     double (&sh_h)[LIFT_NP * LIFT_NP] = L.sh_h;
     double (&sh_d)[LIFT_NP] = L.sh_d;
     double (&s_vs)[CEL_P] = L.s_vs, (&s_jsh)[9] = L.s_jsh, (&s_tsh)[27] = L.s_tsh;
-    double (&s_rec)[LIFT_NT][ACC_N] = L.s_rec;
-    double (&s_jz)[LIFT_NT][LIFT_JZ] = L.s_jz;
+    double (&s_rec)[LIFT_NT][ACC_N + 1] = L.s_rec;
+    double (&s_jz)[LIFT_NT][LIFT_JZP] = L.s_jz;
     double (&s_kap)[LIFT_NT][10] = L.s_kap, (&s_lam)[LIFT_NT][10] = L.s_lam, (&s_El)[LIFT_NT][2] = L.s_El, (&s_Ell)[LIFT_NT][2] = L.s_Ell;
     KLShared &K = L.K;
     double &sh_v = L.sh_v;
@@ -1875,6 +1966,7 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
     const bool want_hess = (flags & CELESTE_FLAG_HESS) != 0;
     const bool want_kl = (flags & CELESTE_FLAG_KL) != 0;
 
+    const int vo = vis_off[t], n_vis = vis_off[t + 1] - vo;   // (first use far below: the loads are in flight meanwhile)
     if (tid < CEL_P) s_vs[tid] = ldc<COH>(vp + (size_t)t * CEL_P + tid);
     if constexpr (!COH) {
         if (tid >= CEL_P && tid < CEL_P + 9) s_jsh[tid - CEL_P] = geo[t].jsh[tid - CEL_P];
@@ -1884,17 +1976,28 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
     if (tid < LIFT_NP) sh_d[tid] = 0.0;
     if (tid == 0) { sh_v = 0.0; sh_cnt[0] = 0.0; sh_cnt[1] = 0.0; sh_bad = 0; }
     __syncthreads();
+    const double *vs = s_vs;
+    // One-thread and few-thread pieces run on threads of the fourth wavefront (192..255) while the other wavefronts are in
+    // the first pass; their results are read after that pass's barrier (the Jacobians need the shape derivatives) or at
+    // the very end (KL value, finiteness).  lift_wave_sync: LDS hand-over inside one wavefront.
+    auto lift_wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     if constexpr (COH) {
         // the target moved since the batch's tables were made: its shape derivatives from its current parameters
         // (source_geo_values, the function setup_thread fills the table with)
-        __shared__ SrcGeo own_geo;
-        if (tid == 0) { source_geo_values(s_vs, &own_geo); L.own_finite = own_geo.finite; }
-        __syncthreads();
-        if (tid < 9) s_jsh[tid] = own_geo.jsh[tid];
-        else if (tid < 36) s_tsh[tid - 9] = own_geo.tsh[tid - 9];
-        __syncthreads();
+        if (tid == 191) {   // (third wavefront; the fourth carries the KL pieces)
+            SrcGeo own_geo;
+            source_geo_values(s_vs, &own_geo);
+            L.own_finite = own_geo.finite;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) s_jsh[q] = own_geo.jsh[q];
+#pragma unroll
+            for (int q = 0; q < 27; ++q) s_tsh[q] = own_geo.tsh[q];
+        }
     }
-    const double *vs = s_vs;
 
     // KL per (type, component) terms: 16 threads of the last wave, concurrent with the first lift pass
     if (want_kl && tid >= 240 && tid < 256) {
@@ -1926,13 +2029,37 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
         K.g_r[i] = (mu1 - mu2) / var2;
         K.g_v[i] = .5 * (-1.0 / var1 + 1.0 / var2);
     }
+    // ---- KL value (elbo_kl.jl:140-154): by the same wavefront, while the others are in the second pass ----
+    auto kl_value = [&]() {
+        if (want_kl && tid >= 192 && tid < 256) {
+            lift_wave_sync();
+            if (tid >= 238 && tid < 240) {
+                const int i = tid - 238;
+                double ck = 0, cm = 0;
+                for (int d = 0; d < 8; ++d) { const double k = vs[28 + 8 * i + d]; ck += k * K.t[8 * i + d]; cm += k * K.m[8 * i + d]; }
+                K.ck[i] = ck; K.cm[i] = cm;
+            }
+            lift_wave_sync();
+            if (tid == 238) {
+                double kl = 0;
+                for (int i = 0; i < 2; ++i) kl -= vs[26 + i] * (K.ta[i] + K.ck[i] + K.g[i] + K.cm[i]);
+                const double x = vs[5], mu = prior->p.gal_radius_px_mean, s2 = prior->p.gal_radius_px_var;
+                kl += -0.5 * (log(2.0 * M_PI) + log(s2) + (x - mu) * (x - mu) / s2);
+                L.klv = kl;
+            }
+        }
+    };
 
     LIFT_TICK(0);
     // the images the target appears in (its visit list), LIFT_NT at a time
-    const int vo = vis_off[t], n_vis = vis_off[t + 1] - vo;
+    bool kl_done = false;
     for (int n0 = 0; n0 < n_vis; n0 += LIFT_NT) {
         const int nt = min(LIFT_NT, n_vis - n0);
+        // (the descriptor of this thread's first Hessian entry: in flight during the first two passes)
+        const int n_pairs = LIFT_NP * (LIFT_NP + 1) / 2;
+        uint4 pd_next = *reinterpret_cast<const uint4 *>(c_lift.pdesc[tid < n_pairs ? tid : 0]);
         // pass 1: chunk records -> per-image record; brightness moments and exponent coefficients
+        if (tid >= 200 && tid < 200 + 4 * nt) { const int q = tid - 200; L.s_J[q >> 2][q & 3] = patches[vo + n0 + (q >> 2)].J[q & 3]; }
         for (int k = tid; k < nt * ACC_N; k += nthr) {
             const int i = k / ACC_N, e = k - i * ACC_N;
             const DevPatch &P = patches[vo + n0 + i];   // tables are indexed by visit
@@ -1954,8 +2081,10 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
             }
             s_rec[i][e] = s;
         }
+        if (tid < nt) s_rec[tid][LIFT_REC_ZERO] = 0.0;
         if (want_grad) {
-            for (int k = tid; k < nt * 12; k += nthr) {
+            // (threads 96 ...: the first 84 have a second record to sum, the last 64 carry the KL pieces)
+            for (int k = tid >= 96 ? tid - 96 : tid + nthr - 96; k < nt * 12; k += nthr) {
                 const int i = k / 12, q = k - i * 12;
                 const int b = images[vis_img[vo + n0 + i]].band - 1;
                 if (q < 10) {
@@ -1971,82 +2100,80 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
         }
         __syncthreads();
         LIFT_TICK(1);
+        if (!kl_done) { kl_value(); kl_done = true; }
         if (tid == 0) for (int i = 0; i < nt; ++i) {
             sh_v += lg_sum ? s_rec[i][0] - lg_sum[vo + n0 + i] : s_rec[i][0];
             sh_cnt[0] += s_rec[i][ACC_CNT]; sh_cnt[1] += s_rec[i][ACC_CNT + 1];
         }
         if (want_grad) {
-            // pass 2: the non-zero entries of the 10 x 28 Jacobians of the reduced variables
-            for (int k = tid; k < nt * LIFT_JZ; k += nthr) {
-                const int i = k / LIFT_JZ, slot = k - i * LIFT_JZ;
-                int p, a, st0, cn0, sd0, cls0;
-                jz_unrank(slot, p, a);
-                param_rows(p, st0, cn0, sd0, cls0);
-                const int r = st0 + a * sd0;
+            // pass 2: the 10 x 28 Jacobians of the reduced variables, 3 slots per parameter (parameter p moves 2, 1, 3 or 2
+            // rows -- param_rows; the unused slots hold 0)
+            for (int k = tid; k < nt * LIFT_JZP; k += nthr) {
+                const int i = k / LIFT_JZP, slot = k - i * LIFT_JZP;
+                const int p = slot / 3, a = slot - 3 * p;
                 double v = 0.0;
-                if (r >= 4 && r < 6) { if (p < 2) v = patches[vo + n0 + i].J[(r - 4) + 2 * p]; }
-                else if (r == 6) { if (p == 2) v = 1.0; }
-                else if (r >= 7) { if (p >= 3 && p < 6) v = s_jsh[(r - 7) + 3 * (p - 3)]; }
-                else {
-                    const int ty = r & 1;          // rows 0,1 = c_i; rows 2,3 = q_i
-                    const bool isq = r >= 2;
-                    int st, cn, sd, cls;
-                    param_rows(p, st, cn, sd, cls);
-                    if (cls == 3 + ty) {
-                        const int slot = bright_slot(p);
-                        const double Ev = isq ? s_Ell[i][ty] : s_El[i][ty];
-                        if (slot < 0) v = Ev;
-                        else v = vs[26 + ty] * Ev * (isq ? s_lam[i][slot] : s_kap[i][slot]);
-                    }
+                if (p < 2) { if (a < 2) v = L.s_J[i][a + 2 * p]; }                        // rows 4, 5: pixel position
+                else if (p == 2) { if (a == 0) v = 1.0; }                                 // row 6: gal_frac_dev
+                else if (p < 6) v = s_jsh[a + 3 * (p - 3)];                               // rows 7..9: the covariance entries
+                else if (a < 2) {                                                         // rows ty (a = 0: c_ty), 2 + ty (a = 1: q_ty)
+                    const int ty = p < 10 ? ((p - 6) & 1) : (p < 26 ? (((p - 10) >> 2) & 1) : p - 26);
+                    const bool isq = a == 1;
+                    const int bs = bright_slot(p);
+                    const double Ev = isq ? s_Ell[i][ty] : s_El[i][ty];
+                    if (bs < 0) v = Ev;
+                    else v = vs[26 + ty] * Ev * (isq ? s_lam[i][bs] : s_kap[i][bs]);
                 }
                 s_jz[i][slot] = v;
             }
             __syncthreads();
             LIFT_TICK(2);
             // pass 3: gradient and upper-triangle Hessian; every entry is owned by one thread
-            const int n_pairs = LIFT_NP * (LIFT_NP + 1) / 2;
             for (int k = tid; k < n_pairs + LIFT_NP; k += nthr) {
+                const uint4 pd = pd_next;
+                if (k + nthr < n_pairs) pd_next = *reinterpret_cast<const uint4 *>(c_lift.pdesc[k + nthr]);
                 if (k >= n_pairs) {
                     const int p = k - n_pairs;
                     int st, cn, sd, cls;
                     param_rows(p, st, cn, sd, cls);
                     double s = 0.0;
                     for (int i = 0; i < nt; ++i)
-                        for (int a = 0; a < cn; ++a) { const int r = st + a * sd; s += s_jz[i][jz_off(p) + a] * s_rec[i][1 + r]; }
+                        for (int a = 0; a < cn; ++a) { const int r = st + a * sd; s += s_jz[i][3 * p + a] * s_rec[i][1 + r]; }
                     sh_d[p] += s;
                     continue;
                 }
                 if (!want_hess) continue;
-                // unrank k -> (p1 <= p2)
-                int p2 = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
-                while ((p2 + 1) * (p2 + 2) / 2 <= k) ++p2;
-                while (p2 * (p2 + 1) / 2 > k) --p2;
-                const int p1 = k - p2 * (p2 + 1) / 2;
-                int st1, cn1, sd1, cls1, st2, cn2, sd2, cls2;
-                param_rows(p1, st1, cn1, sd1, cls1);
-                param_rows(p2, st2, cn2, sd2, cls2);
+                // J1' R J2 over the (up to 3 x 3) rows the two parameters move: the record entries from c_lift.pdesc, terms
+                // that do not exist are 0 x 0 (LIFT_REC_ZERO, empty Jacobian slots)
+                const int p1 = (pd.z >> 8) & 0xff, p2 = (pd.z >> 16) & 0xff, code = pd.z >> 24;
+                int ri[9];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ri[q] = (pd.x >> (8 * q)) & 0xff; ri[4 + q] = (pd.y >> (8 * q)) & 0xff; }
+                ri[8] = pd.z & 0xff;
+                const int ty = p1 < 10 ? ((p1 - 6) & 1) : (p1 < 26 ? (((p1 - 10) >> 2) & 1) : p1 - 26);   // (code 2 only)
+                const int b1 = bright_slot(p1), b2 = bright_slot(p2);
                 double s = 0.0;
-                const int o1 = jz_off(p1), o2 = jz_off(p2);
                 for (int i = 0; i < nt; ++i) {
                     const double *rec = s_rec[i];
                     const double *jz = s_jz[i];
-                    for (int a = 0; a < cn1; ++a) {
-                        const int r1 = st1 + a * sd1;
-                        const double j1 = jz[o1 + a];
+                    // (all fifteen LDS reads of the image first: one wait instead of one per term)
+                    double rr[9], j1[3];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) rr[q] = rec[ri[q]];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) j1[a] = jz[3 * p1 + a];
+                    const double j20 = jz[3 * p2], j21 = jz[3 * p2 + 1], j22 = jz[3 * p2 + 2];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
                         double inner = 0.0;
-                        for (int c = 0; c < cn2; ++c) {
-                            const int r2 = st2 + c * sd2;
-                            const int lo = r1 < r2 ? r1 : r2, hi = r1 < r2 ? r2 : r1;
-                            inner += rec[hidx(lo, hi)] * jz[o2 + c];
-                        }
-                        s += j1 * inner;
+                        inner += rr[3 * a] * j20;
+                        inner += rr[3 * a + 1] * j21;
+                        inner += rr[3 * a + 2] * j22;
+                        s += j1[a] * inner;
                     }
                     // second derivatives of the reduced variables
-                    if (cls1 == 2 && cls2 == 2) {
+                    if (code == 1) {
                         for (int sg = 0; sg < 3; ++sg) s += rec[1 + 7 + sg] * s_tsh[sg + 3 * (p1 - 3) + 9 * (p2 - 3)];
-                    } else if (cls1 == cls2 && cls1 >= 3 && cls1 <= 4) {
-                        const int ty = cls1 - 3;
-                        const int b1 = bright_slot(p1), b2 = bright_slot(p2);
+                    } else if (code == 2) {
                         const double gc = rec[1 + ty], gq = rec[1 + 2 + ty];
                         const double El = s_El[i][ty], Ell = s_Ell[i][ty], ai = vs[26 + ty];
                         if (b1 >= 0 && b2 >= 0)
@@ -2062,23 +2189,9 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
         LIFT_TICK(3);
     }
 
-    // ---- KL value (elbo_kl.jl:140-154) ----
-    __syncthreads();   // the per-component KL terms were written by other threads (a target may have no visit at all)
-    if (want_kl && tid < 2) {
-        const int i = tid;
-        double ck = 0, cm = 0;
-        for (int d = 0; d < 8; ++d) { const double k = vs[28 + 8 * i + d]; ck += k * K.t[8 * i + d]; cm += k * K.m[8 * i + d]; }
-        K.ck[i] = ck; K.cm[i] = cm;
-    }
-    __syncthreads();
-    if (want_kl && tid == 0) {
-        double kl = 0;
-        for (int i = 0; i < 2; ++i) kl -= vs[26 + i] * (K.ta[i] + K.ck[i] + K.g[i] + K.cm[i]);
-        const double x = vs[5], mu = prior->p.gal_radius_px_mean, s2 = prior->p.gal_radius_px_var;
-        kl += -0.5 * (log(2.0 * M_PI) + log(s2) + (x - mu) * (x - mu) / s2);
-        sh_v += kl;
-    }
-    __syncthreads();
+    if (!kl_done) kl_value();   // (a target may have no visit at all)
+    __syncthreads();   // the KL pieces were written by threads of the fourth wavefront
+    if (want_kl && tid == 0) sh_v += L.klv;
     LIFT_TICK(4);
 
     // ---- assemble, check finiteness (elbo_objective.jl:487,490), store exactly symmetric ----
@@ -2093,13 +2206,14 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
     if (want_hess && o_h && COH) {
         // (the fused optimiser: o_h is in LDS) every entry (p1 <= p2) of the upper triangle is formed once and stored at
         // (p1, p2) and (p2, p1): half the kl_hess evaluations of the loop below, same values
-        for (int k = tid; k < CELESTE_HP; k += nthr) {
-            int p2 = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
-            while ((p2 + 1) * (p2 + 2) / 2 <= k) ++p2;
-            while (p2 * (p2 + 1) / 2 > k) --p2;
-            const int p1 = k - p2 * (p2 + 1) / 2;
+        // (entries without a KL term first, the others grouped by the branch of kl_hess they take: c_lift.order)
+        unsigned ad_next = c_lift.adesc[tid < CELESTE_HP ? tid : 0];
+        for (int kk = tid; kk < CELESTE_HP; kk += nthr) {
+            const unsigned ad = ad_next;
+            if (kk + nthr < CELESTE_HP) ad_next = c_lift.adesc[kk + nthr];
+            const int k = ad & 0x3ff, p1 = (ad >> 10) & 0x3f, p2 = (ad >> 16) & 0x3f;
             double v = (p2 < LIFT_NP) ? sh_h[p1 + LIFT_NP * p2] : 0.0;
-            if (want_kl) v += kl_hess(K, prior, vs, p1, p2);
+            if (want_kl && (ad >> 22)) v += kl_hess(K, prior, vs, p1, p2);
             if (!isfinite(v)) bad = 1;
             if (!(flags & CELESTE_FLAG_PACKED_HESS)) { o_h[p1 + CEL_P * p2] = v; o_h[p2 + CEL_P * p1] = v; }
             else o_h[k] = v;   // upper triangle, by columns: (p1, p2) at p2 (p2 + 1) / 2 + p1
@@ -2110,7 +2224,7 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
             const int c2 = k / CEL_P, c1 = k - c2 * CEL_P;
             const int p1 = c1 < c2 ? c1 : c2, p2 = c1 < c2 ? c2 : c1;
             double v = (p2 < LIFT_NP) ? sh_h[p1 + LIFT_NP * p2] : 0.0;
-            if (want_kl) v += kl_hess(K, prior, vs, p1, p2);
+            if (want_kl && c_lift.akl[p2 * (p2 + 1) / 2 + p1]) v += kl_hess(K, prior, vs, p1, p2);
             if (!isfinite(v)) bad = 1;
             if (!(flags & CELESTE_FLAG_PACKED_HESS)) o_h[k] = v;
             else if (c1 <= c2) o_h[c2 * (c2 + 1) / 2 + c1] = v;   // upper triangle, by columns

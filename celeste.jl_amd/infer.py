@@ -17,6 +17,7 @@ batch form one launch ("layer"): no two of them are neighbours, so optimising th
 the reference's schedule.
 """
 import logging
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -232,6 +233,9 @@ def infer_box(images, box: BoundingBox, catalog, method: str = "joint_vi", cfg: 
             raise ValueError("unknown method: %s" % method)
     finally:
         ctx.close()
-    return [OptimizedSource(float(catalog[t].pos[0]), float(catalog[t].pos[1]), vs[k].copy(), bad_sky(catalog[t], images),
-                            t in failed)
+    # the sky check is a median over a 101 x 101 box per source (numpy releases the GIL in it): a few host threads
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+        flags = list(pool.map(lambda t: bad_sky(catalog[t], images), targets, chunksize=64))
+    return [OptimizedSource(float(catalog[t].pos[0]), float(catalog[t].pos[1]), vs[k].copy(), flags[k], t in failed)
             for k, t in enumerate(targets)]

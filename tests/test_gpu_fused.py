@@ -234,8 +234,12 @@ def test_joint_dataflow_launch_equals_the_layered_schedule(crowded):
     for t in targets:
         vp0[t] = generic_init_source(f.catalog[t].pos)
     bad = int(np.argmax([len(n) for n in f.neighbors]))
-    for case, cfg in (("clean", cel.ElboConfig(max_iters=8)), ("failing", cel.ElboConfig(max_iters=5)), ("eig", cel.ElboConfig(max_iters=4))):
+    with _env(CELESTE_FORCE_VISIT_LISTS=1):
+        ctx_lists = cel.FieldContext(f.images, f.patches, f.neighbors)      # the sparse-patch-list code path
+    for case, cfg in (("clean", cel.ElboConfig(max_iters=8)), ("failing", cel.ElboConfig(max_iters=5)), ("eig", cel.ElboConfig(max_iters=4)),
+                      ("visit lists", cel.ElboConfig(max_iters=5)), ("no iterations", cel.ElboConfig(max_iters=0))):
         vp = vp0.copy()
+        ctx = ctx_lists if case == "visit lists" else crowded[1]
         tg = targets
         if case == "failing":
             vp[bad, 7] = np.nan
