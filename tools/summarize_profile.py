@@ -84,12 +84,17 @@ rs = find(traffic, "record_sum_kernel")
 sys.path.insert(0, os.path.join(root, "tools"))
 import count_flops
 flops = count_flops.main()   # FP64 flops per visited pixel in the ISA of the kernels as they are in this tree
-json.dump({"pixel_kernel_bytes_per_launch": px.get("fetch_bytes", 0) + px.get("write_bytes", 0),
-           "flops_per_pixel_visit": flops,
-           "fetch_bytes": px.get("fetch_bytes"), "write_bytes": px.get("write_bytes"),
-           "record_sum_bytes_per_launch": (rs.get("fetch_bytes", 0) + rs.get("write_bytes", 0)) or None,
-           "pixel_kernel_valu_utilization": valu_util,
-           "source": "profiles/%s_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KiB x 1024; "
-                     "record_sum FETCH_SIZE doubled per the gfx950 16 B/lane correction, pixel kernel uncorrected)" % tag},
-          open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+path = os.path.join(dst, "hbm_traffic.json")
+d = json.load(open(path)) if os.path.exists(path) else {}      # (count_flops --write keeps its instruction-mix keys here too)
+new = {"pixel_kernel_bytes_per_launch": px.get("fetch_bytes", 0) + px.get("write_bytes", 0),
+       "flops_per_pixel_visit": flops,
+       "fetch_bytes": px.get("fetch_bytes"), "write_bytes": px.get("write_bytes"),
+       "pixel_kernel_valu_utilization": valu_util,
+       "source": "profiles/%s_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KiB x 1024; "
+                 "record_sum FETCH_SIZE doubled per the gfx950 16 B/lane correction, pixel kernel uncorrected)" % tag}
+rsb = (rs.get("fetch_bytes", 0) + rs.get("write_bytes", 0)) or None
+if rsb is not None or "record_sum_bytes_per_launch" not in d:     # (PMC passes without the split sweeps keep the last measured figure)
+    new["record_sum_bytes_per_launch"] = rsb
+d.update(new)
+json.dump(d, open(path, "w"), indent=1)
 print("\n".join(lines))
