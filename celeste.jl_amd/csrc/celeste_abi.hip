@@ -159,7 +159,7 @@ struct celeste_ctx {
         int max_resident = 0;               // workgroups of optim_fused_kernel the device holds at once
     } fused;
     // device scratch of the less travelled entry points (eval_multi, render_expected): grown on demand, kept
-    struct Scratch { void *p = nullptr; size_t cap = 0; } scratch[13];
+    struct Scratch { void *p = nullptr; size_t cap = 0; } scratch[24];   // 13..22: celeste_joint_infer
     // timing
     int timing = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1612,10 +1612,11 @@ static int joint_dataflow(celeste_ctx_t *c, int64_t total, const int32_t *target
     int32_t *d_dep = nullptr, *d_succ_off = nullptr, *d_succ = nullptr, *d_rarr = nullptr;
     int rc = CELESTE_OK;
 #define JD_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto out; } } while (0)
-    JD_TRY(hipMalloc((void **)&d_dep, (size_t)E * sizeof(int32_t)));
-    JD_TRY(hipMalloc((void **)&d_succ_off, ((size_t)E + 1) * sizeof(int32_t)));
-    JD_TRY(hipMalloc((void **)&d_succ, std::max<size_t>(succ_flat.size(), 1) * sizeof(int32_t)));
-    JD_TRY(hipMalloc((void **)&d_rarr, (size_t)E * sizeof(int32_t)));
+    // (kept between calls: a schedule per box is the normal use)
+    JD_TRY(scratch_get(c, 19, (size_t)E * sizeof(int32_t), &d_dep));
+    JD_TRY(scratch_get(c, 20, ((size_t)E + 1) * sizeof(int32_t), &d_succ_off));
+    JD_TRY(scratch_get(c, 21, std::max<size_t>(succ_flat.size(), 1) * sizeof(int32_t), &d_succ));
+    JD_TRY(scratch_get(c, 22, (size_t)E * sizeof(int32_t), &d_rarr));
     if ((size_t)E * CEL_P > fb.cap_saved) {
         JD_TRY(hipStreamSynchronize(stream));
         if (fb.d_saved) { (void)hipFree(fb.d_saved); fb.d_saved = nullptr; }
@@ -1646,8 +1647,6 @@ static int joint_dataflow(celeste_ctx_t *c, int64_t total, const int32_t *target
 out:
 #undef JD_TRY
     if (rc != CELESTE_OK) (void)hipStreamSynchronize(stream);
-    void *ptrs[] = {d_dep, d_succ_off, d_succ, d_rarr};
-    for (void *q : ptrs) if (q) (void)hipFree(q);
     return rc;
 }
 
@@ -1697,12 +1696,12 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
     bool any_fused = false;
     int abort_rc = CELESTE_OK;
 #define JI_TRY(expr) do { if ((expr) != hipSuccess) { rc = CELESTE_ERR_HIP; goto done; } } while (0)
-    JI_TRY(hipMalloc((void **)&d_all, (size_t)total * sizeof(int32_t)));
-    JI_TRY(hipMalloc((void **)&d_it, (size_t)total * sizeof(int32_t)));
-    JI_TRY(hipMalloc((void **)&d_ev, (size_t)total * sizeof(int32_t)));
-    JI_TRY(hipMalloc((void **)&d_stt, (size_t)total * sizeof(int32_t)));
-    JI_TRY(hipMalloc((void **)&d_el, (size_t)total * sizeof(double)));
-    if (pos_centers) JI_TRY(hipMalloc((void **)&d_pos, (size_t)total * 2 * sizeof(double)));
+    JI_TRY(scratch_get(c, 13, (size_t)total * sizeof(int32_t), &d_all));
+    JI_TRY(scratch_get(c, 14, (size_t)total * sizeof(int32_t), &d_it));
+    JI_TRY(scratch_get(c, 15, (size_t)total * sizeof(int32_t), &d_ev));
+    JI_TRY(scratch_get(c, 16, (size_t)total * sizeof(int32_t), &d_stt));
+    JI_TRY(scratch_get(c, 17, (size_t)total * sizeof(double), &d_el));
+    if (pos_centers) JI_TRY(scratch_get(c, 18, (size_t)total * 2 * sizeof(double), &d_pos));
     JI_TRY(hipMemcpyAsync(d_all, layer_targets, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     if (pos_centers) JI_TRY(hipMemcpyAsync(d_pos, pos_centers, (size_t)total * 2 * sizeof(double), hipMemcpyHostToDevice, stream));
     memcpy(ob.h_vp, vp, vp_bytes);
@@ -1747,8 +1746,6 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
 done:
 #undef JI_TRY
     (void)hipStreamSynchronize(stream);
-    void *ptrs[] = {d_all, d_it, d_ev, d_stt, d_el, d_pos};
-    for (void *q : ptrs) if (q) (void)hipFree(q);
     return rc;
 }
 

@@ -32,15 +32,17 @@ for e in range(E):
     for u in nb[t]: readers[u].append(e)
 
 
-def simulate(P=512, t_chunk=19.5, t_step=130.0, t_start=5.0, t_render=13.0, n_render=5, t_end=9.0, busy_factor=1.0, label=""):
+def simulate(P=512, t_chunk=19.5, t_step=130.0, t_start=5.0, t_render=13.0, n_render=5, t_end=9.0, busy_factor=1.0, label="", urgent=None):
     """event simulation: a workgroup takes the queue's items in order; the last chunk item of an evaluation continues with
     the lift + step (t_step) and pushes the next evaluation's items; busy_factor stretches item times while every
     workgroup is busy (two waves per SIMD)."""
     depc = dep.copy()
     left = ev.copy()                       # evaluations left per entry
-    q = collections.deque()
+    q = collections.deque(); qh = collections.deque()
+    def put(item):
+        (qh if urgent is not None and urgent[item[1]] else q).append(item)
     for e in range(E):
-        if depc[e] == 0: q.append(("S", e))
+        if depc[e] == 0: put(("S", e))
     free = [(0.0, w) for w in range(P)]    # (time a workgroup becomes free, id)
     heapq.heapify(free)
     pending = []                           # (time, seq, items to push)
@@ -49,20 +51,18 @@ def simulate(P=512, t_chunk=19.5, t_step=130.0, t_start=5.0, t_render=13.0, n_re
     while done < E:
         # release pushes up to the time the next workgroup is free
         tfree, w = free[0]
-        while pending and (not q or pending[0][0] <= tfree):
+        while pending and ((not q and not qh) or pending[0][0] <= tfree):
             tp, _, items = heapq.heappop(pending)
-            q.extend((k, e, tp) if len((k, e)) == 2 else (k, e) for k, e in items)
-            if not q: continue
-            break
-        if not q:
+            for k, e in items: put((k, e, tp))
+        if not q and not qh:
             if not pending: break
             continue
-        item = q.popleft()
+        item = qh.popleft() if qh else q.popleft()
         kind, e = item[0], item[1]
         tavail = item[2] if len(item) > 2 else 0.0
         tfree, w = heapq.heappop(free)
         t0 = max(tfree, tavail)
-        stretch = busy_factor if len(q) > P else 1.0
+        stretch = busy_factor if len(q) + len(qh) > P else 1.0
         nch = max(1, int(chunks[tg[e]]))
         if kind == "S":
             t1 = t0 + t_start; heapq.heappush(pending, (t1, seq, [("R", e)] * n_render)); seq += 1
@@ -97,3 +97,14 @@ simulate(t_step=105.0, label="lift + step - 25 us")
 simulate(t_chunk=16.0, label="chunk item - 3.5 us")
 simulate(P=1024, label="1024 workgroups")
 simulate(P=100000, label="unbounded workgroups (critical path)")
+
+# priority: bottom level of every entry from A-PRIORI estimates of its evaluations (sweep means), urgent = the top share
+per_sweep = E // 3
+est = np.array([22.0 if e < per_sweep else (5.6 if e < 2 * per_sweep else 3.2) for e in range(E)])
+for name, cost in (("a-priori estimates", est), ("true evaluation counts (oracle)", ev.astype(float))):
+    bl = np.zeros(E)
+    for e in range(E - 1, -1, -1):
+        bl[e] = cost[e] + (max(bl[s2] for s2 in succ[e]) if succ[e] else 0.0)
+    for share in (0.1, 0.25, 0.5):
+        thr = np.quantile(bl, 1 - share)
+        simulate(urgent=bl >= thr, label="two queues, urgent = top %d %% by bottom level (%s)" % (100 * share, name))
