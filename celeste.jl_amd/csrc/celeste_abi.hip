@@ -833,9 +833,17 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     }
     if (render_neighbors) {
     if (c->n_value_items > 0)
-        hipLaunchKernelGGL(value_kernel, dim3((unsigned)c->n_value_items), dim3(64), 0, stream,
-                           c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_val_off,
-                           c->d_value_items, c->NC, c->chunk_px, c->d_val);
+    {
+        // (single-precision mode: the neighbours' densities in fp32 too, their moments in fp64)
+        if (flags & CELESTE_FLAG_FP32)
+            hipLaunchKernelGGL(value_kernel<float>, dim3((unsigned)c->n_value_items), dim3(64), 0, stream,
+                               c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_val_off,
+                               c->d_value_items, c->NC, c->chunk_px, c->d_val);
+        else
+            hipLaunchKernelGGL(value_kernel<double>, dim3((unsigned)c->n_value_items), dim3(64), 0, stream,
+                               c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_val_off,
+                               c->d_value_items, c->NC, c->chunk_px, c->d_val);
+    }
     }
     if (render_only) { HIP_TRY(hipGetLastError()); return CELESTE_OK; }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));

@@ -371,6 +371,42 @@ __device__ inline double galaxy_value(const Comp *tc, int NC, double dx, double 
     return v;
 }
 
+// The same two densities in single precision (CELESTE_FLAG_FP32: the neighbours' light is rendered in the arithmetic of
+// the per-pixel terms).
+__device__ inline float star_value_f(const double *__restrict__ coef, float xh, float xw) {
+    int ix = (int)floorf(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
+    int iy = (int)floorf(xw); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
+    float wx[4], wy[4];
+    bspline_w(xh - (float)ix, wx); bspline_w(xw - (float)iy, wy);
+    const double *c0 = coef + (ix - 1) + CEL_COEF * (iy - 1);
+    float y = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const double *cb = c0 + CEL_COEF * b;
+        const float r = (float)cb[0] * wx[0] + (float)cb[1] * wx[1] + (float)cb[2] * wx[2] + (float)cb[3] * wx[3];
+        y += r * wy[b];
+    }
+    return y < 0 ? 1e-3f * __expf(y) : 1e-3f * (y + 1.0f);
+}
+// two components per instruction (v_pk_fma_f32): tcf holds, per PAIR of components, 6 slots of two floats --
+// p11, p12, p22, xi1, xi2, w0 of components c, c + 1 in the two halves (NC = 14 psf_K is even)
+typedef float vf2 __attribute__((ext_vector_type(2)));
+__device__ inline float galaxy_value_f(const float *tcf, int NC, float dx, float dy) {
+    const vf2 *tp = reinterpret_cast<const vf2 *>(tcf);
+    const vf2 dxx = (vf2)(dx), dyy = (vf2)(dy);
+    vf2 v = (vf2)(0.0f);
+    for (int c = 0; c < NC; c += 2) {
+        const vf2 *k = tp + 3 * c;
+        const vf2 p11 = k[0], p12 = k[1], p22 = k[2], xi1 = k[3], xi2 = k[4], w0 = k[5];
+        const vf2 d1 = dxx - xi1, d2 = dyy - xi2;
+        const vf2 u = p11 * d1 + p12 * d2, vv = p12 * d1 + p22 * d2;
+        const vf2 q = -0.5f * (d1 * u + d2 * vv);
+        const vf2 e = {__expf(q.x), __expf(q.y)};
+        v += w0 * e;
+    }
+    return v.x + v.y;
+}
+
 // ---- cross-lane helpers (wave64) ----------------------------------------------------------------
 __device__ inline double wave_sum(double x) {
 #pragma unroll
@@ -716,18 +752,26 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
 // the light of one neighbour on pixels [p0, p1) of an overlap rectangle (h fastest, RH rows, corner (h_lo, w_lo) in 0-based
 // image coordinates), into the neighbour's own patch buffer `out`: value_kernel's loop, one wavefront.  COH: the values
 // are for workgroups of the same launch (write-through stores).
-template <bool COH>
+template <bool COH, typename R = double>
 __device__ __forceinline__ void value_pixels(int lane, const DevPatch &P, const SrcImg &si, const Comp *__restrict__ tc, int NC,
                                              const double *__restrict__ coefs, const double *__restrict__ etab, int h_lo,
-                                             int w_lo, int RH, int p0, int p1, double2 *__restrict__ out) {
+                                             int w_lo, int RH, int p0, int p1, double2 *__restrict__ out,
+                                             const float *__restrict__ tcf = nullptr) {
     const double *__restrict__ coef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
     for (int idx = p0 + lane; idx < p1; idx += 64) {
         const int rw = idx / RH, rh = idx - rw * RH;
         const int h0 = h_lo + rh, w0 = w_lo + rw;  // 0-based image coordinates
         const double hh = (double)(h0 + 1), ww = (double)(w0 + 1);
-        const double f0 = star_value(coef, hh + sh0, ww + sw0);
-        const double f1 = galaxy_value(tc, NC, hh - si.m1, ww - si.m2, etab);
+        double f0, f1;
+        if constexpr (sizeof(R) == 8) {
+            f0 = star_value(coef, hh + sh0, ww + sw0);
+            f1 = galaxy_value(tc, NC, hh - si.m1, ww - si.m2, etab);
+        } else {
+            // the two densities in single precision (differences of coordinates formed in double), the moments in double
+            f0 = (double)star_value_f(coef, (float)(hh + sh0), (float)(ww + sw0));
+            f1 = (double)galaxy_value_f(tcf, NC, (float)(hh - si.m1), (float)(ww - si.m2));
+        }
         const double En = si.c0 * f0 + si.c1 * f1;                      // E_G_s.v  (elbo_objective.jl:62-65)
         const double E2n = si.q0 * (f0 * f0) + si.q1 * (f1 * f1);
         double2 *const o = out + ((h0 - P.off_h) + (int64_t)P.H2 * (w0 - P.off_w));
@@ -746,6 +790,7 @@ __device__ __forceinline__ void value_pixels(int lane, const DevPatch &P, const 
 #ifdef VALUE_TIMING   // debug builds (tools/variants): shader clocks per section of the value kernel
 __device__ unsigned long long g_value_clk[8];
 #endif
+template <typename R>
 __global__ void __launch_bounds__(64)
 value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
@@ -784,8 +829,17 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
         for (int i = threadIdx.x; i < NC * 8; i += 64) dst[i] = src[i];
         __syncthreads();
     }
+    __shared__ float tcf[sizeof(R) == 4 ? 6 * 14 * CEL_MAXK : 2];
+    if constexpr (sizeof(R) == 4) {
+        if ((int)threadIdx.x < NC) {      // pair-interleaved single-precision records (galaxy_value_f)
+            const Comp k = tc[threadIdx.x];
+            float *o = tcf + 12 * (threadIdx.x >> 1) + (threadIdx.x & 1);
+            o[0] = (float)k.p11; o[2] = (float)k.p12; o[4] = (float)k.p22; o[6] = (float)k.xi1; o[8] = (float)k.xi2; o[10] = (float)k.w0;
+        }
+        __syncthreads();
+    }
     VT(1);
-    value_pixels<false>(threadIdx.x, P, si, tc, NC, coefs, etab, h_lo, w_lo, RH, p0, p1, val + val_off[sn]);
+    value_pixels<false, R>(threadIdx.x, P, si, tc, NC, coefs, etab, h_lo, w_lo, RH, p0, p1, val + val_off[sn], tcf);
     VT(2);
 #ifdef VALUE_TIMING
     if (threadIdx.x == 0) {
