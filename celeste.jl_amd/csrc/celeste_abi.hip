@@ -1572,7 +1572,7 @@ cleanup:
 
 
 // ---- joint inference as ONE launch: the schedule's entries as a dataflow (fused_kernels.h, joint mode) ----------------
-#define JOINT_DATAFLOW_MAX 65536
+#define JOINT_DATAFLOW_MAX 262144
 // *ran = false (and CELESTE_OK): the schedule does not fit the launch's encodings -- the caller runs it layer by layer
 static int joint_dataflow(celeste_ctx_t *c, int64_t total, const int32_t *targets, const int32_t *d_all, const double *d_pos,
                           const OptParams &op, uint32_t flags, int32_t *d_it, int32_t *d_ev, double *d_el, int32_t *d_stt,

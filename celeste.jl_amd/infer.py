@@ -17,7 +17,6 @@ batch form one launch ("layer"): no two of them are neighbours, so optimising th
 the reference's schedule.
 """
 import logging
-import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -207,7 +206,14 @@ def bad_sky(ce, images) -> bool:
     px = px[~np.isnan(px)]
     if px.size == 0:
         return False
-    return (claimed_sky + 5) < float(np.median(px))
+    # median(px) by selection (what np.median does, without its per-call overhead: 2000 sources took 0.3 s)
+    k = px.size // 2
+    if px.size % 2:
+        med = float(np.partition(px, k)[k])
+    else:
+        part = np.partition(px, [k - 1, k])
+        med = float((part[k - 1] + part[k]) * px.dtype.type(0.5))
+    return (claimed_sky + 5) < med
 
 
 def infer_box(images, box: BoundingBox, catalog, method: str = "joint_vi", cfg: Optional[ElboConfig] = None,
@@ -233,9 +239,6 @@ def infer_box(images, box: BoundingBox, catalog, method: str = "joint_vi", cfg: 
             raise ValueError("unknown method: %s" % method)
     finally:
         ctx.close()
-    # the sky check is a median over a 101 x 101 box per source (numpy releases the GIL in it): a few host threads
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
-        flags = list(pool.map(lambda t: bad_sky(catalog[t], images), targets, chunksize=64))
-    return [OptimizedSource(float(catalog[t].pos[0]), float(catalog[t].pos[1]), vs[k].copy(), flags[k], t in failed)
+    return [OptimizedSource(float(catalog[t].pos[0]), float(catalog[t].pos[1]), vs[k].copy(), bad_sky(catalog[t], images),
+                            t in failed)
             for k, t in enumerate(targets)]

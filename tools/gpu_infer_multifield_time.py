@@ -19,3 +19,9 @@ for rep in range(2):
     one_node_joint_infer(ctx, f.catalog, tg, f.neighbors, schedule="coloring"); t2 = time.time()
 print("%d fields, %d images, %d sources: single infer %.3f s (%.0f sources/s); joint infer (3 sweeps, colouring) %.3f s "
       "(%.0f sources/s)" % (grid[0] * grid[1], len(f.images), S, t1 - t0, S / (t1 - t0), t2 - t1, S / (t2 - t1)))
+for mode in ("1", "0"):
+    os.environ["CELESTE_JOINT_DATAFLOW"] = mode
+    for rep in range(2):
+        t3 = time.time(); one_node_joint_infer(ctx, f.catalog, tg, f.neighbors); t4 = time.time()
+    print("joint infer, the reference's Cyclades schedule (batches of 400, 3 sweeps), %s: %.3f s (%.0f sources/s)"
+          % ("one dataflow launch" if mode == "1" else "layer by layer", t4 - t3, S / (t4 - t3)))
