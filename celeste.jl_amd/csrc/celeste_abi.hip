@@ -1689,9 +1689,14 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
     if (rc != CELESTE_OK) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t stream = c->stream;
-    // CELESTE_JOINT_DATAFLOW=0: layer by layer (one fused or chained optimisation per layer)
-    bool dataflow = total <= JOINT_DATAFLOW_MAX && optim_use_fused(c, 1, 1, op);
-    if (const char *e = getenv("CELESTE_JOINT_DATAFLOW")) if (atoi(e) == 0) dataflow = false;
+    // One dataflow launch for the whole schedule when its layers are of the size the fused launch is the better driver
+    // for (Cyclades batches); schedules with huge layers (a greedy colouring of a 30 000-source scene: 15 000 sources in
+    // the first) run layer by layer, where the lock-step kernels spend half the chip time per evaluation (measured on
+    // config 5's scene: colouring 0.60 s layered / 0.99 s dataflow, Cyclades 2.39 s layered / 0.99 s dataflow).
+    // CELESTE_JOINT_DATAFLOW=0 / 1 forces one or the other.
+    const bool can_dataflow = total <= JOINT_DATAFLOW_MAX && optim_use_fused(c, 1, 1, op);
+    bool dataflow = can_dataflow && widest <= FUSED_AUTO_MAX;
+    if (const char *e = getenv("CELESTE_JOINT_DATAFLOW")) dataflow = can_dataflow && atoi(e) != 0;
     rc = optim_buffers(c, dataflow ? (size_t)total : widest, stream);
     if (rc != CELESTE_OK) return rc;
     auto &ob = c->opt;

@@ -23,7 +23,7 @@ from typing import Callable, List, Optional, Sequence
 import numpy as np
 
 from .elbo import ElboConfig, FieldContext
-from .params import catalog_init_source, generic_init_source
+from .params import catalog_init_source, generic_init_source, init_source_table  # noqa: F401
 from .parallel import sharded_maximize
 from .partition import color_classes, partition_cyclades_dynamic
 
@@ -55,10 +55,8 @@ def one_node_single_infer(ctx: FieldContext, catalog, target_sources: Sequence[i
                           cfg: Optional[ElboConfig] = None, failed: Optional[set] = None) -> np.ndarray:
     """Returns the optimised parameters, one row per target (OptimizedSource.vs).  Targets that failed are logged,
     keep their initial row and are added to `failed` (the reference drops them from its result list)."""
-    vp_nbr = np.stack([catalog_init_source(ce) for ce in catalog])
-    vp = vp_nbr.copy()
-    for t in target_sources:
-        vp[t] = generic_init_source(catalog[t].pos)
+    vp_nbr = init_source_table(catalog)
+    vp = init_source_table(catalog, target_sources)
     cfg = cfg or default_infer_config()
     new, _, _, _, st = ctx.maximize_batch(vp, list(target_sources), cfg, vp_neighbors=vp_nbr, raise_on_error=False)
     _report_failures(target_sources, st, "one_node_single_infer", failed)
@@ -130,9 +128,7 @@ def one_node_joint_infer(ctx: FieldContext, catalog, target_sources: Sequence[in
     one process per GPU, images replicated (every rank builds the same FieldContext), layers sharded.
     A source that fails in some layer keeps the row it had before that layer (logged, added to `failed`)."""
     targets = list(target_sources)
-    vp = np.stack([catalog_init_source(ce) for ce in catalog])
-    for t in targets:
-        vp[t] = generic_init_source(catalog[t].pos)
+    vp = init_source_table(catalog, targets)
     cfg = cfg or default_infer_config()
     if world == 1:
         # the whole schedule in one call: the parameter table stays in HBM across all layers (celeste_joint_infer)

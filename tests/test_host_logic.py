@@ -367,3 +367,19 @@ def test_patch_table_is_get_sky_patches_without_the_objects():
     t2 = model.patch_table(f.images, f.catalog, radius_override_pix=6.0)
     p2 = model.get_sky_patches(f.images, f.catalog, radius_override_pix=6.0)
     assert all(p2[s][n].box == ((b[0], b[1]), (b[2], b[3])) for (s, n, b) in zip(t2.source, t2.image, t2.box))
+
+
+def test_init_source_table_equals_the_per_entry_functions():
+    """params.init_source_table (the table of setup_vecs in one array) against catalog_init_source / generic_init_source"""
+    import numpy as np
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.params import catalog_init_source, generic_init_source, init_source_table
+    f = synthetic.make_field(120, 130, 25, seed=4)
+    cat = f.catalog
+    ref = np.stack([catalog_init_source(ce) for ce in cat])
+    assert np.array_equal(ref, init_source_table(cat))
+    tg = [t for t in range(len(cat)) if t % 3 != 1]
+    for t in tg:
+        ref[t] = generic_init_source(cat[t].pos)
+    assert np.array_equal(ref, init_source_table(cat, tg))
+    assert init_source_table([], []).shape == (0, 44)

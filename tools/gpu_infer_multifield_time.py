@@ -25,3 +25,16 @@ for mode in ("1", "0"):
         t3 = time.time(); one_node_joint_infer(ctx, f.catalog, tg, f.neighbors); t4 = time.time()
     print("joint infer, the reference's Cyclades schedule (batches of 400, 3 sweeps), %s: %.3f s (%.0f sources/s)"
           % ("one dataflow launch" if mode == "1" else "layer by layer", t4 - t3, S / (t4 - t3)))
+from celeste_jl_amd.infer import joint_layers, default_infer_config
+from celeste_jl_amd.params import catalog_init_source, generic_init_source
+vp = np.stack([catalog_init_source(ce) for ce in f.catalog])
+for t in tg:
+    vp[t] = generic_init_source(f.catalog[t].pos)
+for schedule in ("cyclades", "coloring"):
+    layers = joint_layers(tg, f.neighbors, schedule=schedule)
+    centers = [vp[l, 0:2].copy() for l in layers]
+    for mode in ("1", "0"):
+        os.environ["CELESTE_JOINT_DATAFLOW"] = mode
+        t5 = time.time(); out = ctx.joint_infer(vp, layers, default_infer_config(), pos_centers=centers); t6 = time.time()
+        print("celeste_joint_infer, %s, %d layers (largest %d), dataflow=%s: %.3f s; evaluations %d (mean %.1f per entry, max %d)"
+              % (schedule, len(layers), max(map(len, layers)), mode, t6 - t5, out[2].sum(), out[2].mean(), out[2].max()))
