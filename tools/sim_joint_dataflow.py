@@ -32,7 +32,7 @@ for e in range(E):
     for u in nb[t]: readers[u].append(e)
 
 
-def simulate(P=512, t_chunk=19.5, t_step=130.0, t_start=5.0, t_render=13.0, n_render=5, t_end=9.0, busy_factor=1.0, label="", urgent=None):
+def simulate(P=512, t_chunk=19.5, t_step=130.0, t_start=5.0, t_render=13.0, n_render=5, t_end=9.0, busy_factor=1.0, label="", urgent=None, t_chunk_busy=None):
     """event simulation: a workgroup takes the queue's items in order; the last chunk item of an evaluation continues with
     the lift + step (t_step) and pushes the next evaluation's items; busy_factor stretches item times while every
     workgroup is busy (two waves per SIMD)."""
@@ -71,7 +71,7 @@ def simulate(P=512, t_chunk=19.5, t_step=130.0, t_start=5.0, t_render=13.0, n_re
             if rarr[e] == n_render:
                 heapq.heappush(pending, (t1, seq, [("C", e)] * nch)); seq += 1
         else:
-            t1 = t0 + t_chunk * stretch; arrivals[e] += 1
+            t1 = t0 + (t_chunk_busy if (t_chunk_busy is not None and len(q) + len(qh) > P) else t_chunk * stretch); arrivals[e] += 1
             if arrivals[e] == nch:
                 arrivals[e] = 0
                 t1 += t_step * (stretch if busy_factor > 1 else 1.0)
@@ -98,6 +98,8 @@ simulate(t_chunk=16.0, label="chunk item - 3.5 us")
 simulate(P=1024, label="1024 workgroups")
 simulate(P=100000, label="unbounded workgroups (critical path)")
 
+simulate(t_step=118.0, label="lift - 12 us (this round's lift)")
+simulate(t_step=118.0, t_chunk_busy=14.3, label="... + four records per workgroup while the queue is long")
 # priority: bottom level of every entry from A-PRIORI estimates of its evaluations (sweep means), urgent = the top share
 per_sweep = E // 3
 est = np.array([22.0 if e < per_sweep else (5.6 if e < 2 * per_sweep else 3.2) for e in range(E)])
