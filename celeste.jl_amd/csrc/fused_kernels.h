@@ -213,7 +213,7 @@ __device__ __forceinline__ void fused_push_eval(const FusedArgs &A, const int ti
 }
 
 // ---- joint mode: the start of an entry ----
-__device__ __forceinline__ void joint_start(const FusedArgs &A, FusedShared &F, const int tid, const int e) {
+__device__ __noinline__ void joint_start(const FusedArgs &A, FusedShared &F, const int tid, const int e) {
     const int t = A.targets[e];
     double *const row = A.vp + (size_t)t * CEL_P;
     OptState *const js = reinterpret_cast<OptState *>(F.ev_h);          // (LDS scratch: no evaluation is in flight here)
@@ -240,7 +240,7 @@ __device__ __forceinline__ void joint_start(const FusedArgs &A, FusedShared &F, 
 }
 
 // ---- joint mode: one group of value-kernel items of an entry's source, one item per wavefront ----
-__device__ __forceinline__ void joint_render(const FusedArgs &A, FusedShared &F, const int tid, const int code) {
+__device__ __noinline__ void joint_render(const FusedArgs &A, FusedShared &F, const int tid, const int code) {
     const int lane = tid & 63, wave = tid >> 6;
     const int e = code >> A.j_gshift, g = code & ((1 << A.j_gshift) - 1);
     const int t = A.targets[e];
@@ -289,7 +289,7 @@ __device__ __forceinline__ void joint_render(const FusedArgs &A, FusedShared &F,
 }
 
 // ---- joint mode: the end of an entry (its last step has been stored and drained) ----
-__device__ __forceinline__ void joint_end(const FusedArgs &A, FusedShared &F, const int tid, const int e) {
+__device__ __noinline__ void joint_end(const FusedArgs &A, FusedShared &F, const int tid, const int e) {
     const int lane = tid & 63, wave = tid >> 6;
     const int t = A.targets[e];
     double *const row = A.vp + (size_t)t * CEL_P;
@@ -351,6 +351,19 @@ __device__ __forceinline__ void joint_end(const FusedArgs &A, FusedShared &F, co
             for (int i = tid; i < nready; i += FUSED_NT) stc<true>(&A.q_items[base + i], A.j_R + ready[i]);
     }
     __syncthreads();
+}
+
+// the lift and the Newton step of a target whose records are complete; returns whether the target is done.
+// NOT inlined: the persistent loop around it then keeps the register allocation of the pixel code it mostly runs.
+__device__ __noinline__ int fused_lift_step(const FusedArgs &A, FusedShared &F, const int tid, const int ti) {
+    const int t = A.targets[ti];
+    if (tid == 0) stc<true>(&A.arrivals[ti], 0);
+    lift_target<true>(F.lift, tid, ti, t, A.vp, A.images, A.patches, A.geo, A.nbr_off, A.nbr_idx, A.acc, A.prior, A.vis_off,
+                      A.vis_img, A.N, A.M, A.CH, A.chunk_px, A.flags, &F.ev_v, F.ev_d, F.ev_h, nullptr, &F.ev_status,
+                      A.lg_sum, A.rec_off);
+    __syncthreads();
+    return optim_step_target<true, FUSED_NT>(F.step, tid, A.st[ti], A.Hstate + (size_t)ti * NF * NF,
+                                             A.vp + (size_t)t * CEL_P, F.ev_h, F.ev_d, -F.ev_v, F.ev_status, A.op);
 }
 
 template <bool JOINT>
@@ -442,15 +455,7 @@ optim_fused_kernel(const FusedArgs A) {
         if (!last) continue;
 
         // ---- the target's evaluation is complete: lift, Newton step ----
-        const int t = A.targets[ti];
-        if (tid == 0) stc<true>(&A.arrivals[ti], 0);
-        lift_target<true>(F.lift, tid, ti, t, A.vp, A.images, A.patches, A.geo, A.nbr_off, A.nbr_idx, A.acc, A.prior, A.vis_off,
-                          A.vis_img, A.N, A.M, A.CH, A.chunk_px, A.flags, &F.ev_v, F.ev_d, F.ev_h, nullptr, &F.ev_status,
-                          A.lg_sum, A.rec_off);
-        __syncthreads();
-        FT(4);
-        const int done = optim_step_target<true, FUSED_NT>(F.step, tid, A.st[ti], A.Hstate + (size_t)ti * NF * NF,
-                                                           A.vp + (size_t)t * CEL_P, F.ev_h, F.ev_d, -F.ev_v, F.ev_status, A.op);
+        const int done = fused_lift_step(A, F, tid, ti);
         FT(5);
         drain_stores();      // the target's row of vp, its state and saved Hessian are in memory ...
         __syncthreads();     // ... before its next items (or the end of the launch) become visible
