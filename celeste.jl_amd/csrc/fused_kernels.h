@@ -353,6 +353,71 @@ __device__ __noinline__ void joint_end(const FusedArgs &A, FusedShared &F, const
     __syncthreads();
 }
 
+// one chunk record on the calling workgroup: the four 64-pixel iterations on its four wavefronts, the record stored, the
+// target's arrival counted (F.last: this record completed the target's evaluation).  Returns the target's slot.
+// NOT inlined: its register allocation is then the pixel loop's own (pixel_kernel's), whatever surrounds the call.
+template <bool JOINT>
+__device__ __noinline__ int fused_chunk_record(const FusedArgs &A, FusedShared &F, const int tid, const int item) {
+    const int lane = tid & 63, wave = tid >> 6;
+    FT_DECL;
+    const int4 d0 = A.chunk_desc[2 * item], d1 = A.chunk_desc[2 * item + 1];
+    const int ti = d0.x;
+    const int j = d0.y, ch = d0.z, t = d0.w, v = d1.x, n = d1.y;
+    const DevPatch &P = A.patches[v];
+    const int npx = P.H2 * P.W2;
+    const int p0 = ch * A.chunk_px, p1 = min(npx, p0 + A.chunk_px);
+    // the target's current parameters (another workgroup stepped it), then its tables for this image
+    if (tid < CEL_P) F.theta[tid] = ldc<true>(A.vp + (size_t)t * CEL_P + tid);
+    if (wave == 2) F.etab[lane] = g_exp2_table[lane];
+    for (int i = tid; i < ACC_N * ACC_SLOTS; i += FUSED_NT) F.sacc[i] = 0.0;
+    if (tid == 0) F.turn = 0;
+    __syncthreads();
+    if (wave == 0) {
+        prep_visit_values<false>(lane, F.theta, P, A.images[n].band - 1, A.K, &F.si, F.tc);
+        if (lane < A.NC) comp_extra(F.tc[lane], F.tcx + COMPX * lane);
+    } else if (wave == 1) brightness_moments_wave(lane, F.theta, P, A.images[n].band - 1, &F.si);
+    __syncthreads();
+    FT(1);
+    const int base = p0 + 64 * wave;
+    if (base < p1) {
+        PixWork<double> W;
+        W.img = &A.images[n]; W.P = &P; W.patches = A.patches; W.bitmaps = A.bitmaps; W.nbr_idx = A.nbr_idx;
+        W.nb0 = A.nbr_off[t]; W.nb1 = A.nbr_off[t + 1];
+        W.nv = A.nbr_vis ? A.nbr_vis + A.nv_base[t] + (int64_t)j * (W.nb1 - W.nb0) : nullptr;
+        W.val_off = A.val_off; W.val = A.val; W.active_rank = nullptr; W.my_rank = 0;
+        W.N = A.N; W.n = n; W.NC = A.NC; W.v = v;
+        W.si = F.si;
+        W.tc = F.tc; W.tcx = F.tcx; W.tcr = reinterpret_cast<const CompR<double> *>(F.tc);
+        W.etab = F.etab;
+        W.tcoef = A.coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
+        W.tile_off = nullptr; W.rec = nullptr;
+        double a[3] = {0.0, 0.0, 0.0};
+        volatile int *turn = &F.turn;
+        // pixel_kernel's wavefront adds iteration after iteration into the slots; here iteration w belongs to
+        // wavefront w, and the wavefronts take turns in the same order
+        pixel_iter<2, double, false, FUSED_GATED != 0, JOINT>(W, base, p1, lane, F.sacc + (lane & (ACC_SLOTS - 1)), a, [&]() {
+            while (*turn != wave) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the adds have been performed ...
+        if (lane == 0) *turn = wave + 1;                          // ... before the next wavefront starts its own
+    }
+    __syncthreads();
+    FT(2);
+    if (wave == 0) {
+        double *out = A.acc + (size_t)item * ACC_N;
+        fold_record_slots<2>(F.sacc, lane, [&](int e, double s) { stc<true>(out + e, s); });
+        drain_stores();
+        if (lane == 0) {
+            const int before = __hip_atomic_fetch_add(&A.arrivals[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            F.last = before == A.tgt_rec[ti].y - 1;
+        }
+    }
+    __syncthreads();
+    FT(3); FT_COUNT(14);
+    return ti;
+}
+
 // the lift and the Newton step of a target whose records are complete; returns whether the target is done.
 // NOT inlined: the persistent loop around it then keeps the register allocation of the pixel code it mostly runs.
 __device__ __noinline__ int fused_lift_step(const FusedArgs &A, FusedShared &F, const int tid, const int ti) {
@@ -391,63 +456,8 @@ optim_fused_kernel(const FusedArgs A) {
             continue;
         }
         if (item >= 0) {
-            // ---- one chunk record ----
-            const int4 d0 = A.chunk_desc[2 * item], d1 = A.chunk_desc[2 * item + 1];
-            ti = d0.x;
-            const int j = d0.y, ch = d0.z, t = d0.w, v = d1.x, n = d1.y;
-            const DevPatch &P = A.patches[v];
-            const int npx = P.H2 * P.W2;
-            const int p0 = ch * A.chunk_px, p1 = min(npx, p0 + A.chunk_px);
-            // the target's current parameters (another workgroup stepped it), then its tables for this image
-            if (tid < CEL_P) F.theta[tid] = ldc<true>(A.vp + (size_t)t * CEL_P + tid);
-            if (wave == 2) F.etab[lane] = g_exp2_table[lane];
-            for (int i = tid; i < ACC_N * ACC_SLOTS; i += FUSED_NT) F.sacc[i] = 0.0;
-            if (tid == 0) F.turn = 0;
-            __syncthreads();
-            if (wave == 0) {
-                prep_visit_values<false>(lane, F.theta, P, A.images[n].band - 1, A.K, &F.si, F.tc);
-                if (lane < A.NC) comp_extra(F.tc[lane], F.tcx + COMPX * lane);
-            } else if (wave == 1) brightness_moments_wave(lane, F.theta, P, A.images[n].band - 1, &F.si);
-            __syncthreads();
-            FT(1);
-            const int base = p0 + 64 * wave;
-            if (base < p1) {
-                PixWork<double> W;
-                W.img = &A.images[n]; W.P = &P; W.patches = A.patches; W.bitmaps = A.bitmaps; W.nbr_idx = A.nbr_idx;
-                W.nb0 = A.nbr_off[t]; W.nb1 = A.nbr_off[t + 1];
-                W.nv = A.nbr_vis ? A.nbr_vis + A.nv_base[t] + (int64_t)j * (W.nb1 - W.nb0) : nullptr;
-                W.val_off = A.val_off; W.val = A.val; W.active_rank = nullptr; W.my_rank = 0;
-                W.N = A.N; W.n = n; W.NC = A.NC; W.v = v;
-                W.si = F.si;
-                W.tc = F.tc; W.tcx = F.tcx; W.tcr = reinterpret_cast<const CompR<double> *>(F.tc);
-                W.etab = F.etab;
-                W.tcoef = A.coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
-                W.tile_off = nullptr; W.rec = nullptr;
-                double a[3] = {0.0, 0.0, 0.0};
-                volatile int *turn = &F.turn;
-                // pixel_kernel's wavefront adds iteration after iteration into the slots; here iteration w belongs to
-                // wavefront w, and the wavefronts take turns in the same order
-                pixel_iter<2, double, false, FUSED_GATED != 0, JOINT>(W, base, p1, lane, F.sacc + (lane & (ACC_SLOTS - 1)), a, [&]() {
-                    while (*turn != wave) __builtin_amdgcn_s_sleep(1);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                });
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the adds have been performed ...
-                if (lane == 0) *turn = wave + 1;                          // ... before the next wavefront starts its own
-            }
-            __syncthreads();
-            FT(2);
-            if (wave == 0) {
-                double *out = A.acc + (size_t)item * ACC_N;
-                fold_record_slots<2>(F.sacc, lane, [&](int e, double s) { stc<true>(out + e, s); });
-                drain_stores();
-                if (lane == 0) {
-                    const int before = __hip_atomic_fetch_add(&A.arrivals[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    F.last = before == A.tgt_rec[ti].y - 1;
-                }
-            }
-            __syncthreads();
+            ti = fused_chunk_record<JOINT>(A, F, tid, item);
             last = F.last != 0;
-            FT(3); FT_COUNT(14);
         } else {
             ti = FQ_DIRECT0 - item;
             last = true;
