@@ -418,15 +418,18 @@ __device__ __noinline__ int fused_chunk_record(const FusedArgs &A, FusedShared &
     return ti;
 }
 
-// the lift and the Newton step of a target whose records are complete; returns whether the target is done.
-// NOT inlined: the persistent loop around it then keeps the register allocation of the pixel code it mostly runs.
-__device__ __noinline__ int fused_lift_step(const FusedArgs &A, FusedShared &F, const int tid, const int ti) {
+// the lift, then the Newton step (returns whether the target is done) of a target whose records are complete.
+// NOT inlined: every phase of the persistent loop keeps its own register allocation.
+__device__ __noinline__ void fused_lift(const FusedArgs &A, FusedShared &F, const int tid, const int ti) {
     const int t = A.targets[ti];
     if (tid == 0) stc<true>(&A.arrivals[ti], 0);
     lift_target<true>(F.lift, tid, ti, t, A.vp, A.images, A.patches, A.geo, A.nbr_off, A.nbr_idx, A.acc, A.prior, A.vis_off,
                       A.vis_img, A.N, A.M, A.CH, A.chunk_px, A.flags, &F.ev_v, F.ev_d, F.ev_h, nullptr, &F.ev_status,
                       A.lg_sum, A.rec_off);
     __syncthreads();
+}
+__device__ __noinline__ int fused_step(const FusedArgs &A, FusedShared &F, const int tid, const int ti) {
+    const int t = A.targets[ti];
     return optim_step_target<true, FUSED_NT>(F.step, tid, A.st[ti], A.Hstate + (size_t)ti * NF * NF,
                                              A.vp + (size_t)t * CEL_P, F.ev_h, F.ev_d, -F.ev_v, F.ev_status, A.op);
 }
@@ -465,7 +468,9 @@ optim_fused_kernel(const FusedArgs A) {
         if (!last) continue;
 
         // ---- the target's evaluation is complete: lift, Newton step ----
-        const int done = fused_lift_step(A, F, tid, ti);
+        fused_lift(A, F, tid, ti);
+        FT(4);
+        const int done = fused_step(A, F, tid, ti);
         FT(5);
         drain_stores();      // the target's row of vp, its state and saved Hessian are in memory ...
         __syncthreads();     // ... before its next items (or the end of the launch) become visible
