@@ -44,11 +44,12 @@ def _report_failures(targets, status, where: str, failed: Optional[set]):
     """A source whose ELBO turned non-finite is logged and skipped -- the reference's production / multi-thread
     behaviour (Log.exception in process_sources_kernel! and one_node_single_infer, ParallelRun.jl:389-396, 582-597):
     its row stays where it was, every other source of the batch keeps its result."""
-    for t, st in zip(targets, status):
-        if st != 0:
-            log.warning("%s: source %d skipped (status %d)", where, int(t), int(st))
-            if failed is not None:
-                failed.add(int(t))
+    status = np.asarray(status)
+    for k in np.flatnonzero(status):
+        t = targets[int(k)]
+        log.warning("%s: source %d skipped (status %d)", where, int(t), int(status[k]))
+        if failed is not None:
+            failed.add(int(t))
 
 
 def one_node_single_infer(ctx: FieldContext, catalog, target_sources: Sequence[int],
