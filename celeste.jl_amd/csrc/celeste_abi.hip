@@ -136,7 +136,7 @@ struct celeste_ctx {
     // buffers of celeste_maximize_batch, kept between calls (grown on demand)
     struct OptBuffers {
         size_t cap = 0;
-        double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_H = nullptr, *d_pos = nullptr;
+        double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_H = nullptr, *d_T = nullptr, *d_pos = nullptr;
         int32_t *d_targets = nullptr, *d_act[2] = {nullptr, nullptr}, *d_evt[2] = {nullptr, nullptr}, *d_count = nullptr,
                 *d_st = nullptr;
         void *d_state = nullptr;
@@ -603,7 +603,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     {
         auto &o = c->opt;
-        void *optr[] = {o.d_vp, o.d_v, o.d_d, o.d_h, o.d_H, o.d_pos, o.d_targets, o.d_act[0], o.d_act[1], o.d_evt[0], o.d_evt[1],
+        void *optr[] = {o.d_vp, o.d_v, o.d_d, o.d_h, o.d_H, o.d_T, o.d_pos, o.d_targets, o.d_act[0], o.d_act[1], o.d_evt[0], o.d_evt[1],
                         o.d_count, o.d_st, o.d_state};
         for (void *q : optr) if (q) (void)hipFree(q);
         void *hptr[] = {o.h_vp, o.h_state, o.h_count};
@@ -664,7 +664,7 @@ static void fused_args_tables(celeste_ctx_t *c, FusedArgs &A) {
     A.prior = c->d_prior; A.vis_off = c->d_vis_off; A.vis_img = c->d_vis_img; A.lg_sum = c->d_lg_sum; A.rec_off = c->d_rec_off;
     A.N = c->N; A.NC = c->NC; A.K = c->K; A.M = c->M; A.CH = c->CH; A.chunk_px = c->chunk_px;
     A.acc = c->d_acc;
-    A.st = nullptr; A.Hstate = nullptr; A.q_items = nullptr; A.q_ctl = nullptr; A.q_cap = 0; A.timeout_ticks = 0;
+    A.st = nullptr; A.Hstate = nullptr; A.Tstate = nullptr; A.q_items = nullptr; A.q_ctl = nullptr; A.q_cap = 0; A.timeout_ticks = 0;
     A.j_R = 0; A.j_gshift = 0; A.j_dep = nullptr; A.j_succ_off = nullptr; A.j_succ = nullptr; A.j_vitem_off = nullptr;
     A.j_vitems = nullptr; A.j_render_arr = nullptr; A.j_saved = nullptr; A.j_pos = nullptr; A.j_srcimg = nullptr;
     A.j_comps = nullptr; A.j_geo = nullptr;
@@ -1296,14 +1296,14 @@ static int optim_buffers(celeste_ctx_t *c, size_t n, hipStream_t stream) {
     if (n > ob.cap) {   // (re)allocate every per-target buffer at the new capacity
         void **grow[] = {(void **)&ob.d_v, (void **)&ob.d_d, (void **)&ob.d_h, (void **)&ob.d_H, (void **)&ob.d_pos,
                          (void **)&ob.d_targets, (void **)&ob.d_act[0], (void **)&ob.d_act[1], (void **)&ob.d_evt[0],
-                         (void **)&ob.d_evt[1], (void **)&ob.d_st, &ob.d_state};
+                         (void **)&ob.d_evt[1], (void **)&ob.d_st, &ob.d_state, (void **)&ob.d_T};
         const size_t bytes[] = {sizeof(double), CEL_P * sizeof(double), CEL_P * CEL_P * sizeof(double), NF * NF * sizeof(double),
                                 2 * sizeof(double), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t),
-                                sizeof(int32_t), sizeof(int32_t), sizeof(OptState)};
+                                sizeof(int32_t), sizeof(int32_t), sizeof(OptState), TRI_STATE * sizeof(double)};
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         ob.cap = 0;
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < 13; ++k) {
             if (*grow[k]) { (void)hipFree(*grow[k]); *grow[k] = nullptr; }
             HIP_TRY(hipMalloc(grow[k], n * bytes[k]));
         }
@@ -1387,7 +1387,7 @@ static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, co
     fused_args_tables(c, A);
     A.targets = d_targets; A.n_targets = n_targets; A.vp = d_vp;
     A.chunk_desc = fb.d_chunk_desc; A.tgt_rec = fb.d_tgt_rec;
-    A.st = (OptState *)ob.d_state; A.Hstate = ob.d_H; A.op = op; A.flags = flags;
+    A.st = (OptState *)ob.d_state; A.Hstate = ob.d_H; A.Tstate = ob.d_T; A.op = op; A.flags = flags;
     if (J) {
         A.j_R = (int)rec; A.j_gshift = J->gshift; A.j_dep = J->d_dep; A.j_succ_off = J->d_succ_off; A.j_succ = J->d_succ;
         A.j_vitem_off = c->d_vitem_off; A.j_vitems = c->d_vitems_src; A.j_render_arr = J->d_render_arr; A.j_saved = J->d_saved;
@@ -1431,7 +1431,7 @@ static int optim_run_chained(celeste_ctx_t *c, double *d_vp, int32_t n_targets, 
         if (st1 != CELESTE_OK) return st1;
         hipLaunchKernelGGL(optim_step_kernel, dim3(n_upper), dim3(64), 0, stream, d_vp, d_targets, d_act[cur],
                            d_v, d_d, d_h, d_st, op, d_state, d_H, d_act[1 - cur], d_evt[1 - cur], d_cnt[1 - cur],
-                           it == 0 ? nullptr : d_cnt[cur], ob.d_count + 2, &ob.h_count[it % RING]);
+                           it == 0 ? nullptr : d_cnt[cur], ob.d_count + 2, &ob.h_count[it % RING], ob.d_T);
         HIP_TRY(hipEventRecord(ob.ev[it % RING], stream));
         cur = 1 - cur;
     }

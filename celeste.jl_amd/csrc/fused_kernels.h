@@ -78,7 +78,7 @@ struct FusedArgs {
     double *acc;                   // chunk records, 68 doubles each
     const int4 *chunk_desc;        // per record, two entries: {ti, j, chunk, target} {visit, image, 0, 0}
     const int2 *tgt_rec;           // per target: {first record, number of records}
-    OptState *st; double *Hstate; OptParams op; uint32_t flags;
+    OptState *st; double *Hstate; double *Tstate; OptParams op; uint32_t flags;   // Tstate: TRI_STATE doubles per target (optim_step_target)
     // the queue
     int32_t *q_items; int32_t *q_ctl; int32_t *arrivals; int q_cap;
     long long timeout_ticks;       // wall_clock64 ticks (100 MHz) a workgroup waits for its ticket before it gives up
@@ -431,7 +431,8 @@ __device__ __noinline__ void fused_lift(const FusedArgs &A, FusedShared &F, cons
 __device__ __noinline__ int fused_step(const FusedArgs &A, FusedShared &F, const int tid, const int ti) {
     const int t = A.targets[ti];
     return optim_step_target<true, FUSED_NT>(F.step, tid, A.st[ti], A.Hstate + (size_t)ti * NF * NF,
-                                             A.vp + (size_t)t * CEL_P, F.ev_h, F.ev_d, -F.ev_v, F.ev_status, A.op);
+                                             A.vp + (size_t)t * CEL_P, F.ev_h, F.ev_d, -F.ev_v, F.ev_status, A.op,
+                                             A.Tstate ? A.Tstate + (size_t)ti * TRI_STATE : nullptr);
 }
 
 template <bool JOINT>

@@ -50,6 +50,7 @@
 #ifndef OPTIM_Q3_SOLVE
 #define OPTIM_Q3_SOLVE 0      // 1: y' (T + lambda I)^-1 y by a second full solve instead of the forward sweep
 #endif
+#define TRI_STATE (NF * NF + 4 * NF + 4)   // reflectors, (td, te, hv, Q'g) per row, wmin, wmax, wmin_lower, norm_bound
 #define LDA 45  // leading dimension of the LDS matrix (holds the 44 x 44 bound-space Hessian first; odd: no bank conflicts)
 
 struct OptState {                 // per target slot
@@ -658,15 +659,18 @@ struct TriLds { double *A, *hv, *td, *te, *te2, *q; };   // hv, te, q: tred_wave
 // tridiagonal-space solver solved it (false: the hard case it hands to the eigen-decomposition).
 struct TrResult { double p, m; int interior, solved; };
 
-// Trust-region step in the tridiagonal basis.  In: L.A = H (destroyed), g (lane register), delta.
-// Out: step p (lane register), model decrease m, interior flag; solved = 0 in the hard case (caller falls
-// back to the eigen-decomposition).
-// NOT inlined: the function is 22 k instructions long and its register allocation (248 VGPRs at the edge of the two-waves-
-// per-SIMD budget) should not depend on the kernel around it -- optim_step_kernel, tr_solve_kernel and optim_fused_kernel
-// call the same code, so their steps agree bit for bit by construction.
-__device__ __noinline__ TrResult tri_tr_solve(TriLds L, double g, double delta, int ln, int secular_iters) {
-    double p_out = 0.0, m_out = 0.0;
-    int interior_out = 0;
+// Trust-region step in the tridiagonal basis, in two parts so that a REJECTED step -- same Hessian, same gradient, smaller
+// radius (19 % of the iterations of a joint-inference run) -- repeats only the second:
+//   tri_reduce   In: L.A = H (destroyed), g (lane register).  T = Q' H Q, Q' g, the extreme eigenvalues of T.  Leaves
+//                the reflectors in L.A and (td, te^2) in LDS; everything else is in the TriForm it returns (per lane:
+//                td, te, hv, gt; uniform: wmin, wmax, wmin_lower, norm_bound).
+//   tri_step     In: that state and delta.  Out: step p (lane register), model decrease m, interior flag; solved = 0 in
+//                the hard case (caller falls back to the eigen-decomposition).
+// NOT inlined: 22 k instructions between them, and their register allocation (248 VGPRs at the edge of the two-waves-
+// per-SIMD budget) should not depend on the kernel around them -- optim_step_kernel, tr_solve_kernel and
+// optim_fused_kernel call the same code, so their steps agree bit for bit by construction.
+struct TriForm { double td, te, hv, gt, wmin, wmax, wmin_lower, norm_bound; };
+__device__ __noinline__ TriForm tri_reduce(TriLds L, double g, int ln) {
     const bool fr = ln < NF;
     OPT_TICK_DECL;
     // T = Q' H Q and gt = Q' g (reflections n-1 ... 2 in turn) in one pass
@@ -693,7 +697,6 @@ __device__ __noinline__ TrResult tri_tr_solve(TriLds L, double g, double delta, 
     OPT_TICK(4);
     // Gershgorin interval, extreme eigenvalues
     double wmin, wmax, wmin_lower, norm_bound;
-    bool wide;
     {
         const double te_next = __shfl_down(te_l, 1, 64);
         const double ea = fabs(te_l), eb = (ln + 1 < NF) ? fabs(te_next) : 0.0;
@@ -702,7 +705,7 @@ __device__ __noinline__ TrResult tri_tr_solve(TriLds L, double g, double delta, 
         const double pad = 4.440892098500626e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300;
         lo -= pad; hi += pad;
         norm_bound = fmax(fabs(lo), fabs(hi));
-        wide = poly_wide_range(norm_bound);
+        const bool wide = poly_wide_range(norm_bound);
         const bool narrow = norm_bound > 8.673617379884035e-19 && norm_bound < 1.152921504606847e18;   // 2^-60 .. 2^60
 #if STURM_IMPL == 0
         double unused;
@@ -713,10 +716,24 @@ __device__ __noinline__ TrResult tri_tr_solve(TriLds L, double g, double delta, 
         tri_extremes(L.td, L.te2, lo, hi, ln, wide, narrow, wmin, wmin_lower, wmax);
 #endif
     }
+    OPT_TICK(5);
+    return TriForm{td_l, te_l, hv_l, gt_l, wmin, wmax, wmin_lower, norm_bound};
+}
+
+__device__ __noinline__ TrResult tri_step(TriLds L, TriForm TF, double delta, int ln, int secular_iters) {
+    double p_out = 0.0, m_out = 0.0;
+    int interior_out = 0;
+    const bool fr = ln < NF;
+    OPT_TICK_DECL;
+    const double td_l = TF.td, te_l = TF.te, hv_l = TF.hv, gt_l = TF.gt;
+    const double wmin = TF.wmin, wmax = TF.wmax, wmin_lower = TF.wmin_lower, norm_bound = TF.norm_bound;
+    const double te2_l = te_l * te_l;
+    const bool wide = poly_wide_range(norm_bound);
+    if (fr) { L.td[ln] = td_l; L.te2[ln] = te2_l; }   // (the hard-case test counts eigenvalues of T from LDS; a repeated step comes here without tri_reduce)
+    wave_sync();
     const double d2 = delta * delta;
     int interior = 0;
     double y = 0.0, ip_l, mk_l;
-    OPT_TICK(5);
     if (wmin >= 1e-8) {
         tri_factor(td_l, te_l, te2_l, 0.0, wide, ln, ip_l, mk_l);
         y = tri_solve(te_l, ip_l, mk_l, -gt_l, ln);
@@ -828,6 +845,11 @@ __device__ __noinline__ TrResult tri_tr_solve(TriLds L, double g, double delta, 
     return TrResult{p_out, m_out, interior_out, 1};
 }
 
+// both parts in a row
+__device__ __forceinline__ TrResult tri_tr_solve(TriLds L, double g, double delta, int ln, int secular_iters) {
+    return tri_step(L, tri_reduce(L, g, ln), delta, ln, secular_iters);
+}
+
 // The same sub-problem through the full eigen-decomposition (Optim.jl's own route): the hard-case fallback of
 // tri_tr_solve, and OptParams.solver = 1.  In: A = H (LDS, destroyed), g, delta.  w, e, q, cv: NF doubles of LDS each.
 __device__ __noinline__ TrResult eig_tr_solve(double *A, double *w, double *e, double *q, double *cvs, double g, double delta_in,
@@ -935,7 +957,9 @@ struct StepShared {
 template <bool COH, int NTHR>
 __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, OptState &S, double *__restrict__ Hs, double *__restrict__ vp_row,
                                                  const double *__restrict__ h, const double *__restrict__ ev_d, double ft_in,
-                                                 int st_in, const OptParams &op) {
+                                                 int st_in, const OptParams &op, double *__restrict__ Ts = nullptr) {
+    // Ts (optional, TRI_STATE doubles per target): the reduced form of the last accepted point's sub-problem (tri_reduce),
+    // so that a rejected step -- same Hessian and gradient, smaller radius -- goes straight to tri_step
     constexpr int PARTS = NTHR / 64;
     double *const sA = Z.sA, *const sx = Z.sx, *const sg = Z.sg, *const sw = Z.sw, *const se = Z.se, *const scv = Z.scv;
     double *const sU = Z.sU;
@@ -953,6 +977,17 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
     const double S_f = ldc<COH>(&S.f), S_m = ldc<COH>(&S.m), S_delta = ldc<COH>(&S.delta);
     const int S_iter = ldc<COH>(&S.iter), S_interior = ldc<COH>(&S.interior), S_evals = ldc<COH>(&S.evals);
 
+    // Is the step rejected?  Only the value decides (rho, below), and every thread can tell from the scalars it holds.
+    // A rejected point's gradient and Hessian are never used: the chain rule is skipped.
+    bool rejected = false;
+    if (st_in == CELESTE_OK && S_iter >= 0) {
+        double rho;
+        if (fabs(S_m) <= 2.220446049250313e-16) rho = 1.0;
+        else if (S_m > 0) rho = 0.25 - 1.0;
+        else rho = (S_f - ft_in) / (0 - S_m);
+        rejected = !(rho > 0.1);
+    }
+    if (!rejected) {
     // ---- chain rule to the free parameters at the evaluated point xt (propagate_derivatives!) ----
     if (tid < CEL_P) sd[tid] = ev_d[tid];
     if (tid < NF) sx[tid] = ldc<COH>(&S.xt[tid]);
@@ -1061,6 +1096,7 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
     OPT_TICK(12);
     if (ln < NF) for (int i = part; i < ln; i += PARTS) sA[ln + LDA * i] = sA[i + LDA * ln];   // exactly symmetric
     __syncthreads();
+    }
 
     OPT_TICK(0);
     // ---- accept / reject, radius update, convergence (N&W Alg. 4.1 as in Optim.jl's NewtonTrustRegion) ----
@@ -1094,12 +1130,17 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
     }
     __syncthreads();
     const int accept = s_flag[0], done = s_flag[1];
+#ifdef OPTIM_TIMING
+    if (!accept && tid == 0) atomicAdd(&g_optim_clk[13], 2400ull);   // (counted as 1 us per rejected step in tools/gpu_optim_sections.py)
+#endif
     if (accept) {
         if (tid < NF) { stc<COH>(&S.x[tid], sx[tid]); stc<COH>(&S.g[tid], sgt[tid]); sg[tid] = sgt[tid]; }
         if (!done) for (int k = tid; k < NF * NF; k += NTHR) { const int j = k / NF; stc<COH>(&Hs[k], sA[(k - j * NF) + LDA * j]); }
     } else {
         if (tid < NF) { sx[tid] = ldc<COH>(&S.x[tid]); sg[tid] = ldc<COH>(&S.g[tid]); }
-        if (!done) for (int k = tid; k < NF * NF; k += NTHR) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = ldc<COH>(&Hs[k]); }
+        // the sub-problem's matrix: its reduced form if it was kept (reflectors; tri_step needs nothing else of H), else H
+        const double *const src = (Ts && op.solver != 1) ? Ts : Hs;
+        if (!done) for (int k = tid; k < NF * NF; k += NTHR) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = ldc<COH>(&src[k]); }
     }
     __syncthreads();
     OPT_TICK(1);
@@ -1115,7 +1156,24 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
         TrResult R = {0.0, 0.0, 0, 0};
         if (op.solver != 1) {
             const TriLds L = {sA, sw, std_, se, ste2, sq};
-            R = tri_tr_solve(L, fr ? sg[tid] : 0.0, Z.s_delta, tid, op.secular_iters);
+            TriForm TF;
+            if (Ts && !accept) {
+                // a repeated step: the reduced form from the accepted point's solve
+                const double *v = Ts + NF * NF;
+                TF.td = fr ? ldc<COH>(v + tid) : 0.0; TF.te = fr ? ldc<COH>(v + NF + tid) : 0.0;
+                TF.hv = fr ? ldc<COH>(v + 2 * NF + tid) : 0.0; TF.gt = fr ? ldc<COH>(v + 3 * NF + tid) : 0.0;
+                TF.wmin = ldc<COH>(v + 4 * NF); TF.wmax = ldc<COH>(v + 4 * NF + 1);
+                TF.wmin_lower = ldc<COH>(v + 4 * NF + 2); TF.norm_bound = ldc<COH>(v + 4 * NF + 3);
+            } else {
+                TF = tri_reduce(L, fr ? sg[tid] : 0.0, tid);
+                if (Ts) {   // kept for the steps that may be rejected from here (stores only: nothing waits for them)
+                    for (int k = tid; k < NF * NF; k += 64) { const int j = k / NF; stc<COH>(&Ts[k], sA[(k - j * NF) + LDA * j]); }
+                    double *v = Ts + NF * NF;
+                    if (fr) { stc<COH>(v + tid, TF.td); stc<COH>(v + NF + tid, TF.te); stc<COH>(v + 2 * NF + tid, TF.hv); stc<COH>(v + 3 * NF + tid, TF.gt); }
+                    if (tid == 0) { stc<COH>(v + 4 * NF, TF.wmin); stc<COH>(v + 4 * NF + 1, TF.wmax); stc<COH>(v + 4 * NF + 2, TF.wmin_lower); stc<COH>(v + 4 * NF + 3, TF.norm_bound); }
+                }
+            }
+            R = tri_step(L, TF, Z.s_delta, tid, op.secular_iters);
             if (!R.solved) {   // hard case: restore H and diagonalise it
                 for (int k = tid; k < NF * NF; k += 64) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = ldc<COH>(&Hs[k]); }
                 wave_sync();
@@ -1147,7 +1205,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
                   const int32_t *__restrict__ ev_status, OptParams op, OptState *__restrict__ st,
                   double *__restrict__ Hstate, int32_t *__restrict__ next_active, int32_t *__restrict__ next_targets,
                   int32_t *__restrict__ next_count, int32_t *__restrict__ live, int32_t *__restrict__ blocks_done,
-                  volatile int32_t *__restrict__ host_count) {
+                  volatile int32_t *__restrict__ host_count, double *__restrict__ Tstate) {
     // The launch's last workgroup to finish publishes the number of targets still running to page-locked host memory
     // (the host sizes later launches by it), clears the counter this launch read (`live`: the launch after next
     // counts into it) and re-arms blocks_done: no memset and no copy between two Newton iterations.
@@ -1168,7 +1226,7 @@ optim_step_kernel(double *__restrict__ vp, const int32_t *__restrict__ targets, 
     const int t = targets[slot];
     const int done = optim_step_target<false, 64>(Z, threadIdx.x, st[slot], Hstate + (size_t)slot * NF * NF, vp + (size_t)t * CEL_P,
                                                   ev_h + (size_t)li * CEL_P * CEL_P, ev_d + (size_t)li * CEL_P, -ev_v[li],
-                                                  ev_status[li], op);
+                                                  ev_status[li], op, Tstate ? Tstate + (size_t)slot * TRI_STATE : nullptr);
     if (!done && threadIdx.x == 0) {
         const int pos = atomicAdd(next_count, 1);
         next_active[pos] = slot; next_targets[pos] = t;

@@ -14,7 +14,8 @@ lib = cabi.load_library()
 has_clk = hasattr(lib, "celeste_optim_clocks")
 NAMES = ["chain rule: symmetrise (+ rest)", "accept/copy H", "sub-problem total", "  tridiagonalisation", "  Q'g", "  extreme eigenvalues",
          "  interior try + secular", "  model + Qy", "tail", "chain rule: loads, box / simplex transforms",
-         "chain rule: simplex Jacobians, gradient", "chain rule: H J (rows, from HBM)", "chain rule: J' (H J) (columns)"]
+         "chain rule: simplex Jacobians, gradient", "chain rule: H J (rows, from HBM)", "chain rule: J' (H J) (columns)",
+         "rejected steps (1 us = every step rejected)"]
 
 
 def clocks(reset=True):
