@@ -283,6 +283,31 @@ def test_joint_dataflow_launch_equals_the_layered_schedule(crowded):
 
 
 
+def test_the_persistent_launches_do_not_depend_on_how_much_of_the_grid_is_resident(crowded):
+    """optim_fused_kernel never lets a workgroup wait for a particular other workgroup, so it must finish -- with the same
+    bits -- on ONE workgroup, on a handful, and on more workgroups than the device can hold at once (the late ones only
+    ever see the EXIT items).  Batch optimisation and the joint dataflow launch."""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd.infer import joint_layers
+    f, ctx = crowded
+    S = len(f.catalog)
+    tg = list(range(S))
+    cfg = cel.ElboConfig(max_iters=6)
+    layers = joint_layers(tg, f.neighbors, batch_size=12, n_iters=2, rng=np.random.default_rng(11))
+    with _env(CELESTE_OPT_FUSED=1, CELESTE_JOINT_DATAFLOW=1):
+        ref_b = ctx.maximize_batch(f.vp, tg[::2], cfg)
+        ref_j = ctx.joint_infer(f.vp, layers, cfg)
+        for grid in (1, 7, 1500):
+            with _env(CELESTE_FUSED_GRID=grid):
+                ctx2 = cel.FieldContext(f.images, f.patches, f.neighbors)     # (the grid is read once per context)
+                got_b = ctx2.maximize_batch(f.vp, tg[::2], cfg)
+                got_j = ctx2.joint_infer(f.vp, layers, cfg)
+                ctx2.close()
+            _assert_identical(ref_b, got_b, "batch, %d workgroups" % grid)
+            _assert_identical(ref_j, got_j, "joint schedule, %d workgroups" % grid)
+
+
+
 def test_one_node_joint_infer_uses_the_entry_and_reports_failures(crowded):
     import celeste_jl_amd as cel
     from celeste_jl_amd.infer import one_node_joint_infer
