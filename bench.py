@@ -541,7 +541,29 @@ def secondary_figures(ctx, fld, targets, args, costs):
     lat = np.sort(np.array(lat[10:]))
     out["single_call_latency_us"] = {"median": float(np.median(lat) * 1e6), "p90": float(lat[int(0.9 * len(lat))] * 1e6),
                                      "calls": int(len(lat)), "what": "celeste_elbo_eval for one target (value + gradient + Hessian "
-                                     "+ KL), vp up and results down included"}
+                                     "+ KL) on the whole-field context (2000 sources: the 704 KB table goes up with every call), "
+                                     "results down included"}
+    # the literal drop-in (ElboMaximize.jl:166 inside process_source, ParallelRun.jl:468-488): one context per source over
+    # ElboArgs(images, patches[[s; neighbors], :], [1]) on a shared image handle -- the table is the source and its neighbours
+    iset = cel.cabi.ImageSet(fld.images)
+    lat = []
+    for k in range(24):
+        t = int(targets[(k * 97) % S])
+        loc = [t] + [int(x) for x in fld.neighbors[t]]
+        pctx = cel.FieldContext(fld.images, [fld.patches[s2] for s2 in loc], [list(range(1, len(loc)))] + [[] for _ in loc[1:]],
+                                image_set=iset)
+        vloc = np.ascontiguousarray(fld.vp[loc])
+        for rep in range(12):
+            t1 = time.perf_counter()
+            pctx.eval_batch(vloc, [0], FLAGS_ALL, pinned=False)
+            if rep >= 2:
+                lat.append(time.perf_counter() - t1)
+        pctx.close()
+    iset.close()
+    lat = np.sort(np.array(lat))
+    out["single_call_latency_us"]["per_source_context"] = {
+        "median": float(np.median(lat) * 1e6), "p90": float(lat[int(0.9 * len(lat))] * 1e6), "calls": int(len(lat)),
+        "what": "the same call on per-source contexts (the source and its neighbours) sharing one image handle"}
     # ElboMaximize.maximize! (Newton trust region, <= 50 iterations, KL on) for every source of the field,
     # neighbours frozen; wall time includes H2D/D2H
     ctx.maximize_batch(fld.vp, targets, cel.ElboConfig(max_iters=1))  # warm-up: the call's buffers at full size

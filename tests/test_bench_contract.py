@@ -34,6 +34,7 @@ def test_bench_json_line():
     # what the engine does where the reference calls it: one elbo() per call, a Cyclades-sized layer, the
     # joint-inference schedule through celeste_joint_infer, rank 0's shard for N ranks
     assert d["single_call_latency_us"]["median"] > 0 and d["single_call_latency_us"]["calls"] == 200
+    assert d["single_call_latency_us"]["per_source_context"]["median"] > 0
     lay = d["optimizer"]["cyclades_layer"]
     assert lay["failed"] == 0 and lay["us_per_newton_iteration_of_the_slowest_target"] > 0 and lay["driver"] == "fused"
     assert d["joint_infer"]["seconds"] > 0 and d["joint_infer"]["layers"] >= 3 and d["joint_infer"]["failed"] == 0
