@@ -131,6 +131,8 @@ struct celeste_ctx {
     double *p_v = nullptr, *p_d = nullptr, *p_h = nullptr;
     int64_t *p_cnt = nullptr;
     size_t pin_cap = 0;
+    // small host-pointer calls (eval_small): one block up (table + targets), one block down (all outputs)
+    double *d_small_in = nullptr, *p_small_in = nullptr, *d_small_out = nullptr, *p_small_out = nullptr;
     static const int MAX_PARTS = 8;
     hipEvent_t part_done[MAX_PARTS] = {}, part_copied[MAX_PARTS] = {};
     // buffers of celeste_maximize_batch, kept between calls (grown on demand)
@@ -620,7 +622,9 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
         if (c->part_done[i]) (void)hipEventDestroy(c->part_done[i]);
         if (c->part_copied[i]) (void)hipEventDestroy(c->part_copied[i]);
     }
-    void *pins[] = {c->p_vp, c->p_targets, c->p_status, c->p_v, c->p_d, c->p_h, c->p_cnt};
+    void *pins[] = {c->p_vp, c->p_targets, c->p_status, c->p_v, c->p_d, c->p_h, c->p_cnt, c->p_small_in, c->p_small_out};
+    if (c->d_small_in) (void)hipFree(c->d_small_in);
+    if (c->d_small_out) (void)hipFree(c->d_small_out);
     for (void *q : pins) if (q) (void)hipHostFree(q);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -953,6 +957,51 @@ static int pinned_grow(T **p, size_t n) {
     return CELESTE_OK;
 }
 
+// A few targets per call (the literal drop-in: one elbo() per call): two copies instead of seven and no second stream --
+// the table and the target list go up as ONE block, every output comes down as ONE block on the context's stream.
+#define EVAL_SMALL_MAX 32
+static int eval_small(celeste_ctx_t *c, const double *vp, int32_t n_targets, const int32_t *targets, uint32_t flags, double *v,
+                      double *d, double *h, int64_t *counters, int32_t *status) {
+    const size_t n = (size_t)n_targets, HS = (flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;
+    const size_t vp_n = (size_t)c->S * CEL_P;
+    const size_t in_n = vp_n + EVAL_SMALL_MAX / 2;                                     // doubles: table, then 32 int32
+    const size_t per = 1 + CEL_P + (size_t)CEL_P * CEL_P + 2 + 1, out_n = EVAL_SMALL_MAX * per;
+    if (!c->d_small_in) {
+        HIP_TRY(hipMalloc((void **)&c->d_small_in, in_n * sizeof(double)));
+        HIP_TRY(hipHostMalloc((void **)&c->p_small_in, in_n * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&c->d_small_out, out_n * sizeof(double)));
+        HIP_TRY(hipHostMalloc((void **)&c->p_small_out, out_n * sizeof(double), hipHostMallocDefault));
+    }
+    memcpy(c->p_small_in, vp, vp_n * sizeof(double));
+    memcpy(c->p_small_in + vp_n, targets, n * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(c->d_small_in, c->p_small_in, (vp_n + (n + 1) / 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // the block of outputs: v[n], d[n x 44], h[n x HS], counters[n x 2], status[n]
+    double *const b_v = c->d_small_out, *const b_d = b_v + n, *const b_h = b_d + n * CEL_P;
+    int64_t *const b_c = reinterpret_cast<int64_t *>(b_h + n * HS);
+    int32_t *const b_s = reinterpret_cast<int32_t *>(b_c + 2 * n);
+    const size_t bytes = (n * (1 + CEL_P + HS + 2)) * sizeof(double) + n * sizeof(int32_t);
+    int64_t n_chunks = 0;
+    for (int t = 0; t < n_targets; ++t) n_chunks += c->h_src_chunks[targets[t]];
+    int st = launch_eval(c, c->d_small_in, n_targets, reinterpret_cast<const int32_t *>(c->d_small_in + vp_n), flags, b_v, b_d, b_h,
+                         b_c, b_s, c->stream, true, nullptr, n_chunks);
+    if (st != CELESTE_OK) { (void)hipStreamSynchronize(c->stream); return st; }
+    if (hipMemcpyAsync(c->p_small_out, c->d_small_out, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipStreamSynchronize(c->stream); return CELESTE_ERR_HIP; }
+    const double *const o_v = c->p_small_out, *const o_d = o_v + n, *const o_h = o_d + n * CEL_P;
+    const int64_t *const o_c = reinterpret_cast<const int64_t *>(o_h + n * HS);
+    const int32_t *const o_s = reinterpret_cast<const int32_t *>(o_c + 2 * n);
+    if (v) memcpy(v, o_v, n * sizeof(double));
+    if (d && (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS))) memcpy(d, o_d, n * CEL_P * sizeof(double));
+    if (h && (flags & CELESTE_FLAG_HESS)) memcpy(h, o_h, n * HS * sizeof(double));
+    if (counters) memcpy(counters, o_c, n * 2 * sizeof(int64_t));
+    int worst = CELESTE_OK;
+    for (int t = 0; t < n_targets; ++t) {
+        if (status) status[t] = o_s[t];
+        if (o_s[t] != CELESTE_OK && worst == CELESTE_OK) worst = o_s[t];
+    }
+    return worst;
+}
+
 // The host-pointer sweep (what the Julia shim calls).  vp and the target list go up through page-locked staging;
 // the batch is cut into up to MAX_PARTS parts that are evaluated back to back on the context's stream, and each
 // part's results are copied down on the copy stream while the next part computes -- straight into the caller's
@@ -966,6 +1015,7 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
     if (n_targets == 0) return CELESTE_OK;
     for (int t = 0; t < n_targets; ++t) if (targets[t] < 0 || targets[t] >= c->S) return CELESTE_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
+    if (n_targets <= EVAL_SMALL_MAX && !c->timing && v) return eval_small(c, vp, n_targets, targets, flags, v, d, h, counters, status);
     const bool want_h = h && (flags & CELESTE_FLAG_HESS);
     const bool want_d = d && (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS));
     const size_t HS = (flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;   // doubles per Hessian
