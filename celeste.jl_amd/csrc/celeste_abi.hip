@@ -1311,7 +1311,7 @@ extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, cons
 // ---- maximize! for a batch of targets (ElboMaximize.jl:228-242; neighbours frozen at the input vp) ----------
 // Two drivers of the same device functions:
 //  * fused (optim_fused_kernel, fused_kernels.h): ONE persistent launch in which every target iterates at its own pace --
-//    the default for batches of up to FUSED_AUTO_MAX targets (Cyclades layers, a rank's shard), where the chained
+//    the default for batches of up to FUSED_AUTO_MAX targets (Cyclades layers, a rank's shard at N >= 4), where the chained
 //    driver's four dependent launches per Newton iteration leave the chip idle;
 //  * chained: work list -> pixel_kernel -> lift_kernel -> optim_step_kernel per Newton iteration, all targets in
 //    lock-step, for large batches that fill the chip kernel by kernel.  Its Newton loop is device resident: the host
@@ -1320,7 +1320,8 @@ extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, cons
 //    memory and the kernels that depend on it read it there.  The counts come back through page-locked slots with an
 //    event each, so the host never waits for the iteration it just enqueued.
 // Results are bit-identical (tests/test_gpu_fused.py).  CELESTE_OPT_FUSED=0 / 1 forces one or the other.
-#define FUSED_AUTO_MAX 1024
+#define FUSED_AUTO_MAX 640          // (measured, config 3: 500 targets 11.3 vs 12.8 ms chained, 750 targets 15.3 vs 14.9, 1000 19.7 vs 18.0)
+#define JOINT_DATAFLOW_WIDEST 1024  // widest layer of a schedule that still runs as one dataflow launch
 
 static int optim_config(const celeste_optim_config_t *cfg_in, OptParams *op, uint32_t *flags) {
     celeste_optim_config_t cfg = {1e-4, 1.0, 50, 1, 1e-7, 1e-6, 1e-8, 1.0, 1e9, 0, 0};
@@ -1745,7 +1746,7 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
     // config 5's scene: colouring 0.60 s layered / 0.99 s dataflow, Cyclades 2.39 s layered / 0.99 s dataflow).
     // CELESTE_JOINT_DATAFLOW=0 / 1 forces one or the other.
     const bool can_dataflow = total <= JOINT_DATAFLOW_MAX && optim_use_fused(c, 1, 1, op);
-    bool dataflow = can_dataflow && widest <= FUSED_AUTO_MAX;
+    bool dataflow = can_dataflow && widest <= JOINT_DATAFLOW_WIDEST;
     if (const char *e = getenv("CELESTE_JOINT_DATAFLOW")) dataflow = can_dataflow && atoi(e) != 0;
     rc = optim_buffers(c, dataflow ? (size_t)total : widest, stream);
     if (rc != CELESTE_OK) return rc;
