@@ -308,7 +308,7 @@ int celeste_maximize_batch(celeste_ctx_t *ctx, double *vp, const double *vp_neig
  * lets a multi-GPU driver all-gather the optimised rows over RCCL straight from it (parallel.sharded_maximize).
  * d_vp_neighbors (may be NULL = d_vp) and d_pos_centers (n_targets x 2, may be NULL) as above; the per-target outputs
  * d_iterations / d_f_evals / d_elbo / d_status (device, may be NULL) are written when the batch is done.  Targets must be
- * distinct (not checked here: they live on the device).  Batches of up to 1024 targets run as ONE persistent launch
+ * distinct (not checked here: they live on the device).  Batches of up to 640 targets run as ONE persistent launch
  * (every target iterates at its own pace) and the call is asynchronous; larger batches run the lock-step driver,
  * which blocks the host until the batch has converged.  A failing target gets its input row back and its status set
  * (CELESTE_ERR_HIP for every target if the launch itself gave up). */
@@ -328,7 +328,11 @@ int celeste_maximize_batch_device(celeste_ctx_t *ctx, double *d_vp, const double
  * centres of the position boxes, which the reference pins at the initial positions (ParallelRun.jl:96-100).  The
  * per-entry outputs (may be NULL) are indexed like layer_targets.  A source that fails in some layer keeps the row it
  * had before that layer (status set, the rest of the schedule goes on: ParallelRun.jl:389-396); the return value is the
- * first such status. */
+ * first such status.
+ * Execution: schedules whose layers hold up to 1024 sources run as ONE launch in which an optimisation starts as soon as
+ * the optimisations it depends on -- the earlier ones of its source and of its neighbours -- have ended (a dataflow over
+ * the entries; the layer boundaries themselves are not waited for); wider schedules run layer by layer.  Both leave the
+ * same table, the same per-entry outputs, bit for bit (CELESTE_JOINT_DATAFLOW=0 / 1 forces one or the other). */
 int celeste_joint_infer(celeste_ctx_t *ctx, double *vp, int32_t n_layers, const int64_t *layer_offsets,
                         const int32_t *layer_targets, const double *pos_centers, const celeste_optim_config_t *cfg,
                         int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status);
