@@ -213,6 +213,55 @@ def bad_sky(ce, images) -> bool:
     return (claimed_sky + 5) < med
 
 
+def bad_sky_flags(entries, images, device=None, force_torch: bool = False) -> List[bool]:
+    """bad_sky for many catalog entries at once: the 101 x 101 boxes of all sources are gathered and sorted on the GPU
+    (torch: device memory and a sort -- plumbing), the median taken from the sorted rows exactly as np.median takes it.
+    Used when torch's CUDA runtime is already up in this process (its first use costs ~0.8 s, more than the per-entry
+    loop takes for a whole field); otherwise, and for a handful of sources, the per-entry function is used."""
+    entries = list(entries)
+    img = next((im for im in images if im.b == 4), None)
+    if img is None or not entries:
+        return [False] * len(entries)
+    try:
+        import torch
+        use = force_torch or (torch.cuda.is_available() and torch.cuda.is_initialized() and len(entries) >= 64)
+    except ImportError:       # pragma: no cover
+        use = False
+    if not use:
+        return [bad_sky(ce, images) for ce in entries]
+    dev = torch.device("cuda", device or 0) if torch.cuda.is_available() else torch.device("cpu")
+    H, W = img.H, img.W
+    pos = np.array([ce.pos for ce in entries], dtype=np.float64).reshape(-1, 2)
+    pc = (pos - img.wcs_world0) @ np.asarray(img.wcs_jacobian).T + img.wcs_pix0          # world_to_pix, row by row
+    hc = np.clip(np.rint(pc[:, 0]).astype(np.int64), 1, H)
+    wc = np.clip(np.rint(pc[:, 1]).astype(np.int64), 1, W)
+    claimed = img.sky[hc - 1, wc - 1].astype(np.float64) * np.asarray(img.nelec_per_nmgy)[hc - 1].astype(np.float64)
+    # clamp_box(box_around_point(img, pos, 50), (H, W)): inclusive 1-based ranges, possibly empty
+    h0 = np.clip(np.rint(pc[:, 0] - 50.0).astype(np.int64), 1, H + 1); h1 = np.clip(np.rint(pc[:, 0] + 50.0).astype(np.int64), 0, H)
+    w0 = np.clip(np.rint(pc[:, 1] - 50.0).astype(np.int64), 1, W + 1); w1 = np.clip(np.rint(pc[:, 1] + 50.0).astype(np.int64), 0, W)
+    px = torch.from_numpy(np.ascontiguousarray(img.pixels, dtype=np.float32)).to(dev)
+    out = np.zeros(len(entries), dtype=bool)
+    B = 102                                                                              # a box has at most 102 rows / columns
+    off = torch.arange(B, device=dev)
+    for lo in range(0, len(entries), 4096):
+        sl = slice(lo, min(len(entries), lo + 4096))
+        th0 = torch.from_numpy(h0[sl]).to(dev); th1 = torch.from_numpy(h1[sl]).to(dev)
+        tw0 = torch.from_numpy(w0[sl]).to(dev); tw1 = torch.from_numpy(w1[sl]).to(dev)
+        rows = th0[:, None] + off[None, :]; cols = tw0[:, None] + off[None, :]           # 1-based
+        okr = rows <= th1[:, None]; okc = cols <= tw1[:, None]
+        vals = px[(rows.clamp(1, H) - 1)[:, :, None], (cols.clamp(1, W) - 1)[:, None, :]]
+        vals = torch.where(okr[:, :, None] & okc[:, None, :], vals, torch.full_like(vals, float("nan"))).reshape(vals.shape[0], -1)
+        n = (~torch.isnan(vals)).sum(dim=1)
+        srt = torch.sort(vals, dim=1).values                                             # NaNs last
+        k = torch.div(n, 2, rounding_mode="floor")
+        hi = srt.gather(1, k.clamp(max=srt.shape[1] - 1)[:, None])[:, 0]
+        lo_ = srt.gather(1, (k - 1).clamp(min=0)[:, None])[:, 0]
+        med = torch.where(n % 2 == 1, hi, (lo_ + hi) * 0.5)                              # float32, like np.median
+        res = (torch.from_numpy(claimed[sl] + 5.0).to(dev) < med.double()) & (n > 0)
+        out[sl] = res.cpu().numpy()
+    return [bool(x) for x in out]
+
+
 def infer_box(images, box: BoundingBox, catalog, method: str = "joint_vi", cfg: Optional[ElboConfig] = None,
               n_iters: int = NUM_JOINT_VI_ITERS, device: int = 0, schedule: str = "cyclades") -> List[OptimizedSource]:
     """infer_box / _infer_box (ParallelRun.jl:610-672) for a given catalog: patches for every catalog entry, targets
@@ -236,6 +285,6 @@ def infer_box(images, box: BoundingBox, catalog, method: str = "joint_vi", cfg: 
             raise ValueError("unknown method: %s" % method)
     finally:
         ctx.close()
-    return [OptimizedSource(float(catalog[t].pos[0]), float(catalog[t].pos[1]), vs[k].copy(), bad_sky(catalog[t], images),
-                            t in failed)
+    flags = bad_sky_flags([catalog[t] for t in targets], images, device)
+    return [OptimizedSource(float(catalog[t].pos[0]), float(catalog[t].pos[1]), vs[k].copy(), flags[k], t in failed)
             for k, t in enumerate(targets)]

@@ -383,3 +383,20 @@ def test_init_source_table_equals_the_per_entry_functions():
         ref[t] = generic_init_source(cat[t].pos)
     assert np.array_equal(ref, init_source_table(cat, tg))
     assert init_source_table([], []).shape == (0, 44)
+
+
+def test_bad_sky_flags_equal_the_per_entry_check():
+    """infer.bad_sky_flags (all boxes gathered and sorted at once) against bad_sky (ParallelRun.jl:437-460), with clipped
+    boxes, NaN pixels and both outcomes present"""
+    import numpy as np
+    from celeste_jl_amd import synthetic
+    from celeste_jl_amd.infer import bad_sky, bad_sky_flags
+    f = synthetic.make_field(260, 300, 60, seed=9, margin=2)
+    img = next(im for im in f.images if im.b == 4)
+    img.pixels[40:60, 100:130] = np.nan
+    img.pixels[150:, :] += 30
+    ref = [bad_sky(ce, f.images) for ce in f.catalog]
+    assert 0 < sum(ref) < len(ref)
+    assert bad_sky_flags(f.catalog, f.images, force_torch=True) == ref
+    assert bad_sky_flags(f.catalog[:3], f.images) == ref[:3]
+    assert bad_sky_flags([], f.images) == []
