@@ -138,7 +138,7 @@ struct celeste_ctx {
     // buffers of celeste_maximize_batch, kept between calls (grown on demand)
     struct OptBuffers {
         size_t cap = 0;
-        double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_H = nullptr, *d_T = nullptr, *d_pos = nullptr;
+        double *d_vp = nullptr, *d_v = nullptr, *d_d = nullptr, *d_h = nullptr, *d_H = nullptr, *d_T = nullptr, *d_S = nullptr, *d_pos = nullptr;
         int32_t *d_targets = nullptr, *d_act[2] = {nullptr, nullptr}, *d_evt[2] = {nullptr, nullptr}, *d_count = nullptr,
                 *d_st = nullptr;
         void *d_state = nullptr;
@@ -605,7 +605,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     {
         auto &o = c->opt;
-        void *optr[] = {o.d_vp, o.d_v, o.d_d, o.d_h, o.d_H, o.d_T, o.d_pos, o.d_targets, o.d_act[0], o.d_act[1], o.d_evt[0], o.d_evt[1],
+        void *optr[] = {o.d_vp, o.d_v, o.d_d, o.d_h, o.d_H, o.d_T, o.d_S, o.d_pos, o.d_targets, o.d_act[0], o.d_act[1], o.d_evt[0], o.d_evt[1],
                         o.d_count, o.d_st, o.d_state};
         for (void *q : optr) if (q) (void)hipFree(q);
         void *hptr[] = {o.h_vp, o.h_state, o.h_count};
@@ -668,7 +668,7 @@ static void fused_args_tables(celeste_ctx_t *c, FusedArgs &A) {
     A.prior = c->d_prior; A.vis_off = c->d_vis_off; A.vis_img = c->d_vis_img; A.lg_sum = c->d_lg_sum; A.rec_off = c->d_rec_off;
     A.N = c->N; A.NC = c->NC; A.K = c->K; A.M = c->M; A.CH = c->CH; A.chunk_px = c->chunk_px;
     A.acc = c->d_acc;
-    A.st = nullptr; A.Hstate = nullptr; A.Tstate = nullptr; A.q_items = nullptr; A.q_ctl = nullptr; A.q_cap = 0; A.timeout_ticks = 0;
+    A.st = nullptr; A.Hstate = nullptr; A.Tstate = nullptr; A.Spec = nullptr; A.q_items = nullptr; A.q_ctl = nullptr; A.q_cap = 0; A.timeout_ticks = 0;
     A.j_R = 0; A.j_gshift = 0; A.j_dep = nullptr; A.j_succ_off = nullptr; A.j_succ = nullptr; A.j_vitem_off = nullptr;
     A.j_vitems = nullptr; A.j_render_arr = nullptr; A.j_saved = nullptr; A.j_pos = nullptr; A.j_srcimg = nullptr;
     A.j_comps = nullptr; A.j_geo = nullptr;
@@ -1347,14 +1347,14 @@ static int optim_buffers(celeste_ctx_t *c, size_t n, hipStream_t stream) {
     if (n > ob.cap) {   // (re)allocate every per-target buffer at the new capacity
         void **grow[] = {(void **)&ob.d_v, (void **)&ob.d_d, (void **)&ob.d_h, (void **)&ob.d_H, (void **)&ob.d_pos,
                          (void **)&ob.d_targets, (void **)&ob.d_act[0], (void **)&ob.d_act[1], (void **)&ob.d_evt[0],
-                         (void **)&ob.d_evt[1], (void **)&ob.d_st, &ob.d_state, (void **)&ob.d_T};
+                         (void **)&ob.d_evt[1], (void **)&ob.d_st, &ob.d_state, (void **)&ob.d_T, (void **)&ob.d_S};
         const size_t bytes[] = {sizeof(double), CEL_P * sizeof(double), CEL_P * CEL_P * sizeof(double), NF * NF * sizeof(double),
                                 2 * sizeof(double), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t),
-                                sizeof(int32_t), sizeof(int32_t), sizeof(OptState), TRI_STATE * sizeof(double)};
+                                sizeof(int32_t), sizeof(int32_t), sizeof(OptState), TRI_STATE * sizeof(double), 2 * SPEC_STATE * sizeof(double)};
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         ob.cap = 0;
-        for (int k = 0; k < 13; ++k) {
+        for (int k = 0; k < 14; ++k) {
             if (*grow[k]) { (void)hipFree(*grow[k]); *grow[k] = nullptr; }
             HIP_TRY(hipMalloc(grow[k], n * bytes[k]));
         }
@@ -1439,6 +1439,9 @@ static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, co
     A.targets = d_targets; A.n_targets = n_targets; A.vp = d_vp;
     A.chunk_desc = fb.d_chunk_desc; A.tgt_rec = fb.d_tgt_rec;
     A.st = (OptState *)ob.d_state; A.Hstate = ob.d_H; A.Tstate = ob.d_T; A.op = op; A.flags = flags;
+    A.Spec = ob.d_S;
+    if (const char *e = getenv("CELESTE_FUSED_SPEC")) if (atoi(e) == 0) A.Spec = nullptr;
+    if (A.Spec) HIP_TRY(hipMemsetAsync(ob.d_S, 0xFF, n * 2 * SPEC_STATE * sizeof(double), stream));   // no tag matches an iteration
     if (J) {
         A.j_R = (int)rec; A.j_gshift = J->gshift; A.j_dep = J->d_dep; A.j_succ_off = J->d_succ_off; A.j_succ = J->d_succ;
         A.j_vitem_off = c->d_vitem_off; A.j_vitems = c->d_vitems_src; A.j_render_arr = J->d_render_arr; A.j_saved = J->d_saved;

@@ -79,6 +79,7 @@ struct FusedArgs {
     const int4 *chunk_desc;        // per record, two entries: {ti, j, chunk, target} {visit, image, 0, 0}
     const int2 *tgt_rec;           // per target: {first record, number of records}
     OptState *st; double *Hstate; double *Tstate; OptParams op; uint32_t flags;   // Tstate: TRI_STATE doubles per target (optim_step_target)
+    double *Spec;                  // 2 x SPEC_STATE doubles per target: the quarter-radius step computed ahead (fused_speculate); nullptr: off
     // the queue
     int32_t *q_items; int32_t *q_ctl; int32_t *arrivals; int q_cap;
     long long timeout_ticks;       // wall_clock64 ticks (100 MHz) a workgroup waits for its ticket before it gives up
@@ -432,7 +433,51 @@ __device__ __noinline__ int fused_step(const FusedArgs &A, FusedShared &F, const
     const int t = A.targets[ti];
     return optim_step_target<true, FUSED_NT>(F.step, tid, A.st[ti], A.Hstate + (size_t)ti * NF * NF,
                                              A.vp + (size_t)t * CEL_P, F.ev_h, F.ev_d, -F.ev_v, F.ev_status, A.op,
-                                             A.Tstate ? A.Tstate + (size_t)ti * TRI_STATE : nullptr);
+                                             A.Tstate ? A.Tstate + (size_t)ti * TRI_STATE : nullptr,
+                                             A.Spec ? A.Spec + (size_t)ti * 2 * SPEC_STATE : nullptr);
+}
+
+// While the trial point of target ti is being evaluated by other workgroups, the workgroup that queued it computes what
+// a REJECTION of that point would ask for: the step from the same accepted point with a quarter of the radius (tri_step on
+// the reduced form kept in Tstate).  If the point is indeed rejected (19 % of the iterations), the step is there
+// (optim_step_target, `spec`): 66 -> 42 us for such an iteration.  Same code, same inputs as the step computed on
+// demand, so the same bits; skipped while the queue is long (the workgroup has better things to do) and in the hard
+// case.  The tag -- the iteration the step belongs to -- is written last.
+__device__ __noinline__ void fused_speculate(const FusedArgs &A, FusedShared &F, const int tid, const int ti) {
+    if (tid == 0) {
+        const int h = ldc<true>(&A.q_ctl[FQC_HEAD]), t = ldc<true>(&A.q_ctl[FQC_TAIL]);
+        F.last = t - h <= (int)gridDim.x / 4;        // (HEAD runs ahead of TAIL by the idle workgroups' tickets when the queue is empty)
+    }
+    __syncthreads();
+    const bool go = F.last != 0;
+    __syncthreads();
+    if (!go) return;
+    StepShared &Z = F.step;
+    OptState &S = A.st[ti];
+    const double *const Ts = A.Tstate + (size_t)ti * TRI_STATE;
+    for (int k = tid; k < NF * NF; k += FUSED_NT) { const int j = k / NF; Z.sA[(k - j * NF) + LDA * j] = ldc<true>(&Ts[k]); }
+    if (tid < NF) Z.sx[tid] = ldc<true>(&S.x[tid]);
+    __syncthreads();
+    if (tid < 64) {
+        const bool fr = tid < NF;
+        const double *v = Ts + NF * NF;
+        TriForm TF;
+        TF.td = fr ? ldc<true>(v + tid) : 0.0; TF.te = fr ? ldc<true>(v + NF + tid) : 0.0;
+        TF.hv = fr ? ldc<true>(v + 2 * NF + tid) : 0.0; TF.gt = fr ? ldc<true>(v + 3 * NF + tid) : 0.0;
+        TF.wmin = ldc<true>(v + 4 * NF); TF.wmax = ldc<true>(v + 4 * NF + 1);
+        TF.wmin_lower = ldc<true>(v + 4 * NF + 2); TF.norm_bound = ldc<true>(v + 4 * NF + 3);
+        const double delta = 0.25 * Z.s_delta;                            // what a rejection makes of the radius (this workgroup's own step left it here)
+        const TriLds L = {Z.sA, Z.sw, Z.sU, Z.se, Z.sU + NF, Z.sgt_q};  // (optim_step_target's layout)
+        const TrResult R = tri_step(L, TF, delta, tid, A.op.secular_iters);
+        double *const Sp = A.Spec + ((size_t)ti * 2 + (Z.s_iter & 1)) * SPEC_STATE;
+        if (R.solved) {
+            if (fr) stc<true>(Sp + tid, Z.sx[tid] + R.p);
+            if (tid == 0) { stc<true>(Sp + NF, R.m); stc<true>(Sp + NF + 1, R.interior ? 1.0 : 0.0); }
+            drain_stores();
+            if (tid == 0) stc<true>(Sp + NF + 2, (double)Z.s_iter);       // (not read back from memory: the target may have moved on)
+        }
+    }
+    __syncthreads();
 }
 
 template <bool JOINT>
@@ -475,8 +520,10 @@ optim_fused_kernel(const FusedArgs A) {
         FT(5);
         drain_stores();      // the target's row of vp, its state and saved Hessian are in memory ...
         __syncthreads();     // ... before its next items (or the end of the launch) become visible
-        if (!done) fused_push_eval(A, tid, &F.done, ti);
-        else {
+        if (!done) {
+            fused_push_eval(A, tid, &F.done, ti);
+            if (A.Spec && A.op.solver != 1) fused_speculate(A, F, tid, ti);
+        } else {
             if (JOINT) joint_end(A, F, tid, ti);
             if (tid == 0)
                 F.done = __hip_atomic_fetch_add(&A.q_ctl[FQC_LIVE], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;

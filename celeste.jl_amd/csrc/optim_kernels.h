@@ -50,6 +50,8 @@
 #ifndef OPTIM_Q3_SOLVE
 #define OPTIM_Q3_SOLVE 0      // 1: y' (T + lambda I)^-1 y by a second full solve instead of the forward sweep
 #endif
+#define SPEC_STATE (NF + 3)                // trial point, model decrease, interior flag, iteration tag; two of them per target,
+                                           // used in turn (a slow writer can never meet the next one in the same block)
 #define TRI_STATE (NF * NF + 4 * NF + 4)   // reflectors, (td, te, hv, Q'g) per row, wmin, wmax, wmin_lower, norm_bound
 #define LDA 45  // leading dimension of the LDS matrix (holds the 44 x 44 bound-space Hessian first; odd: no bank conflicts)
 
@@ -952,14 +954,19 @@ struct StepShared {
     double sU[9 * NF];         // chain-rule tables, then the solver's vectors (disjoint lifetimes)
     int s_flag[2];             // 0: accept, 1: done
     double s_delta;            // trust-region radius after the update
+    int s_iter;                // iteration counter after the update (the tag of a step computed ahead, fused_speculate)
 };
 
 template <bool COH, int NTHR>
 __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, OptState &S, double *__restrict__ Hs, double *__restrict__ vp_row,
                                                  const double *__restrict__ h, const double *__restrict__ ev_d, double ft_in,
-                                                 int st_in, const OptParams &op, double *__restrict__ Ts = nullptr) {
+                                                 int st_in, const OptParams &op, double *__restrict__ Ts = nullptr,
+                                                 const double *__restrict__ Sp = nullptr) {
     // Ts (optional, TRI_STATE doubles per target): the reduced form of the last accepted point's sub-problem (tri_reduce),
     // so that a rejected step -- same Hessian and gradient, smaller radius -- goes straight to tri_step
+    // Sp (optional, SPEC_STATE doubles per target): the quarter-radius step from that point, computed ahead of time by the
+    // fused kernel while the trial point was being evaluated (fused_speculate): trial point, model decrease, interior flag,
+    // and the iteration it belongs to
     constexpr int PARTS = NTHR / 64;
     double *const sA = Z.sA, *const sx = Z.sx, *const sg = Z.sg, *const sw = Z.sw, *const se = Z.se, *const scv = Z.scv;
     double *const sU = Z.sU;
@@ -1123,13 +1130,14 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
             } else if (gmax <= op.gtol) done = 1;   // already stationary at the starting point: no iteration at all
             if (accept) stc<COH>(&S.f, ft);
             stc<COH>(&S.delta, delta); Z.s_delta = delta;
-            stc<COH>(&S.iter, S_iter + 1);
+            stc<COH>(&S.iter, S_iter + 1); Z.s_iter = S_iter + 1;
             if (S_iter + 1 >= op.max_iters) done = 1;
             s_flag[0] = accept; s_flag[1] = done;
         }
     }
     __syncthreads();
     const int accept = s_flag[0], done = s_flag[1];
+    bool spec = false;
 #ifdef OPTIM_TIMING
     if (!accept && tid == 0) atomicAdd(&g_optim_clk[13], 2400ull);   // (counted as 1 us per rejected step in tools/gpu_optim_sections.py)
 #endif
@@ -1138,9 +1146,12 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
         if (!done) for (int k = tid; k < NF * NF; k += NTHR) { const int j = k / NF; stc<COH>(&Hs[k], sA[(k - j * NF) + LDA * j]); }
     } else {
         if (tid < NF) { sx[tid] = ldc<COH>(&S.x[tid]); sg[tid] = ldc<COH>(&S.g[tid]); }
+        // was this very step computed ahead of time?  (the tag is the iteration it was computed for; stale ones never match)
+        if (Sp) Sp += (S_iter & 1) * SPEC_STATE;
+        spec = Sp && !done && op.solver != 1 && ldc<COH>(Sp + NF + 2) == (double)S_iter;
         // the sub-problem's matrix: its reduced form if it was kept (reflectors; tri_step needs nothing else of H), else H
         const double *const src = (Ts && op.solver != 1) ? Ts : Hs;
-        if (!done) for (int k = tid; k < NF * NF; k += NTHR) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = ldc<COH>(&src[k]); }
+        if (!done && !spec) for (int k = tid; k < NF * NF; k += NTHR) { const int j = k / NF; sA[(k - j * NF) + LDA * j] = ldc<COH>(&src[k]); }
     }
     __syncthreads();
     OPT_TICK(1);
@@ -1154,7 +1165,10 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
     if (part == 0) {
         const bool fr = tid < NF;
         TrResult R = {0.0, 0.0, 0, 0};
-        if (op.solver != 1) {
+        if (spec) {
+            // the step the rejection calls for is already there: trial point (taken as it is below), model decrease, interior flag
+            R.m = ldc<COH>(Sp + NF); R.interior = ldc<COH>(Sp + NF + 1) != 0.0; R.solved = 1;
+        } else if (op.solver != 1) {
             const TriLds L = {sA, sw, std_, se, ste2, sq};
             TriForm TF;
             if (Ts && !accept) {
@@ -1183,7 +1197,7 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
         OPT_TICK(2);   // the whole sub-problem (sections 3-7 are its parts)
         if (tid == 0) { stc<COH>(&S.m, R.m); stc<COH>(&S.interior, R.interior); }
         if (fr) {
-            const double xn = sx[tid] + R.p;
+            const double xn = spec ? ldc<COH>(Sp + tid) : sx[tid] + R.p;
             stc<COH>(&S.xt[tid], xn); sx[tid] = xn;
         }
     }
