@@ -1509,6 +1509,8 @@ static int optim_run(celeste_ctx_t *c, double *d_vp, const double *d_pos, int32_
     }
     hipLaunchKernelGGL(save_rows_kernel, dim3((unsigned)((n * CEL_P + 255) / 256)), dim3(256), 0, stream, d_vp, d_targets,
                        n_targets, fb.d_saved);
+    // (no reduced form yet: NaN everywhere -- the first sub-problem of every target starts its eigenvalue search cold)
+    HIP_TRY(hipMemsetAsync(ob.d_T, 0xFF, n * TRI_STATE * sizeof(double), stream));
     hipLaunchKernelGGL(optim_init_kernel, dim3((n_targets + 63) / 64), dim3(64), 0, stream, d_vp, d_targets, n_targets, op,
                        (OptState *)ob.d_state, ob.d_act[0], d_pos);
     const bool fused = optim_use_fused(c, n_targets, n_chunks, op);
@@ -1696,6 +1698,7 @@ static int joint_dataflow(celeste_ctx_t *c, int64_t total, const int32_t *target
     rc = optim_render(c, ob.d_vp, E, d_all, n_chunks, stream);
     if (rc != CELESTE_OK) goto out;
     {
+        JD_TRY(hipMemsetAsync(ob.d_T, 0xFF, (size_t)E * TRI_STATE * sizeof(double), stream));
         JointLaunch J = {d_dep, d_succ_off, d_succ, d_rarr, fb.d_saved, d_pos, gshift, groups};
         rc = optim_run_fused(c, ob.d_vp, E, d_all, n_chunks, op, flags, stream, &J);
         if (rc != CELESTE_OK) goto out;
