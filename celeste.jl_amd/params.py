@@ -126,11 +126,21 @@ def init_source_table(catalog, target_sources=(), max_gal_radius_px=math.inf) ->
     star = np.fromiter((bool(ce.is_star) for ce in catalog), dtype=bool, count=S)
     ret[:, ids.is_star[0]] = np.where(star, 0.8, 0.2)
     ret[:, ids.is_star[1]] = np.where(star, 0.2, 0.8)
-    ret[:, ids.flux_loc[0]] = [math.log(max(0.1, ce.star_fluxes[2])) for ce in catalog]
-    ret[:, ids.flux_loc[1]] = [math.log(max(0.1, ce.gal_fluxes[2])) for ce in catalog]
+    sf = np.array([ce.star_fluxes for ce in catalog], dtype=np.float64).reshape(S, -1)
+    gf = np.array([ce.gal_fluxes for ce in catalog], dtype=np.float64).reshape(S, -1)
+    ret[:, ids.flux_loc[0]] = [math.log(x) for x in np.maximum(0.1, sf[:, 2]).tolist()]
+    ret[:, ids.flux_loc[1]] = [math.log(x) for x in np.maximum(0.1, gf[:, 2]).tolist()]
+
+    def colors(f, c):       # _get_color(f[c + 1], f[c]) for every row; the logarithm through math.log like the scalar function
+        c2, c1 = f[:, c + 1], f[:, c]
+        both = (c2 > 0) & (c1 > 0)
+        out = np.where((c2 > 0) & (c1 <= 0), 3.0, np.where((c2 <= 0) & (c1 > 0), -3.0, 0.0))
+        if both.any():
+            out[both] = np.clip([math.log(r) for r in (c2[both] / c1[both]).tolist()], -9.0, 9.0)
+        return out
     for c in range(4):
-        ret[:, ids.color_mean[c, 0]] = [_get_color(ce.star_fluxes[c + 1], ce.star_fluxes[c]) for ce in catalog]
-        ret[:, ids.color_mean[c, 1]] = [_get_color(ce.gal_fluxes[c + 1], ce.gal_fluxes[c]) for ce in catalog]
+        ret[:, ids.color_mean[c, 0]] = colors(sf, c)
+        ret[:, ids.color_mean[c, 1]] = colors(gf, c)
     ret[:, ids.gal_frac_dev] = np.clip(np.array([ce.gal_frac_dev for ce in catalog], dtype=np.float64), 0.015, 0.985)
     ab = np.clip(np.array([ce.gal_axis_ratio for ce in catalog], dtype=np.float64), 0.015, 0.985)
     ret[:, ids.gal_axis_ratio] = np.where(star, 0.8, ab)
