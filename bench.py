@@ -16,6 +16,9 @@ and the per-source results (value + 44-gradient) are all-gathered over RCCL afte
 the only exchange of the path) on a second stream, overlapping the kernels of the next sweep; every gather is complete
 before the clock stops.  --scaling weak gives every rank its own field instead (round-1 behaviour).
 --backend gloo stages the gather through the host (lets two ranks share one GPU; used by the tests).
+A plain `python bench.py --gpus N` (no launcher, no RANK in the environment) starts its N ranks itself under
+torch.distributed.run; however it was started, the run refuses to go on unless WORLD_SIZE == --gpus, RCCL has a device per
+rank, and an all_reduce over the gather's backend counts N ranks (`ranks_seen` in the line).
 
 Prints ONE JSON line on rank 0 (contract in the task description).
 """
@@ -184,6 +187,22 @@ def cpu_baseline(problem, vp, targets, seconds_target=15.0):
                          len(os.sched_getaffinity(0)), dt, dt2)}
 
 
+def self_launch(n):
+    """Re-run this command line as n ranks under torch.distributed.run on this node (rendezvous on 127.0.0.1, a free
+    port); returns the launcher's exit code.  stdout is inherited: rank 0's JSON line is this process's output."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +227,17 @@ def main():
     ap.add_argument("--check-dir", default=None,
                     help="every rank writes its gathered (v, d) of the last sweep to <dir>/rank<r>.npz (tests)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ and not args.pmc_child:
+        # a plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, the same launcher and
+        # arguments the driver uses) -- the line must never describe fewer ranks than --gpus asked for
+        sys.exit(self_launch(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        # never mislabel: the line's n_gpus is the number of ranks that swept, and it must be what --gpus asked for
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%s: launch %d ranks (or run the plain "
+                         "`python bench.py --gpus %d`, which starts them itself)"
+                         % (args.gpus, os.environ.get("WORLD_SIZE", "1"), args.gpus, args.gpus))
     # Libraries write to file descriptor 1 behind Python's back (RCCL prints a five-line version banner when its first
     # communicator comes up): until the result line is due, fd 1 points at stderr, so that rank 0's stdout carries the
     # one JSON line and nothing else.
@@ -238,16 +268,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = args.gpus > 1 or world > 1 or "RANK" in os.environ   # launched by torch.distributed.run
     n_dev = torch.cuda.device_count()
+    ranks_seen = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl" and local_rank >= n_dev:
-            raise SystemExit("rank %d has no GPU of its own (%d visible): RCCL needs one device per rank; "
-                             "use --backend gloo to share a device" % (local_rank, n_dev))
+        if args.backend == "nccl" and (world > n_dev or local_rank >= n_dev):
+            raise SystemExit("%d ranks on %d visible GPU(s): RCCL needs one device per rank; "
+                             "use --backend gloo to share a device" % (world, n_dev))
         dev_index = local_rank % n_dev
         torch.cuda.set_device(dev_index)
         dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # the ranks that really take part, counted over the backend the gather uses
+        ones = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", dev_index) if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if ranks_seen != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks (all_reduce saw %d), --gpus says %d"
+                             % (dist.get_world_size(), ranks_seen, args.gpus))
     else:
         dev_index = 0
         torch.cuda.set_device(0)
@@ -329,6 +367,32 @@ def main():
     ctx.enable_timing(False)
     kms = np.array(kms).mean(axis=0)
     sync()
+
+    # N > 1: every rank's sweep of its own shard WITHOUT the catalog gather (same launches, wall clock between two
+    # device synchronisations) -- what separates load imbalance / small-shard latency from the cost of the exchange
+    sweep_only_ms = None
+    if use_dist and world > 1:
+        blk0 = sweep.blocks[0].data_ptr()
+        cs = sweep.compute_stream.cuda_stream
+
+        def shard_only():
+            if sweep.n > 0:
+                ctx.eval_batch_device(d_vp.data_ptr(), sweep.n, sweep.d_tg.data_ptr(), flags, blk0, blk0 + 8 * sweep.width,
+                                      sweep.d_h.data_ptr() if sweep.d_h is not None else 0, sweep.d_cnt.data_ptr(),
+                                      sweep.d_st.data_ptr(), cs)
+        for _ in range(3):
+            shard_only()
+        torch.cuda.synchronize(dev)
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            shard_only()
+        torch.cuda.synchronize(dev)
+        mine_ms = torch.tensor([(time.perf_counter() - ts) / args.steps * 1e3], dtype=torch.float64,
+                               device=dev if args.backend == "nccl" else "cpu")
+        allms = [torch.zeros_like(mine_ms) for _ in range(world)]
+        dist.all_gather(allms, mine_ms)
+        sweep_only_ms = [float(t.item()) for t in allms]
+        sync()
 
     extras = world == 1 and not args.no_extras
     d_tg = sweep.d_tg
@@ -454,7 +518,8 @@ def main():
                            "" if world == 1 else ", sharded by source across %d GPUs" % world))
         out = {
             "metric": "sources/sec (ELBO value+gradient+Hessian+KL per target source)",
-            "value": value, "unit": "sources/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "sources/sec", "n_gpus": world, "ranks_seen": ranks_seen,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -490,6 +555,9 @@ def main():
                                        "instruction_mix": facts.get("instruction_mix_f32" if args.dtype == "f32" else "instruction_mix")}
             if args.dtype == "f64":
                 out["roofline"]["fp64"] = out["roofline"]["valu"]
+        if sweep_only_ms is not None:
+            out["config"]["sweep_ms_without_gather_per_rank"] = sweep_only_ms
+            out["config"]["gather_and_imbalance_ms"] = ms_per_step - max(sweep_only_ms)
         out.update(out_extra)
         if split is not None:
             out["split_variant"] = split

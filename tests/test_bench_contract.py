@@ -54,6 +54,38 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
 
 
+def test_bench_refuses_a_rank_count_that_is_not_what_gpus_says():
+    """started by a launcher with fewer (or more) ranks than --gpus: no line, non-zero exit -- never a line that says
+    n_gpus 1 for a run that was asked to be 8 (checked before anything touches a device, so it runs here)"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr and "{" not in out.stdout
+    env["WORLD_SIZE"] = "2"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and "{" not in out.stdout
+
+
+def test_bench_plain_invocation_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-runs itself under torch.distributed.run with N processes on
+    127.0.0.1 (the command is checked here; the ranks themselves need a GPU: test_gpu_round2.py)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    import subprocess as sp
+    monkeypatch.setattr(sp, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert cmd[-5].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
 @pytest.mark.gpu
 def test_bench_config5_mode_small_grid():
     """bench.py --config 5: overlapping fields through the sparse patch list, fp32 component loop, the 1e-4 check

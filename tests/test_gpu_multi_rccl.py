@@ -40,10 +40,20 @@ def _rccl_bench_equals_single_rank(tmp_path, n):
     import celeste_jl_amd as cel
     sys.path.insert(0, ROOT)
     import bench
+    # the plain form, exactly what the driver types for N = 1: bench.py starts its N ranks itself
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "nccl", "--steps", "5",
+                          "--warmup", "2", "--no-extras", "--check-dir", str(tmp_path)], capture_output=True, text=True,
+                         timeout=1200, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")][0])
+    # ... and under the launcher, the way the driver starts N > 1: the same line
     out = _launch(n, [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "nccl", "--steps", "5", "--warmup", "2",
-                      "--no-extras", "--check-dir", str(tmp_path)])
-    d = json.loads([ln for ln in out.splitlines() if ln.strip().startswith("{")][0])
+                      "--no-extras"])
+    d2 = json.loads([ln for ln in out.splitlines() if ln.strip().startswith("{")][0])
+    assert d2["n_gpus"] == n == d2["ranks_seen"] and d2["config"]["shard_sizes"] == d["config"]["shard_sizes"]
     S = 2000
+    assert d["ranks_seen"] == n and len(d["config"]["sweep_ms_without_gather_per_rank"]) == n
     assert d["n_gpus"] == n and d["scaling"] == "strong" and d["config"]["gather_backend"] == "nccl"
     sizes = d["config"]["shard_sizes"]
     assert len(sizes) == n and sum(sizes) == S == d["config"]["sources_per_step"] and min(sizes) > 0

@@ -68,6 +68,40 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu_equals_single_rank(tmp_path):
     assert seen.all()
 
 
+def test_bench_plain_invocation_runs_two_ranks_by_itself(tmp_path):
+    """`python bench.py --gpus 2 --backend gloo` with NO launcher and no RANK in the environment: bench.py starts its two
+    ranks itself, the line says n_gpus 2 and ranks_seen 2, and both ranks hold the single-rank catalog bit for bit"""
+    import celeste_jl_amd as cel
+    sys.path.insert(0, ROOT)
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--height", "420", "--width", "380",
+           "--sources", "180", "--seed", "7", "--steps", "3", "--warmup", "1", "--check-dir", str(tmp_path)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["gather_backend"] == "gloo"
+    assert sum(d["config"]["shard_sizes"]) == 180 and len(d["config"]["shard_sizes"]) == 2
+    per_rank = d["config"]["sweep_ms_without_gather_per_rank"]
+    assert len(per_rank) == 2 and min(per_rank) > 0 and max(per_rank) <= d["ms_per_step"] * 1.5
+    fld = bench.build_field(420, 380, 180, 7)
+    ctx = cel.FieldContext(fld.images, fld.patches, fld.neighbors)
+    v, dd, h, cnt, st = ctx.eval_batch(fld.vp, np.arange(180), ALL)
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert np.array_equal(z["v"], v) and np.array_equal(z["d"], dd), "rank %d gathered catalog" % r
+    # RCCL cannot put two ranks on this box's one device: the plain form must refuse, not print a line for fewer ranks
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--height", "300", "--width", "260",
+                              "--sources", "60", "--steps", "1", "--warmup", "0", "--no-extras"],
+                             capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+        assert "RCCL needs one device per rank" in out.stderr
+
+
 def test_bench_single_rank_under_the_launcher(tmp_path):
     """N = 1 launched the way the driver launches N > 1 (torch.distributed.run, RCCL group of one)"""
     d = _launch_bench(tmp_path, 1, ["--height", "300", "--width", "260", "--sources", "60", "--steps", "3", "--warmup", "1",
