@@ -815,7 +815,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     } else {
         hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 63) / 64)), dim3(64), 0, stream, d_vp, geo_S,
                            c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
-                           render_neighbors ? c->d_needed : nullptr, c->stamp, prep_mark, c->d_nbr_off, c->d_nbr_idx);
+                           render_neighbors ? c->d_needed : nullptr, c->stamp, prep_mark, c->d_nbr_off, c->d_nbr_idx, d_live);
         hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
                            c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, G, (int)c->dense, c->d_work_blk, d_live);
         hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * (n_classes + 1),
@@ -868,7 +868,9 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         A.targets = d_targets; A.n_targets = n_targets; A.vp = const_cast<double *>(d_vp);
         A.chunk_desc = fb.d_chunk_desc; A.tgt_rec = fb.d_tgt_rec; A.arrivals = fb.d_arrivals; A.flags = flags;
         memset(&A.op, 0, sizeof A.op);
-        const unsigned rec_bound = (unsigned)std::max<size_t>(grid_need, 1);
+        // no stride loop in this kernel: the grid must cover every record.  h_top_chunks bounds DISTINCT targets only, and
+        // the device-pointer entry allows repeats -- there the bound is n_targets x the chunk-richest source
+        const unsigned rec_bound = (unsigned)std::max<size_t>(n_chunks >= 0 ? grid_need : work_need, 1);
         hipLaunchKernelGGL(eval_fused_kernel, dim3(rec_bound + (unsigned)n_targets), dim3(FUSED_NT), 0, stream, A, c->d_srcimg,
                            c->d_comps, c->d_work_total, (int)rec_bound, d_v, d_d, d_h, d_counters, d_status);
         if (c->timing) { HIP_TRY(hipEventRecord(c->ev[2], stream)); HIP_TRY(hipEventRecord(c->ev[3], stream)); c->ev_valid = 1; c->ev_split = 0; }
@@ -966,12 +968,10 @@ static int eval_small(celeste_ctx_t *c, const double *vp, int32_t n_targets, con
     const size_t vp_n = (size_t)c->S * CEL_P;
     const size_t in_n = vp_n + EVAL_SMALL_MAX / 2;                                     // doubles: table, then 32 int32
     const size_t per = 1 + CEL_P + (size_t)CEL_P * CEL_P + 2 + 1, out_n = EVAL_SMALL_MAX * per;
-    if (!c->d_small_in) {
-        HIP_TRY(hipMalloc((void **)&c->d_small_in, in_n * sizeof(double)));
-        HIP_TRY(hipHostMalloc((void **)&c->p_small_in, in_n * sizeof(double), hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **)&c->d_small_out, out_n * sizeof(double)));
-        HIP_TRY(hipHostMalloc((void **)&c->p_small_out, out_n * sizeof(double), hipHostMallocDefault));
-    }
+    if (!c->d_small_in) HIP_TRY(hipMalloc((void **)&c->d_small_in, in_n * sizeof(double)));
+    if (!c->p_small_in) HIP_TRY(hipHostMalloc((void **)&c->p_small_in, in_n * sizeof(double), hipHostMallocDefault));
+    if (!c->d_small_out) HIP_TRY(hipMalloc((void **)&c->d_small_out, out_n * sizeof(double)));
+    if (!c->p_small_out) HIP_TRY(hipHostMalloc((void **)&c->p_small_out, out_n * sizeof(double), hipHostMallocDefault));
     memcpy(c->p_small_in, vp, vp_n * sizeof(double));
     memcpy(c->p_small_in + vp_n, targets, n * sizeof(int32_t));
     HIP_TRY(hipMemcpyAsync(c->d_small_in, c->p_small_in, (vp_n + (n + 1) / 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1470,7 +1470,10 @@ static int optim_run_chained(celeste_ctx_t *c, double *d_vp, int32_t n_targets, 
     OptState *const d_state = (OptState *)ob.d_state;
     constexpr int RING = celeste_ctx::OptBuffers::RING;
     HIP_TRY(hipMemsetAsync(ob.d_count, 0, 3 * sizeof(int32_t), stream));   // (an earlier call may have stopped mid-loop)
+    // both lists start as the full target list: the step kernel only rewrites the first *next_count entries of the other
+    // list, and the launches are sized by a count two iterations old -- entries past the live count must be valid ids
     HIP_TRY(hipMemcpyAsync(d_evt[0], d_targets, n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d_evt[1], d_targets, n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
     int32_t n_upper = n_targets;
     int cur = 0;
     for (int it = 0; it <= op.max_iters + 1; ++it) {
@@ -1696,6 +1699,9 @@ static int joint_dataflow(celeste_ctx_t *c, int64_t total, const int32_t *target
     // the batch's bookkeeping for all entries (visit items, record offsets), every source's tables and shape derivatives
     // from the input table; the entries refresh them as they end
     rc = optim_render(c, ob.d_vp, E, d_all, n_chunks, stream);
+    // (a flattened schedule too large for one batch's index space is a limit of THIS driver, not of the call: the caller
+    // runs it layer by layer -- nothing has touched the table yet)
+    if (rc == CELESTE_ERR_INVALID_ARG) { rc = CELESTE_OK; goto out; }
     if (rc != CELESTE_OK) goto out;
     {
         JD_TRY(hipMemsetAsync(ob.d_T, 0xFF, (size_t)E * TRI_STATE * sizeof(double), stream));
@@ -1707,6 +1713,12 @@ static int joint_dataflow(celeste_ctx_t *c, int64_t total, const int32_t *target
                            d_all, E, ob.d_vp, (const double *)nullptr, d_it, d_ev, d_el, d_stt, fb.d_q_ctl);
         JD_TRY(hipGetLastError());
         JD_TRY(hipStreamSynchronize(stream));      // (the host vectors above are in flight until here)
+        if (fb.h_ctl && fb.h_ctl[FQC_ABORT] == 2) {
+            // the launch ran out of queue capacity (a time-out stays an error: something is wrong with the device): the
+            // table is partly optimised -- put the caller's table back and let the layered driver run the schedule
+            JD_TRY(hipMemcpyAsync(ob.d_vp, ob.h_vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice, stream));
+            goto out;
+        }
         *ran = true;
     }
 out:

@@ -471,7 +471,11 @@ __device__ inline void setup_thread(int k, const double *__restrict__ vp, int S,
                                     const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
                                     const int32_t *__restrict__ vis_img, int M, int2 *__restrict__ items,
                                     int32_t *__restrict__ is_target, int32_t stamp, int32_t *__restrict__ prep_mark,
-                                    const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx) {
+                                    const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
+                                    const int32_t *__restrict__ live = nullptr) {
+    // live (optional): the number of leading entries of `targets` that are valid -- n_targets is then the host's upper
+    // bound (the chained optimiser runs ahead of the device) and the entries past *live are stale or never written
+    if (live) n_targets = min(n_targets, *live);
     // S < 0: the neighbours are frozen (an optimiser iteration) -- only the targets have moved since the batch's SrcGeo
     // table was made, and the neighbours' entries (their finiteness flags) keep describing the parameters they were
     // rendered with
@@ -494,9 +498,10 @@ __global__ void setup_kernel(const double *__restrict__ vp, int S, SrcGeo *__res
                              const int32_t *__restrict__ targets, int n_targets, const int32_t *__restrict__ vis_off,
                              const int32_t *__restrict__ vis_img, int M, int2 *__restrict__ items,
                              int32_t *__restrict__ is_target, int32_t stamp, int32_t *__restrict__ prep_mark,
-                             const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx) {
+                             const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,
+                             const int32_t *__restrict__ live) {
     setup_thread(blockIdx.x * blockDim.x + threadIdx.x, vp, S, geo, targets, n_targets, vis_off, vis_img, M, items, is_target,
-                 stamp, prep_mark, nbr_off, nbr_idx);
+                 stamp, prep_mark, nbr_off, nbr_idx, live);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -695,7 +700,7 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
         // pipeline (26 us for 2000 sources in two 1024-thread blocks; spread over 32 CUs the same work takes 3 us)
         if (threadIdx.x < WORK1_SETUP)
             setup_thread((blockIdx.x - 1) * WORK1_SETUP + threadIdx.x, vp, S, geo, targets, n_targets, vis_off, vis_img, M,
-                         items, is_target, stamp, prep_mark, nbr_off, nbr_idx);
+                         items, is_target, stamp, prep_mark, nbr_off, nbr_idx, live);
         return;
     }
     __shared__ int s_part[WORK1_NT / 64];

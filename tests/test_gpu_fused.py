@@ -425,3 +425,33 @@ def test_eval_fused_kernel_equals_pixel_and_lift_kernels(crowded):
         with _env(CELESTE_EVAL_FUSED=mode):
             out.append(ctx.eval_batch(bad, [4, 5], 7, raise_on_error=False))
     assert np.array_equal(out[0][4], out[1][4]) and out[0][4][0] == cabi.ERR_NONFINITE_INPUT
+
+
+def test_eval_fused_kernel_with_repeated_targets_through_the_device_pointer_entry(crowded):
+    """celeste_elbo_eval_batch_device does not know its targets on the host: a short list that repeats the chunk-richest
+    source is LONGER than the bound for distinct targets, and eval_fused_kernel has no stride loop -- every slot must still
+    be evaluated and lifted, and a second launch on the same context must not find stale arrival counters"""
+    import torch
+    f, ctx = crowded
+    S = len(f.catalog)
+    base = ctx.eval_batch(f.vp, list(range(S)), 7)
+    cnt = base[3][:, 0] + base[3][:, 1]
+    rich = int(np.argmax(cnt))              # (most pixel visits = most chunk records)
+    dev = torch.device("cuda", ctx.device)
+    d_vp = torch.tensor(f.vp, dtype=torch.float64, device=dev)
+    for tg in ([rich] * 24, [rich, 1, rich, rich, 2, rich, rich, rich], [rich] * 32):
+        n = len(tg)
+        d_tg = torch.tensor(tg, dtype=torch.int32, device=dev)
+        for rep in range(2):
+            d_v = torch.full((n,), np.nan, dtype=torch.float64, device=dev)
+            d_d = torch.full((n, 44), np.nan, dtype=torch.float64, device=dev)
+            d_h = torch.full((n, 44, 44), np.nan, dtype=torch.float64, device=dev)
+            d_c = torch.zeros(n, 2, dtype=torch.int64, device=dev)
+            d_s = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            with _env(CELESTE_EVAL_FUSED=1):
+                ctx.eval_batch_device(d_vp.data_ptr(), n, d_tg.data_ptr(), 7, d_v.data_ptr(), d_d.data_ptr(), d_h.data_ptr(),
+                                      d_c.data_ptr(), d_s.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            torch.cuda.synchronize(dev)
+            assert (d_s.cpu().numpy() == 0).all(), (tg, rep, d_s.cpu().numpy())
+            assert np.array_equal(d_v.cpu().numpy(), base[0][tg]) and np.array_equal(d_d.cpu().numpy(), base[1][tg])
+            assert np.array_equal(d_h.cpu().numpy(), base[2][tg]) and np.array_equal(d_c.cpu().numpy(), base[3][tg])
