@@ -47,6 +47,16 @@ def export(name):
     add("gal_fluxes", [c.gal_fluxes for c in f.catalog], np.float64)
     add("gal_shape", [[c.gal_frac_dev, c.gal_axis_ratio, c.gal_angle, c.gal_radius_px] for c in f.catalog], np.float64)   # S x 4
     add("vp", f.vp, np.float64)                                            # S x 44
+    # For callers that do NOT rebuild the patches themselves (tests/cabi_caller.c, a C program compiled against
+    # include/celeste_mi355x.h): the patch geometry of Model.get_sky_patches and the neighbour lists of
+    # Model.find_neighbors as the package's host logic computes them.  tools/reference_golden.jl ignores these arrays --
+    # the reference builds its own.
+    add("patch_box", [[p.bitmap_offset[0], p.bitmap_offset[1], p.active_pixel_bitmap.shape[0], p.active_pixel_bitmap.shape[1]]
+                      for row in f.patches for p in row], np.int32)        # (S N) x 4, row s N + n: off_h, off_w, H2, W2
+    add("patch_center", [[p.pixel_center[0], p.pixel_center[1]] for row in f.patches for p in row], np.float64)   # (S N) x 2
+    off = np.cumsum([0] + [len(r) for r in f.neighbors])
+    add("nbr_offsets", off, np.int64)                                      # S + 1 (CSR)
+    add("nbr_index", [j for r in f.neighbors for j in r] or [0], np.int32)  # 0-based source ids (one dummy entry if none)
     os.makedirs(os.path.join(HERE, "raw"), exist_ok=True)
     off = 0
     with open(os.path.join(HERE, "raw", name + ".bin"), "wb") as fb, open(os.path.join(HERE, "raw", name + ".txt"), "w") as ft:

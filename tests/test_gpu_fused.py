@@ -455,3 +455,56 @@ def test_eval_fused_kernel_with_repeated_targets_through_the_device_pointer_entr
             assert (d_s.cpu().numpy() == 0).all(), (tg, rep, d_s.cpu().numpy())
             assert np.array_equal(d_v.cpu().numpy(), base[0][tg]) and np.array_equal(d_d.cpu().numpy(), base[1][tg])
             assert np.array_equal(d_h.cpu().numpy(), base[2][tg]) and np.array_equal(d_c.cpu().numpy(), base[3][tg])
+
+
+def test_joint_infer_dataflow_equals_the_cpu_restatement(crowded, oracle):
+    """celeste_joint_infer's dataflow launch (the production loop, ParallelRun.jl:135-196, 302-397) held DIRECTLY to the
+    CPU restatement of maximize! driving the same schedule -- not through the layered device schedule: 40 crowded
+    sources, Cyclades batches of 12, 2 sweeps, position boxes pinned at the initial positions.  Same bars as
+    test_joint_inference_on_the_device_equals_the_cpu_restatement: every parameter within 1e-6 at three Newton
+    iterations per entry (well-conditioned sub-problems); at six, the objective reached within 1e-9."""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd.infer import joint_infer_sweeps, joint_layers
+    from celeste_jl_amd.params import catalog_init_source, generic_init_source
+    f, ctx = crowded
+    S = len(f.catalog)
+    targets = [t for t in range(S) if t % 8 != 5]              # five sources stay frozen neighbours
+    frozen = [t for t in range(S) if t % 8 == 5]
+    vp0 = np.stack([catalog_init_source(ce) for ce in f.catalog])
+    for t in targets:
+        vp0[t] = generic_init_source(f.catalog[t].pos)
+
+    def run(max_iters):
+        layers = joint_layers(targets, f.neighbors, batch_size=12, n_iters=2, rng=np.random.default_rng(3))
+        centers = [vp0[layer, 0:2].copy() for layer in layers]
+        with _env(CELESTE_JOINT_DATAFLOW=1, CELESTE_OPT_FUSED=1):
+            dev, its, evals, el, st = ctx.joint_infer(vp0, layers, cel.ElboConfig(max_iters=max_iters), pos_centers=centers)
+        assert (st == 0).all() and its.max() == max_iters
+
+        def layer_cpu(vp, layer, pc):
+            rows = []
+            for t, c in zip(layer, pc):
+                r = oracle.maximize(ctx.problem, vp, t, oracle.OptCfg(max_iters=max_iters), pos_center=c)
+                assert r[4] == 0
+                rows.append(r[0][t])
+            return np.stack(rows)
+        cpu = joint_infer_sweeps(layer_cpu, vp0.copy(), targets, f.neighbors, batch_size=12, n_iters=2,
+                                 rng=np.random.default_rng(3))
+        absdiff = np.abs(dev - cpu)
+        med = np.median((absdiff / np.maximum(np.abs(cpu), 1e-3))[targets])
+        moved = np.abs(cpu[targets] - vp0[targets]).max()
+        worst = np.unravel_index(np.argmax(absdiff), absdiff.shape)
+        print("dataflow launch vs CPU restatement, %d layers / %d entries, max_iters %d: max |diff| %.2e (source %d parameter "
+              "%d), median relative %.1e; parameters moved by up to %.2g"
+              % (len(layers), sum(map(len, layers)), max_iters, absdiff.max(), worst[0], worst[1], med, moved))
+        assert moved > 0.1 and np.array_equal(dev[frozen], vp0[frozen])
+        return dev, cpu, absdiff.max(), med
+    _, _, absdiff, med = run(3)
+    assert absdiff <= 1e-6 and med <= 1e-9, (absdiff, med)
+    dev, cpu, absdiff, med = run(6)
+    tg = np.array(targets, dtype=np.int32)
+    e_dev = ctx.eval_batch(dev, tg, 4)[0]
+    e_cpu = ctx.eval_batch(cpu, tg, 4)[0]
+    rel = np.abs(e_dev - e_cpu) / np.abs(e_cpu)
+    print("    ELBO reached, dataflow vs CPU tables: max relative difference %.1e" % rel.max())
+    assert med <= 1e-9 and rel.max() <= 1e-9, (absdiff, med, rel.max())

@@ -24,7 +24,7 @@ const OUT = joinpath(ROOT, "tests", "golden", "ref")
 # one line of the manifest: name dtype ndims dim1 [dim2 ...] byte_offset; arrays are little-endian, column-major
 function read_arrays(name)
     arrays = Dict{String,Any}()
-    types = Dict("int64" => Int64, "float32" => Float32, "float64" => Float64)
+    types = Dict("int64" => Int64, "int32" => Int32, "float32" => Float32, "float64" => Float64)
     open(joinpath(RAW, name * ".bin")) do io
         for line in eachline(joinpath(RAW, name * ".txt"))
             tok = split(strip(line))
