@@ -221,9 +221,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the timed sweep and the roofline")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not run the rocprofv3 counter passes; report the committed profiles/hbm_traffic.json figures")
-    ap.add_argument("--pmc-child", default=None, choices=("fused", "split"), help=argparse.SUPPRESS)   # the profiled child of live_pmc
+    ap.add_argument("--pmc-child", default=None, choices=("fused", "split", "optim"), help=argparse.SUPPRESS)   # the profiled child of live_pmc / tools/profile_round.sh
     ap.add_argument("--no-config5", action="store_true",
                     help="config 3, one GPU: do not append the config5 sub-record (a short full-size --config 5 --dtype f32 run)")
+    ap.add_argument("--kernels-in-pass", action="store_true",
+                    help="record the kernels' HIP-event durations inside the timed steps themselves (one synchronisation per "
+                         "step) instead of in a pass of their own: kernels_ms then sums to at most ms_per_step by construction")
     ap.add_argument("--check-dir", default=None,
                     help="every rank writes its gathered (v, d) of the last sweep to <dir>/rank<r>.npz (tests)")
     args = ap.parse_args()
@@ -328,11 +331,19 @@ def main():
     for _ in range(args.warmup):
         sweep.step(d_vp.data_ptr())
     sync()
+    kms_in_pass = []
+    if args.kernels_in_pass:      # (the config-5 sub-record: steps of several ms, one synchronisation per step costs nothing)
+        ctx.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sweep.step(d_vp.data_ptr())
+        if args.kernels_in_pass:
+            sweep.wait()
+            kms_in_pass.append(ctx.last_kernel_ms())
     sync()
     dt = time.perf_counter() - t0
+    if args.kernels_in_pass:
+        ctx.enable_timing(False)
     if args.pmc_child == "split":   # the profiled child of live_pmc(split=True): a few sweeps of the split variant
         d_v0 = torch.zeros(S, dtype=torch.float64, device=dev)
         d_d0 = torch.zeros(S, 44, dtype=torch.float64, device=dev)
@@ -340,6 +351,18 @@ def main():
             ctx.eval_batch_device(d_vp.data_ptr(), S, sweep.d_tg.data_ptr(), FLAGS_ALL | cabi.FLAG_SPLIT, d_v0.data_ptr(),
                                   d_d0.data_ptr(), sweep.d_h.data_ptr(), sweep.d_cnt.data_ptr(), sweep.d_st.data_ptr(),
                                   torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        return
+    if args.pmc_child == "optim":
+        # the kernels that dominate a run with extras, alone under the profiler (tools/profile_round.sh): maximize! of every
+        # source (lock-step driver: optim_step_kernel + the sweep's kernels), of a Cyclades-sized layer (optim_fused_kernel<false>)
+        # and the joint-inference schedule as one dataflow launch (optim_fused_kernel<true>)
+        from celeste_jl_amd.infer import one_node_joint_infer
+        ctx.maximize_batch(fld.vp, targets, cel.ElboConfig())
+        layer = conflict_free_layer(fld, S, 80)
+        for _ in range(3):
+            ctx.maximize_batch(fld.vp, layer, cel.ElboConfig())
+        one_node_joint_infer(ctx, fld.catalog, [int(t) for t in targets], fld.neighbors)
         torch.cuda.synchronize(dev)
         return
     if args.pmc_child:     # the profiled child of live_pmc(): the sweeps are all rocprofv3 needs
@@ -365,7 +388,7 @@ def main():
         sweep.wait()
         kms.append(ctx.last_kernel_ms())
     ctx.enable_timing(False)
-    kms = np.array(kms).mean(axis=0)
+    kms = np.array(kms_in_pass if kms_in_pass else kms).mean(axis=0)
     sync()
 
     # N > 1: every rank's sweep of its own shard WITHOUT the catalog gather (same launches, wall clock between two
@@ -578,6 +601,20 @@ def main():
         dist.destroy_process_group()
 
 
+def conflict_free_layer(fld, S, n):
+    """n sources no two of which are neighbours (a Cyclades-sized layer), drawn with a fixed seed"""
+    rng = np.random.default_rng(5)
+    nb = [set(map(int, x)) for x in fld.neighbors]
+    chosen, blocked = [], set()
+    for t in rng.permutation(S):
+        if int(t) in blocked:
+            continue
+        chosen.append(int(t)); blocked |= nb[int(t)]; blocked.add(int(t))
+        if len(chosen) == min(n, S):
+            break
+    return np.array(chosen, dtype=np.int32)
+
+
 def secondary_figures(ctx, fld, targets, args, costs):
     """Figures next to the headline (rank 0, one GPU) that say how the engine behaves where the reference actually calls
     it: the host-pointer API the Julia shim binds, one elbo() per call (the literal drop-in of ElboMaximize.jl:166),
@@ -640,18 +677,10 @@ def secondary_figures(ctx, fld, targets, args, costs):
     dt_opt = time.perf_counter() - t1
     out["optimizer"] = {"optimized_sources_per_sec": S / dt_opt, "seconds": dt_opt,
                         "mean_newton_iterations": float(its.mean()), "elbo_evaluations": int(evals.sum()),
+                        "evals_per_sec": float(evals.sum()) / dt_opt,
                         "failed": int((ost != 0).sum())}
     # a Cyclades-sized layer: 80 conflict-free targets in one call (the fused optimiser launch)
-    rng = np.random.default_rng(5)
-    nb = [set(map(int, x)) for x in fld.neighbors]
-    chosen, blocked = [], set()
-    for t in rng.permutation(S):
-        if int(t) in blocked:
-            continue
-        chosen.append(int(t)); blocked |= nb[int(t)]; blocked.add(int(t))
-        if len(chosen) == min(80, S):
-            break
-    layer = np.array(chosen, dtype=np.int32)
+    layer = conflict_free_layer(fld, S, 80)
     ctx.maximize_batch(fld.vp, layer, cel.ElboConfig(max_iters=2))
     t1 = time.perf_counter()
     reps = 5
@@ -671,6 +700,14 @@ def secondary_figures(ctx, fld, targets, args, costs):
     failed = set()
     one_node_joint_infer(ctx, fld.catalog, tg, fld.neighbors, failed=failed)
     dt_joint = time.perf_counter() - t1
+    # the C call alone (celeste_joint_infer on the prepared table and schedule), with its evaluation count
+    from celeste_jl_amd.infer import default_infer_config
+    from celeste_jl_amd.params import init_source_table
+    vp_j = init_source_table(fld.catalog, tg)
+    centers = [vp_j[layer, 0:2].copy() for layer in layers]
+    t1 = time.perf_counter()
+    _, _, jevals, _, _ = ctx.joint_infer(vp_j, layers, default_infer_config(), pos_centers=centers)
+    dt_jcall = time.perf_counter() - t1
     # the same schedule layer by layer (one fused optimiser launch per layer): what the dataflow launch replaces
     os.environ["CELESTE_JOINT_DATAFLOW"] = "0"
     one_node_joint_infer(ctx, fld.catalog, tg[:50], fld.neighbors)
@@ -682,7 +719,9 @@ def secondary_figures(ctx, fld, targets, args, costs):
                           "(ParallelRun.jl:135-196), celeste_joint_infer: ONE dataflow launch -- an entry starts when the entries "
                           "it depends on have ended; the table stays in HBM; host time (initial rows, colouring) included",
                           "layers": len(layers), "entries": int(sum(map(len, layers))), "largest_layer": max(map(len, layers)),
-                          "failed": len(failed), "layer_by_layer_seconds": dt_layered}
+                          "failed": len(failed), "layer_by_layer_seconds": dt_layered,
+                          "c_call_seconds": dt_jcall, "elbo_evaluations": int(jevals.sum()),
+                          "evals_per_sec": float(jevals.sum()) / dt_jcall}
     # rank 0's cost-balanced shard of THIS field for N ranks, swept on this GPU (device-pointer API, HIP events)
     dev = torch.device("cuda", ctx.device)
     d_vp = torch.tensor(fld.vp, dtype=torch.float64, device=dev)
@@ -723,8 +762,8 @@ def config5_record(args):
     """BASELINE configs[4] on this one GPU, as a child run of this script (`--config 5 --dtype f32`, full size: 16 fields,
     80 images, 30 000 sources): throughput, the fp32-vs-fp64 check on every source, the fp32 kernel's VALU roofline."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--config", "5", "--dtype", "f32", "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline", "--no-extras", "--height", str(args.height), "--width", str(args.width)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "5", "--dtype", "f32", "--steps", "10", "--warmup", "2",
+           "--kernels-in-pass", "--no-cpu-baseline", "--no-extras", "--height", str(args.height), "--width", str(args.width)]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -737,7 +776,7 @@ def config5_record(args):
         d = json.loads(line[-1])
     except Exception as e:   # (the headline does not depend on it)
         return {"error": repr(e)}
-    keep = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "kernels_ms", "fp32_vs_fp64_device",
+    keep = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "kernels_ms", "fp32_vs_fp64_device",
                               "pixel_visits_per_sec_rank0", "fp64_pixel_kernel_ms", "fp32_speedup_over_fp64_pixel_kernel") if k in d}
     keep["workload"] = d["config"]["workload"]
     keep["sources_per_step"] = d["config"]["sources_per_step"]

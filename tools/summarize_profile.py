@@ -78,6 +78,57 @@ if pk:
               "* SQ_ACTIVE_INST_VALU = %.3g quad-cycles -> **%.0f %% of all SIMD issue cycles are VALU** (FP64-bound)."
               % (pk["SQ_ACTIVE_INST_VALU"], 100 * valu_util),
               "* SQ_WAVE_CYCLES / SIMD-cycles = %.2f resident waves per SIMD." % (pk["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles), ""]
+# ---- the optimiser / joint-inference kernels (bench.py --pmc-child optim), when the round's run has those passes ----
+def sums(sub):
+    """per kernel: every counter SUMMED over all its dispatches of the child run, and the number of dispatches"""
+    out = {}
+    for f in glob.glob(os.path.join(src, sub, "*counter_collection.csv")):
+        df = pd.read_csv(f)
+        df["k"] = df.Kernel_Name.map(short)
+        for (k, c), g in df.groupby(["k", "Counter_Name"]):
+            out.setdefault(k, {})[c] = float(g.Counter_Value.sum())
+            out[k]["dispatches"] = int(len(g))
+    return out
+
+
+opt_sq, opt_lds, opt_f, opt_w = sums("opt_sq"), sums("opt_lds"), sums("opt_fetch"), sums("opt_write")
+optim = {}
+if opt_sq:
+    okt = glob.glob(os.path.join(src, "opt_trace", "*kernel_trace.csv"))
+    dur = {}
+    if okt:
+        t = pd.read_csv(okt[0]); t["k"] = t.Kernel_Name.map(short); t["ns"] = t.End_Timestamp - t.Start_Timestamp
+        dur = {k: (float(g.ns.sum()), int(len(g))) for k, g in t.groupby("k")}
+        shutil.copy(glob.glob(os.path.join(src, "opt_trace", "*kernel_stats.csv"))[0], os.path.join(dst, tag + "_optim_kernel_stats.csv"))
+    lines += ["## Optimiser and joint-inference kernels (`bench.py --pmc-child optim`: maximize! of all 2000 sources with the "
+              "lock-step driver, three 80-target layers through the fused launch, the joint schedule as one dataflow launch; "
+              "counters SUMMED over the kernel's dispatches, separate passes)", "",
+              "| kernel | dispatches | total ms (kernel-trace) | VALU issue = ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024) | "
+              "resident waves / SIMD | WAIT_INST_ANY / WAVE_CYCLES | WAIT_ANY / WAVE_CYCLES | FETCH MB | WRITE MB | "
+              "LDS bank-conflict cycles / LDS active cycles |", "|---|---|---|---|---|---|---|---|---|---|"]
+    for k in sorted(opt_sq):
+        if not (k.startswith("optim_") or k.startswith("pixel_kernel<2, double") or k.startswith("lift_kernel")):
+            continue
+        c, l = opt_sq[k], opt_lds.get(k, {})
+        simd = c.get("GRBM_GUI_ACTIVE", 0) / 8.0 * 1024.0
+        wc = max(c.get("SQ_WAVE_CYCLES", 0), 1.0)
+        wc2 = max(l.get("SQ_WAVE_CYCLES", wc), 1.0)
+        row = {"dispatches": c.get("dispatches"), "total_ms": dur.get(k, (float("nan"), 0))[0] / 1e6,
+               "valu_issue": c.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / max(simd, 1.0),
+               "waves_per_simd": c.get("SQ_WAVE_CYCLES", 0) * 4.0 / max(simd, 1.0),
+               "wait_inst_any": c.get("SQ_WAIT_INST_ANY", 0) / wc,
+               "wait_any": (l.get("SQ_WAIT_ANY", float("nan")) / wc) if l else float("nan"),
+               "fetch_mb": opt_f.get(k, {}).get("FETCH_SIZE", float("nan")) * 1024 / 1e6,
+               "write_mb": opt_w.get(k, {}).get("WRITE_SIZE", float("nan")) * 1024 / 1e6,
+               "lds_conflict": (l.get("SQ_LDS_BANK_CONFLICT", 0) / max(l.get("SQ_LDS_IDX_ACTIVE", 0), 1.0)) if l else float("nan")}
+        optim[k] = row
+        lines.append("| %s | %s | %.2f | %.3f | %.2f | %.3f | %.3f | %.1f | %.1f | %.3f |"
+                     % (k, row["dispatches"], row["total_ms"], row["valu_issue"], row["waves_per_simd"], row["wait_inst_any"],
+                        row["wait_any"], row["fetch_mb"], row["write_mb"], row["lds_conflict"]))
+    lines += ["", "(persistent launches: GRBM_GUI_ACTIVE covers the whole launch, so `VALU issue` is the fraction of the CHIP's "
+              "issue slots the launch used -- a latency-bound dataflow fills few of them by design; scratch traffic shows up in "
+              "FETCH / WRITE.)", ""]
+    json.dump(optim, open(os.path.join(dst, tag + "_optim_pmc.json"), "w"), indent=1)
 open(os.path.join(dst, tag + "_pmc_summary.md"), "w").write("\n".join(lines))
 px = find(traffic, "pixel_kernel<2, double")
 rs = find(traffic, "record_sum_kernel")
