@@ -383,8 +383,12 @@ def main():
     # ---- dominant-kernel duration: HIP events recorded by the library on the launch stream, averaged ----
     ctx.enable_timing(True)
     kms = []
+    blk0 = sweep.blocks[0].data_ptr()
     for _ in range(min(20, max(3, args.steps))):
-        sweep.step(d_vp.data_ptr())
+        if sweep.n > 0:
+            ctx.eval_batch_device(d_vp.data_ptr(), sweep.n, sweep.d_tg.data_ptr(), flags, blk0, blk0 + 8 * sweep.width,
+                                  sweep.d_h.data_ptr() if sweep.d_h is not None else 0, sweep.d_cnt.data_ptr(),
+                                  sweep.d_st.data_ptr(), sweep.compute_stream.cuda_stream)
         sweep.wait()
         kms.append(ctx.last_kernel_ms())
     ctx.enable_timing(False)
@@ -395,7 +399,6 @@ def main():
     # device synchronisations) -- what separates load imbalance / small-shard latency from the cost of the exchange
     sweep_only_ms = None
     if use_dist and world > 1:
-        blk0 = sweep.blocks[0].data_ptr()
         cs = sweep.compute_stream.cuda_stream
 
         def shard_only():
@@ -722,34 +725,26 @@ def secondary_figures(ctx, fld, targets, args, costs):
                           "failed": len(failed), "layer_by_layer_seconds": dt_layered,
                           "c_call_seconds": dt_jcall, "elbo_evaluations": int(jevals.sum()),
                           "evals_per_sec": float(jevals.sum()) / dt_jcall}
-    # rank 0's cost-balanced shard of THIS field for N ranks, swept on this GPU (device-pointer API, HIP events)
+    # rank 0's cost-balanced shard of THIS field for N ranks, swept on this GPU by the driver the ranks run
+    # (parallel.DeviceShardedSweep, no gather)
+    from celeste_jl_amd.parallel import DeviceShardedSweep
     dev = torch.device("cuda", ctx.device)
     d_vp = torch.tensor(fld.vp, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream(dev)
     proj = {}
     for world in (1, 2, 4, 8):
-        mine = np.asarray(shard_targets(costs, world)[0], dtype=np.int32)
-        n = int(mine.size)
-        d_tg = torch.tensor(mine, device=dev)
-        blk = torch.zeros(n * 45, dtype=torch.float64, device=dev)
-        d_h = torch.zeros(n, 44, 44, dtype=torch.float64, device=dev)
-        d_cnt = torch.zeros(n, 2, dtype=torch.int64, device=dev)
-        d_st = torch.zeros(n, dtype=torch.int32, device=dev)
-
-        def sweep():
-            ctx.eval_batch_device(d_vp.data_ptr(), n, d_tg.data_ptr(), FLAGS_ALL, blk.data_ptr(), blk.data_ptr() + 8 * n,
-                                  d_h.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), stream.cuda_stream)
+        sw = DeviceShardedSweep(ctx, targets, costs, 0, 1, FLAGS_ALL, shards=[shard_targets(costs, world)[0]])
         for _ in range(3):
-            sweep()
+            sw.step(d_vp.data_ptr())
         torch.cuda.synchronize(dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         K = 20
         e0.record(stream)
         for _ in range(K):
-            sweep()
+            sw.step(d_vp.data_ptr())
         e1.record(stream)
         torch.cuda.synchronize(dev)
-        proj[str(world)] = {"targets_rank0": n, "ms_per_sweep": e0.elapsed_time(e1) / K}
+        proj[str(world)] = {"targets_rank0": sw.n, "ms_per_sweep": e0.elapsed_time(e1) / K}
     for world in (2, 4, 8):
         proj[str(world)]["compute_bound_efficiency"] = proj["1"]["ms_per_sweep"] / (world * proj[str(world)]["ms_per_sweep"])
     out["shard_projection"] = dict(proj, note="rank 0's shard of this field for N ranks, swept on ONE GPU: the strong-scaling "

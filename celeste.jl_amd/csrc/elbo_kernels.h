@@ -1055,6 +1055,15 @@ __device__ __forceinline__ void lds_issue_comp(LdsComp &r, unsigned addr, unsign
                  "ds_read_b128 %3, %6\n\tds_read_b128 %4, %6 offset:16"
                  : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d), "=&v"(r.e) : "v"(addr), "v"(addrx) : "memory");
 }
+// the same with the component's position inside its run of prototypes as immediate offsets (the loop over a run fully
+// unrolled): no per-component address arithmetic, no v_mov of a scalar address into a VGPR
+template <int OFF, int OFFX>
+__device__ __forceinline__ void lds_issue_comp_imm(LdsComp &r, unsigned addr, unsigned addrx) {
+    asm volatile("ds_read_b128 %0, %5 offset:%7\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %5 offset:%9\n\t"
+                 "ds_read_b128 %3, %6 offset:%10\n\tds_read_b128 %4, %6 offset:%11"
+                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d), "=&v"(r.e) : "v"(addr), "v"(addrx),
+                   "i"(OFF), "i"(OFF + 16), "i"(OFF + 32), "i"(OFFX), "i"(OFFX + 16) : "memory");
+}
 __device__ __forceinline__ void lds_wait_comp(LdsComp &r) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e));
 }
@@ -1072,6 +1081,16 @@ __device__ __forceinline__ void comp_extra(const Comp &k, double *__restrict__ x
 #ifndef PIXEL_SCHED_BARRIER
 #define PIXEL_SCHED_BARRIER 1
 #endif
+// PX_HALF_D: the quadratic form as hd1 u + hd2 v with hd = -d / 2 formed once per run of prototypes (one multiply per
+// component less, same bits: a factor 1/2 commutes with rounding).  PX_IMM_OFF: the runs of 8 / 6 prototypes fully unrolled,
+// records read at immediate offsets from the run's base (two v_mov and the scalar address arithmetic per component less).
+// Together 138 -> 132 VALU per two components, 0.543 -> 0.531 ms on the bench field.
+#ifndef PX_HALF_D
+#define PX_HALF_D 1
+#endif
+#ifndef PX_IMM_OFF
+#define PX_IMM_OFF 1
+#endif
 
 template <int MODE, typename R>
 __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int nc, R dx, R dy, R dev, const double *etab,
@@ -1084,6 +1103,8 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
         // 18 accumulations per component instead of 24.
         R U0[6] = {0, 0, 0, 0, 0, 0}, U1[6] = {0, 0, 0, 0, 0, 0};
         R S2a = 0, S2b = 0, S2c = 0, S3a = 0, S3b = 0, S3c = 0, S3d = 0, S4a = 0, S4b = 0, S4c = 0, S4d = 0, S4e = 0;
+        R hd1 = 0, hd2 = 0;   // -d / 2 of the current run of prototypes (PX_HALF_D)
+        (void)hd1; (void)hd2;
         auto body_regs = [&](R p11, R p12, R p22, R w0, R wd, R nu, R m2p12, R m3p11, R m3p12, R m3p22, R (&U)[6], R d1, R d2,
                              auto &&after_exp_issue) {
             struct { R p11, p12, p22, w0, wd, nu; } k = {p11, p12, p22, w0, wd, nu};
@@ -1093,11 +1114,18 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             R xr, tj = 0, pe = 0;
             int ni = 0;
             if constexpr (sizeof(R) == 8) {
-                const double x = -0.5 * (d1 * u + d2 * v);
+#if PX_HALF_D
+                double x = __builtin_fma(hd1, u, hd2 * v);        // hd = -d / 2, formed once per run of prototypes
+#else
+                double x = -0.5 * (d1 * u + d2 * v);
+#endif
+                // (v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64 issue FASTER than v_fma_f64 on this chip -- 4.6 / 4.7 / 5.1 against
+                // 5.7 cycles per wave instruction, tools/fp64_rate_probe.hip -- so the magic-number rounding and exponent
+                // arithmetic that replace them with fp64 adds and 32-bit integer operations lost 2 %: measured, removed)
                 const double n = rint(x * EXP_INV_STEP);
+                ni = (int)n;
                 double r = __builtin_fma(n, -EXP_STEP_HI, x);
                 xr = __builtin_fma(n, EXP_STEP_LO, r);
-                ni = (int)n;
                 tj = etab[ni & (EXP_T - 1)];
             } else xr = (R)-0.5 * (d1 * u + d2 * v);
             after_exp_issue();
@@ -1153,24 +1181,60 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
                     lds_issue_comp(nxt, base + 64u * cn, basex + (unsigned)(COMPX * 8) * cn);
                 });
             };
+#if PX_IMM_OFF
+            // runs of 8 / 6 prototypes fully unrolled: component j of a run is read at (run base) + 64 j, an immediate; the
+            // request that follows a run's last component lands on the next run's first record (or, after the very last
+            // run, on the 96 bytes behind the tables -- inside the workgroup's LDS, never used)
+            auto half_imm = [&](LdsComp &k, LdsComp &nxt, auto JN, unsigned vb, unsigned vbx, R (&U)[6], R d1, R d2) {
+                constexpr int jn = decltype(JN)::value;
+                lds_wait_comp(k);
+                body_regs(k.a.x, k.a.y, k.b.x, k.b.y, k.c.x, k.c.y, k.d.x, k.d.y, k.e.x, k.e.y, U, d1, d2, [&]() {
+                    lds_issue_comp_imm<64 * jn, COMPX * 8 * jn>(nxt, vb, vbx);
+                });
+            };
+#define IC(n) std::integral_constant<int, n>()
             for (int c0 = 0; c0 < n_dev; c0 += 8) {
                 const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+                hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
+                const unsigned vb = base + 64u * (unsigned)c0, vbx = basex + (unsigned)(COMPX * 8) * (unsigned)c0;
+                half_imm(ra, rb, IC(1), vb, vbx, U0, d1, d2); half_imm(rb, ra, IC(2), vb, vbx, U0, d1, d2);
+                half_imm(ra, rb, IC(3), vb, vbx, U0, d1, d2); half_imm(rb, ra, IC(4), vb, vbx, U0, d1, d2);
+                half_imm(ra, rb, IC(5), vb, vbx, U0, d1, d2); half_imm(rb, ra, IC(6), vb, vbx, U0, d1, d2);
+                half_imm(ra, rb, IC(7), vb, vbx, U0, d1, d2); half_imm(rb, ra, IC(8), vb, vbx, U0, d1, d2);
+            }
+            for (int c0 = n_dev; c0 < nc; c0 += 6) {
+                const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+                hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
+                const unsigned vb = base + 64u * (unsigned)c0, vbx = basex + (unsigned)(COMPX * 8) * (unsigned)c0;
+                half_imm(ra, rb, IC(1), vb, vbx, U1, d1, d2); half_imm(rb, ra, IC(2), vb, vbx, U1, d1, d2);
+                half_imm(ra, rb, IC(3), vb, vbx, U1, d1, d2); half_imm(rb, ra, IC(4), vb, vbx, U1, d1, d2);
+                half_imm(ra, rb, IC(5), vb, vbx, U1, d1, d2); half_imm(rb, ra, IC(6), vb, vbx, U1, d1, d2);
+            }
+#undef IC
+#else
+            for (int c0 = 0; c0 < n_dev; c0 += 8) {
+                const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+                hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
                 for (int c = c0; c < c0 + 8; c += 2) { half(ra, rb, c + 1, U0, d1, d2); half(rb, ra, c + 2, U0, d1, d2); }
             }
             for (int c0 = n_dev; c0 < nc; c0 += 6) {
                 const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+                hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
                 for (int c = c0; c < c0 + 6; c += 2) { half(ra, rb, c + 1, U1, d1, d2); half(rb, ra, c + 2, U1, d1, d2); }
             }
+#endif
             lds_wait_comp(ra);   // the last (unused) request must land before its registers are reused
         } else
 #endif
         {
         for (int c0 = 0; c0 < n_dev; c0 += 8) {
             const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+            hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
             for (int c = c0; c < c0 + 8; ++c) body(c, U0, d1, d2);
         }
         for (int c0 = n_dev; c0 < nc; c0 += 6) {
             const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+            hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
             for (int c = c0; c < c0 + 6; ++c) body(c, U1, d1, d2);
         }
         }
@@ -1610,7 +1674,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     // (the fp64 copy is what the value-only mode and the fp64 loop read: the single-precision instantiations with
     // derivatives do not keep it -- 3.5 KB of LDS less per workgroup, which is what lets a third wavefront per SIMD in)
     constexpr bool keep_tc = sizeof(R) == 8 || MODE == 0;
-    __shared__ Comp tc[keep_tc ? 14 * CEL_MAXK : 1];
+    __shared__ Comp tc[keep_tc ? 14 * CEL_MAXK + 1 : 1];   // (+ 1: the unrolled component loop requests one record past the last)
     __shared__ float tcr_f[sizeof(R) == 4 ? PKSLOTS * 14 * CEL_MAXK : 1];   // PKSLOTS slots of two floats per pair of components
     {
         const double *src = reinterpret_cast<const double *>(comps + (size_t)v * NC);
@@ -1634,7 +1698,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
         etab[lane] = tabv;
         __syncthreads();
     }
-    __shared__ double tcx[(MODE == 2 || MODE == 3) && sizeof(R) == 8 ? COMPX * 14 * CEL_MAXK : 1];
+    __shared__ double tcx[(MODE == 2 || MODE == 3) && sizeof(R) == 8 ? COMPX * (14 * CEL_MAXK + 1) : 1];
     if constexpr ((MODE == 2 || MODE == 3) && sizeof(R) == 8) {
         if (lane < NC) comp_extra(tc[lane], tcx + COMPX * lane);
         __syncthreads();
