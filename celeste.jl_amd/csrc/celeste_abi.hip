@@ -697,6 +697,7 @@ static int fused_buffers(celeste_ctx_t *c, size_t n, size_t rec, hipStream_t str
     return CELESTE_OK;
 }
 
+#define VALUE_WIDE_MAX 768     // batches up to this size render the neighbours' light with four wavefronts per item
 // render_neighbors = false keeps the neighbours' pre-rendered light of an earlier call (frozen neighbours
 // during an optimisation, ParallelRun.jl:474-488)
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
@@ -805,13 +806,20 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         const unsigned setup_blocks = (unsigned)((setup_threads + WORK1_SETUP - 1) / WORK1_SETUP);
         // neighbours frozen: the targets' tables are filled by extra blocks of this launch (one launch less per iteration)
         prep_fused = !render_neighbors && !getenv("CELESTE_NO_FUSED_PREP");
-        const unsigned prep_blocks = prep_fused ? (unsigned)((n_visits + WORK1_NT / 64 - 1) / (WORK1_NT / 64)) : 0u;
+        // neighbours (re)rendered: every visit's tables by this launch as well when the context has few of them (a one-field
+        // context: 10 000 visits, 15 us of work that hides under the list builder's block) -- a small batch's chain is one
+        // launch shorter
+        const bool prep_all_here = render_neighbors && !tables_current && c->V > 0 && c->V <= WORK1_PREP_ALL_MAX &&
+                                   !getenv("CELESTE_NO_FUSED_PREP");
+        const int prep_n = prep_all_here ? (int)c->V : n_visits;
+        if (prep_all_here) prep_fused = true;
+        const unsigned prep_blocks = prep_fused ? (unsigned)((prep_n + WORK1_NT / 64 - 1) / (WORK1_NT / 64)) : 0u;
         hipLaunchKernelGGL(setup_worklist_kernel, dim3(1 + setup_blocks + prep_blocks), dim3(WORK1_NT),
                            0, stream, d_vp, geo_S, c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M,
                            c->dense ? nullptr : c->d_items, render_neighbors ? c->d_needed : nullptr, c->stamp, c->d_patches,
                            c->N, c->CH, c->chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live, prep_mark,
                            c->d_nbr_off, c->d_nbr_idx, c->d_rec_off, (int)setup_blocks, c->d_images, c->K, c->d_srcimg,
-                           c->d_comps);
+                           c->d_comps, prep_all_here ? (int)c->V : 0, c->d_vis_src);
     } else {
         hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 63) / 64)), dim3(64), 0, stream, d_vp, geo_S,
                            c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
@@ -826,7 +834,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     }
     // per-(source, image) constants: of every source when the neighbours are (re)rendered, else of the targets only
     if (render_neighbors) {
-        if (c->V > 0 && !tables_current)
+        if (c->V > 0 && !tables_current && !prep_fused)
             hipLaunchKernelGGL(prep_kernel, dim3((unsigned)c->V), dim3(64), 0, stream, d_vp, c->d_images, c->d_patches,
                                c->d_vis_src, c->d_vis_img, c->N, c->K, c->d_srcimg, c->d_comps, nullptr, c->d_vis_off, c->M,
                                (int)c->dense, nullptr, prep_mark, c->stamp);
@@ -839,14 +847,16 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     if (c->n_value_items > 0)
     {
         // (single-precision mode: the neighbours' densities in fp32 too, their moments in fp64)
-        if (flags & CELESTE_FLAG_FP32)
-            hipLaunchKernelGGL(value_kernel<float>, dim3((unsigned)c->n_value_items), dim3(64), 0, stream,
-                               c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_val_off,
-                               c->d_value_items, c->NC, c->chunk_px, c->d_val);
-        else
-            hipLaunchKernelGGL(value_kernel<double>, dim3((unsigned)c->n_value_items), dim3(64), 0, stream,
-                               c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_val_off,
-                               c->d_value_items, c->NC, c->chunk_px, c->d_val);
+        // small batches leave the chip mostly idle: an item's four 64-pixel iterations then run side by side on four
+        // wavefronts (same values; chunk_px = 256 is what the items were cut for)
+        const bool wide_items = n_targets <= VALUE_WIDE_MAX && c->chunk_px == 256 && !getenv("CELESTE_NO_WIDE_VALUE");
+#define LAUNCH_VALUE(R, WAVES)                                                                                              \
+        hipLaunchKernelGGL((value_kernel<R, WAVES>), dim3((unsigned)c->n_value_items), dim3(64 * WAVES), 0, stream,       \
+                           c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_val_off,          \
+                           c->d_value_items, c->NC, c->chunk_px, c->d_val)
+        if (flags & CELESTE_FLAG_FP32) { if (wide_items) LAUNCH_VALUE(float, 4); else LAUNCH_VALUE(float, 1); }
+        else { if (wide_items) LAUNCH_VALUE(double, 4); else LAUNCH_VALUE(double, 1); }
+#undef LAUNCH_VALUE
     }
     }
     if (render_only) { HIP_TRY(hipGetLastError()); return CELESTE_OK; }

@@ -665,6 +665,7 @@ work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPat
 #define WORK1_NT 1024
 #define WORK1_SETUP 64        // setup_thread items per block of the fused launch (blocks 1 ..)
 #define WORK1_MAX_VISITS 4096
+#define WORK1_PREP_ALL_MAX 16384   // visits of a context whose tables the fused launch fills wholesale (neighbours rendered)
 __global__ void __launch_bounds__(WORK1_NT)
 setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo, const int32_t *__restrict__ targets,
                       int n_targets, const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int M,
@@ -674,11 +675,17 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
                       int32_t *__restrict__ prep_mark, const int64_t *__restrict__ nbr_off,
                       const int32_t *__restrict__ nbr_idx, int32_t *__restrict__ rec_off,
                       int setup_blocks, const DevImage *__restrict__ images, int K, SrcImg *__restrict__ srcimg,
-                      Comp *__restrict__ comps) {
+                      Comp *__restrict__ comps, int prep_all_V, const int32_t *__restrict__ vis_src) {
     if ((int)blockIdx.x > setup_blocks) {
+        const int k = ((int)blockIdx.x - setup_blocks - 1) * (WORK1_NT / 64) + (int)(threadIdx.x >> 6);
+        if (prep_all_V > 0) {
+            // neighbours about to be rendered, a context of few visits: the tables of EVERY visit are filled by this
+            // launch (prep_kernel's all-visits mode without a launch of its own, and without waiting for the marks)
+            if (k < prep_all_V) prep_visit(threadIdx.x & 63, vis_src[k], vis_img[k], k, vp, images, patches, K, srcimg, comps);
+            return;
+        }
         // frozen neighbours (an optimiser iteration): the tables of the targets' own visits are filled by this launch
         // too, one wavefront per candidate visit -- prep_kernel's targets mode without a launch of its own
-        const int k = ((int)blockIdx.x - setup_blocks - 1) * (WORK1_NT / 64) + (int)(threadIdx.x >> 6);
         const int ti = k / M, j = k - ti * M;
         if (ti >= n_targets || (live && ti >= *live)) return;
         const int s = targets[ti];
@@ -795,8 +802,10 @@ __device__ __forceinline__ void value_pixels(int lane, const DevPatch &P, const 
 #ifdef VALUE_TIMING   // debug builds (tools/variants): shader clocks per section of the value kernel
 __device__ unsigned long long g_value_clk[8];
 #endif
-template <typename R>
-__global__ void __launch_bounds__(64)
+// WAVES = 4 (small, latency-bound batches): the item's up to four 64-pixel iterations on four wavefronts of one workgroup
+// instead of one after the other -- same values (every pixel is computed on its own), a quarter of the item's latency.
+template <typename R, int WAVES = 1>
+__global__ void __launch_bounds__(64 * WAVES)
 value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
              const int32_t *__restrict__ is_target, int32_t stamp, const int64_t *__restrict__ val_off,
@@ -831,7 +840,7 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
     {
         const double *src = reinterpret_cast<const double *>(comps + (size_t)sn * NC);
         double *dst = reinterpret_cast<double *>(tc);
-        for (int i = threadIdx.x; i < NC * 8; i += 64) dst[i] = src[i];
+        for (int i = threadIdx.x; i < NC * 8; i += 64 * WAVES) dst[i] = src[i];
         __syncthreads();
     }
     __shared__ float tcf[sizeof(R) == 4 ? 6 * 14 * CEL_MAXK : 2];
@@ -844,7 +853,12 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
         __syncthreads();
     }
     VT(1);
-    value_pixels<false, R>(threadIdx.x, P, si, tc, NC, coefs, etab, h_lo, w_lo, RH, p0, p1, val + val_off[sn], tcf);
+    if constexpr (WAVES == 1)
+        value_pixels<false, R>(threadIdx.x, P, si, tc, NC, coefs, etab, h_lo, w_lo, RH, p0, p1, val + val_off[sn], tcf);
+    else {
+        const int q0 = p0 + 64 * (int)(threadIdx.x >> 6);
+        if (q0 < p1) value_pixels<false, R>(threadIdx.x & 63, P, si, tc, NC, coefs, etab, h_lo, w_lo, RH, q0, min(p1, q0 + 64), val + val_off[sn], tcf);
+    }
     VT(2);
 #ifdef VALUE_TIMING
     if (threadIdx.x == 0) {
@@ -1002,6 +1016,48 @@ __device__ __forceinline__ void accum_entries(const TT &T, double *__restrict__ 
     if constexpr (E + 1 < ACC_N) accum_entries<MODE, E + 1>(T, slot);
 }
 
+// Single-precision mode: FOUR consecutive entries per LDS add.  The slot of a lane is lane & 15, so the lanes l, l + 16,
+// l + 32, l + 48 of one ds_add_f64 meet in one address and the LDS unit serialises them; at the fp32 kernel's pace (an
+// iteration is half as long as the fp64 kernel's) the 65 four-way-conflicting adds per iteration are what its wavefronts
+// queue on.  Here the four rows of 16 lanes are folded in registers first -- v_permlane16_swap / v_permlane32_swap put the
+// partial sums of entries E .. E + 3 into rows 0 .. 3 of ONE register (three swaps and three fp32 adds for four entries) --
+// and row r of the wavefront adds its entry E + r: 17 conflict-free adds instead of 65 four-way ones.  The sum of a slot's
+// four lanes is formed in fp32 in a fixed order, (l + l16) + (l32 + l48): reproducible, inside the mode's 1e-4 by orders
+// of magnitude.  Entries a mode does not produce, and the identically zero ones, enter as 0.
+template <int MODE, int E, class TT>
+__device__ __forceinline__ float entry_or_zero(const TT &T) {
+    constexpr bool hess_only = E > ZV && E < ACC_CNT;
+    if constexpr (E >= ACC_N || (MODE == 1 && hess_only) || entry_is_zero<E < ACC_N ? E : 0>()) return 0.0f;
+    else return (float)record_entry<E>(T);
+}
+template <int MODE, int E>
+constexpr bool group_is_empty() {    // none of E .. E + 3 is produced
+    bool any = false;
+    for (int k = 0; k < 4; ++k) {
+        const int e = E + k;
+        if (e >= ACC_N) continue;
+        const bool hess_only = e > ZV && e < ACC_CNT;
+        if (MODE == 1 && hess_only) continue;
+        any = true;
+    }
+    return !any;
+}
+__device__ __forceinline__ float fold_rows_pair16(float a, float b) {   // rows (a01, b01, a23, b23)
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int MODE, int E, class TT>
+__device__ __forceinline__ void accum_entries_rows(const TT &T, double *__restrict__ slot_row) {
+    if constexpr (!group_is_empty<MODE, E>()) {
+        const float s01 = fold_rows_pair16(entry_or_zero<MODE, E>(T), entry_or_zero<MODE, E + 1>(T));
+        const float s23 = fold_rows_pair16(entry_or_zero<MODE, E + 2>(T), entry_or_zero<MODE, E + 3>(T));
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+        const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // row r: entry E + r, slot lane & 15
+        __hip_atomic_fetch_add(slot_row + ACC_SLOTS * E, (double)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if constexpr (E + 4 < ACC_N) accum_entries_rows<MODE, E + 4>(T, slot_row);
+}
+
 // the same in two steps: the values (pinned in registers by an empty asm, so that they are formed where this is called),
 // then the adds
 template <int MODE, int E, class TT>
@@ -1090,6 +1146,9 @@ __device__ __forceinline__ void comp_extra(const Comp &k, double *__restrict__ x
 #endif
 #ifndef PX_IMM_OFF
 #define PX_IMM_OFF 1
+#endif
+#ifndef F32_ROW_FOLD
+#define F32_ROW_FOLD 1
 #endif
 
 template <int MODE, typename R>
@@ -1612,6 +1671,12 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
             add_entries<MODE, 0>(ent, slot_s);
         } else {
             gate();
+#if F32_ROW_FOLD
+            if constexpr (sizeof(S) == 4) {
+                static_assert(ACC_N % 4 == 0, "entries are added four at a time");
+                accum_entries_rows<MODE, 0>(T, slot_s + ACC_SLOTS * (lane >> 4));
+            } else
+#endif
             accum_entries<MODE, 0>(T, slot_s);
         }
     }
