@@ -17,7 +17,7 @@ dev = torch.device("cuda", 0)
 d_vp = torch.tensor(fld.vp, dtype=torch.float64, device=dev)
 P = 44
 t1 = None
-for world in (1, 2, 4, 8, 16):
+for world in [int(w) for w in os.environ.get('WORLDS', '1,2,4,8,16').split(',')]:
     shards = shard_targets(costs, world)
     mine = np.asarray(shards[0], dtype=np.int32)
     n = mine.size
