@@ -38,6 +38,11 @@ FLAGS_ALL = 1 | 2 | 4
 HBM_PEAK_GBS = 8000.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X FP64 vector (non-matrix) peak
 FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X FP32 vector peak (packed)
+# What a stream of independent FMAs SUSTAINS on this chip (tools/fp64_rate_probe.hip under rocprofv3 --pmc GRBM_GUI_ACTIVE,
+# profiles/r04_fp64_issue_rates.txt): v_fma_f64 issues one wave-instruction per 4.94 cycles per SIMD at 2.08 GHz, v_pk_fma_f32
+# one per 4.85 cycles at 2.32 GHz -- 64 lanes x 2 (x 2 packed) flop x 1024 SIMDs
+FP64_SUSTAINED_FMA_TFLOPS = 64 * 2 / 4.94 * 1024 * 2.083e9 / 1e12      # 55.3
+FP32_SUSTAINED_FMA_TFLOPS = 64 * 4 / 4.85 * 1024 * 2.317e9 / 1e12      # 125.2
 
 
 def profile_facts():
@@ -576,7 +581,12 @@ def main():
             # executed flops: the compiled ISA's count per visit x the (pixel, active source) pairs the kernel counted --
             # not the patches' areas, which include the last-column pixels that skip the component loop
             fl = fpp * pixel_visits_local / (kms[1] * 1e-3) / 1e12
+            sus = FP32_SUSTAINED_FMA_TFLOPS if args.dtype == "f32" else FP64_SUSTAINED_FMA_TFLOPS
             out["roofline"]["valu"] = {"achieved": fl, "peak": peak_fl, "unit": "TFLOP/s", "frac": fl / peak_fl,
+                                       "sustained_fma_peak": sus, "frac_of_sustained": fl / sus,
+                                       "sustained_source": "profiles/r04_fp64_issue_rates.txt: independent FMAs issue every "
+                                                           "4.9 cycles per SIMD at the clock the chip holds under them, "
+                                                           "0.70 (fp64) / 0.80 (packed fp32) of the nominal peak",
                                        "flops_per_pixel_visit": fpp, "pixel_visits": pixel_visits_local, "dtype": args.dtype,
                                        "instruction_mix": facts.get("instruction_mix_f32" if args.dtype == "f32" else "instruction_mix")}
             if args.dtype == "f64":
