@@ -666,6 +666,7 @@ work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPat
 #define WORK1_SETUP 64        // setup_thread items per block of the fused launch (blocks 1 ..)
 #define WORK1_MAX_VISITS 4096
 #define WORK1_PREP_ALL_MAX 16384   // visits of a context whose tables the fused launch fills wholesale (neighbours rendered)
+#define WORK1_PREP_ALL_MIN_TARGETS 64
 __global__ void __launch_bounds__(WORK1_NT)
 setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo, const int32_t *__restrict__ targets,
                       int n_targets, const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int M,
