@@ -122,6 +122,28 @@ function elbo(ea::ElboArgs, vp::VariationalParams{Float64}, ctx::MI355XContext,
 end
 
 
+# ---- no call-site change at all: the reference's own signature, dispatched on Float64 --------------------------------
+# `bound_result = elbo(ea, vp, get_elbo_vars(), cfg.bvn_bundle)` (ElboMaximize.jl:166) stays as it is: a context registered
+# for `ea` (register_context!, where process_source builds the ElboArgs, ParallelRun.jl:482) makes this more specific method
+# -- vp::VariationalParams{Float64} against the reference's VariationalParams{T} -- evaluate on the device; an ElboArgs
+# without a context, and every non-Float64 element type (the ForwardDiff.Dual calls of test/test_elbo.jl:232-237), falls
+# through to the reference's method (elbo_objective.jl:482-492) via `invoke`.
+const MI355X_CONTEXTS = ObjectIdDict()                   # ElboArgs => MI355XContext (identity keyed; Julia 0.6: ObjectIdDict)
+register_context!(ea::ElboArgs, imgs::MI355XImages) = (MI355X_CONTEXTS[ea] = MI355XContext(ea, imgs))
+release_context!(ea::ElboArgs) = delete!(MI355X_CONTEXTS, ea)      # the context's finalizer frees the device tables
+
+function elbo(ea::ElboArgs, vp::VariationalParams{Float64}, elbo_vars::ElboIntermediateVariables{Float64},
+              bvn_bundle::BvnBundle{Float64})
+    ctx = get(MI355X_CONTEXTS, ea, nothing)
+    if ctx === nothing || ea.Sa != 1 || ea.active_sources != [1]
+        return invoke(elbo, Tuple{ElboArgs, VariationalParams, ElboIntermediateVariables, BvnBundle}, ea, vp, elbo_vars, bvn_bundle)
+    end
+    elbo(ea, vp, ctx::MI355XContext, elbo_vars)          # the method above; `bvn_bundle` is not needed on the device
+end
+elbo(ea::ElboArgs, vp::VariationalParams{Float64}, elbo_vars::ElboIntermediateVariables{Float64}) =
+    elbo(ea, vp, elbo_vars, BvnBundle{Float64}(ea.psf_K, ea.S))
+
+
 # ---- whole-box entry points (one context over every catalogued source of the box; see INTEGRATION.md) ----------
 
 """Page-locked output buffers (celeste_host_alloc): the library DMAs results straight into them, overlapped with the
