@@ -341,6 +341,36 @@ __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
     return ldexp(exp_poly(r) * tj, ni >> EXP_TAB_LOG2);
 }
 
+// log(x) for the per-pixel term (x = E_G > 0, normal): x = 2^e m with m in [sqrt(1/2), sqrt 2), s = (m - 1) / (m + 1),
+// log m = 2 s (1 + s^2/3 + s^4/5 + ... + s^20/21) (truncation 1e-17 relative), e ln2 in a high part whose product with e is
+// exact and a low part.  <= 2 ulp against a 40-digit reference over 1e-5 .. 1e6 and around 1 (tests/test_oracle_micro.py
+// holds the kernel to the oracle's libm log at 1e-12 on the pixel term); 32 instructions where the library's is ~80.
+// Non-positive, subnormal or NaN arguments (never reached on valid inputs) give NaN, +inf gives +inf.
+__device__ __forceinline__ double rcp_pos(double b) {      // 1 / b, b > 0 normal: hardware estimate + two Newton steps (<= 1 ulp)
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+}
+__device__ __forceinline__ double log_pos(double x) {
+    const bool ok = x > 2.2250738585072014e-308 && x < INFINITY;   // else NaN (x <= 0, subnormal, NaN) or +inf: no library path
+    const double bad = x == INFINITY ? x : __builtin_nan("");
+    double m = __builtin_amdgcn_frexp_mant(x);             // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.7071067811865476;
+    m = low ? m + m : m; e = low ? e - 1 : e;
+    const double a = m - 1.0, b = m + 1.0, r = rcp_pos(b);
+    double sq = a * r;
+    sq = __builtin_fma(__builtin_fma(-b, sq, a), r, sq);   // (m - 1) / (m + 1) to half an ulp
+    const double z = sq * sq;
+    double p = 1.0 / 21.0;
+    p = __builtin_fma(p, z, 1.0 / 19.0); p = __builtin_fma(p, z, 1.0 / 17.0); p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0); p = __builtin_fma(p, z, 1.0 / 11.0); p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0); p = __builtin_fma(p, z, 1.0 / 5.0); p = __builtin_fma(p, z, 1.0 / 3.0);
+    const double t = sq * z * p, ef = (double)e;
+    const double lg = __builtin_fma(ef, 0x1.62e42fee00000p-1, (sq + sq) + __builtin_fma(ef, 0x1.a39ef35793c76p-33, t + t));
+    return ok ? lg : bad;
+}
+
 // star_light_density! value only (fsm_util.jl:221-237): softpluslikeinv(itp[h - m1 + 26, w - m2 + 26])
 __device__ inline double star_value(const double *__restrict__ coef, double xh, double xw) {
     int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
@@ -1614,7 +1644,8 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
             }
             // softpluslikeinv and its derivatives; not C2 at 0, branch exactly (fsm_util.jl:222)
             S gv, gp, gpp;
-            if (y < 0) { gv = (S)1e-3 * exp_s(y); gp = gv; gpp = gv; }
+            // (fp64: the table-driven exponential of the component loop -- y <= 0 here -- instead of the library's)
+            if (y < 0) { if constexpr (sizeof(S) == 8) gv = (S)1e-3 * (S)exp_nonpos((double)y, etab); else gv = (S)1e-3 * exp_s(y); gp = gv; gpp = gv; }
             else { gv = (S)1e-3 * (y + (S)1.0); gp = (S)1e-3; gpp = (S)0.0; }
             T.f0 = gv;
             const S ym1 = -yx, ym2 = -yy;  // d(index)/dm = -1
@@ -1630,9 +1661,11 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
             const S B = q0 * (T.f0 * T.f0) + q1 * (T.f1 * T.f1);     // E_G2_s.v
             const S E = valid ? Ebar + A : (S)1.0;                   // E_G.v
             const S V = Vbar + (B - A * A);                          // var_G.v
-            const S iE = (S)1.0 / E;
+            S iE, logE;
+            if constexpr (sizeof(S) == 8) { iE = (S)rcp_pos((double)E); logE = (S)log_pos((double)E); }   // (E > 0; a non-finite E stays non-finite)
+            else { iE = (S)1.0 / E; logE = log_s(E); }
             const S iE2 = iE * iE, iE3 = iE2 * iE;
-            T.vterm = (valid && !(MULTI && dup)) ? x * (log_iota + (log_s(E) - V * ((S)0.5 * iE2))) - iota * E - lgx : (S)0.0;
+            T.vterm = (valid && !(MULTI && dup)) ? x * (log_iota + (logE - V * ((S)0.5 * iE2))) - iota * E - lgx : (S)0.0;
             T.cnt_act = own ? (S)1.0 : (S)0.0;
             T.cnt_inact = (S)n_inact;
             // derivative weights are zero unless the active source covers the pixel, which zeroes every
