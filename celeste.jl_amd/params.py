@@ -78,9 +78,18 @@ def generic_init_source(init_pos) -> np.ndarray:
     return ret
 
 
+def _jmax(a: float, b: float) -> float:
+    """Julia's max: NaN if either argument is (Python's max(0.1, nan) is 0.1, np.maximum agrees with Julia)"""
+    return float(np.maximum(a, b))
+
+
+def _jmin(a: float, b: float) -> float:
+    return float(np.minimum(a, b))
+
+
 def _get_color(c2: float, c1: float) -> float:
     if c2 > 0 and c1 > 0:
-        return min(max(math.log(c2 / c1), -9.0), 9.0)
+        return _jmin(_jmax(math.log(c2 / c1), -9.0), 9.0)
     if c2 > 0 and c1 <= 0:
         return 3.0
     if c2 <= 0 and c1 > 0:
@@ -93,14 +102,14 @@ def catalog_init_source(ce: CatalogEntry, max_gal_radius_px=math.inf) -> np.ndar
     ret = generic_init_source(ce.pos)
     ret[ids.is_star[0]] = 0.8 if ce.is_star else 0.2
     ret[ids.is_star[1]] = 0.2 if ce.is_star else 0.8
-    ret[ids.flux_loc[0]] = math.log(max(0.1, ce.star_fluxes[2]))
-    ret[ids.flux_loc[1]] = math.log(max(0.1, ce.gal_fluxes[2]))
+    ret[ids.flux_loc[0]] = math.log(_jmax(0.1, ce.star_fluxes[2]))
+    ret[ids.flux_loc[1]] = math.log(_jmax(0.1, ce.gal_fluxes[2]))
     ret[ids.color_mean[:, 0]] = [_get_color(ce.star_fluxes[c + 1], ce.star_fluxes[c]) for c in range(4)]
     ret[ids.color_mean[:, 1]] = [_get_color(ce.gal_fluxes[c + 1], ce.gal_fluxes[c]) for c in range(4)]
-    ret[ids.gal_frac_dev] = min(max(ce.gal_frac_dev, 0.015), 0.985)
-    ret[ids.gal_axis_ratio] = 0.8 if ce.is_star else min(max(ce.gal_axis_ratio, 0.015), 0.985)
+    ret[ids.gal_frac_dev] = _jmin(_jmax(ce.gal_frac_dev, 0.015), 0.985)
+    ret[ids.gal_axis_ratio] = 0.8 if ce.is_star else _jmin(_jmax(ce.gal_axis_ratio, 0.015), 0.985)
     ret[ids.gal_angle] = ce.gal_angle
-    ret[ids.gal_radius_px] = 0.2 if ce.is_star else min(max_gal_radius_px, max(ce.gal_radius_px, 0.2))
+    ret[ids.gal_radius_px] = 0.2 if ce.is_star else _jmin(max_gal_radius_px, _jmax(ce.gal_radius_px, 0.2))
     return ret
 
 

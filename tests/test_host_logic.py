@@ -383,6 +383,19 @@ def test_init_source_table_equals_the_per_entry_functions():
         ref[t] = generic_init_source(cat[t].pos)
     assert np.array_equal(ref, init_source_table(cat, tg))
     assert init_source_table([], []).shape == (0, 44)
+    # a NaN flux / shape propagates as Julia's max / min propagate it (DeterministicVI.jl:68-69: log(max(0.1, NaN)) is NaN; Python's
+    # built-in max(0.1, nan) would give 0.1), identically in both routes
+    import copy
+    bad = copy.deepcopy(cat[:4])
+    bad[0].star_fluxes = np.array(bad[0].star_fluxes, dtype=float); bad[0].star_fluxes[2] = np.nan
+    bad[1].gal_radius_px = float("nan")
+    bad[2].gal_fluxes = np.array(bad[2].gal_fluxes, dtype=float); bad[2].gal_fluxes[1] = np.nan
+    bad[1].is_star = False
+    one = np.stack([catalog_init_source(ce) for ce in bad])
+    tab = init_source_table(bad)
+    assert np.array_equal(one, tab, equal_nan=True)
+    from celeste_jl_amd.params import ids
+    assert np.isnan(one[0, ids.flux_loc[0]]) and np.isnan(one[1, ids.gal_radius_px]) and np.isfinite(one[3]).all()
 
 
 def test_bad_sky_flags_equal_the_per_entry_check():
