@@ -1134,34 +1134,36 @@ template <> __device__ __forceinline__ float fma_r<float>(float a, float b, floa
 // nu, nu^2.  (dx, dy) = pixel - m_pos.  Returns sum f; fills the S* members of T.
 // ---- explicit LDS reads of a component record (PIXEL_LDS_PINGPONG) -------------------------------------------
 typedef double dbl2 __attribute__((ext_vector_type(2)));
-struct LdsComp { dbl2 a, b, c, d, e; };   // {p11, p12} {p22, w0} {wd, nu} | {-2 p12, -3 p11} {-3 p12, -3 p22}
+struct LdsComp { dbl2 a, b, c, d, e, f; };   // {p11, p12} {p22, w0} {wd, nu} | {-2 p12, -3 p11} {-3 p12, -3 p22} {-4 p12, -2 p12^2}
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
 __device__ __forceinline__ void lds_issue_comp(LdsComp &r, unsigned addr, unsigned addrx) {
-    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
-                 "ds_read_b128 %3, %6\n\tds_read_b128 %4, %6 offset:16"
-                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d), "=&v"(r.e) : "v"(addr), "v"(addrx) : "memory");
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
+                 "ds_read_b128 %3, %7\n\tds_read_b128 %4, %7 offset:16\n\tds_read_b128 %5, %7 offset:32"
+                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d), "=&v"(r.e), "=&v"(r.f) : "v"(addr), "v"(addrx) : "memory");
 }
 // the same with the component's position inside its run of prototypes as immediate offsets (the loop over a run fully
 // unrolled): no per-component address arithmetic, no v_mov of a scalar address into a VGPR
 template <int OFF, int OFFX>
 __device__ __forceinline__ void lds_issue_comp_imm(LdsComp &r, unsigned addr, unsigned addrx) {
-    asm volatile("ds_read_b128 %0, %5 offset:%7\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %5 offset:%9\n\t"
-                 "ds_read_b128 %3, %6 offset:%10\n\tds_read_b128 %4, %6 offset:%11"
-                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d), "=&v"(r.e) : "v"(addr), "v"(addrx),
-                   "i"(OFF), "i"(OFF + 16), "i"(OFF + 32), "i"(OFFX), "i"(OFFX + 16) : "memory");
+    asm volatile("ds_read_b128 %0, %6 offset:%8\n\tds_read_b128 %1, %6 offset:%9\n\tds_read_b128 %2, %6 offset:%10\n\t"
+                 "ds_read_b128 %3, %7 offset:%11\n\tds_read_b128 %4, %7 offset:%12\n\tds_read_b128 %5, %7 offset:%13"
+                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d), "=&v"(r.e), "=&v"(r.f) : "v"(addr), "v"(addrx),
+                   "i"(OFF), "i"(OFF + 16), "i"(OFF + 32), "i"(OFFX), "i"(OFFX + 16), "i"(OFFX + 32) : "memory");
 }
 __device__ __forceinline__ void lds_wait_comp(LdsComp &r) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(r.f));
 }
 // The multiples of a component's precision matrix that the third- and fourth-order Hermite polynomials need, formed once
 // per workgroup next to the staged record (COMPX doubles per component in LDS): with them u^2 v - p11 v - 2 p12 u =
 // fma(v, ha, u * (-2 p12)) etc. are one multiply and one FMA, where -2 u, -3 ha, -3 hc, -2 hb each cost an instruction of
 // their own -- 5 of the loop's 72 VALU instructions per component.
-#define COMPX 4
+// (round 4: two more for the xxyy polynomial in the form ha hc - 4 p12 hb - 2 p12^2 -- two FMAs instead of a multiply and two)
+#define COMPX 6
 __device__ __forceinline__ void comp_extra(const Comp &k, double *__restrict__ x) {
     x[0] = -2.0 * k.p12; x[1] = -3.0 * k.p11; x[2] = -3.0 * k.p12; x[3] = -3.0 * k.p22;
+    x[4] = -4.0 * k.p12; x[5] = -2.0 * (k.p12 * k.p12);
 }
 #ifndef PIXEL_LDS_PINGPONG
 #define PIXEL_LDS_PINGPONG 1
@@ -1196,8 +1198,12 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
         R S2a = 0, S2b = 0, S2c = 0, S3a = 0, S3b = 0, S3c = 0, S3d = 0, S4a = 0, S4b = 0, S4c = 0, S4d = 0, S4e = 0;
         R hd1 = 0, hd2 = 0;   // -d / 2 of the current run of prototypes (PX_HALF_D)
         (void)hd1; (void)hd2;
-        auto body_regs = [&](R p11, R p12, R p22, R w0, R wd, R nu, R m2p12, R m3p11, R m3p12, R m3p22, R (&U)[6], R d1, R d2,
-                             auto &&after_exp_issue) {
+        // GW (a std::integral_constant<bool>): the sums of orders 2 .. 4 are accumulated with the d-weights g = wd e as well
+        // (the de Vaucouleurs loop: f = theta_0 g there, applied ONCE to the twelve sums when the loop ends -- three weight
+        // products per component instead of five)
+        auto body_regs = [&](R p11, R p12, R p22, R w0, R wd, R nu, R m2p12, R m3p11, R m3p12, R m3p22, R m4p12, R m2p12sq,
+                             R (&U)[6], R d1, R d2, auto GW, auto &&after_exp_issue) {
+            constexpr bool gw = decltype(GW)::value;
             struct { R p11, p12, p22, w0, wd, nu; } k = {p11, p12, p22, w0, wd, nu};
             const R u = k.p11 * d1 + k.p12 * d2, v = k.p12 * d1 + k.p22 * d2;
             // exp_nonpos in two halves: the table entry is requested as soon as its index is known, the Hermite
@@ -1231,7 +1237,7 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             // fourth order
             const R h4a = fma_r<R>(u, h3a, ha * m3p11);
             const R h4b = fma_r<R>(v, h3a, ha * m3p12);
-            const R h4c = fma_r<R>(u, h3c, fma_r<R>(hb, m2p12, -hc * k.p11));
+            const R h4c = fma_r<R>(ha, hc, fma_r<R>(hb, m4p12, m2p12sq));   // u^2 v^2 - p22 u^2 - p11 v^2 - 4 p12 u v + p11 p22 + 2 p12^2
             const R h4d = fma_r<R>(u, h3d, hc * m3p12);
             const R h4e = fma_r<R>(v, h3d, hc * m3p22);
             R e;
@@ -1242,7 +1248,10 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
 #endif
                 e = ldexp(pe * tj, ni >> EXP_TAB_LOG2);   // eval_bvn_pdf!
             } else e = exp_np<R>(xr, etab);
-            const R f = k.w0 * e, g = k.wd * e, fn = f * k.nu, gn = g * k.nu, fnn = fn * k.nu;
+            const R g = k.wd * e, gn = g * k.nu;
+            R f, fn, fnn;
+            if constexpr (gw) { f = g; fn = gn; fnn = gn * k.nu; }
+            else { f = k.w0 * e; fn = f * k.nu; fnn = fn * k.nu; }
             U[0] += g; U[1] = fma_r<R>(u, g, U[1]); U[2] = fma_r<R>(v, g, U[2]);
             U[3] = fma_r<R>(ha, gn, U[3]); U[4] = fma_r<R>(hb, gn, U[4]); U[5] = fma_r<R>(hc, gn, U[5]);
             S2a = fma_r<R>(ha, f, S2a); S2b = fma_r<R>(hb, f, S2b); S2c = fma_r<R>(hc, f, S2c);
@@ -1255,8 +1264,14 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
         auto body = [&](int c, R (&U)[6], R d1, R d2) {
             const CompR<R> k = tc[c];
             body_regs(k.p11, k.p12, k.p22, k.w0, k.wd, k.nu, (R)tcx[COMPX * c], (R)tcx[COMPX * c + 1], (R)tcx[COMPX * c + 2],
-                      (R)tcx[COMPX * c + 3], U, d1, d2, []() {});
+                      (R)tcx[COMPX * c + 3], (R)tcx[COMPX * c + 4], (R)tcx[COMPX * c + 5], U, d1, d2, std::false_type(), []() {});
         };
+        // the de Vaucouleurs sums of orders 2 .. 4 were accumulated d-weighted (GW): f = theta_0 g
+        auto scale_dev = [&](R th) {
+            S2a *= th; S2b *= th; S2c *= th; S3a *= th; S3b *= th; S3c *= th; S3d *= th;
+            S4a *= th; S4b *= th; S4c *= th; S4d *= th; S4e *= th;
+        };
+        (void)scale_dev;
         // runs of 8 (de Vaucouleurs) / 6 (exponential) prototypes share a PSF component, i.e. the offset xiBar_k
 #if PIXEL_LDS_PINGPONG
         if constexpr (sizeof(R) == 8) {
@@ -1267,9 +1282,9 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             const unsigned base = lds_addr(tc), basex = lds_addr(tcx);
             LdsComp ra, rb;
             lds_issue_comp(ra, base, basex);
-            auto half = [&](LdsComp &k, LdsComp &nxt, int c_next, R (&U)[6], R d1, R d2) {
+            auto half = [&](LdsComp &k, LdsComp &nxt, int c_next, R (&U)[6], R d1, R d2, auto GW) {
                 lds_wait_comp(k);
-                body_regs(k.a.x, k.a.y, k.b.x, k.b.y, k.c.x, k.c.y, k.d.x, k.d.y, k.e.x, k.e.y, U, d1, d2, [&]() {
+                body_regs(k.a.x, k.a.y, k.b.x, k.b.y, k.c.x, k.c.y, k.d.x, k.d.y, k.e.x, k.e.y, k.f.x, k.f.y, U, d1, d2, GW, [&]() {
                     const unsigned cn = (unsigned)(c_next < nc ? c_next : nc - 1);
                     lds_issue_comp(nxt, base + 64u * cn, basex + (unsigned)(COMPX * 8) * cn);
                 });
@@ -1278,10 +1293,10 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             // runs of 8 / 6 prototypes fully unrolled: component j of a run is read at (run base) + 64 j, an immediate; the
             // request that follows a run's last component lands on the next run's first record (or, after the very last
             // run, on the 96 bytes behind the tables -- inside the workgroup's LDS, never used)
-            auto half_imm = [&](LdsComp &k, LdsComp &nxt, auto JN, unsigned vb, unsigned vbx, R (&U)[6], R d1, R d2) {
+            auto half_imm = [&](LdsComp &k, LdsComp &nxt, auto JN, unsigned vb, unsigned vbx, R (&U)[6], R d1, R d2, auto GW) {
                 constexpr int jn = decltype(JN)::value;
                 lds_wait_comp(k);
-                body_regs(k.a.x, k.a.y, k.b.x, k.b.y, k.c.x, k.c.y, k.d.x, k.d.y, k.e.x, k.e.y, U, d1, d2, [&]() {
+                body_regs(k.a.x, k.a.y, k.b.x, k.b.y, k.c.x, k.c.y, k.d.x, k.d.y, k.e.x, k.e.y, k.f.x, k.f.y, U, d1, d2, GW, [&]() {
                     lds_issue_comp_imm<64 * jn, COMPX * 8 * jn>(nxt, vb, vbx);
                 });
             };
@@ -1290,30 +1305,34 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
                 const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
                 hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
                 const unsigned vb = base + 64u * (unsigned)c0, vbx = basex + (unsigned)(COMPX * 8) * (unsigned)c0;
-                half_imm(ra, rb, IC(1), vb, vbx, U0, d1, d2); half_imm(rb, ra, IC(2), vb, vbx, U0, d1, d2);
-                half_imm(ra, rb, IC(3), vb, vbx, U0, d1, d2); half_imm(rb, ra, IC(4), vb, vbx, U0, d1, d2);
-                half_imm(ra, rb, IC(5), vb, vbx, U0, d1, d2); half_imm(rb, ra, IC(6), vb, vbx, U0, d1, d2);
-                half_imm(ra, rb, IC(7), vb, vbx, U0, d1, d2); half_imm(rb, ra, IC(8), vb, vbx, U0, d1, d2);
+                const std::true_type GWT;
+                half_imm(ra, rb, IC(1), vb, vbx, U0, d1, d2, GWT); half_imm(rb, ra, IC(2), vb, vbx, U0, d1, d2, GWT);
+                half_imm(ra, rb, IC(3), vb, vbx, U0, d1, d2, GWT); half_imm(rb, ra, IC(4), vb, vbx, U0, d1, d2, GWT);
+                half_imm(ra, rb, IC(5), vb, vbx, U0, d1, d2, GWT); half_imm(rb, ra, IC(6), vb, vbx, U0, d1, d2, GWT);
+                half_imm(ra, rb, IC(7), vb, vbx, U0, d1, d2, GWT); half_imm(rb, ra, IC(8), vb, vbx, U0, d1, d2, GWT);
             }
+            scale_dev(dev);
             for (int c0 = n_dev; c0 < nc; c0 += 6) {
                 const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
                 hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
                 const unsigned vb = base + 64u * (unsigned)c0, vbx = basex + (unsigned)(COMPX * 8) * (unsigned)c0;
-                half_imm(ra, rb, IC(1), vb, vbx, U1, d1, d2); half_imm(rb, ra, IC(2), vb, vbx, U1, d1, d2);
-                half_imm(ra, rb, IC(3), vb, vbx, U1, d1, d2); half_imm(rb, ra, IC(4), vb, vbx, U1, d1, d2);
-                half_imm(ra, rb, IC(5), vb, vbx, U1, d1, d2); half_imm(rb, ra, IC(6), vb, vbx, U1, d1, d2);
+                const std::false_type GWF;
+                half_imm(ra, rb, IC(1), vb, vbx, U1, d1, d2, GWF); half_imm(rb, ra, IC(2), vb, vbx, U1, d1, d2, GWF);
+                half_imm(ra, rb, IC(3), vb, vbx, U1, d1, d2, GWF); half_imm(rb, ra, IC(4), vb, vbx, U1, d1, d2, GWF);
+                half_imm(ra, rb, IC(5), vb, vbx, U1, d1, d2, GWF); half_imm(rb, ra, IC(6), vb, vbx, U1, d1, d2, GWF);
             }
 #undef IC
 #else
             for (int c0 = 0; c0 < n_dev; c0 += 8) {
                 const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
                 hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
-                for (int c = c0; c < c0 + 8; c += 2) { half(ra, rb, c + 1, U0, d1, d2); half(rb, ra, c + 2, U0, d1, d2); }
+                for (int c = c0; c < c0 + 8; c += 2) { half(ra, rb, c + 1, U0, d1, d2, std::true_type()); half(rb, ra, c + 2, U0, d1, d2, std::true_type()); }
             }
+            scale_dev(dev);
             for (int c0 = n_dev; c0 < nc; c0 += 6) {
                 const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
                 hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
-                for (int c = c0; c < c0 + 6; c += 2) { half(ra, rb, c + 1, U1, d1, d2); half(rb, ra, c + 2, U1, d1, d2); }
+                for (int c = c0; c < c0 + 6; c += 2) { half(ra, rb, c + 1, U1, d1, d2, std::false_type()); half(rb, ra, c + 2, U1, d1, d2, std::false_type()); }
             }
 #endif
             lds_wait_comp(ra);   // the last (unused) request must land before its registers are reused

@@ -70,10 +70,10 @@ def analyse(txt, symbol, psf_k=2):
     report = []
     for (a, b), n in zip(comp, n_comp):
         c = stats(lines[a:b + 1])
-        # components per trip: the fp64 loop requests every record with five explicit ds_read_b128 (a run of 8 / 6
+        # components per trip: the fp64 loop requests every record with six explicit ds_read_b128 (a run of 8 / 6
         # prototypes is unrolled: 8 / 6 per trip); the packed fp32 loop handles one pair per trip
         reads = sum("ds_read_b128" in l for l in lines[a:b + 1])
-        per_trip = reads // 5 if reads >= 25 else 2
+        per_trip = reads // 6 if reads >= 30 else 2
         trips = n // per_trip
         report.append("component loop (%d trips of %d components): %d fp64 + %d fp32 flops, %d VALU (%d FMA-class) per trip"
                       % (trips, per_trip, c["f64"], c["f32"], c["valu"], c["fma"]))
