@@ -309,14 +309,25 @@ __device__ __forceinline__ float log_s(float x) { return __logf(x); }
 #define EXP_STEP_LO (2.0164562921995537e-13 * (64 / EXP_T))          // minus its low part
 #define EXP_STEP_FULL (0.010830424696249145 * (64 / EXP_T))           // ln2 / T rounded to double (0x1.62e42fefa39efp-7 for T = 64)
 __device__ double g_exp2_table[64];  // 2^((j mod T) / T), filled once per context by exp_table_kernel
-__global__ void exp_table_kernel() { g_exp2_table[threadIdx.x] = exp2((double)(threadIdx.x & (EXP_T - 1)) * (1.0 / EXP_T)); }
+// (degree 4: the table holds 2^(j / T) / 24 and exp_poly returns 24 exp(r) -- see exp_poly)
+#define EXP_TAB_SCALE (EXP_DEGREE == 4 ? 1.0 / 24.0 : 1.0)
+__global__ void exp_table_kernel() { g_exp2_table[threadIdx.x] = exp2((double)(threadIdx.x & (EXP_T - 1)) * (1.0 / EXP_T)) * EXP_TAB_SCALE; }
 __device__ __forceinline__ void exp_table_init(double *tab) {
     if (threadIdx.x < 64) tab[threadIdx.x] = g_exp2_table[threadIdx.x];  // one coalesced 512-byte read
     __syncthreads();
 }
-// exp(r) - as a polynomial in r of degree EXP_DEGREE (Horner)
+// exp(r) -- as a polynomial in r of degree EXP_DEGREE (Horner).  Degree 4 (the build's default): 24 exp(r) =
+// (((r + 4) r + 12) r + 24) r + 24, the factor 1 / 24 sitting in the table -- one add with an inline constant and three FMAs
+// with ONE non-inline constant each (a scalar register operand), where the monic form 1/24, 1/6, 1/2, 1, 1 needs its first two
+// constants in one instruction, i.e. a v_mov_b64 into a vector register per evaluation: 5 -> 4 VALU instructions.
 __device__ __forceinline__ double exp_poly(double r) {
     double p;
+#if EXP_DEGREE == 4
+    p = r + 4.0;
+    p = __builtin_fma(p, r, 12.0);
+    p = __builtin_fma(p, r, 24.0);
+    return __builtin_fma(p, r, 24.0);
+#endif
 #if EXP_DEGREE >= 6
     p = 1.3888888888888889e-03;                      // 1/6!
     p = __builtin_fma(p, r, 8.333333333333333e-03);  // 1/5!
