@@ -355,8 +355,8 @@ __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
 
 // log(x) for the per-pixel term (x = E_G > 0, normal): x = 2^e m with m in [sqrt(1/2), sqrt 2), s = (m - 1) / (m + 1),
 // log m = 2 s (1 + s^2/3 + s^4/5 + ... + s^20/21) (truncation 1e-17 relative), e ln2 in a high part whose product with e is
-// exact and a low part.  <= 2 ulp against a 40-digit reference over 1e-5 .. 1e6 and around 1 (tests/test_oracle_micro.py
-// holds the kernel to the oracle's libm log at 1e-12 on the pixel term); 32 instructions where the library's is ~80.
+// exact and a low part.  <= 2 ulp against a 40-digit reference over 1e-5 .. 1e6 and around 1 (the micro-parity tests
+// hold the kernel to a libm log at 1e-12 on the pixel term); 32 instructions where the library's is ~80.
 // Non-positive, subnormal or NaN arguments (never reached on valid inputs) give NaN, +inf gives +inf.
 __device__ __forceinline__ double rcp_pos(double b) {      // 1 / b, b > 0 normal: hardware estimate + two Newton steps (<= 1 ulp)
     double r = __builtin_amdgcn_rcp(b);
