@@ -41,8 +41,14 @@
 #ifndef OPTIM_TRED_LDS
 #define OPTIM_TRED_LDS 0   // 1: the LDS-resident tridiagonalisation (tred_wave) in the trust-region solve too
 #endif
-#ifndef OPTIM_UPDATE_FMA2
-#define OPTIM_UPDATE_FMA2 1   // rank-2 update of the tridiagonalisation as two FMAs per entry (0: tred_wave's rounding)
+#ifndef OPTIM_DPP_BOUND_CTRL
+#define OPTIM_DPP_BOUND_CTRL 1
+#endif
+#ifndef OPTIM_TRED_SPLIT
+#define OPTIM_TRED_SPLIT 1    // workgroups of four wavefronts: Q'g by wavefront 1 while wavefront 0 finds the extreme eigenvalues
+#endif
+#ifndef OPTIM_TRED_SQRT
+#define OPTIM_TRED_SQRT 1     // the reduction's square roots without the library's range scaling
 #endif
 #ifndef OPTIM_HARD_SCREEN
 #define OPTIM_HARD_SCREEN 1   // 0: run the eigenvector test of the hard case whenever the smallest eigenvalue is negative
@@ -183,21 +189,35 @@ __device__ __forceinline__ double lane_bcast_u(double x, int src) {
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_add_f64(double x) {
     const long long b = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROWMASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    // all rows written and every lane has a source (quad permutations, mirrors): bound_ctrl, so that the compiler need not
+    // clear the destination first (two v_mov per level; the row broadcasts below do need their zeros)
+    constexpr bool BC = ROWMASK == 0xF && OPTIM_DPP_BOUND_CTRL;
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROWMASK, 0xF, BC);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWMASK, 0xF, BC);
     return x + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ double wave_sum_dpp(double x) {
-    x = dpp_add_f64<0xB1, 0xF>(x);    // quad_perm [1,0,3,2]
-    x = dpp_add_f64<0x4E, 0xF>(x);    // quad_perm [2,3,0,1]
-    x = dpp_add_f64<0x141, 0xF>(x);   // row_half_mirror
-    x = dpp_add_f64<0x140, 0xF>(x);   // row_mirror: every lane holds its 16-lane row sum
-    x = dpp_add_f64<0x142, 0xA>(x);   // row_bcast15 into rows 1, 3
-    x = dpp_add_f64<0x143, 0xC>(x);   // row_bcast31 into rows 2, 3: lane 63 holds the total
-    const long long b = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+// Sum over the wavefront of a value that is ZERO in the lanes >= N (N static), the same in every lane afterwards.  Inside a
+// row of 16 lanes: quad butterflies and row mirrors (DPP, no LDS traffic) -- levels that would only add zeros are left out;
+// the row sums then travel through scalar registers and are combined as (r3 + r2) + (r1 + r0).  Every operation of the
+// sum over all 64 lanes that is left out here adds an exact zero, so the result does not depend on N.  (The chains of
+// dependent FP64 instructions are what the sub-problem's time is made of -- ~25 cycles each, measured on the Sturm
+// recurrences: a sum over <= 16 lanes is 4 dependent additions instead of 6.)
+template <int N>
+__device__ __forceinline__ double wave_sum_n(double x) {
+    if constexpr (N > 1) x = dpp_add_f64<0xB1, 0xF>(x);    // quad_perm [1,0,3,2]
+    if constexpr (N > 2) x = dpp_add_f64<0x4E, 0xF>(x);    // quad_perm [2,3,0,1]
+    if constexpr (N > 4) x = dpp_add_f64<0x141, 0xF>(x);   // row_half_mirror
+    if constexpr (N > 8) x = dpp_add_f64<0x140, 0xF>(x);   // row_mirror: every lane holds its 16-lane row sum
+    const double r0 = lane_bcast_u(x, 0);
+    if constexpr (N <= 16) return r0;
+    const double r1 = lane_bcast_u(x, 16);
+    if constexpr (N <= 32) return r1 + r0;
+    const double r2 = lane_bcast_u(x, 32);
+    if constexpr (N <= 48) return r2 + (r1 + r0);
+    const double r3 = lane_bcast_u(x, 48);
+    return (r3 + r2) + (r1 + r0);
 }
+__device__ __forceinline__ double wave_sum_dpp(double x) { return wave_sum_n<64>(x); }
 
 // Householder reduction of the symmetric NF x NF matrix A (LDS, column-major, full storage) to tridiagonal
 // form.  On exit: row i of A (columns < i) holds the Householder vector u_i, hv[i] = |u_i|^2 / 2 (0: no
@@ -243,79 +263,193 @@ __device__ inline void tred_wave(double *A, double *hv, double *e, double *q, in
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The same reduction with the matrix in registers: lane ln holds row ln (NF doubles, every index static: the NF - 1
-// steps are unrolled by template recursion), the Householder vector's entries and the entries of q reach the other
-// lanes through scalar registers (v_readlane), so a step costs 7 (l + 1) VALU instructions and three wave sums
-// instead of 4 (l + 1) LDS round trips whose latency the LDS version could not hide (76 us per matrix alone on a
-// CU, 86 us with 8 wavefronts per CU sharing the LDS pipe; measured with -DOPTIM_TIMING).  Same arithmetic in the
-// same order as tred_wave.  The reflections are applied to the vector v as they are formed (v <- Q' v), which is
-// their order in Q' and puts that wave sum in the shadow of the matrix-vector product.
+// The same reduction with the matrix in registers: lane ln holds row ln (every index static: the NF - 1 steps are unrolled
+// by template recursion).  The LDS version could not hide its 4 (l + 1) LDS round trips per step (76 us per matrix alone on
+// a CU; measured with -DOPTIM_TIMING).
+//
+// How entry k of the Householder vector u (and of q) reaches the FMAs of every lane decides the cost: a wavefront alone on
+// its SIMD -- the sub-problem of a fused launch -- issues one FP64 instruction per ~6 cycles whatever their dependencies
+// (tools/fp64_rate_probe.hip 1), so the reduction's time is its instruction count.  Through scalar registers (two
+// v_readlane per use) a column costs six of them per step next to its three FMAs: 12 k instructions, 58.4 k cycles
+// (tools/tred_probe.hip).  Here the vector is laid out once per step so that every row of 16 lanes holds it
+// (row_replicate) and the FMAs take their operand through DPP row_newbcast: three instructions per column, 50.7 k cycles
+// with the same bits; without the third per-step vector, the library square root's range scaling and (in the fused launch)
+// the reflections of g: see the figures in DESIGN.md section 6c.
+// (Tried and dropped, round 4: the same reduction shared out over the four wavefronts of a fused workgroup -- columns
+// k = w mod 4 per wavefront, one LDS exchange and one barrier per step, bit-identical.  56.9 k cycles against 58.4 k: the
+// exchange costs 410 of a step's 1450 cycles, as much as the column work it takes off each wavefront.)
 // Out: row i of the LDS matrix A (columns < i) = u_i (for p = Q y later); in lane ln: td = diagonal entry ln,
 // ev = sub-diagonal entry (ln - 1, ln), hvv = |u_ln|^2 / 2 (0: no reflection).
 // ---------------------------------------------------------------------------------------------------------
-template <int I>
+typedef __attribute__((address_space(3))) double lds_double_t;
+__device__ __forceinline__ lds_double_t *as_lds(double *p) { return (lds_double_t *)p; }
+
+// ---- lane broadcasts without v_readlane: row-replicated copies + DPP row_newbcast ----
+// On gfx90a and later v_fmac_f64 takes its first operand through DPP, and row_newbcast:n hands lane n of each row of 16 to
+// the whole row.  For that the vector must stand in every row: R.r[j] holds, in all four rows, row j of the vector (lanes
+// 16 j ... 16 j + 15) -- three swaps per dword (v_permlane16_swap puts rows (0,0,2,2) and (1,1,3,3) side by side,
+// v_permlane32_swap completes them).  Same products, same sums as with a scalar operand: the results do not change.
+// The DPP read needs two wait states behind a VALU write of its operand, and the compiler does not see a DPP instruction
+// in the asm: the s_nop below covers the swaps, and tests/test_dpp_hazard.py checks the compiled code for any other
+// write the register allocator may have put in between.
+struct RowRep { double r[3]; };
+template <int ROWS>   // rows of the vector that are needed (entries < 16 ROWS)
+__device__ __forceinline__ void row_rep_dword(unsigned d, unsigned &o0, unsigned &o1, unsigned &o2) {
+    const auto p = __builtin_amdgcn_permlane16_swap(d, d, false, false);        // p[0] = rows (0,0,2,2), p[1] = rows (1,1,3,3)
+    const auto q = __builtin_amdgcn_permlane32_swap(p[0], p[0], false, false);  // q[0] = rows (0,0,0,0), q[1] = rows (2,2,2,2)
+    o0 = q[0]; o2 = q[1]; o1 = 0u;
+    if constexpr (ROWS >= 2) o1 = __builtin_amdgcn_permlane32_swap(p[1], p[1], false, false)[0];   // rows (1,1,1,1)
+}
+template <int ROWS>
+__device__ __forceinline__ RowRep row_replicate(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    unsigned l0, l1, l2, h0, h1, h2;
+    row_rep_dword<ROWS>((unsigned)b, l0, l1, l2);
+    row_rep_dword<ROWS>((unsigned)(b >> 32), h0, h1, h2);
+    RowRep R;
+    R.r[0] = __builtin_bit_cast(double, ((unsigned long long)h0 << 32) | l0);
+    R.r[1] = __builtin_bit_cast(double, ((unsigned long long)h1 << 32) | l1);
+    R.r[2] = __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
+    if constexpr (ROWS >= 3) asm volatile("s_nop 1" : "+v"(R.r[0]), "+v"(R.r[1]), "+v"(R.r[2]));
+    else if constexpr (ROWS == 2) asm volatile("s_nop 1" : "+v"(R.r[0]), "+v"(R.r[1]));
+    else asm volatile("s_nop 1" : "+v"(R.r[0]));
+    return R;
+}
+// acc += vec[K] * other, vec given by its row-replicated copies
+template <int K>
+__device__ __forceinline__ void fmac_bcast(double &acc, const RowRep &R, double other) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(R.r[K / 16]), "v"(other), "n"(K % 16));
+}
+template <int K, int L>   // A u, columns K ... L, four chains by k mod 4
+__device__ __forceinline__ void tred_matvec_bc(const double (&a)[NF], const RowRep &U, double &c0, double &c1, double &c2, double &c3) {
+    if constexpr (K <= L) {
+        if constexpr ((K & 3) == 0) fmac_bcast<K>(c0, U, a[K]);
+        else if constexpr ((K & 3) == 1) fmac_bcast<K>(c1, U, a[K]);
+        else if constexpr ((K & 3) == 2) fmac_bcast<K>(c2, U, a[K]);
+        else fmac_bcast<K>(c3, U, a[K]);
+        tred_matvec_bc<K + 1, L>(a, U, c0, c1, c2, c3);
+    }
+}
+template <int K>          // a_k <- (a_k - u q_k) - q u_k for the columns K ... 0 (nu, nq: -u and -q of the lane)
+__device__ __forceinline__ void tred_update_bc(double (&a)[NF], const RowRep &U, const RowRep &Q, double nu, double nq) {
+    if constexpr (K >= 0) {
+        fmac_bcast<K>(a[K], Q, nu);
+        fmac_bcast<K>(a[K], U, nq);
+        tred_update_bc<K - 1>(a, U, Q, nu, nq);
+    }
+}
+
+// 1 / h (h > 0): hardware reciprocal + two Newton steps -- half the dependent instructions of an IEEE division
+__device__ __forceinline__ double tred_rcp(double h) {
+    double rh = __builtin_amdgcn_rcp(h);
+    rh = __builtin_fma(__builtin_fma(-h, rh, 1.0), rh, rh);
+    return __builtin_fma(__builtin_fma(-h, rh, 1.0), rh, rh);
+}
+// sqrt(h), h uniform over the wavefront: the library's iteration (v_rsq_f64, one coupled Newton step, two corrections)
+// without its range scaling and special-value selects while h is far from the ends of the exponent range -- always, for
+// sums of squares of Hessian entries, unless a parameter sits so deep in the flat part of its transform that its row
+// underflows; then the library's.
+__device__ __forceinline__ double tred_sqrt(double h) {
+#if OPTIM_TRED_SQRT
+    if (h > 1e-280 && h < 1e280) {
+        const double y = __builtin_amdgcn_rsq(h);
+        double g = h * y, hy = 0.5 * y;
+        const double r = __builtin_fma(-hy, g, 0.5);
+        g = __builtin_fma(g, r, g); hy = __builtin_fma(hy, r, hy);
+        g = __builtin_fma(__builtin_fma(-g, g, h), hy, g);
+        return __builtin_fma(__builtin_fma(-g, g, h), hy, g);
+    }
+#endif
+    return sqrt(h);
+}
+// v <- (I - u u' / h) v, one reflection (element ln of v and of u, u zero in the lanes >= N; rh = tred_rcp(h))
+template <int N>
+__device__ __forceinline__ void tred_reflect(double &v, double u, double rh) {
+    const double vu = wave_sum_n<N>(u * v);
+    v -= (vu * rh) * u;
+}
+
+// REFLECT: apply the reflections to v as they are formed (v <- Q' v); else v is left alone (tred_qtv does it afterwards,
+// from the stored reflectors, with the same operations)
+template <int I, bool REFLECT>
 __device__ __forceinline__ void tred_reg_steps(double (&a)[NF], double *__restrict__ A, double &ev, double &hvv,
                                                double &v, double &td, int ln) {
     if constexpr (I >= 1) {
         constexpr int l = I - 1;
         const bool act = ln <= l;
         if (ln == I) td = a[I];                              // row I and column I are final from here on
+        // (the selects are pinned to their step: left alone the compiler defers all forty to the end of the function and
+        // keeps their lane masks in scalar registers until then -- 80 of them, spilled through v_writelane)
+        asm volatile("" : "+v"(td));
         const double x = act ? a[I] : 0.0;                   // A(ln, I) = A(I, ln): row I left of the diagonal
         if constexpr (l == 0) {
             const double f = lane_bcast_u(x, 0);   // (outside the lane-dependent branch: inside it, x is only
             if (ln == I) { ev = f; hvv = 0.0; }    // guaranteed to be computed for the lanes that take the branch)
         } else {
             const double f = lane_bcast_u(x, l);
-            const double hoff = wave_sum_dpp(ln < l ? x * x : 0.0);
-            if (hoff == 0.0) { if (ln == I) { ev = f; hvv = 0.0; } }   // nothing left of column l: already tridiagonal here
-            else {
-                double h = hoff + f * f;
-                const double g = f >= 0 ? -sqrt(h) : sqrt(h);
-                h -= f * g;
-                const double u = (ln == l) ? f - g : x;      // Householder vector (0 beyond l)
-                if (act) A[I + LDA * ln] = u;
-                if (ln == I) { ev = g; hvv = h; }
-                const double vu = wave_sum_dpp(u * v);       // v <- (I - u u' / h) v
-                double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-                for (int k = 0; k <= l; ++k) {
-                    const double uk = lane_bcast_u(u, k);
-                    if (k & 1) acc1 = __builtin_fma(a[k], uk, acc1);
-                    else acc0 = __builtin_fma(a[k], uk, acc0);
-                }
-                // 1 / h once per step (h > 0): hardware reciprocal + two Newton steps -- half the dependent instructions of
-                // an IEEE division, and the step used to hold two of those
-                double rh = __builtin_amdgcn_rcp(h);
-                rh = __builtin_fma(__builtin_fma(-h, rh, 1.0), rh, rh);
-                rh = __builtin_fma(__builtin_fma(-h, rh, 1.0), rh, rh);
-                v -= (vu * rh) * u;
-                const double p = act ? (acc0 + acc1) * rh : 0.0;
-                const double hh = wave_sum_dpp(p * u) * (0.5 * rh);
-                const double qv = p - hh * u;
-#pragma unroll
-                for (int k = 0; k <= l; ++k) {
-                    const double uk = lane_bcast_u(u, k), qk = lane_bcast_u(qv, k);
-#if OPTIM_UPDATE_FMA2
-                    a[k] = __builtin_fma(-qv, uk, __builtin_fma(-u, qk, a[k]));
-#else
-                    a[k] -= u * qk + qv * uk;
-#endif
-                }
-            }
+            const double hoff = wave_sum_n<l>(ln < l ? x * x : 0.0);
+            // Nothing left of column l (hoff == 0): already tridiagonal here, no reflection -- e = f, hv = 0.  The step is not
+            // branched around: with u = 0 and a harmless h every update below adds an exact zero, and straight-line code
+            // lets the register allocator update the columns in place (around a branch it copied every column in every step:
+            // 1800 of the reduction's 9900 instructions).
+            const bool refl = hoff != 0.0;
+            double h = refl ? hoff + f * f : 1.0;
+            const double sq = tred_sqrt(h), g = f >= 0 ? -sq : sq;
+            h -= f * g;
+            const double u = refl ? ((ln == l) ? f - g : x) : 0.0;   // Householder vector (0 beyond l)
+            if (act) as_lds(A)[I + LDA * ln] = u;
+            if (ln == I) { ev = refl ? g : f; hvv = refl ? h : 0.0; }
+            asm volatile("" : "+v"(ev), "+v"(hvv));
+            const RowRep U = row_replicate<l / 16 + 1>(u);
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;   // A u in four chains by k mod 4
+            tred_matvec_bc<0, l>(a, U, c0, c1, c2, c3);
+            const double rh = tred_rcp(h);
+            if constexpr (REFLECT) tred_reflect<I>(v, u, rh);
+            // q = p - (u'p / 2h) u with p = A u / h, written as rh (P - (K rh / 2) u), P = A u, K = u'P
+            const double P = act ? (c0 + c1) + (c2 + c3) : 0.0;
+            const double K = wave_sum_n<I>(P * u);
+            const double qv = __builtin_fma(-(K * (0.5 * rh)), u, P) * rh;
+            const RowRep Q = row_replicate<l / 16 + 1>(qv);
+            tred_update_bc<l>(a, U, Q, -u, -qv);         // (column l first: the next step starts from it)
         }
-        tred_reg_steps<I - 1>(a, A, ev, hvv, v, td, ln);
+        tred_reg_steps<I - 1, REFLECT>(a, A, ev, hvv, v, td, ln);
     }
 }
+template <bool REFLECT>
 __device__ __forceinline__ void tred_reg(double *__restrict__ A, double &v, double &td, double &ev, double &hvv, int ln) {
     double a[NF];
     const int row = ln < NF ? ln : 0;                        // lanes >= NF: never active, any finite values do
 #pragma unroll
-    for (int k = 0; k < NF; ++k) a[k] = A[row + LDA * k];
+    for (int k = 0; k < NF; ++k) a[k] = as_lds(A)[row + LDA * k];
     wave_sync();                                         // rows of A are overwritten with the u_i below
     td = 0.0; ev = 0.0; hvv = 0.0;                           // e[ln], hv[ln]: each lane keeps its own (lane 0: none)
-    tred_reg_steps<NF - 1>(a, A, ev, hvv, v, td, ln);
+    tred_reg_steps<NF - 1, REFLECT>(a, A, ev, hvv, v, td, ln);
     if (ln == 0) td = a[0];
     wave_sync();
+}
+// The reduction alone, for a workgroup whose other wavefronts take the reflections of g (tred_qtv) meanwhile
+struct TredOut { double td, te, hv, gt; };
+__device__ __noinline__ TredOut tred_only(double *__restrict__ A, const int ln) {
+    double td, ev, hvv, v = 0.0;
+    tred_reg<false>(A, v, td, ev, hvv, ln);
+    return TredOut{td, ev, hvv, 0.0};
+}
+// Q'v after the fact, by one wavefront: the reflections n-1 ... 2 in turn, each exactly as tred_reg applies it (same
+// operands, same operations), from the reflectors in A and hv = |u|^2 / 2 per lane.
+template <int I>
+__device__ __forceinline__ void tred_qtv_steps(const double (&uu)[NF], double hv_l, double &v) {
+    if constexpr (I >= 2) {
+        const double h = lane_bcast_u(hv_l, I);
+        if (h != 0.0) tred_reflect<I>(v, uu[I], tred_rcp(h));
+        tred_qtv_steps<I - 1>(uu, hv_l, v);
+    }
+}
+__device__ __noinline__ double tred_qtv(double *__restrict__ A, double hv_l, double v, const int ln) {
+    double uu[NF];
+#pragma unroll
+    for (int i = 2; i < NF; ++i) uu[i] = ln < i ? as_lds(A)[i + LDA * ln] : 0.0;
+    tred_qtv_steps<NF - 1>(uu, hv_l, v);
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -690,24 +824,10 @@ struct TrResult { double p, m; int interior, solved; };
 // per-SIMD budget) should not depend on the kernel around them -- optim_step_kernel, tr_solve_kernel and
 // optim_fused_kernel call the same code, so their steps agree bit for bit by construction.
 struct TriForm { double td, te, hv, gt, wmin, wmax, wmin_lower, norm_bound; };
-__device__ __noinline__ TriForm tri_reduce(TriLds L, double g, int ln, double wmin_guess = __builtin_nan("")) {
+// second half of tri_reduce: T (one element per lane) -> LDS copy for the Sturm counts, Gershgorin interval, extreme eigenvalues
+__device__ __forceinline__ TriForm tri_reduce_tail(TriLds L, double td_l, double te_l, double hv_l, double gt_l, int ln, double wmin_guess) {
     const bool fr = ln < NF;
     OPT_TICK_DECL;
-    // T = Q' H Q and gt = Q' g (reflections n-1 ... 2 in turn) in one pass
-    double gt_l = fr ? g : 0.0, td_l, te_l, hv_l;
-#if OPTIM_TRED_LDS
-    tred_wave(L.A, L.hv, L.te, L.q, ln);
-    td_l = fr ? L.A[ln + LDA * ln] : 0.0; te_l = fr ? L.te[ln] : 0.0; hv_l = fr ? L.hv[ln] : 0.0;
-    for (int i = NF - 1; i >= 2; --i) {
-        const double h = L.hv[i];
-        if (h == 0.0) continue;
-        const double u = ln < i ? L.A[i + LDA * ln] : 0.0;
-        gt_l -= (wave_sum_dpp(u * gt_l) / h) * u;
-    }
-#else
-    tred_reg(L.A, gt_l, td_l, te_l, hv_l, ln);
-#endif
-    OPT_TICK(3);
     const double te2_l = te_l * te_l;
 #ifdef OPTIM_DEBUG_T
     if (fr && g_dbg_T) { double *o = g_dbg_T + (size_t)blockIdx.x * 4 * NF; o[ln] = td_l; o[NF + ln] = te_l; o[2 * NF + ln] = gt_l; o[3 * NF + ln] = hv_l; }
@@ -739,7 +859,40 @@ __device__ __noinline__ TriForm tri_reduce(TriLds L, double g, int ln, double wm
     OPT_TICK(5);
     return TriForm{td_l, te_l, hv_l, gt_l, wmin, wmax, wmin_lower, norm_bound};
 }
+__device__ __noinline__ TriForm tri_reduce(TriLds L, double g, int ln, double wmin_guess = __builtin_nan("")) {
+    const bool fr = ln < NF;
+    OPT_TICK_DECL;
+    // T = Q' H Q and gt = Q' g (reflections n-1 ... 2 in turn) in one pass
+    double gt_l = fr ? g : 0.0, td_l, te_l, hv_l;
+#if OPTIM_TRED_LDS
+    tred_wave(L.A, L.hv, L.te, L.q, ln);
+    td_l = fr ? L.A[ln + LDA * ln] : 0.0; te_l = fr ? L.te[ln] : 0.0; hv_l = fr ? L.hv[ln] : 0.0;
+    for (int i = NF - 1; i >= 2; --i) {
+        const double h = L.hv[i];
+        if (h == 0.0) continue;
+        const double u = ln < i ? L.A[i + LDA * ln] : 0.0;
+        gt_l -= (wave_sum_dpp(u * gt_l) / h) * u;
+    }
+#else
+    tred_reg<true>(L.A, gt_l, td_l, te_l, hv_l, ln);
+#endif
+    OPT_TICK(3);
+    return tri_reduce_tail(L, td_l, te_l, hv_l, gt_l, ln, wmin_guess);
+}
+// tri_reduce's second half on its own (workgroups of four wavefronts: tred_only and tred_qtv are the first)
+__device__ __noinline__ TriForm tri_spectrum(TriLds L, TredOut T, int ln, double wmin_guess) {
+    return tri_reduce_tail(L, T.td, T.te, T.hv, T.gt, ln, wmin_guess);
+}
 
+// p = Q y: the reflections 2 ... n-1 in turn; reflection i has its vector in the lanes < i
+template <int I>
+__device__ __forceinline__ void tri_qy_steps(const double (&uu)[NF], double rhv_l, double &y) {
+    if constexpr (I < NF) {
+        const double rh = lane_bcast_u(rhv_l, I);
+        if (rh != 0.0) y -= (wave_sum_n<I>(uu[I] * y) * rh) * uu[I];
+        tri_qy_steps<I + 1>(uu, rhv_l, y);
+    }
+}
 __device__ __noinline__ TrResult tri_step(TriLds L, TriForm TF, double delta, int ln, int secular_iters) {
     double p_out = 0.0, m_out = 0.0;
     int interior_out = 0;
@@ -852,11 +1005,7 @@ __device__ __noinline__ TrResult tri_step(TriLds L, TriForm TF, double delta, in
 #pragma unroll
         for (int i = 2; i < NF; ++i) uu[i] = ln < i ? L.A[i + LDA * ln] : 0.0;
         const double rhv_l = hv_l != 0.0 ? 1.0 / hv_l : 0.0;   // one division per lane, in parallel, instead of one in every link of the chain
-#pragma unroll
-        for (int i = 2; i < NF; ++i) {
-            const double rh = lane_bcast_u(rhv_l, i);
-            if (rh != 0.0) y -= (wave_sum_dpp(uu[i] * y) * rh) * uu[i];
-        }
+        tri_qy_steps<2>(uu, rhv_l, y);
     }
     OPT_TICK(7);
     if (interior && ln == 0) atomicAdd(&g_optim_stats[0], 1ull);
@@ -1181,7 +1330,29 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
         return 1;
     }
 
-    // ---- trust-region sub-problem at the accepted point (N&W section 4.3): wavefront 0 ----
+    // ---- trust-region sub-problem at the accepted point (N&W section 4.3): the tridiagonalisation by all four wavefronts
+    // of a large workgroup, the rest by wavefront 0 ----
+    // (a repeated step takes the reduced form kept with the target; `spec`, `accept`, the solver: the same for every thread)
+    const bool reduce_here = !spec && op.solver != 1 && !(Ts && !accept);
+    TriForm TF4 = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if constexpr (PARTS == 4 && OPTIM_TRED_SPLIT) {
+        if (reduce_here) {
+            // wavefront 0: T = Q'HQ, then its extreme eigenvalues; wavefront 1 meanwhile: Q'g from the stored reflectors (the
+            // step itself needs it, the eigenvalues do not) -- the same operations tri_reduce performs, so the same bits
+            TredOut T4 = {0.0, 0.0, 0.0, 0.0};
+            if (part == 0) {
+                OPT_TICK_DECL;
+                T4 = tred_only(sA, ln);
+                OPT_TICK(3);
+                if (ln < NF) sw[ln] = T4.hv;
+            }
+            __syncthreads();
+            if (part == 0) TF4 = tri_spectrum({sA, sw, std_, se, ste2, sq}, T4, ln, wmin_prev);
+            else if (part == 1) { const double gt = tred_qtv(sA, ln < NF ? sw[ln] : 0.0, ln < NF ? sg[ln] : 0.0, ln); if (ln < NF) se[ln] = gt; }
+            __syncthreads();
+            if (part == 0) TF4.gt = ln < NF ? se[ln] : 0.0;
+        }
+    }
     if (part == 0) {
         const bool fr = tid < NF;
         TrResult R = {0.0, 0.0, 0, 0};
@@ -1199,7 +1370,8 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
                 TF.wmin = ldc<COH>(v + 4 * NF); TF.wmax = ldc<COH>(v + 4 * NF + 1);
                 TF.wmin_lower = ldc<COH>(v + 4 * NF + 2); TF.norm_bound = ldc<COH>(v + 4 * NF + 3);
             } else {
-                TF = tri_reduce(L, fr ? sg[tid] : 0.0, tid, wmin_prev);
+                if constexpr (PARTS == 4 && OPTIM_TRED_SPLIT) TF = TF4;
+                else TF = tri_reduce(L, fr ? sg[tid] : 0.0, tid, wmin_prev);
                 if (Ts) {   // kept for the steps that may be rejected from here (stores only: nothing waits for them)
                     for (int k = tid; k < NF * NF; k += 64) { const int j = k / NF; stc<COH>(&Ts[k], sA[(k - j * NF) + LDA * j]); }
                     double *v = Ts + NF * NF;

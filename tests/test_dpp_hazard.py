@@ -1,0 +1,31 @@
+"""The inline-asm DPP instructions of the trust-region solver (csrc/optim_kernels.h: v_fmac_f64_dpp row_newbcast) are outside
+the compiler's hazard recogniser: tools/check_dpp_hazards.py looks at the compiled listing instead (CPU only, ~30 s)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_dpp_hazards as chk   # noqa: E402
+
+
+def test_the_checker_sees_a_hazard_when_there_is_one():
+    lines = ["f:", "\tv_mov_b64_e32 v[4:5], v[8:9]", "\tv_fmac_f64_dpp v[0:1], v[4:5], v[2:3] row_newbcast:3 row_mask:0xf bank_mask:0xf"]
+    n, bad = chk.check(lines)
+    assert n == 1 and len(bad) == 1 and bad[0][2] == [4, 5]
+    ok = [lines[0], lines[1], "\ts_nop 1", lines[2]]
+    assert chk.check(ok) == (1, [])
+    # a swap writes both of its operands
+    sw = ["f:", "\tv_permlane32_swap_b32_e32 v7, v4", "\tv_add_f64 v[10:11], v[12:13], v[14:15]",
+          "\tv_fmac_f64_dpp v[0:1], v[4:5], v[2:3] row_newbcast:0 row_mask:0xf bank_mask:0xf"]
+    assert len(chk.check(sw)[1]) == 1
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_no_dpp_read_within_two_wait_states_of_a_write_in_the_compiled_library():
+    lines = chk.listing()
+    n, bad = chk.check(lines)
+    n_asm = sum("v_fmac_f64_dpp" in l for l in lines)
+    assert n_asm > 2000, "the reduction's broadcast FMAs are in the listing (%d found)" % n_asm
+    assert not bad, bad[:5]

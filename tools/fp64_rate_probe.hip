@@ -4,6 +4,7 @@
 // stalls), 2 waves per SIMD; reported: ns per wave-instruction per SIMD and the ratio to v_fma_f64.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <string>
 
@@ -55,8 +56,9 @@ KERNEL(k_fma_mul, A_FMA_MUL) KERNEL(k_fmac, A_FMAC) KERNEL(k_fma_s, A_FMA_S)
 
 struct Case { const char *name; void (*fn)(double *, double); int per; };
 
-int main() {
-    const int blocks = 256 * 2, threads = 256;   // 2 workgroups of 4 waves per CU = 2 waves per SIMD
+int main(int argc, char **argv) {
+    const int wps = argc > 1 ? atoi(argv[1]) : 2;  // waves per SIMD (default 2; 1: what a lone wavefront on its SIMD gets)
+    const int blocks = 256 * wps, threads = 256;   // wps workgroups of 4 waves per CU
     double *out;
     hipMalloc(&out, (size_t)blocks * threads * sizeof(double));
     Case cases[] = {{"v_fma_f64", k_fma, 1}, {"v_fmac_f64", k_fmac, 1}, {"v_fma_f64 (sgpr operand)", k_fma_s, 1}, {"v_mul_f64", k_mul, 1},
@@ -82,7 +84,7 @@ int main() {
             if (ms < best) best = ms;
         }
         // wave-instructions per SIMD: 2 waves x ITER x 32 x per
-        const double n = 2.0 * ITER * 32 * c.per;
+        const double n = (double)wps * ITER * 32 * c.per;
         const double ns = best * 1e6 / n;
         if (base == 0) base = ns;
         printf("%-42s %8.3f ms  %6.3f ns per wave-instruction per SIMD  = %5.2f x v_fma_f64 (%.2f cycles at 2.4 GHz)\n", c.name, best, ns,
