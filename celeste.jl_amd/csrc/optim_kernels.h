@@ -29,6 +29,7 @@
 #include "elbo_device.h"
 #include "../../include/celeste_mi355x.h"
 
+#include <type_traits>
 #define NF 41
 #ifndef OPTIM_UNROLL_RECURRENCES
 #define OPTIM_UNROLL_RECURRENCES 1
@@ -320,6 +321,23 @@ template <int K>
 __device__ __forceinline__ void fmac_bcast(double &acc, const RowRep &R, double other) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(R.r[K / 16]), "v"(other), "n"(K % 16));
 }
+// vec[K] in every lane (one v_mov_b64 through DPP instead of two v_readlane and a scalar operand)
+template <int K>
+__device__ __forceinline__ double bcast_mov(const RowRep &R) {
+    double o;
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(R.r[K / 16]), "n"(K % 16));
+    return o;
+}
+// f(integral_constant<int, k>) for k = K ... N - 1 (static_for) / k = K ... END downwards (static_for_down): unrolled loops
+// whose index the asm above can take as an immediate
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (K < N) { f(std::integral_constant<int, K>{}); static_for<K + 1, N>(f); }
+}
+template <int K, int END, class F>
+__device__ __forceinline__ void static_for_down(F &&f) {
+    if constexpr (K >= END) { f(std::integral_constant<int, K>{}); static_for_down<K - 1, END>(f); }
+}
 template <int K, int L>   // A u, columns K ... L, four chains by k mod 4
 __device__ __forceinline__ void tred_matvec_bc(const double (&a)[NF], const RowRep &U, double &c0, double &c1, double &c2, double &c3) {
     if constexpr (K <= L) {
@@ -562,13 +580,14 @@ __device__ __forceinline__ void tri_factor(double td_l, double te_l, double te2_
     double pm = 1.0, pc = lane_bcast_u(td_l, 0) + lam;
     double pa = pm, pb = pc;                  // lane k: P_k and P_{k+1} at one scale
     if (!wide) {
-#pragma unroll
-        for (int k = 1; k < NF; ++k) {
-            const double pn = __builtin_fma(lane_bcast_u(td_l, k) + lam, pc, -lane_bcast_u(te2_l, k) * pm);
+        const RowRep TDL = row_replicate<3>(td_l + lam), NE2 = row_replicate<3>(-te2_l);
+        static_for<1, NF>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double pn = __builtin_fma(bcast_mov<k>(TDL), pc, bcast_mov<k>(NE2) * pm);
             if (ln == k) { pa = pc; pb = pn; }
             pm = pc; pc = pn;
-            if (k % POLY_PERIOD == 0) poly_rescale(pm, pc);
-        }
+            if constexpr (k % POLY_PERIOD == 0) poly_rescale(pm, pc);
+        });
     } else {
 #pragma unroll 1
         for (int k = 1; k < NF; ++k) {
@@ -585,30 +604,40 @@ __device__ __forceinline__ void tri_factor(double td_l, double te_l, double te2_
 // y = (T + lam I)^-1 rhs; in: rhs_l = element ln of the right-hand side, returns element ln of y.  The forward
 // sweep stays in registers.
 __device__ __forceinline__ double tri_solve(double te_l, double ip_l, double mk_l, double rhs_l, int ln) {
+    const RowRep NMK = row_replicate<3>(-mk_l), RHS = row_replicate<3>(rhs_l), NTE = row_replicate<3>(-te_l), IP = row_replicate<3>(ip_l);
     double r[NF];
-    double prev = lane_bcast_u(rhs_l, 0);
+    double prev = bcast_mov<0>(RHS);
     r[0] = prev;
-#pragma unroll
-    for (int k = 1; k < NF; ++k) { prev = __builtin_fma(-lane_bcast_u(mk_l, k), prev, lane_bcast_u(rhs_l, k)); r[k] = prev; }
-    double yn = prev * lane_bcast_u(ip_l, NF - 1);
+    static_for<1, NF>([&](auto kc) {          // prev = rhs_k - mk_k prev
+        constexpr int k = decltype(kc)::value;
+        double t = bcast_mov<k>(RHS);
+        fmac_bcast<k>(t, NMK, prev);
+        prev = t; r[k] = t;
+    });
+    double yn = prev * bcast_mov<NF - 1>(IP);
     double mine = ln == NF - 1 ? yn : 0.0;
-#pragma unroll
-    for (int k = NF - 2; k >= 0; --k) {
-        yn = __builtin_fma(-lane_bcast_u(te_l, k + 1), yn, r[k]) * lane_bcast_u(ip_l, k);
+    static_for_down<NF - 2, 0>([&](auto kc) { // y_k = (r_k - te_{k+1} y_{k+1}) / pivot_k
+        constexpr int k = decltype(kc)::value;
+        double t = r[k];
+        fmac_bcast<k + 1>(t, NTE, yn);
+        yn = t * bcast_mov<k>(IP);
         if (ln == k) mine = yn;
-    }
+    });
     return mine;
 }
 // y' (T + lam I)^-1 y = |D^-1/2 L^-1 y|^2 from the factorisation: one forward sweep, no back substitution
 __device__ __forceinline__ double tri_quad(double ip_l, double mk_l, double y_l) {
-    double w = lane_bcast_u(y_l, 0);
-    double q0 = w * w * lane_bcast_u(ip_l, 0), q1 = 0.0;
-#pragma unroll
-    for (int k = 1; k < NF; ++k) {
-        w = __builtin_fma(-lane_bcast_u(mk_l, k), w, lane_bcast_u(y_l, k));
-        const double ipk = lane_bcast_u(ip_l, k);
-        if (k & 1) q1 = __builtin_fma(w * w, ipk, q1); else q0 = __builtin_fma(w * w, ipk, q0);
-    }
+    const RowRep NMK = row_replicate<3>(-mk_l), Y = row_replicate<3>(y_l), IP = row_replicate<3>(ip_l);
+    double w = bcast_mov<0>(Y);
+    double q0 = w * w * bcast_mov<0>(IP), q1 = 0.0;
+    static_for<1, NF>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        double t = bcast_mov<k>(Y);
+        fmac_bcast<k>(t, NMK, w);             // w = y_k - mk_k w
+        w = t;
+        const double ww = w * w;
+        if constexpr (k & 1) fmac_bcast<k>(q1, IP, ww); else fmac_bcast<k>(q0, IP, ww);
+    });
     return q0 + q1;
 }
 // Sturm count #{eigenvalues of T < x} = number of sign changes in P_0 .. P_n; an exact zero takes the sign opposite to
@@ -693,7 +722,7 @@ __device__ inline double tri_extreme(const double *__restrict__ td, const double
 #define WMIN_PASSES (STURM_M == 1 ? 12 : 11)
 #define WMAX_PASSES 3
 template <int NCH, int PERIOD>
-__device__ __forceinline__ bool sturm_counts(const double td_l, const double e2_l, const double (&x)[NCH], int (&c)[NCH]) {
+__device__ __forceinline__ bool sturm_counts(const RowRep &TD, const RowRep &E2, const double (&x)[NCH], int (&c)[NCH]) {
     // Per chain and step: subtract, multiply, FMA for the recurrence; the sign changes are collected as bits -- the XOR of
     // the sign bits of P_k and P_{k-1}, shifted into an accumulator by one v_alignbit -- and counted by two popcounts at
     // the end; |P_k| is folded into a running minimum whose being zero sends the whole pass to the careful loop (an exact
@@ -701,16 +730,16 @@ __device__ __forceinline__ bool sturm_counts(const double td_l, const double e2_
     // cost twice the instructions (34 VALU per two-chain step, issue-bound at 148 cycles: measured).
     double pm[NCH], pc[NCH], tiny[NCH];
     unsigned hp[NCH], acc0[NCH], acc1[NCH];
-    const double td0 = lane_bcast_u(td_l, 0);
+    const double td0 = bcast_mov<0>(TD);
 #pragma unroll
     for (int m = 0; m < NCH; ++m) {
         pm[m] = 1.0; pc[m] = td0 - x[m]; tiny[m] = fabs(pc[m]);
         hp[m] = (unsigned)__double2hiint(pc[m]);
         acc0[m] = hp[m] >> 31; acc1[m] = 0u;          // P_0 = 1 is positive
     }
-#pragma unroll
-    for (int k = 1; k < NF; ++k) {
-        const double tdk = lane_bcast_u(td_l, k), e2k = lane_bcast_u(e2_l, k);
+    static_for<1, NF>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const double tdk = bcast_mov<k>(TD), e2k = bcast_mov<k>(E2);
 #pragma unroll
         for (int m = 0; m < NCH; ++m) {
             const double pn = __builtin_fma(tdk - x[m], pc[m], -e2k * pm[m]);
@@ -722,7 +751,7 @@ __device__ __forceinline__ bool sturm_counts(const double td_l, const double e2_
             pm[m] = pc[m]; pc[m] = pn;
             if (k % PERIOD == 0) poly_rescale(pm[m], pc[m]);
         }
-    }
+    });
     bool zero = false;
 #pragma unroll
     for (int m = 0; m < NCH; ++m) { c[m] = __popc(acc0[m]) + __popc(acc1[m]); zero |= tiny[m] == 0.0; }
@@ -743,6 +772,7 @@ __device__ __forceinline__ void tri_extremes(const double *__restrict__ td, cons
                                              int ln, bool wide, bool narrow, double &wmin, double &wmin_lower, double &wmax,
                                              double guess = __builtin_nan("")) {
     const double td_l = td[ln < NF ? ln : 0], e2_l = te2[ln < NF ? ln : 0];
+    const RowRep TD = row_replicate<3>(td_l), E2 = row_replicate<3>(e2_l);   // T for the chains of every pass (DPP broadcasts)
     double a = lo, b = hi, a2 = lo, b2 = hi;        // brackets of the smallest / the largest eigenvalue
     constexpr int W1 = 64 * STURM_M, W2 = 64;
     bool done1 = false;
@@ -764,8 +794,8 @@ __device__ __forceinline__ void tri_extremes(const double *__restrict__ td, cons
         x[STURM_M] = sturm_shift(a2, b2, ln, W2);   // (idle after WMAX_PASSES: the chain is still cheaper than a second code path)
         bool zero;
         if (wide) zero = true;
-        else if (narrow) zero = sturm_counts<STURM_M + 1, 16>(td_l, e2_l, x, c);
-        else zero = sturm_counts<STURM_M + 1, POLY_PERIOD>(td_l, e2_l, x, c);
+        else if (narrow) zero = sturm_counts<STURM_M + 1, 16>(TD, E2, x, c);
+        else zero = sturm_counts<STURM_M + 1, POLY_PERIOD>(TD, E2, x, c);
         if (wide || __ballot(zero) != 0ull) {       // an exact zero of some P_k, or entries far from one: the careful loop
 #pragma unroll
             for (int m = 0; m <= STURM_M; ++m) c[m] = sturm_count_careful(td, te2, x[m]);
