@@ -575,12 +575,14 @@ __device__ __forceinline__ void poly_rescale(double &pm, double &pc) {
 __device__ __forceinline__ bool poly_wide_range(double norm_bound) { return !(norm_bound > 1e-60 && norm_bound < 1e60); }
 // LDL' of T + lam I (positive definite by construction of lam): ip_l = 1 / pivot ln = P_ln / P_{ln+1} (one division
 // per lane, in parallel), mk_l = multiplier ln
-__device__ __forceinline__ void tri_factor(double td_l, double te_l, double te2_l, double lam, bool wide, int ln,
-                                           double &ip_l, double &mk_l) {
+// (NE2: -te^2 row-replicated -- it does not change from one shift to the next, the caller forms it once; the result carries
+// 1 / pivot and the multipliers both per lane and row-replicated, for the sweeps below)
+struct TriFac { double ip_l, mk_l; RowRep IP, NMK; };
+__device__ __forceinline__ TriFac tri_factor(double td_l, double te_l, double te2_l, const RowRep &NE2, double lam, bool wide, int ln) {
     double pm = 1.0, pc = lane_bcast_u(td_l, 0) + lam;
     double pa = pm, pb = pc;                  // lane k: P_k and P_{k+1} at one scale
     if (!wide) {
-        const RowRep TDL = row_replicate<3>(td_l + lam), NE2 = row_replicate<3>(-te2_l);
+        const RowRep TDL = row_replicate<3>(td_l + lam);
         static_for<1, NF>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const double pn = __builtin_fma(bcast_mov<k>(TDL), pc, bcast_mov<k>(NE2) * pm);
@@ -597,46 +599,52 @@ __device__ __forceinline__ void tri_factor(double td_l, double te_l, double te2_
             poly_rescale(pm, pc);
         }
     }
-    ip_l = pa / pb;
-    const double ip_prev = __shfl_up(ip_l, 1, 64);
-    mk_l = ln >= 1 ? te_l * ip_prev : 0.0;
+    TriFac F;
+    F.ip_l = pa / pb;
+    const double ip_prev = __shfl_up(F.ip_l, 1, 64);
+    F.mk_l = ln >= 1 ? te_l * ip_prev : 0.0;
+    F.IP = row_replicate<3>(F.ip_l); F.NMK = row_replicate<3>(-F.mk_l);
+    return F;
 }
 // y = (T + lam I)^-1 rhs; in: rhs_l = element ln of the right-hand side, returns element ln of y.  The forward
 // sweep stays in registers.
-__device__ __forceinline__ double tri_solve(double te_l, double ip_l, double mk_l, double rhs_l, int ln) {
-    const RowRep NMK = row_replicate<3>(-mk_l), RHS = row_replicate<3>(rhs_l), NTE = row_replicate<3>(-te_l), IP = row_replicate<3>(ip_l);
+// NTE: -te row-replicated (the caller's, like NE2); RHS: the right-hand side row-replicated
+__device__ __forceinline__ double tri_solve(const RowRep &NTE, const TriFac &F, const RowRep &RHS, int ln) {
     double r[NF];
     double prev = bcast_mov<0>(RHS);
     r[0] = prev;
     static_for<1, NF>([&](auto kc) {          // prev = rhs_k - mk_k prev
         constexpr int k = decltype(kc)::value;
         double t = bcast_mov<k>(RHS);
-        fmac_bcast<k>(t, NMK, prev);
+        fmac_bcast<k>(t, F.NMK, prev);
         prev = t; r[k] = t;
     });
-    double yn = prev * bcast_mov<NF - 1>(IP);
+    double yn = prev * bcast_mov<NF - 1>(F.IP);
     double mine = ln == NF - 1 ? yn : 0.0;
     static_for_down<NF - 2, 0>([&](auto kc) { // y_k = (r_k - te_{k+1} y_{k+1}) / pivot_k
         constexpr int k = decltype(kc)::value;
         double t = r[k];
         fmac_bcast<k + 1>(t, NTE, yn);
-        yn = t * bcast_mov<k>(IP);
+        yn = t * bcast_mov<k>(F.IP);
         if (ln == k) mine = yn;
     });
     return mine;
 }
+__device__ __forceinline__ double tri_solve(const RowRep &NTE, const TriFac &F, double rhs_l, int ln) {
+    return tri_solve(NTE, F, row_replicate<3>(rhs_l), ln);
+}
 // y' (T + lam I)^-1 y = |D^-1/2 L^-1 y|^2 from the factorisation: one forward sweep, no back substitution
-__device__ __forceinline__ double tri_quad(double ip_l, double mk_l, double y_l) {
-    const RowRep NMK = row_replicate<3>(-mk_l), Y = row_replicate<3>(y_l), IP = row_replicate<3>(ip_l);
+__device__ __forceinline__ double tri_quad(const TriFac &F, double y_l) {
+    const RowRep Y = row_replicate<3>(y_l);
     double w = bcast_mov<0>(Y);
-    double q0 = w * w * bcast_mov<0>(IP), q1 = 0.0;
+    double q0 = w * w * bcast_mov<0>(F.IP), q1 = 0.0;
     static_for<1, NF>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         double t = bcast_mov<k>(Y);
-        fmac_bcast<k>(t, NMK, w);             // w = y_k - mk_k w
+        fmac_bcast<k>(t, F.NMK, w);           // w = y_k - mk_k w
         w = t;
         const double ww = w * w;
-        if constexpr (k & 1) fmac_bcast<k>(q1, IP, ww); else fmac_bcast<k>(q0, IP, ww);
+        if constexpr (k & 1) fmac_bcast<k>(q1, F.IP, ww); else fmac_bcast<k>(q0, F.IP, ww);
     });
     return q0 + q1;
 }
@@ -791,14 +799,24 @@ __device__ __forceinline__ void tri_extremes(const double *__restrict__ td, cons
             else xw = guess + __builtin_ldexp(d0, 2 * (ln - 33));
             x[0] = fmin(fmax(xw, lo), hi);
         }
-        x[STURM_M] = sturm_shift(a2, b2, ln, W2);   // (idle after WMAX_PASSES: the chain is still cheaper than a second code path)
+        x[STURM_M] = sturm_shift(a2, b2, ln, W2);
         bool zero;
         if (wide) zero = true;
-        else if (narrow) zero = sturm_counts<STURM_M + 1, 16>(TD, E2, x, c);
-        else zero = sturm_counts<STURM_M + 1, POLY_PERIOD>(TD, E2, x, c);
+        else if (with_max) zero = narrow ? sturm_counts<STURM_M + 1, 16>(TD, E2, x, c) : sturm_counts<STURM_M + 1, POLY_PERIOD>(TD, E2, x, c);
+        else {   // the largest eigenvalue's bracket is final: its chain is left out (a wavefront alone on its SIMD is issue-bound,
+                 // the second chain is no longer free since the operands stopped costing four v_readlane per step)
+            double x1[STURM_M];
+            int c1[STURM_M];
+#pragma unroll
+            for (int m = 0; m < STURM_M; ++m) x1[m] = x[m];
+            zero = narrow ? sturm_counts<STURM_M, 16>(TD, E2, x1, c1) : sturm_counts<STURM_M, POLY_PERIOD>(TD, E2, x1, c1);
+#pragma unroll
+            for (int m = 0; m < STURM_M; ++m) c[m] = c1[m];
+            c[STURM_M] = 0;
+        }
         if (wide || __ballot(zero) != 0ull) {       // an exact zero of some P_k, or entries far from one: the careful loop
 #pragma unroll
-            for (int m = 0; m <= STURM_M; ++m) c[m] = sturm_count_careful(td, te2, x[m]);
+            for (int m = 0; m < STURM_M + (with_max ? 1 : 0); ++m) c[m] = sturm_count_careful(td, te2, x[m]);
         }
         int i0 = -1;
 #pragma unroll
@@ -936,10 +954,13 @@ __device__ __noinline__ TrResult tri_step(TriLds L, TriForm TF, double delta, in
     wave_sync();
     const double d2 = delta * delta;
     int interior = 0;
-    double y = 0.0, ip_l, mk_l;
+    double y = 0.0;
+    // row-replicated for the DPP broadcasts of the recurrences below: they are the same for every shift
+    const RowRep NE2 = row_replicate<3>(-te2_l), NTE = row_replicate<3>(-te_l), NG = row_replicate<3>(-gt_l);
+    TriFac F;
     if (wmin >= 1e-8) {
-        tri_factor(td_l, te_l, te2_l, 0.0, wide, ln, ip_l, mk_l);
-        y = tri_solve(te_l, ip_l, mk_l, -gt_l, ln);
+        F = tri_factor(td_l, te_l, te2_l, NE2, 0.0, wide, ln);
+        y = tri_solve(NTE, F, NG, ln);
         interior = wave_sum_dpp(y * y) <= d2;
     }
     if (!interior) {
@@ -947,10 +968,10 @@ __device__ __noinline__ TrResult tri_step(TriLds L, TriForm TF, double delta, in
         double lambda = lambda_lb;
         bool hard = false;
         // first iterate of the secular equation, at lambda_lb
-        tri_factor(td_l, te_l, te2_l, lambda, wide, ln, ip_l, mk_l);
-        y = tri_solve(te_l, ip_l, mk_l, -gt_l, ln);
+        F = tri_factor(td_l, te_l, te2_l, NE2, lambda, wide, ln);
+        y = tri_solve(NTE, F, NG, ln);
         double q2 = wave_sum_dpp(y * y);
-        bool fresh = true;                                       // (ip_l, mk_l, y, q2) belong to `lambda`
+        bool fresh = true;                                       // (F, y, q2) belong to `lambda`
         // Hard-case candidate: g orthogonal (1e-10) to the eigenvectors of every eigenvalue within 1e-10 of the
         // smallest, AND the step at lambda_lb without its components along them no longer than delta.  Those
         // components are at most 1e-10 / (lambda_lb + wmin) each, so a step at lambda_lb that is longer than delta by
@@ -964,14 +985,13 @@ __device__ __noinline__ TrResult tri_step(TriLds L, TriForm TF, double delta, in
             if (mc < 1) mc = 1;
             if (mc > TRI_MAXC) { if (ln == 0) atomicAdd(&g_optim_stats[2], 1ull); return TrResult{0.0, 0.0, 0, 0}; }
             const double shift = wmin_lower - 4.440892098500626e-16 * norm_bound;
-            double ips, mks;
-            tri_factor(td_l, te_l, te2_l, -shift, wide, ln, ips, mks);
+            const TriFac Fs = tri_factor(td_l, te_l, te2_l, NE2, -shift, wide, ln);
             bool orth = true;
             double zc[TRI_MAXC];
             for (int j = 0; j < mc && orth; ++j) {
                 double z = fr ? 1.0 + 0.5 * sin(1.7 * ln + 0.3 + 2.1 * j) : 0.0;
                 for (int it = 0; it < 4; ++it) {
-                    z = tri_solve(te_l, ips, mks, z, ln);
+                    z = tri_solve(NTE, Fs, z, ln);
 #pragma unroll
                     for (int jj = 0; jj < TRI_MAXC; ++jj)
                         if (jj < j) z -= wave_sum_dpp(z * zc[jj]) * zc[jj];
@@ -998,15 +1018,15 @@ __device__ __noinline__ TrResult tri_step(TriLds L, TriForm TF, double delta, in
         int it = 0;
         for (; it < secular_iters; ++it) {
             if (!fresh) {
-                tri_factor(td_l, te_l, te2_l, lambda, wide, ln, ip_l, mk_l);
-                y = tri_solve(te_l, ip_l, mk_l, -gt_l, ln);
+                F = tri_factor(td_l, te_l, te2_l, NE2, lambda, wide, ln);
+                y = tri_solve(NTE, F, NG, ln);
                 q2 = wave_sum_dpp(y * y);
             }
             fresh = false;
 #if OPTIM_Q3_SOLVE
-            const double q3 = wave_sum_dpp(y * tri_solve(te_l, ip_l, mk_l, y, ln));
+            const double q3 = wave_sum_dpp(y * tri_solve(NTE, F, y, ln));
 #else
-            const double q3 = tri_quad(ip_l, mk_l, y);           // y' (T + lambda)^-1 y
+            const double q3 = tri_quad(F, y);                    // y' (T + lambda)^-1 y
 #endif
             const double prev = lambda;
             lambda += q2 * (sqrt(q2) - delta) / (delta * q3);
@@ -1033,7 +1053,7 @@ __device__ __noinline__ TrResult tri_step(TriLds L, TriForm TF, double delta, in
     {
         double uu[NF];
 #pragma unroll
-        for (int i = 2; i < NF; ++i) uu[i] = ln < i ? L.A[i + LDA * ln] : 0.0;
+        for (int i = 2; i < NF; ++i) uu[i] = ln < i ? as_lds(L.A)[i + LDA * ln] : 0.0;
         const double rhv_l = hv_l != 0.0 ? 1.0 / hv_l : 0.0;   // one division per lane, in parallel, instead of one in every link of the chain
         tri_qy_steps<2>(uu, rhv_l, y);
     }
