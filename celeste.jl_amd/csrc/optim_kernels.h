@@ -776,21 +776,26 @@ __device__ __forceinline__ void sturm_narrow(double &a, double &b, int i0, int w
 // Gershgorin interval), instead of spreading them evenly: near convergence the bracket it leaves is a few ulp-decades
 // wide instead of 1/65 of the interval, which saves about three of the twelve passes.  Any guess gives a valid bracket
 // (the counts decide); a poor one costs at most one pass.
+// DO_MIN / DO_MAX: which of the two searches this call runs.  Both (one wavefront does it all): the largest eigenvalue's
+// three passes ride along as a second chain.  A fused workgroup gives the two searches to two wavefronts; they do not depend
+// on each other -- a pass that meets an exact zero recounts all its chains with the careful loop, whose counts are the fast
+// path's whenever that one is valid -- so the brackets, and the results, are the same bit for bit.
+template <bool DO_MIN, bool DO_MAX>
 __device__ __forceinline__ void tri_extremes(const double *__restrict__ td, const double *__restrict__ te2, double lo, double hi,
                                              int ln, bool wide, bool narrow, double &wmin, double &wmin_lower, double &wmax,
                                              double guess = __builtin_nan("")) {
+    static_assert(STURM_M == 1, "one shift of the smallest eigenvalue's bracket per lane");
     const double td_l = td[ln < NF ? ln : 0], e2_l = te2[ln < NF ? ln : 0];
     const RowRep TD = row_replicate<3>(td_l), E2 = row_replicate<3>(e2_l);   // T for the chains of every pass (DPP broadcasts)
     double a = lo, b = hi, a2 = lo, b2 = hi;        // brackets of the smallest / the largest eigenvalue
-    constexpr int W1 = 64 * STURM_M, W2 = 64;
+    constexpr int W = 64;
     bool done1 = false;
-    for (int pass = 0; pass < WMIN_PASSES && !done1; ++pass) {
-        const bool with_max = pass < WMAX_PASSES;
-        double x[STURM_M + 1];
-        int c[STURM_M + 1];
-#pragma unroll
-        for (int m = 0; m < STURM_M; ++m) x[m] = sturm_shift(a, b, ln * STURM_M + m, W1);
-        const bool warm = STURM_M == 1 && pass == 0 && guess > lo && guess < hi;   // (false for a NaN)
+    for (int pass = 0; pass < (DO_MIN ? WMIN_PASSES : WMAX_PASSES) && !done1; ++pass) {
+        const bool with_max = DO_MAX && pass < WMAX_PASSES;
+        double x[2];
+        int c[2] = {0, 0};
+        x[0] = sturm_shift(a, b, ln, W);
+        const bool warm = DO_MIN && pass == 0 && guess > lo && guess < hi;   // (false for a NaN)
         if (warm) {
             const double d0 = fmax(fabs(guess), fmax(fabs(lo), fabs(hi)) * 9.313225746154785e-10) * 3.552713678800501e-15;   // 2^-30, 2^-48
             double xw;
@@ -799,44 +804,37 @@ __device__ __forceinline__ void tri_extremes(const double *__restrict__ td, cons
             else xw = guess + __builtin_ldexp(d0, 2 * (ln - 33));
             x[0] = fmin(fmax(xw, lo), hi);
         }
-        x[STURM_M] = sturm_shift(a2, b2, ln, W2);
+        x[1] = sturm_shift(a2, b2, ln, W);
         bool zero;
         if (wide) zero = true;
-        else if (with_max) zero = narrow ? sturm_counts<STURM_M + 1, 16>(TD, E2, x, c) : sturm_counts<STURM_M + 1, POLY_PERIOD>(TD, E2, x, c);
-        else {   // the largest eigenvalue's bracket is final: its chain is left out (a wavefront alone on its SIMD is issue-bound,
-                 // the second chain is no longer free since the operands stopped costing four v_readlane per step)
-            double x1[STURM_M];
-            int c1[STURM_M];
-#pragma unroll
-            for (int m = 0; m < STURM_M; ++m) x1[m] = x[m];
-            zero = narrow ? sturm_counts<STURM_M, 16>(TD, E2, x1, c1) : sturm_counts<STURM_M, POLY_PERIOD>(TD, E2, x1, c1);
-#pragma unroll
-            for (int m = 0; m < STURM_M; ++m) c[m] = c1[m];
-            c[STURM_M] = 0;
+        else if (DO_MIN && with_max) zero = narrow ? sturm_counts<2, 16>(TD, E2, x, c) : sturm_counts<2, POLY_PERIOD>(TD, E2, x, c);
+        else {   // one chain: the smallest eigenvalue's once the largest's bracket is final (a wavefront alone on its SIMD is
+                 // issue-bound: an idle second chain is not free), or the largest's alone
+            double x1[1] = {DO_MIN ? x[0] : x[1]};
+            int c1[1];
+            zero = narrow ? sturm_counts<1, 16>(TD, E2, x1, c1) : sturm_counts<1, POLY_PERIOD>(TD, E2, x1, c1);
+            c[DO_MIN ? 0 : 1] = c1[0];
         }
         if (wide || __ballot(zero) != 0ull) {       // an exact zero of some P_k, or entries far from one: the careful loop
-#pragma unroll
-            for (int m = 0; m < STURM_M + (with_max ? 1 : 0); ++m) c[m] = sturm_count_careful(td, te2, x[m]);
+            if (DO_MIN) c[0] = sturm_count_careful(td, te2, x[0]);
+            if (with_max) c[1] = sturm_count_careful(td, te2, x[1]);
         }
-        int i0 = -1;
-#pragma unroll
-        for (int m = STURM_M - 1; m >= 0; --m) {
-            const unsigned long long mask = __ballot(c[m] >= 1);
-            if (mask) { const int i = (__ffsll((long long)mask) - 1) * STURM_M + m; if (i0 < 0 || i < i0) i0 = i; }
+        if constexpr (DO_MIN) {
+            const unsigned long long mask = __ballot(c[0] >= 1);
+            const int i0 = mask ? __ffsll((long long)mask) - 1 : -1;
+            if (warm) {      // the shifts were not evenly spaced: the neighbours of the first one that counted an eigenvalue
+                if (i0 < 0) a = __shfl(x[0], 63, 64);
+                else { const double nb = __shfl(x[0], i0, 64), na = i0 > 0 ? __shfl(x[0], i0 - 1, 64) : a; a = na; b = nb; }
+            } else sturm_narrow(a, b, i0, W);
         }
-        if (warm) {      // the shifts were not evenly spaced: the neighbours of the first one that counted an eigenvalue
-            if (i0 < 0) a = __shfl(x[0], 63, 64);
-            else { const double nb = __shfl(x[0], i0, 64), na = i0 > 0 ? __shfl(x[0], i0 - 1, 64) : a; a = na; b = nb; }
-        } else sturm_narrow(a, b, i0, W1);
         if (with_max) {
-            const unsigned long long mask = __ballot(c[STURM_M] >= NF);
-            sturm_narrow(a2, b2, mask ? __ffsll((long long)mask) - 1 : -1, W2);
+            const unsigned long long mask = __ballot(c[1] >= NF);
+            sturm_narrow(a2, b2, mask ? __ffsll((long long)mask) - 1 : -1, W);
         }
-        done1 = b - a <= 8.881784197001252e-16 * fmax(fabs(a), fabs(b)) && !with_max;
+        if constexpr (DO_MIN) done1 = b - a <= 8.881784197001252e-16 * fmax(fabs(a), fabs(b)) && !(pass < WMAX_PASSES);
     }
-    wmin_lower = a;
-    wmin = 0.5 * (a + b);
-    wmax = 0.5 * (a2 + b2);
+    if constexpr (DO_MIN) { wmin_lower = a; wmin = 0.5 * (a + b); }
+    if constexpr (DO_MAX) wmax = 0.5 * (a2 + b2);
 }
 
 // diagnostics: sub-problems solved as interior Newton steps / on the boundary / hard case, total and maximum
@@ -873,18 +871,22 @@ struct TrResult { double p, m; int interior, solved; };
 // optim_fused_kernel call the same code, so their steps agree bit for bit by construction.
 struct TriForm { double td, te, hv, gt, wmin, wmax, wmin_lower, norm_bound; };
 // second half of tri_reduce: T (one element per lane) -> LDS copy for the Sturm counts, Gershgorin interval, extreme eigenvalues
+// (DO_MIN / DO_MAX: tri_extremes)
+template <bool DO_MIN, bool DO_MAX>
 __device__ __forceinline__ TriForm tri_reduce_tail(TriLds L, double td_l, double te_l, double hv_l, double gt_l, int ln, double wmin_guess) {
     const bool fr = ln < NF;
     OPT_TICK_DECL;
     const double te2_l = te_l * te_l;
 #ifdef OPTIM_DEBUG_T
-    if (fr && g_dbg_T) { double *o = g_dbg_T + (size_t)blockIdx.x * 4 * NF; o[ln] = td_l; o[NF + ln] = te_l; o[2 * NF + ln] = gt_l; o[3 * NF + ln] = hv_l; }
+    if (DO_MIN && fr && g_dbg_T) { double *o = g_dbg_T + (size_t)blockIdx.x * 4 * NF; o[ln] = td_l; o[NF + ln] = te_l; o[2 * NF + ln] = gt_l; o[3 * NF + ln] = hv_l; }
 #endif
-    if (fr) { L.td[ln] = td_l; L.te2[ln] = te2_l; }   // the Sturm passes read T from LDS (hoisted: loop invariant)
-    wave_sync();
+    if constexpr (DO_MIN) {   // (the other wavefront of a split search finds them there)
+        if (fr) { L.td[ln] = td_l; L.te2[ln] = te2_l; }   // the Sturm passes read T from LDS (hoisted: loop invariant)
+        wave_sync();
+    }
     OPT_TICK(4);
     // Gershgorin interval, extreme eigenvalues
-    double wmin, wmax, wmin_lower, norm_bound;
+    double wmin = 0.0, wmax = 0.0, wmin_lower = 0.0, norm_bound;
     {
         const double te_next = __shfl_down(te_l, 1, 64);
         const double ea = fabs(te_l), eb = (ln + 1 < NF) ? fabs(te_next) : 0.0;
@@ -895,14 +897,7 @@ __device__ __forceinline__ TriForm tri_reduce_tail(TriLds L, double td_l, double
         norm_bound = fmax(fabs(lo), fabs(hi));
         const bool wide = poly_wide_range(norm_bound);
         const bool narrow = norm_bound > 8.673617379884035e-19 && norm_bound < 1.152921504606847e18;   // 2^-60 .. 2^60
-#if STURM_IMPL == 0
-        double unused;
-        wmin = tri_extreme(L.td, L.te2, lo, hi, 1, 12, ln, wide, wmin_lower);
-        wmax = tri_extreme(L.td, L.te2, lo, hi, NF, 3, ln, wide, unused);
-        (void)narrow;
-#else
-        tri_extremes(L.td, L.te2, lo, hi, ln, wide, narrow, wmin, wmin_lower, wmax, wmin_guess);
-#endif
+        tri_extremes<DO_MIN, DO_MAX>(L.td, L.te2, lo, hi, ln, wide, narrow, wmin, wmin_lower, wmax, wmin_guess);
     }
     OPT_TICK(5);
     return TriForm{td_l, te_l, hv_l, gt_l, wmin, wmax, wmin_lower, norm_bound};
@@ -925,11 +920,17 @@ __device__ __noinline__ TriForm tri_reduce(TriLds L, double g, int ln, double wm
     tred_reg<true>(L.A, gt_l, td_l, te_l, hv_l, ln);
 #endif
     OPT_TICK(3);
-    return tri_reduce_tail(L, td_l, te_l, hv_l, gt_l, ln, wmin_guess);
+    return tri_reduce_tail<true, true>(L, td_l, te_l, hv_l, gt_l, ln, wmin_guess);
 }
-// tri_reduce's second half on its own (workgroups of four wavefronts: tred_only and tred_qtv are the first)
+// tri_reduce's second half on its own, split over two wavefronts of a fused workgroup (tred_only and tred_qtv are the first
+// half): the smallest eigenvalue by the calling wavefront, which wrote T to LDS ...
 __device__ __noinline__ TriForm tri_spectrum(TriLds L, TredOut T, int ln, double wmin_guess) {
-    return tri_reduce_tail(L, T.td, T.te, T.hv, T.gt, ln, wmin_guess);
+    return tri_reduce_tail<true, false>(L, T.td, T.te, T.hv, T.gt, ln, wmin_guess);
+}
+// ... and the largest by another one (T from LDS: L.td, L.te -- the sub-diagonal itself, not its square -- behind a barrier)
+__device__ __noinline__ double tri_spectrum_max(TriLds L, int ln) {
+    const bool fr = ln < NF;
+    return tri_reduce_tail<false, true>(L, fr ? L.td[ln] : 0.0, fr ? L.te[ln] : 0.0, 0.0, 0.0, ln, __builtin_nan("")).wmax;
 }
 
 // p = Q y: the reflections 2 ... n-1 in turn; reflection i has its vector in the lanes < i
@@ -1387,20 +1388,22 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
     TriForm TF4 = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if constexpr (PARTS == 4 && OPTIM_TRED_SPLIT) {
         if (reduce_here) {
-            // wavefront 0: T = Q'HQ, then its extreme eigenvalues; wavefront 1 meanwhile: Q'g from the stored reflectors (the
-            // step itself needs it, the eigenvalues do not) -- the same operations tri_reduce performs, so the same bits
+            // wavefront 0: T = Q'HQ, then its smallest eigenvalue; meanwhile wavefront 1: Q'g from the stored reflectors (the step
+            // itself needs it, the eigenvalues do not), wavefront 2: the largest eigenvalue -- the same operations tri_reduce
+            // performs in one wavefront, so the same bits
             TredOut T4 = {0.0, 0.0, 0.0, 0.0};
             if (part == 0) {
                 OPT_TICK_DECL;
                 T4 = tred_only(sA, ln);
                 OPT_TICK(3);
-                if (ln < NF) sw[ln] = T4.hv;
+                if (ln < NF) { sw[ln] = T4.hv; std_[ln] = T4.td; ste2[ln] = T4.te * T4.te; sq[ln] = T4.te; }
             }
             __syncthreads();
             if (part == 0) TF4 = tri_spectrum({sA, sw, std_, se, ste2, sq}, T4, ln, wmin_prev);
             else if (part == 1) { const double gt = tred_qtv(sA, ln < NF ? sw[ln] : 0.0, ln < NF ? sg[ln] : 0.0, ln); if (ln < NF) se[ln] = gt; }
+            else if (part == 2) { const double wmax = tri_spectrum_max({sA, sw, std_, sq, ste2, sq}, ln); if (ln == 0) scv[0] = wmax; }
             __syncthreads();
-            if (part == 0) TF4.gt = ln < NF ? se[ln] : 0.0;
+            if (part == 0) { TF4.gt = ln < NF ? se[ln] : 0.0; TF4.wmax = scv[0]; }
         }
     }
     if (part == 0) {
