@@ -294,12 +294,22 @@ __device__ __forceinline__ lds_double_t *as_lds(double *p) { return (lds_double_
 // in the asm: the s_nop below covers the swaps, and tests/test_dpp_hazard.py checks the compiled code for any other
 // write the register allocator may have put in between.
 struct RowRep { double r[3]; };
-template <int ROWS>   // rows of the vector that are needed (entries < 16 ROWS)
+// ROWS: the rows of 16 lanes that will look at the copies, 4 = all of them (the tridiagonal recurrences: every lane carries the
+// whole chain).  The reduction's lanes beyond row l / 16 only hold zeros of u and q and finished parts of the matrix, so what
+// they multiply does not matter as long as it is finite: with ROWS = 1 the vector itself serves (row 0 reads its own lanes),
+// with ROWS = 2 one v_permlane16_swap per dword does (rows 0 and 1 then hold row 0 in one register and row 1 in the other).
+template <int ROWS>
 __device__ __forceinline__ void row_rep_dword(unsigned d, unsigned &o0, unsigned &o1, unsigned &o2) {
-    const auto p = __builtin_amdgcn_permlane16_swap(d, d, false, false);        // p[0] = rows (0,0,2,2), p[1] = rows (1,1,3,3)
-    const auto q = __builtin_amdgcn_permlane32_swap(p[0], p[0], false, false);  // q[0] = rows (0,0,0,0), q[1] = rows (2,2,2,2)
-    o0 = q[0]; o2 = q[1]; o1 = 0u;
-    if constexpr (ROWS >= 2) o1 = __builtin_amdgcn_permlane32_swap(p[1], p[1], false, false)[0];   // rows (1,1,1,1)
+    if constexpr (ROWS == 1) { o0 = d; o1 = 0u; o2 = 0u; }
+    else {
+        const auto p = __builtin_amdgcn_permlane16_swap(d, d, false, false);        // p[0] = rows (0,0,2,2), p[1] = rows (1,1,3,3)
+        if constexpr (ROWS == 2) { o0 = p[0]; o1 = p[1]; o2 = 0u; }
+        else {
+            const auto q = __builtin_amdgcn_permlane32_swap(p[0], p[0], false, false);  // q[0] = rows (0,0,0,0), q[1] = rows (2,2,2,2)
+            o0 = q[0]; o2 = q[1];
+            o1 = __builtin_amdgcn_permlane32_swap(p[1], p[1], false, false)[0];     // rows (1,1,1,1)
+        }
+    }
 }
 template <int ROWS>
 __device__ __forceinline__ RowRep row_replicate(double x) {
@@ -582,7 +592,7 @@ __device__ __forceinline__ TriFac tri_factor(double td_l, double te_l, double te
     double pm = 1.0, pc = lane_bcast_u(td_l, 0) + lam;
     double pa = pm, pb = pc;                  // lane k: P_k and P_{k+1} at one scale
     if (!wide) {
-        const RowRep TDL = row_replicate<3>(td_l + lam);
+        const RowRep TDL = row_replicate<4>(td_l + lam);
         static_for<1, NF>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const double pn = __builtin_fma(bcast_mov<k>(TDL), pc, bcast_mov<k>(NE2) * pm);
@@ -603,7 +613,7 @@ __device__ __forceinline__ TriFac tri_factor(double td_l, double te_l, double te
     F.ip_l = pa / pb;
     const double ip_prev = __shfl_up(F.ip_l, 1, 64);
     F.mk_l = ln >= 1 ? te_l * ip_prev : 0.0;
-    F.IP = row_replicate<3>(F.ip_l); F.NMK = row_replicate<3>(-F.mk_l);
+    F.IP = row_replicate<4>(F.ip_l); F.NMK = row_replicate<4>(-F.mk_l);
     return F;
 }
 // y = (T + lam I)^-1 rhs; in: rhs_l = element ln of the right-hand side, returns element ln of y.  The forward
@@ -631,11 +641,11 @@ __device__ __forceinline__ double tri_solve(const RowRep &NTE, const TriFac &F, 
     return mine;
 }
 __device__ __forceinline__ double tri_solve(const RowRep &NTE, const TriFac &F, double rhs_l, int ln) {
-    return tri_solve(NTE, F, row_replicate<3>(rhs_l), ln);
+    return tri_solve(NTE, F, row_replicate<4>(rhs_l), ln);
 }
 // y' (T + lam I)^-1 y = |D^-1/2 L^-1 y|^2 from the factorisation: one forward sweep, no back substitution
 __device__ __forceinline__ double tri_quad(const TriFac &F, double y_l) {
-    const RowRep Y = row_replicate<3>(y_l);
+    const RowRep Y = row_replicate<4>(y_l);
     double w = bcast_mov<0>(Y);
     double q0 = w * w * bcast_mov<0>(F.IP), q1 = 0.0;
     static_for<1, NF>([&](auto kc) {
@@ -786,7 +796,7 @@ __device__ __forceinline__ void tri_extremes(const double *__restrict__ td, cons
                                              double guess = __builtin_nan("")) {
     static_assert(STURM_M == 1, "one shift of the smallest eigenvalue's bracket per lane");
     const double td_l = td[ln < NF ? ln : 0], e2_l = te2[ln < NF ? ln : 0];
-    const RowRep TD = row_replicate<3>(td_l), E2 = row_replicate<3>(e2_l);   // T for the chains of every pass (DPP broadcasts)
+    const RowRep TD = row_replicate<4>(td_l), E2 = row_replicate<4>(e2_l);   // T for the chains of every pass (DPP broadcasts)
     double a = lo, b = hi, a2 = lo, b2 = hi;        // brackets of the smallest / the largest eigenvalue
     constexpr int W = 64;
     bool done1 = false;
@@ -957,7 +967,7 @@ __device__ __noinline__ TrResult tri_step(TriLds L, TriForm TF, double delta, in
     int interior = 0;
     double y = 0.0;
     // row-replicated for the DPP broadcasts of the recurrences below: they are the same for every shift
-    const RowRep NE2 = row_replicate<3>(-te2_l), NTE = row_replicate<3>(-te_l), NG = row_replicate<3>(-gt_l);
+    const RowRep NE2 = row_replicate<4>(-te2_l), NTE = row_replicate<4>(-te_l), NG = row_replicate<4>(-gt_l);
     TriFac F;
     if (wmin >= 1e-8) {
         F = tri_factor(td_l, te_l, te2_l, NE2, 0.0, wide, ln);
