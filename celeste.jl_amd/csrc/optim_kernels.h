@@ -106,6 +106,27 @@ __device__ inline void simplex_probs(const double *x, int g, double *p) {
 }
 
 // serial to_bound (used by one thread per target): x (41) -> vs (44)
+// The same by eight lanes per group (lane = entry i of group g; the three groups side by side): the exponentials -- the
+// expensive part, eight library calls in a row on one lane above -- in parallel, the sum by one lane in simplex_probs's order,
+// the divisions in parallel: the same operations on the same operands, so the same bits.  x: LDS; ebuf[3][8], sbuf[3]: LDS
+// scratch of the calling wavefront.  Returns p[i] of group g (lanes i >= n: nothing meaningful).
+__device__ __forceinline__ double simplex_prob_lane(const double *x, int g, int i, double *ebuf, double *sbuf) {
+    const int n = c_simplex_n[g], f0 = c_simplex_f0[g];
+    double m = x[f0];
+    for (int k = 1; k < n - 1; ++k) m = fmax(m, x[f0 + k]);
+    const double e = i < n - 1 ? exp(x[f0 + i] - m) : exp(-m);    // (i = n - 1: the last entry's exp(-m))
+    if (i < n) ebuf[8 * g + i] = e;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (i == 0) {
+        double sum = ebuf[8 * g + n - 1];
+        for (int k = 0; k < n - 1; ++k) sum += ebuf[8 * g + k];
+        sbuf[g] = sum;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const double sum = sbuf[g];
+    return i < n - 1 ? e / sum : (1.0 / sum) * e;
+}
+
 __device__ inline void to_bound_dev(const double *x, const double *pos0, const OptParams &op, double *vs) {
     for (int i = 0; i < 26; ++i) {
         double lo, hi, sc;
@@ -1147,19 +1168,19 @@ __device__ __noinline__ TrResult eig_tr_solve(double *A, double *w, double *e, d
 }
 
 // to_bound! by one wavefront: x (41, LDS) -> vs (44).  COH: vs is read by other workgroups of the same launch (stc)
+// tmp: 27 doubles of LDS scratch (the simplex groups' exponentials and sums)
 template <bool COH = false>
-__device__ inline void to_bound_wave(const double *x, const double *pos0, const OptParams &op, double *vs, int ln) {
+__device__ inline void to_bound_wave(const double *x, const double *pos0, const OptParams &op, double *vs, int ln, double *tmp) {
     if (ln < 26) {
         double lo, hi, sc;
         box_bounds(ln, pos0, op, lo, hi, sc);
         stc<COH>(vs + ln, (1.0 / (1.0 + exp(-x[ln] / sc))) * (hi - lo) + lo);
-    } else if (ln < 29) {
-        const int g = ln - 26;
-        double p[8];
-        simplex_probs(x, g, p);
+    } else if (ln >= 32 && ln < 56) {
+        const int g = (ln - 32) >> 3, i = (ln - 32) & 7;
+        const double p = simplex_prob_lane(x, g, i, tmp, tmp + 24);
         const int n = c_simplex_n[g];
         const double lo = c_simplex_lo[g];
-        for (int i = 0; i < n; ++i) stc<COH>(vs + c_simplex_b0[g] + i, (1 - n * lo) * p[i] + lo);
+        if (i < n) stc<COH>(vs + c_simplex_b0[g] + i, (1 - n * lo) * p + lo);
     }
 }
 
@@ -1235,7 +1256,11 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
         const double s = 1.0 / (1.0 + exp(-sx[tid] / sc)), w = hi - lo;
         sJb[tid] = w * s * (1 - s) / sc;
         sHb[tid] = w * s * (1 - s) * (1 - 2 * s) / (sc * sc);
-    } else if (tid < 29) simplex_probs(sx, tid - 26, sp[tid - 26]);
+    } else if (tid >= 32 && tid < 56) {   // the simplex groups, eight lanes each (simplex_prob_lane)
+        const int g = (tid - 32) >> 3, i = (tid - 32) & 7;
+        const double p = simplex_prob_lane(sx, g, i, &sp[0][0], &sJs[0][0][0]);
+        if (i < c_simplex_n[g]) sp[g][i] = p;
+    }
     __syncthreads();
     OPT_TICK(9);
     // simplex Jacobians d bound_{b0+a} / d free_{f0+j} = (1 - n lo) p_a ((a == j) - p_j)
@@ -1387,7 +1412,7 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
     OPT_TICK(1);
     if (done) {
         if (tid == 0) stc<COH>(&S.done, 1);
-        to_bound_wave<COH>(sx, S.pos0, op, vp_row, tid);
+        to_bound_wave<COH>(sx, S.pos0, op, vp_row, tid, sU);
         return 1;
     }
 
@@ -1457,7 +1482,7 @@ __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, O
         }
     }
     __syncthreads();
-    to_bound_wave<COH>(sx, S.pos0, op, vp_row, tid);   // next evaluation point
+    to_bound_wave<COH>(sx, S.pos0, op, vp_row, tid, sU);   // next evaluation point
     OPT_TICK(8);
 #ifdef OPTIM_TIMING
     if (tid == 0) atomicAdd(&g_optim_clk[15], 1ull);
