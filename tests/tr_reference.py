@@ -104,6 +104,13 @@ def random_problems(rng, n=41):
     # 11: double lowest eigenvalue, g orthogonal to both (cluster of 2 in the hard-case test)
     wd = rng.uniform(1, 50, n); wd[0] = wd[1] = -1.0
     out += [("hard case, double eigenvalue", sym(Q @ np.diag(wd) @ Q.T), Q[:, 2:] @ (rng.standard_normal(n - 2) * 0.05), 5.0)]
+    # 12: parameters deep in the flat part of their transform: rows and columns scaled by 1e-150, so that their squares
+    # leave the exponent range (the reduction's norms underflow to denormals or to zero; its fast square root hands over
+    # to the library's there)
+    wu = 10.0 ** rng.uniform(0, 5, n)
+    D = np.ones(n); D[[3, 19, 33]] = 1e-150
+    Hu = sym(Q @ np.diag(wu) @ Q.T) * D[:, None] * D[None, :]
+    out += [("underflowing rows", sym(Hu), rng.standard_normal(n) * D, 1.0)]
     return out
 
 
