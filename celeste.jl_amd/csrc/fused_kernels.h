@@ -94,6 +94,18 @@ struct FusedArgs {
     const double *j_pos;           // per entry: centre of the position box (nullptr: the position at its start)
     SrcImg *j_srcimg; Comp *j_comps; SrcGeo *j_geo;     // the context's per-visit / per-source tables, refreshed in flight
 };
+// How the phases of the persistent kernel see the launch's arguments: in place, in the kernel-argument segment (constant
+// address space: scalar loads through the scalar cache).  Passed as `const FusedArgs &` they were a copy on the kernel's
+// stack -- 464 B of scratch per lane, every field a flat load from it in front of the access it serves.
+typedef const __attribute__((address_space(4))) FusedArgs &FusedArgsK;
+// (handed down as a plain pointer and made wave-uniform again inside every phase: a pointer that arrives as a function
+// argument is a per-lane value to the compiler, and the loads through it would be vector loads)
+__device__ __forceinline__ FusedArgsK fused_args(const FusedArgs *p) {
+    const unsigned long long b = (unsigned long long)(size_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return *(const __attribute__((address_space(4))) FusedArgs *)(size_t)(((unsigned long long)hi << 32) | lo);
+}
+
 
 // per batch, once: the targets' record ranges, the description of every record, the first round of queue items
 // (q_items == nullptr: no queue -- eval_fused_kernel)
@@ -169,7 +181,8 @@ __device__ unsigned long long g_fused_clk[16];
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // thread 0: the next queue item of this workgroup (FQ_EXIT when the launch is over or has been aborted)
-__device__ __forceinline__ int fused_pop(const FusedArgs &A) {
+__device__ __forceinline__ int fused_pop(const FusedArgs *Ap) {
+    FusedArgsK A = fused_args(Ap);
     // (the abort word is looked at while waiting, not here: one dependent round trip less on every pop)
     const int ticket = __hip_atomic_fetch_add(&A.q_ctl[FQC_HEAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket >= A.q_cap) {
@@ -194,7 +207,8 @@ __device__ __forceinline__ int fused_pop(const FusedArgs &A) {
 // the whole workgroup: append `count` items first, first + 1, ... (count > 0), or the one item `first` (count == 0), or
 // `-count` copies of `first` (count < 0).  Every store of the calling workgroup that the items' consumers depend on must
 // have been drained (drain_stores + __syncthreads) before.
-__device__ __forceinline__ void fused_push(const FusedArgs &A, const int tid, int *s_base, int first, int count) {
+__device__ __forceinline__ void fused_push(const FusedArgs *Ap, const int tid, int *s_base, int first, int count) {
+    FusedArgsK A = fused_args(Ap);
     const int n = count > 0 ? count : (count == 0 ? 1 : -count);
     if (tid == 0) *s_base = __hip_atomic_fetch_add(&A.q_ctl[FQC_TAIL], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -207,14 +221,16 @@ __device__ __forceinline__ void fused_push(const FusedArgs &A, const int tid, in
 }
 
 // the entry's evaluation items: its chunk records, or the direct item of a source that visits no pixel
-__device__ __forceinline__ void fused_push_eval(const FusedArgs &A, const int tid, int *s_base, int ti) {
+__device__ __forceinline__ void fused_push_eval(const FusedArgs *Ap, const int tid, int *s_base, int ti) {
+    FusedArgsK A = fused_args(Ap);
     const int2 tr = A.tgt_rec[ti];
-    if (tr.y > 0) fused_push(A, tid, s_base, tr.x, tr.y);
-    else fused_push(A, tid, s_base, FQ_DIRECT0 - ti, 0);
+    if (tr.y > 0) fused_push(Ap, tid, s_base, tr.x, tr.y);
+    else fused_push(Ap, tid, s_base, FQ_DIRECT0 - ti, 0);
 }
 
 // ---- joint mode: the start of an entry ----
-__device__ __noinline__ void joint_start(const FusedArgs &A, FusedShared &F, const int tid, const int e) {
+static __device__ __noinline__ void joint_start(const FusedArgs *Ap, FusedShared &F, const int tid, const int e) {
+    FusedArgsK A = fused_args(Ap);
     const int t = A.targets[e];
     double *const row = A.vp + (size_t)t * CEL_P;
     OptState *const js = reinterpret_cast<OptState *>(F.ev_h);          // (LDS scratch: no evaluation is in flight here)
@@ -236,12 +252,13 @@ __device__ __noinline__ void joint_start(const FusedArgs &A, FusedShared &F, con
     drain_stores();
     __syncthreads();
     const int n_it = A.j_vitem_off[t + 1] - A.j_vitem_off[t];
-    if (n_it > 0) fused_push(A, tid, &F.done, A.j_R + A.n_targets + (e << A.j_gshift), (n_it + FUSED_WAVES - 1) / FUSED_WAVES);
-    else fused_push_eval(A, tid, &F.done, e);
+    if (n_it > 0) fused_push(Ap, tid, &F.done, A.j_R + A.n_targets + (e << A.j_gshift), (n_it + FUSED_WAVES - 1) / FUSED_WAVES);
+    else fused_push_eval(Ap, tid, &F.done, e);
 }
 
 // ---- joint mode: one group of value-kernel items of an entry's source, one item per wavefront ----
-__device__ __noinline__ void joint_render(const FusedArgs &A, FusedShared &F, const int tid, const int code) {
+static __device__ __noinline__ void joint_render(const FusedArgs *Ap, FusedShared &F, const int tid, const int code) {
+    FusedArgsK A = fused_args(Ap);
     const int lane = tid & 63, wave = tid >> 6;
     const int e = code >> A.j_gshift, g = code & ((1 << A.j_gshift) - 1);
     const int t = A.targets[e];
@@ -286,11 +303,12 @@ __device__ __noinline__ void joint_render(const FusedArgs &A, FusedShared &F, co
     __syncthreads();
     const bool last = F.last != 0;
     __syncthreads();
-    if (last) fused_push_eval(A, tid, &F.done, e);
+    if (last) fused_push_eval(Ap, tid, &F.done, e);
 }
 
 // ---- joint mode: the end of an entry (its last step has been stored and drained) ----
-__device__ __noinline__ void joint_end(const FusedArgs &A, FusedShared &F, const int tid, const int e) {
+static __device__ __noinline__ void joint_end(const FusedArgs *Ap, FusedShared &F, const int tid, const int e) {
+    FusedArgsK A = fused_args(Ap);
     const int lane = tid & 63, wave = tid >> 6;
     const int t = A.targets[e];
     double *const row = A.vp + (size_t)t * CEL_P;
@@ -358,7 +376,8 @@ __device__ __noinline__ void joint_end(const FusedArgs &A, FusedShared &F, const
 // target's arrival counted (F.last: this record completed the target's evaluation).  Returns the target's slot.
 // NOT inlined: its register allocation is then the pixel loop's own (pixel_kernel's), whatever surrounds the call.
 template <bool JOINT>
-__device__ __noinline__ int fused_chunk_record(const FusedArgs &A, FusedShared &F, const int tid, const int item) {
+static __device__ __noinline__ int fused_chunk_record(const FusedArgs *Ap, FusedShared &F, const int tid, const int item) {
+    FusedArgsK A = fused_args(Ap);
     const int lane = tid & 63, wave = tid >> 6;
     FT_DECL;
     const int4 d0 = A.chunk_desc[2 * item], d1 = A.chunk_desc[2 * item + 1];
@@ -421,7 +440,8 @@ __device__ __noinline__ int fused_chunk_record(const FusedArgs &A, FusedShared &
 
 // the lift, then the Newton step (returns whether the target is done) of a target whose records are complete.
 // NOT inlined: every phase of the persistent loop keeps its own register allocation.
-__device__ __noinline__ void fused_lift(const FusedArgs &A, FusedShared &F, const int tid, const int ti) {
+static __device__ __noinline__ void fused_lift(const FusedArgs *Ap, FusedShared &F, const int tid, const int ti) {
+    FusedArgsK A = fused_args(Ap);
     const int t = A.targets[ti];
     if (tid == 0) stc<true>(&A.arrivals[ti], 0);
     lift_target<true>(F.lift, tid, ti, t, A.vp, A.images, A.patches, A.geo, A.nbr_off, A.nbr_idx, A.acc, A.prior, A.vis_off,
@@ -429,7 +449,8 @@ __device__ __noinline__ void fused_lift(const FusedArgs &A, FusedShared &F, cons
                       A.lg_sum, A.rec_off);
     __syncthreads();
 }
-__device__ __noinline__ int fused_step(const FusedArgs &A, FusedShared &F, const int tid, const int ti) {
+static __device__ __noinline__ int fused_step(const FusedArgs *Ap, FusedShared &F, const int tid, const int ti) {
+    FusedArgsK A = fused_args(Ap);
     const int t = A.targets[ti];
     return optim_step_target<true, FUSED_NT>(F.step, tid, A.st[ti], A.Hstate + (size_t)ti * NF * NF,
                                              A.vp + (size_t)t * CEL_P, F.ev_h, F.ev_d, -F.ev_v, F.ev_status, A.op,
@@ -443,7 +464,8 @@ __device__ __noinline__ int fused_step(const FusedArgs &A, FusedShared &F, const
 // (optim_step_target, `spec`): 66 -> 42 us for such an iteration.  Same code, same inputs as the step computed on
 // demand, so the same bits; skipped while the queue is long (the workgroup has better things to do) and in the hard
 // case.  The tag -- the iteration the step belongs to -- is written last.
-__device__ __noinline__ void fused_speculate(const FusedArgs &A, FusedShared &F, const int tid, const int ti) {
+static __device__ __noinline__ void fused_speculate(const FusedArgs *Ap, FusedShared &F, const int tid, const int ti) {
+    FusedArgsK A = fused_args(Ap);
     if (tid == 0) {
         const int h = ldc<true>(&A.q_ctl[FQC_HEAD]), t = ldc<true>(&A.q_ctl[FQC_TAIL]);
         F.last = t - h <= (int)gridDim.x / 4;        // (HEAD runs ahead of TAIL by the idle workgroups' tickets when the queue is empty)
@@ -480,9 +502,15 @@ __device__ __noinline__ void fused_speculate(const FusedArgs &A, FusedShared &F,
     __syncthreads();
 }
 
+// disable_tail_calls: nothing here is a tail call, but without the attribute the optimiser marks the calls of the phases
+// `tail` (no stack object of this function escapes any more), and a function with such a caller is no longer eligible for
+// the no-callee-saved-registers convention: every phase then saved and restored up to a hundred VGPRs through scratch.
 template <bool JOINT>
-__global__ void __launch_bounds__(FUSED_NT, 2)
-optim_fused_kernel(const FusedArgs A) {
+__global__ void __launch_bounds__(FUSED_NT, 2) __attribute__((disable_tail_calls))
+optim_fused_kernel(const FusedArgs A_) {
+    (void)A_;   // (the launch's only argument: read where it lies, FusedArgsK)
+    const FusedArgs *const Ap = (const FusedArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    FusedArgsK A = fused_args(Ap);
     __shared__ FusedShared F;
     for (;;) {
         // The thread index passes through an opaque asm in every trip: otherwise the compiler hoists everything that
@@ -492,7 +520,7 @@ optim_fused_kernel(const FusedArgs A) {
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6;
         FT_DECL;
-        if (tid == 0) F.item = fused_pop(A);
+        if (tid == 0) F.item = fused_pop(Ap);
         __syncthreads();
         const int item = F.item;
         if (item == FQ_EXIT) break;
@@ -500,12 +528,12 @@ optim_fused_kernel(const FusedArgs A) {
         int ti;
         bool last;
         if (JOINT && item >= A.j_R) {
-            if (item < A.j_R + A.n_targets) joint_start(A, F, tid, item - A.j_R);
-            else joint_render(A, F, tid, item - A.j_R - A.n_targets);
+            if (item < A.j_R + A.n_targets) joint_start(Ap, F, tid, item - A.j_R);
+            else joint_render(Ap, F, tid, item - A.j_R - A.n_targets);
             continue;
         }
         if (item >= 0) {
-            ti = fused_chunk_record<JOINT>(A, F, tid, item);
+            ti = fused_chunk_record<JOINT>(Ap, F, tid, item);
             last = F.last != 0;
         } else {
             ti = FQ_DIRECT0 - item;
@@ -514,23 +542,23 @@ optim_fused_kernel(const FusedArgs A) {
         if (!last) continue;
 
         // ---- the target's evaluation is complete: lift, Newton step ----
-        fused_lift(A, F, tid, ti);
+        fused_lift(Ap, F, tid, ti);
         FT(4);
-        const int done = fused_step(A, F, tid, ti);
+        const int done = fused_step(Ap, F, tid, ti);
         FT(5);
         drain_stores();      // the target's row of vp, its state and saved Hessian are in memory ...
         __syncthreads();     // ... before its next items (or the end of the launch) become visible
         if (!done) {
-            fused_push_eval(A, tid, &F.done, ti);
-            if (A.Spec && A.op.solver != 1) fused_speculate(A, F, tid, ti);
+            fused_push_eval(Ap, tid, &F.done, ti);
+            if (A.Spec && A.op.solver != 1) fused_speculate(Ap, F, tid, ti);
         } else {
-            if (JOINT) joint_end(A, F, tid, ti);
+            if (JOINT) joint_end(Ap, F, tid, ti);
             if (tid == 0)
                 F.done = __hip_atomic_fetch_add(&A.q_ctl[FQC_LIVE], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
             __syncthreads();
             const bool all_done = F.done != 0;
             __syncthreads();
-            if (all_done) fused_push(A, tid, &F.done, FQ_EXIT, -(int)gridDim.x);
+            if (all_done) fused_push(Ap, tid, &F.done, FQ_EXIT, -(int)gridDim.x);
         }
         FT(6); FT_COUNT(15);
     }

@@ -75,7 +75,8 @@ struct OptParams {
     int32_t secular_iters, pad;   // cap of the Newton iterations on lambda (20: to convergence; Optim.jl stops after 5)
 };
 
-__device__ __forceinline__ void box_bounds(int i, const double *pos0, const OptParams &op, double &lo, double &hi,
+template <class OP>   // OptParams in any address space (the fused kernel reads it in the kernel-argument segment)
+__device__ __forceinline__ void box_bounds(int i, const double *pos0, const OP &op, double &lo, double &hi,
                                            double &scale) {
     scale = 1.0;
     if (i < 2) { lo = pos0[i] - op.loc_width; hi = pos0[i] + op.loc_width; scale = op.loc_scale; }
@@ -127,7 +128,8 @@ __device__ __forceinline__ double simplex_prob_lane(const double *x, int g, int 
     return i < n - 1 ? e / sum : (1.0 / sum) * e;
 }
 
-__device__ inline void to_bound_dev(const double *x, const double *pos0, const OptParams &op, double *vs) {
+template <class OP>
+__device__ inline void to_bound_dev(const double *x, const double *pos0, const OP &op, double *vs) {
     for (int i = 0; i < 26; ++i) {
         double lo, hi, sc;
         box_bounds(i, pos0, op, lo, hi, sc);
@@ -145,7 +147,8 @@ __device__ inline void to_bound_dev(const double *x, const double *pos0, const O
 // enforce! + to_free! + first trial point; one thread per target
 // One thread: the start of maximize! for one target -- vs: its 44 parameters (enforced in place, then set to the first
 // evaluation point), S: its optimiser state, pos: the centre of its position box (nullptr: its current position)
-__device__ inline void optim_init_values(double *__restrict__ vs, const OptParams &op, const double *__restrict__ pos, OptState &S) {
+template <class OP>
+__device__ inline void optim_init_values(double *__restrict__ vs, const OP &op, const double *__restrict__ pos, OptState &S) {
     // the position box stays where the first ElboConfig put it (ParallelRun.jl:96-100); default: current position
     S.pos0[0] = pos ? pos[0] : vs[0];
     S.pos0[1] = pos ? pos[1] : vs[1];
@@ -1169,8 +1172,8 @@ __device__ __noinline__ TrResult eig_tr_solve(double *A, double *w, double *e, d
 
 // to_bound! by one wavefront: x (41, LDS) -> vs (44).  COH: vs is read by other workgroups of the same launch (stc)
 // tmp: 27 doubles of LDS scratch (the simplex groups' exponentials and sums)
-template <bool COH = false>
-__device__ inline void to_bound_wave(const double *x, const double *pos0, const OptParams &op, double *vs, int ln, double *tmp) {
+template <bool COH = false, class OP>
+__device__ inline void to_bound_wave(const double *x, const double *pos0, const OP &op, double *vs, int ln, double *tmp) {
     if (ln < 26) {
         double lo, hi, sc;
         box_bounds(ln, pos0, op, lo, hi, sc);
@@ -1206,10 +1209,10 @@ struct StepShared {
     int s_iter;                // iteration counter after the update (the tag of a step computed ahead, fused_speculate)
 };
 
-template <bool COH, int NTHR>
+template <bool COH, int NTHR, class OP>
 __device__ __forceinline__ int optim_step_target(StepShared &Z, const int tid, OptState &S, double *__restrict__ Hs, double *__restrict__ vp_row,
                                                  const double *__restrict__ h, const double *__restrict__ ev_d, double ft_in,
-                                                 int st_in, const OptParams &op, double *__restrict__ Ts = nullptr,
+                                                 int st_in, const OP &op, double *__restrict__ Ts = nullptr,
                                                  const double *__restrict__ Sp = nullptr) {
     // Ts (optional, TRI_STATE doubles per target): the reduced form of the last accepted point's sub-problem (tri_reduce),
     // so that a rejected step -- same Hessian and gradient, smaller radius -- goes straight to tri_step
