@@ -29,3 +29,14 @@ def test_no_dpp_read_within_two_wait_states_of_a_write_in_the_compiled_library()
     n_asm = sum("v_fmac_f64_dpp" in l for l in lines)
     assert n_asm > 2000, "the reduction's broadcast FMAs are in the listing (%d found)" % n_asm
     assert not bad, bad[:5]
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+@pytest.mark.parametrize("src", ["tred_probe.hip", "fp64_rate_probe.hip"])
+def test_the_probes_compile_against_the_tree(tmp_path, src):
+    """tools/*.hip include the product's kernel headers (tred_probe) or stand alone (fp64_rate_probe): they must keep building"""
+    import subprocess
+    out = tmp_path / "probe"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-o", str(out), os.path.join(ROOT, "tools", src)],
+                          stderr=subprocess.DEVNULL)
+    assert out.exists()
