@@ -986,8 +986,13 @@ static int eval_small(celeste_ctx_t *c, const double *vp, int32_t n_targets, con
     memcpy(c->p_small_in, vp, vp_n * sizeof(double));
     memcpy(c->p_small_in + vp_n, targets, n * sizeof(int32_t));
     HIP_TRY(hipMemcpyAsync(c->d_small_in, c->p_small_in, (vp_n + (n + 1) / 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    // the block of outputs: v[n], d[n x 44], h[n x HS], counters[n x 2], status[n]
-    double *const b_v = c->d_small_out, *const b_d = b_v + n, *const b_h = b_d + n * CEL_P;
+    // the block of outputs: v[n], d[n x 44], h[n x HS], counters[n x 2], status[n].  The kernels write it straight into the
+    // page-locked host block: no copy down (84 -> 81 us per call on a per-source context; CELESTE_SMALL_ZERO_COPY=0: device
+    // block + copy)
+    static const bool zero_copy = !(getenv("CELESTE_SMALL_ZERO_COPY") && atoi(getenv("CELESTE_SMALL_ZERO_COPY")) == 0);
+    double *out_dev = c->d_small_out;
+    if (zero_copy) HIP_TRY(hipHostGetDevicePointer((void **)&out_dev, c->p_small_out, 0));
+    double *const b_v = out_dev, *const b_d = b_v + n, *const b_h = b_d + n * CEL_P;
     int64_t *const b_c = reinterpret_cast<int64_t *>(b_h + n * HS);
     int32_t *const b_s = reinterpret_cast<int32_t *>(b_c + 2 * n);
     const size_t bytes = (n * (1 + CEL_P + HS + 2)) * sizeof(double) + n * sizeof(int32_t);
@@ -996,7 +1001,7 @@ static int eval_small(celeste_ctx_t *c, const double *vp, int32_t n_targets, con
     int st = launch_eval(c, c->d_small_in, n_targets, reinterpret_cast<const int32_t *>(c->d_small_in + vp_n), flags, b_v, b_d, b_h,
                          b_c, b_s, c->stream, true, nullptr, n_chunks);
     if (st != CELESTE_OK) { (void)hipStreamSynchronize(c->stream); return st; }
-    if (hipMemcpyAsync(c->p_small_out, c->d_small_out, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+    if ((!zero_copy && hipMemcpyAsync(c->p_small_out, c->d_small_out, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
         hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipStreamSynchronize(c->stream); return CELESTE_ERR_HIP; }
     const double *const o_v = c->p_small_out, *const o_d = o_v + n, *const o_h = o_d + n * CEL_P;
     const int64_t *const o_c = reinterpret_cast<const int64_t *>(o_h + n * HS);
