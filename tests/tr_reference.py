@@ -110,7 +110,9 @@ def random_problems(rng, n=41):
     wu = 10.0 ** rng.uniform(0, 5, n)
     D = np.ones(n); D[[3, 19, 33]] = 1e-150
     Hu = sym(Q @ np.diag(wu) @ Q.T) * D[:, None] * D[None, :]
-    out += [("underflowing rows", sym(Hu), rng.standard_normal(n) * D, 1.0)]
+    # (a small radius: the step is then on the boundary with a multiplier far above the three vanishing eigenvalues -- next to
+    # them the problem is a hard case whose answer is a matter of tolerances, which is not what this family is about)
+    out += [("underflowing rows", sym(Hu), rng.standard_normal(n) * D, 1e-3)]
     return out
 
 
