@@ -1336,7 +1336,7 @@ extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, cons
 //    memory and the kernels that depend on it read it there.  The counts come back through page-locked slots with an
 //    event each, so the host never waits for the iteration it just enqueued.
 // Results are bit-identical (tests/test_gpu_fused.py).  CELESTE_OPT_FUSED=0 / 1 forces one or the other.
-#define FUSED_AUTO_MAX 640          // (measured, config 3: 500 targets 11.3 vs 12.8 ms chained, 750 targets 15.3 vs 14.9, 1000 19.7 vs 18.0)
+#define FUSED_AUTO_MAX 880          // (measured, config 3, end of round 4: 500 targets 9.1 vs 11.2 ms chained, 750: 12.5 vs 13.1, 1000: 16.2 vs 15.6)
 #define JOINT_DATAFLOW_WIDEST 1024  // widest layer of a schedule that still runs as one dataflow launch
 
 static int optim_config(const celeste_optim_config_t *cfg_in, OptParams *op, uint32_t *flags) {
