@@ -1337,7 +1337,7 @@ extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, cons
 //    event each, so the host never waits for the iteration it just enqueued.
 // Results are bit-identical (tests/test_gpu_fused.py).  CELESTE_OPT_FUSED=0 / 1 forces one or the other.
 #define FUSED_AUTO_MAX 880          // (measured, config 3, end of round 4: 500 targets 9.1 vs 11.2 ms chained, 750: 12.5 vs 13.1, 1000: 16.2 vs 15.6)
-#define JOINT_DATAFLOW_WIDEST 1024  // widest layer of a schedule that still runs as one dataflow launch
+#define JOINT_DATAFLOW_WIDEST 4096  // widest layer of a schedule that still runs as one dataflow launch (measured: 3821 -> 0.158 s against 0.185 layer by layer; 14 782 -> 0.64 against 0.52)
 
 static int optim_config(const celeste_optim_config_t *cfg_in, OptParams *op, uint32_t *flags) {
     celeste_optim_config_t cfg = {1e-4, 1.0, 50, 1, 1e-7, 1e-6, 1e-8, 1.0, 1e9, 0, 0};
