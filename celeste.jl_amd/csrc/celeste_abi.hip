@@ -159,6 +159,7 @@ struct celeste_ctx {
         double *d_saved = nullptr;          // the targets' rows before the optimisation
         int32_t *h_ctl = nullptr;           // page-locked copy of the queue control words of the last launch
         int max_resident = 0;               // workgroups of optim_fused_kernel the device holds at once
+        int cus = 0;                        // compute units of the device
     } fused;
     // device scratch of the less travelled entry points (eval_multi, render_expected): grown on demand, kept
     struct Scratch { void *p = nullptr; size_t cap = 0; } scratch[24];   // 13..22: celeste_joint_infer
@@ -1336,6 +1337,7 @@ extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, cons
 //    memory and the kernels that depend on it read it there.  The counts come back through page-locked slots with an
 //    event each, so the host never waits for the iteration it just enqueued.
 // Results are bit-identical (tests/test_gpu_fused.py).  CELESTE_OPT_FUSED=0 / 1 forces one or the other.
+#define FUSED_SMALL_TARGETS 160    // batches up to this size run the fused launch with one workgroup per CU (measured: 96 ... 256 alike, 400 loses)
 #define FUSED_AUTO_MAX 880          // (measured, config 3, end of round 4: 500 targets 9.1 vs 11.2 ms chained, 750: 12.5 vs 13.1, 1000: 16.2 vs 15.6)
 #define JOINT_DATAFLOW_WIDEST 4096  // widest layer of a schedule that still runs as one dataflow launch (measured: 3821 -> 0.158 s against 0.185 layer by layer; 14 782 -> 0.64 against 0.52)
 
@@ -1427,9 +1429,18 @@ static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, co
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, optim_fused_kernel<true>, FUSED_NT, 0));
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
         fb.max_resident = std::max(1, std::min(per_cu, 2) * cus);
+        fb.cus = cus;
         if (const char *e = getenv("CELESTE_FUSED_GRID")) if (atoi(e) > 0) fb.max_resident = atoi(e);
     }
-    const int G = (int)std::max<size_t>(1, std::min<size_t>((size_t)fb.max_resident, rec + n));
+    // A small batch (one layer of a Cyclades schedule: 80 targets, ~900 records) gets ONE workgroup per CU: its wavefronts then
+    // have their SIMDs to themselves in every phase (a chunk item takes 6 us instead of 11 next to a second workgroup's), and the
+    // launch is latency-bound -- 86.7 -> 81.5 us per Newton iteration of the layer.  Larger batches need the second workgroup's
+    // throughput (the joint schedule of config 3: 0.060 s with two per CU, 0.079 s with one; layers of up to 400: 0.183 s against
+    // 0.171 layer by layer).  CELESTE_FUSED_SMALL overrides the threshold, CELESTE_FUSED_GRID the grid.
+    static const int small_targets = getenv("CELESTE_FUSED_SMALL") ? atoi(getenv("CELESTE_FUSED_SMALL")) : FUSED_SMALL_TARGETS;
+    size_t resident = (size_t)fb.max_resident;
+    if (!J && n_targets <= small_targets && fb.cus > 0 && !getenv("CELESTE_FUSED_GRID")) resident = std::min<size_t>(resident, (size_t)fb.cus);
+    const int G = (int)std::max<size_t>(1, std::min<size_t>(resident, rec + n));
     const size_t q_cap = (rec + n) * ((size_t)op.max_iters + 2) + (J ? n + J->render_groups : 0) + (size_t)G + 64;
     if (q_cap > 0x7fffffffull) return CELESTE_ERR_INVALID_ARG;
     { int stb = fused_buffers(c, n, rec, stream); if (stb != CELESTE_OK) return stb; }
