@@ -40,3 +40,31 @@ def test_the_probes_compile_against_the_tree(tmp_path, src):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-o", str(out), os.path.join(ROOT, "tools", src)],
                           stderr=subprocess.DEVNULL)
     assert out.exists()
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_register_and_scratch_budgets_of_the_hot_kernels():
+    """what DESIGN.md states about the compiled kernels, read from the listing's kernel descriptors: the pixel kernels spill
+    nothing and fit two (fp64) / three (fp32) wavefronts per SIMD; the persistent optimiser launch keeps its arguments out of
+    scratch (592 B per lane before round 4's change, 128 after); the lock-step step kernel 96 B"""
+    import re
+    txt = "\n".join(chk.listing())
+    desc = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", txt, re.S):
+        g = lambda k: int(re.search(r"\.amdhsa_%s (\S+)" % k, m.group(2)).group(1))
+        desc[m.group(1)] = (g("next_free_vgpr"), g("private_segment_fixed_size"), g("group_segment_fixed_size"))
+    def one(prefix):
+        hits = [v for k, v in desc.items() if k.startswith(prefix)]
+        assert len(hits) == 1, (prefix, len(hits))
+        return hits[0]
+    v, s, l = one("_Z12pixel_kernelILi2EdLb0EE")
+    assert s == 0 and v <= 256 and l <= 16 * 1024
+    v, s, l = one("_Z12pixel_kernelILi2EfLb0EE")
+    assert s == 0 and v <= 168
+    for k in ("_Z18optim_fused_kernelILb0EE", "_Z18optim_fused_kernelILb1EE"):
+        v, s, l = one(k)
+        assert s <= 128 and v <= 256 and 2 * l <= 160 * 1024, (k, v, s, l)
+    v, s, l = one("_Z17optim_step_kernel")
+    assert s <= 96 and v <= 256 and 8 * l <= 160 * 1024
+    v, s, l = one("_Z17eval_fused_kernel")
+    assert s == 0
