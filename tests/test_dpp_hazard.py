@@ -9,6 +9,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import check_dpp_hazards as chk   # noqa: E402
 
+_LISTING = []
+
+
+def compiled_listing():
+    """the device listing of the tree, compiled once per test session"""
+    if not _LISTING:
+        _LISTING.append(chk.listing())
+    return _LISTING[0]
+
 
 def test_the_checker_sees_a_hazard_when_there_is_one():
     lines = ["f:", "\tv_mov_b64_e32 v[4:5], v[8:9]", "\tv_fmac_f64_dpp v[0:1], v[4:5], v[2:3] row_newbcast:3 row_mask:0xf bank_mask:0xf"]
@@ -24,7 +33,7 @@ def test_the_checker_sees_a_hazard_when_there_is_one():
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 def test_no_dpp_read_within_two_wait_states_of_a_write_in_the_compiled_library():
-    lines = chk.listing()
+    lines = compiled_listing()
     n, bad = chk.check(lines)
     n_asm = sum("v_fmac_f64_dpp" in l for l in lines)
     assert n_asm > 2000, "the reduction's broadcast FMAs are in the listing (%d found)" % n_asm
@@ -48,7 +57,7 @@ def test_register_and_scratch_budgets_of_the_hot_kernels():
     nothing and fit two (fp64) / three (fp32) wavefronts per SIMD; the persistent optimiser launch keeps its arguments out of
     scratch (592 B per lane before round 4's change, 128 after); the lock-step step kernel 96 B"""
     import re
-    txt = "\n".join(chk.listing())
+    txt = "\n".join(compiled_listing())
     desc = {}
     for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", txt, re.S):
         g = lambda k: int(re.search(r"\.amdhsa_%s (\S+)" % k, m.group(2)).group(1))
