@@ -217,6 +217,12 @@ def main():
     ap.add_argument("--dtype", default=None, choices=("f64", "f32"))
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
+    ap.add_argument("--driver", default="ranks", choices=("ranks", "group"),
+                    help="ranks: one process per GPU, torch.distributed (the default, what the launcher starts); group: ONE "
+                         "process, the N devices behind the C ABI (celeste_group_*: worker threads, RCCL inside the library)")
+    ap.add_argument("--group-devices", default=None,
+                    help="--driver group: comma-separated HIP ordinals of the members (default 0..N-1; a repeated ordinal puts "
+                         "several members on one device -- tests)")
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--width", type=int, default=1489)
     ap.add_argument("--sources", type=int, default=None)
@@ -237,6 +243,10 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.driver == "group":
+        if int(os.environ.get("RANK", "0")) != 0:
+            return               # (started under a launcher: the group lives in ONE process -- rank 0's)
+        return group_main(args)
     if args.gpus > 1 and "RANK" not in os.environ and not args.pmc_child:
         # a plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, the same launcher and
         # arguments the driver uses) -- the line must never describe fewer ranks than --gpus asked for
@@ -612,6 +622,106 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def group_main(args):
+    """--driver group: the same sweep, the same line, from ONE process through celeste_group_* -- the reference's own shape
+    (N workers inside one process, ParallelRun.jl:546-607).  `ranks_seen` is ncclCommCount of the library's communicator."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if args.dtype is None:
+        args.dtype = "f32" if args.config == 5 else "f64"
+    if args.steps is None:
+        args.steps = 200 if args.config == 3 else 10
+    if args.sources is None:
+        args.sources = 2000 if args.config == 3 else 30000
+    if args.seed is None:
+        args.seed = 3 if args.config == 3 else 5
+    import torch
+    from celeste_jl_amd import cabi
+    from celeste_jl_amd.group import FieldGroup
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    cabi.load_library()
+    devices = [int(x) for x in args.group_devices.split(",")] if args.group_devices else list(range(args.gpus))
+    if len(devices) != args.gpus and not args.group_devices:
+        raise SystemExit("--gpus %d but %d devices" % (args.gpus, len(devices)))
+    if max(devices) >= torch.cuda.device_count():
+        raise SystemExit("--driver group over devices %s: only %d visible" % (devices, torch.cuda.device_count()))
+    flags = FLAGS_ALL | (cabi.FLAG_FP32 if args.dtype == "f32" else 0)
+    if args.config == 3:
+        fld = build_field(args.height, args.width, args.sources, args.seed)
+    else:
+        fld = build_multifield(tuple(int(x) for x in args.grid.split(",")), args.height, args.width, args.sources, args.seed)
+    S = len(fld.catalog)
+    targets = np.arange(S, dtype=np.int32)
+    g = FieldGroup(fld.images, fld.patches, fld.neighbors, devices=devices)
+    info = g.info()
+    g.plan(fld.vp, targets, flags)                       # everything resident: table, shards, gather blocks
+    sizes, costs = g.shard_sizes()
+    for _ in range(args.warmup):
+        g.sweep()
+    g.wait()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.sweep()
+    g.wait()
+    dt = time.perf_counter() - t0
+    v, d, _, cnt, st = g.results(hessians=False)
+    assert (st == 0).all() and np.isfinite(v).all() and np.isfinite(d).all()
+    if args.check_dir:
+        os.makedirs(args.check_dir, exist_ok=True)
+        np.savez(os.path.join(args.check_dir, "group.npz"), v=v, d=d)
+    g.enable_timing(True)
+    kms, ev_ms, ga_ms = [], [], []
+    for _ in range(min(20, max(3, args.steps))):
+        g.sweep()
+        g.wait()
+        kms.append(g.last_kernel_ms(0))
+        a, b = g.last_sweep_ms()
+        ev_ms.append(a); ga_ms.append(b)
+    g.enable_timing(False)
+    kms = np.array(kms).mean(axis=0)
+    ev_ms, ga_ms = np.array(ev_ms).mean(axis=0), np.array(ga_ms).mean(axis=0)
+    pixel_visits = int(cnt[:, 0].sum())
+    facts = profile_facts() or {}
+    fpp = facts.get("flops_per_pixel_visit_f32" if args.dtype == "f32" else "flops_per_pixel_visit")
+    peak_fl = FP32_VECTOR_PEAK_TFLOPS if args.dtype == "f32" else FP64_VECTOR_PEAK_TFLOPS
+    # member 0's share of the visits (its launch is the one timed), by shard cost
+    visits0 = pixel_visits * costs[0] / max(1, sum(costs))
+    n = len(devices)
+    out = {"metric": "sources/sec (ELBO value+gradient+Hessian+KL per target source)",
+           "value": S / (dt / args.steps), "unit": "sources/sec", "n_gpus": info["n_devices"], "ranks_seen": info["rccl_ranks"],
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "timing_method": "wall clock around K celeste_group_sweep calls between two celeste_group_sweep_wait (all members' "
+                            "streams drained, every catalog gather complete); kernels_ms: HIP events in a pass of its own",
+           "config": {"workload": ("BASELINE.json configs[%d]: synthetic %dx%dx5 field, %d sources, %s, one process, %d group "
+                                   "member(s) on devices %s" % (2 if n == 1 else 3, args.height, args.width, S, args.dtype, n, devices))
+                      if args.config == 3 else "BASELINE.json configs[4] through a device group of %d member(s) on %s" % (n, devices),
+                      "driver": "group (celeste_group_*: one process, worker thread + stream per member, images replicated, "
+                                "targets sharded by estimate_time, one all-gather of (v, d, counters, status) per sweep)",
+                      "sources_per_step": S, "shard_sizes": sizes, "shard_costs": costs,
+                      "gather_backend": info["exchange"], "members": n, "devices": devices,
+                      "catalog_gather_bytes_per_step": n * (max(sizes) * 47 + (max(sizes) + 1) // 2) * 8,
+                      "pixel_visits_per_sweep": pixel_visits,
+                      "member_eval_ms": [float(x) for x in ev_ms], "member_gather_ms": [float(x) for x in ga_ms]},
+           "kernels_ms": {"prep": float(kms[0]), "pixel": float(kms[1]), "lift": float(kms[2])}}
+    if fpp:
+        fl = fpp * visits0 / (kms[1] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "fp32_valu" if args.dtype == "f32" else "fp64_valu", "achieved": fl, "peak": peak_fl,
+                           "unit": "TFLOP/s", "frac": fl / peak_fl, "traffic": None, "kernel_ms": float(kms[1]),
+                           "kernel": "pixel_kernel<2, %s>" % ("float" if args.dtype == "f32" else "double"),
+                           "note": "member 0's launch; its share of the pixel visits by shard cost"}
+    if not args.no_cpu_baseline and n == 1 and args.config == 3:
+        out["cpu_baseline"] = cpu_baseline(g.problem, fld.vp, targets)
+    g.close()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
 
 def conflict_free_layer(fld, S, n):

@@ -67,6 +67,15 @@ class OptimConfigT(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class GroupInfoT(C.Structure):
+    """celeste_group_info_t"""
+    _fields_ = [("n_members", C.c_int32), ("n_devices", C.c_int32), ("exchange", C.c_int32), ("rccl_ranks", C.c_int32),
+                ("devices", C.c_int32 * 16)]
+
+
+EXCHANGE_RCCL, EXCHANGE_PEER_COPY = 1, 2
+
+
 class CelesteError(RuntimeError):
     def __init__(self, status: int, msg: str):
         super().__init__("celeste_mi355x status %d: %s" % (status, msg))
@@ -82,8 +91,12 @@ EXPORTED_SYMBOLS = [
     "celeste_images_create", "celeste_images_destroy", "celeste_ctx_create_on",
     "celeste_host_alloc", "celeste_host_free", "celeste_host_register", "celeste_host_unregister",
     "celeste_maximize_batch_device", "celeste_joint_infer",
+    "celeste_group_create", "celeste_group_destroy", "celeste_group_info", "celeste_group_elbo_eval_batch",
+    "celeste_group_sweep_plan", "celeste_group_sweep", "celeste_group_sweep_wait", "celeste_group_sweep_results",
+    "celeste_group_shard_sizes", "celeste_group_enable_timing", "celeste_group_last_sweep_ms", "celeste_group_last_kernel_ms",
+    "celeste_group_maximize_batch", "celeste_group_joint_infer",
 ]
-ABI_VERSION = 200   # CELESTE_ABI_VERSION of include/celeste_mi355x.h these structs were written against
+ABI_VERSION = 210   # CELESTE_ABI_VERSION of include/celeste_mi355x.h these structs were written against
 
 _lib = None
 
@@ -154,6 +167,25 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.celeste_host_free.restype = None
     lib.celeste_host_register.argtypes = [vp, C.c_size_t]
     lib.celeste_host_unregister.argtypes = [vp]
+    c_float_p_ = C.POINTER(C.c_float)
+    lib.celeste_group_create.argtypes = [C.POINTER(ProblemT), C.c_int32, c_int32_p, C.POINTER(vp)]
+    lib.celeste_group_destroy.argtypes = [vp]
+    lib.celeste_group_destroy.restype = None
+    lib.celeste_group_info.argtypes = [vp, C.POINTER(GroupInfoT)]
+    lib.celeste_group_elbo_eval_batch.argtypes = [vp, c_double_p, C.c_int32, c_int32_p, C.c_uint32, c_double_p, c_double_p,
+                                                  c_double_p, c_int64_p, c_int32_p]
+    lib.celeste_group_sweep_plan.argtypes = [vp, c_double_p, C.c_int32, c_int32_p, C.c_uint32]
+    lib.celeste_group_sweep.argtypes = [vp]
+    lib.celeste_group_sweep_wait.argtypes = [vp]
+    lib.celeste_group_sweep_results.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_int64_p, c_int32_p]
+    lib.celeste_group_shard_sizes.argtypes = [vp, c_int32_p, c_int64_p]
+    lib.celeste_group_enable_timing.argtypes = [vp, C.c_int]
+    lib.celeste_group_last_sweep_ms.argtypes = [vp, c_float_p_, c_float_p_]
+    lib.celeste_group_last_kernel_ms.argtypes = [vp, C.c_int32, c_float_p_]
+    lib.celeste_group_maximize_batch.argtypes = [vp, c_double_p, c_double_p, c_double_p, C.c_int32, c_int32_p,
+                                                 C.POINTER(OptimConfigT), c_int32_p, c_int32_p, c_double_p, c_int32_p]
+    lib.celeste_group_joint_infer.argtypes = [vp, c_double_p, C.c_int32, C.c_int32, c_int64_p, c_int64_p, c_int32_p, c_double_p,
+                                              C.POINTER(OptimConfigT), c_int32_p, c_int32_p, c_double_p, c_int32_p, c_int64_p]
     _lib = lib
     return lib
 

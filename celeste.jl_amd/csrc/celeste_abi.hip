@@ -17,6 +17,8 @@
 #include "optim_kernels.h"
 #include "fused_kernels.h"
 
+struct celeste_group;
+
 // Evaluation batches of up to this many targets run eval_fused_kernel (launch_eval): a batch whose chunk records fit the
 // chip in one round of 256-thread workgroups is latency-bound, and four wavefronts per record + the lift in the same
 // launch shorten its critical path.  Beyond that the chip is full and pixel_kernel's one wavefront per record (its
@@ -1660,11 +1662,17 @@ cleanup:
 // ---- joint inference as ONE launch: the schedule's entries as a dataflow (fused_kernels.h, joint mode) ----------------
 #define JOINT_DATAFLOW_MAX 262144
 // *ran = false (and CELESTE_OK): the schedule does not fit the launch's encodings -- the caller runs it layer by layer
-static int joint_dataflow(celeste_ctx_t *c, int64_t total, const int32_t *targets, const int32_t *d_all, const double *d_pos,
+// d_table: the parameter table the schedule runs against (n_sources x 44, HBM); d_restore: a device copy of it as it was on
+// entry (the launch may give up half way -- queue capacity -- and the layered driver then starts from the entry state)
+static int joint_dataflow(celeste_ctx_t *c, double *d_table, const double *d_restore, int64_t total, const int32_t *targets,
+                          const int32_t *d_all, const double *d_pos,
                           const OptParams &op, uint32_t flags, int32_t *d_it, int32_t *d_ev, double *d_el, int32_t *d_stt,
                           hipStream_t stream, bool *ran) {
     *ran = false;
     const int E = (int)total;
+    // a flattened schedule too large for one batch's index space (launch_eval's n_targets x M x CH bound) is a limit of THIS
+    // driver, not of the call: the caller runs it layer by layer.  Every other CELESTE_ERR_INVALID_ARG below is an error.
+    if ((size_t)E * c->M * c->CH > 0x7fffffffull) return CELESTE_OK;
     auto &ob = c->opt;
     auto &fb = c->fused;
     // An entry waits for the last earlier entry that wrote a row it reads -- its source's, its neighbours' -- and for
@@ -1725,25 +1733,23 @@ static int joint_dataflow(celeste_ctx_t *c, int64_t total, const int32_t *target
     JD_TRY(hipMemsetAsync(d_rarr, 0, (size_t)E * sizeof(int32_t), stream));
     // the batch's bookkeeping for all entries (visit items, record offsets), every source's tables and shape derivatives
     // from the input table; the entries refresh them as they end
-    rc = optim_render(c, ob.d_vp, E, d_all, n_chunks, stream);
-    // (a flattened schedule too large for one batch's index space is a limit of THIS driver, not of the call: the caller
-    // runs it layer by layer -- nothing has touched the table yet)
-    if (rc == CELESTE_ERR_INVALID_ARG) { rc = CELESTE_OK; goto out; }
+    rc = optim_render(c, d_table, E, d_all, n_chunks, stream);
     if (rc != CELESTE_OK) goto out;
     {
         JD_TRY(hipMemsetAsync(ob.d_T, 0xFF, (size_t)E * TRI_STATE * sizeof(double), stream));
         JointLaunch J = {d_dep, d_succ_off, d_succ, d_rarr, fb.d_saved, d_pos, gshift, groups};
-        rc = optim_run_fused(c, ob.d_vp, E, d_all, n_chunks, op, flags, stream, &J);
+        rc = optim_run_fused(c, d_table, E, d_all, n_chunks, op, flags, stream, &J);
         if (rc != CELESTE_OK) goto out;
         // (failed entries gave their rows back in flight: no saved rows here)
         hipLaunchKernelGGL(optim_finalize_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, stream, (const OptState *)ob.d_state,
-                           d_all, E, ob.d_vp, (const double *)nullptr, d_it, d_ev, d_el, d_stt, fb.d_q_ctl);
+                           d_all, E, d_table, (const double *)nullptr, d_it, d_ev, d_el, d_stt, fb.d_q_ctl);
         JD_TRY(hipGetLastError());
         JD_TRY(hipStreamSynchronize(stream));      // (the host vectors above are in flight until here)
         if (fb.h_ctl && fb.h_ctl[FQC_ABORT] == 2) {
             // the launch ran out of queue capacity (a time-out stays an error: something is wrong with the device): the
-            // table is partly optimised -- put the caller's table back and let the layered driver run the schedule
-            JD_TRY(hipMemcpyAsync(ob.d_vp, ob.h_vp, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyHostToDevice, stream));
+            // table is partly optimised -- put the entry state back and let the layered driver run the schedule
+            JD_TRY(hipMemcpyAsync(d_table, d_restore, (size_t)c->S * CEL_P * sizeof(double), hipMemcpyDefault, stream));
+            fb.h_ctl[FQC_ABORT] = 0;               // (the layered driver's own launches set it again if THEY give up)
             goto out;
         }
         *ran = true;
@@ -1755,13 +1761,12 @@ out:
 }
 
 // ---- joint inference: a schedule of layers against one device-resident parameter table -------------------------
-extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layers, const int64_t *layer_offsets,
-                                   const int32_t *layer_targets, const double *pos_centers,
-                                   const celeste_optim_config_t *cfg_in, int32_t *iterations, int32_t *f_evals,
-                                   double *elbo, int32_t *status) {
-    if (!c || !vp || n_layers < 0 || (n_layers > 0 && (!layer_offsets || !layer_targets))) return CELESTE_ERR_INVALID_ARG;
-    if (n_layers == 0) return CELESTE_OK;
-    if (layer_offsets[0] != 0) return CELESTE_ERR_INVALID_ARG;
+// The schedule against the table at d_table (n_sources x 44, HBM, updated in place).  d_entry: a device snapshot of the
+// table as it is on entry, or nullptr -- then ob.h_vp (page-locked) must hold it.  Blocks until the schedule is done; the
+// per-entry outputs are host pointers (may be NULL).
+static int joint_run(celeste_ctx_t *c, double *d_table, const double *d_entry, int32_t n_layers, const int64_t *layer_offsets,
+                     const int32_t *layer_targets, const double *pos_centers, const celeste_optim_config_t *cfg_in,
+                     int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status, bool validate) {
     const int64_t total = layer_offsets[n_layers];
     size_t widest = 0;
     std::vector<uint8_t> seen;
@@ -1769,11 +1774,12 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
     for (int l = 0; l < n_layers; ++l) {
         const int64_t lo = layer_offsets[l], hi = layer_offsets[l + 1];
         if (hi < lo || hi - lo > 0x7fffffff) return CELESTE_ERR_INVALID_ARG;
-        if (check_distinct_targets(c, (int32_t)(hi - lo), layer_targets + lo, seen) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
+        if (validate && check_distinct_targets(c, (int32_t)(hi - lo), layer_targets + lo, seen) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
         // the sources of a layer are optimised simultaneously: none may be another's neighbour
         for (int64_t e = lo; e < hi; ++e) {
             const int t = layer_targets[e];
-            for (int64_t q = c->h_nbr_off[t]; q < c->h_nbr_off[t + 1]; ++q) if (seen[c->h_nbr_idx[q]]) return CELESTE_ERR_INVALID_ARG;
+            if (validate)
+                for (int64_t q = c->h_nbr_off[t]; q < c->h_nbr_off[t + 1]; ++q) if (seen[c->h_nbr_idx[q]]) return CELESTE_ERR_INVALID_ARG;
             layer_chunks[l] += c->h_src_chunks[t];
         }
         widest = std::max(widest, (size_t)(hi - lo));
@@ -1796,7 +1802,6 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
     rc = optim_buffers(c, dataflow ? (size_t)total : widest, stream);
     if (rc != CELESTE_OK) return rc;
     auto &ob = c->opt;
-    const size_t vp_bytes = (size_t)c->S * CEL_P * sizeof(double);
     // the whole schedule and the per-entry outputs live on the device for the duration of the call
     int32_t *d_all = nullptr, *d_it = nullptr, *d_ev = nullptr, *d_stt = nullptr;
     double *d_pos = nullptr, *d_el = nullptr;
@@ -1813,11 +1818,10 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
     if (pos_centers) JI_TRY(scratch_get(c, 18, (size_t)total * 2 * sizeof(double), &d_pos));
     JI_TRY(hipMemcpyAsync(d_all, layer_targets, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     if (pos_centers) JI_TRY(hipMemcpyAsync(d_pos, pos_centers, (size_t)total * 2 * sizeof(double), hipMemcpyHostToDevice, stream));
-    memcpy(ob.h_vp, vp, vp_bytes);
-    JI_TRY(hipMemcpyAsync(ob.d_vp, ob.h_vp, vp_bytes, hipMemcpyHostToDevice, stream));
     if (dataflow) {
         // one launch for the whole schedule (fused_kernels.h, joint mode)
-        rc = joint_dataflow(c, total, layer_targets, d_all, d_pos, op, flags, d_it, d_ev, d_el, d_stt, stream, &dataflow);
+        rc = joint_dataflow(c, d_table, d_entry ? d_entry : ob.h_vp, total, layer_targets, d_all, d_pos, op, flags, d_it, d_ev,
+                            d_el, d_stt, stream, &dataflow);
         if (rc != CELESTE_OK) goto done;
         any_fused = dataflow;
     }
@@ -1827,15 +1831,14 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
         const int32_t n = (int32_t)(layer_offsets[l + 1] - lo);
         if (n == 0) continue;
         // every layer sees the table as the layers before it left it (ParallelRun.jl:372-397)
-        rc = optim_render(c, ob.d_vp, n, d_all + lo, layer_chunks[l], stream);
+        rc = optim_render(c, d_table, n, d_all + lo, layer_chunks[l], stream);
         if (rc != CELESTE_OK) goto done;
         bool fused = false;
-        rc = optim_run(c, ob.d_vp, d_pos ? d_pos + 2 * lo : nullptr, n, d_all + lo, layer_chunks[l], op, flags, d_it + lo,
+        rc = optim_run(c, d_table, d_pos ? d_pos + 2 * lo : nullptr, n, d_all + lo, layer_chunks[l], op, flags, d_it + lo,
                        d_ev + lo, d_el + lo, d_stt + lo, stream, &fused);
         if (rc != CELESTE_OK) goto done;
         any_fused |= fused;
     }
-    JI_TRY(hipMemcpyAsync(ob.h_vp, ob.d_vp, vp_bytes, hipMemcpyDeviceToHost, stream));
     JI_TRY(hipMemcpyAsync(h_it.data(), d_it, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     JI_TRY(hipMemcpyAsync(h_ev.data(), d_ev, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     JI_TRY(hipMemcpyAsync(h_st.data(), d_stt, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -1851,10 +1854,37 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
         if (h_st[e] != CELESTE_OK && rc == CELESTE_OK) rc = h_st[e];
     }
     if (abort_rc != CELESTE_OK) rc = abort_rc;
-    else memcpy(vp, ob.h_vp, vp_bytes);   // failed targets already hold their pre-layer rows (optim_finalize_kernel)
 done:
 #undef JI_TRY
     (void)hipStreamSynchronize(stream);
+    return rc;
+}
+
+extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layers, const int64_t *layer_offsets,
+                                   const int32_t *layer_targets, const double *pos_centers,
+                                   const celeste_optim_config_t *cfg_in, int32_t *iterations, int32_t *f_evals,
+                                   double *elbo, int32_t *status) {
+    if (!c || !vp || n_layers < 0 || (n_layers > 0 && (!layer_offsets || !layer_targets))) return CELESTE_ERR_INVALID_ARG;
+    if (n_layers == 0) return CELESTE_OK;
+    if (layer_offsets[0] != 0) return CELESTE_ERR_INVALID_ARG;
+    if (layer_offsets[n_layers] == 0) return CELESTE_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // vp is uploaded once, stays in HBM across all layers and is written back at the end
+    int rc = optim_buffers(c, 1, c->stream);
+    if (rc != CELESTE_OK) return rc;
+    auto &ob = c->opt;
+    const size_t vp_bytes = (size_t)c->S * CEL_P * sizeof(double);
+    memcpy(ob.h_vp, vp, vp_bytes);
+    HIP_TRY(hipMemcpyAsync(ob.d_vp, ob.h_vp, vp_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = joint_run(c, ob.d_vp, nullptr, n_layers, layer_offsets, layer_targets, pos_centers, cfg_in, iterations, f_evals, elbo,
+                   status, true);
+    // failed targets already hold their pre-layer rows (optim_finalize_kernel); a launch that gave up leaves vp untouched
+    if (rc == CELESTE_OK || rc == CELESTE_ERR_NONFINITE_INPUT || rc == CELESTE_ERR_NONFINITE_RESULT) {
+        double *const h_out = ob.h_vp + (size_t)c->S * CEL_P;
+        if (hipMemcpyAsync(h_out, ob.d_vp, vp_bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) return CELESTE_ERR_HIP;
+        memcpy(vp, h_out, vp_bytes);
+    }
     return rc;
 }
 
@@ -1974,3 +2004,6 @@ extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = CELESTE_ERR_HIP;
     return rc;
 }
+
+// ---- one process, N devices (celeste_group_*) ----------------------------------------------------------------------
+#include "group.h"

@@ -1,0 +1,806 @@
+// group.h -- one process, N devices: the source-partition loop of the reference behind the C ABI.
+//
+// The reference drains one source list with N workers inside one process (one_node_single_infer, ParallelRun.jl:546-607;
+// process_sources_dynamic!, :302-369).  A celeste_group_t is that loop over HIP devices: the images are replicated on every
+// member device (one celeste_ctx_t each), a call's targets are cost-sharded over the members (estimate_time = sum of active
+// pixels, ParallelRun.jl:45-56, longest first onto the least loaded member), every member runs on its own worker thread
+// and stream, and the per-source results are exchanged with ONE ncclAllGather (RCCL over xGMI) on communicators from
+// ncclCommInitAll -- the "catalog gather", the only exchange of the path.  Included by celeste_abi.hip (one translation unit).
+//
+// Exchange modes: RCCL when the members sit on distinct devices (also a group of one: the collective then runs with one
+// rank); PEER -- plain hipMemcpyAsync between the members' buffers -- when a device appears twice (RCCL refuses duplicate
+// devices in one communicator).  PEER exists so that the shard / gather bookkeeping can be exercised on a one-GPU box; both
+// modes fill the same buffers with the same bytes.
+#pragma once
+#include <rccl/rccl.h>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#define GROUP_MAX_MEMBERS 16
+enum { GROUP_EXCHANGE_RCCL = 1, GROUP_EXCHANGE_PEER = 2 };
+
+#define GROUP_ROW (CEL_P + 5)      // optimiser exchange row: {target, iterations, f_evals, elbo, status, theta[44]}
+#define GROUP_JROW (CEL_P + 1)     // joint exchange row: {target, theta[44]}
+
+// rows of the member's own targets -> its exchange block
+__global__ void group_pack_kernel(const double *__restrict__ vp, const int32_t *__restrict__ targets, int n,
+                                  const int32_t *__restrict__ it, const int32_t *__restrict__ ev, const double *__restrict__ el,
+                                  const int32_t *__restrict__ st, double *__restrict__ block, int row) {
+    const int i = blockIdx.x, k = threadIdx.x;
+    if (i >= n) return;
+    const int t = targets[i];
+    double *out = block + (size_t)i * row;
+    const int head = row - CEL_P;
+    if (k == 0) {
+        out[0] = (double)t;
+        if (head > 1) { out[1] = it ? (double)it[i] : 0.0; out[2] = ev ? (double)ev[i] : 0.0; out[3] = el ? el[i] : 0.0; out[4] = st ? (double)st[i] : 0.0; }
+    }
+    if (k < CEL_P) out[head + k] = vp[(size_t)t * CEL_P + k];
+}
+
+// the other members' rows -> this member's table (its own rows are already there)
+struct GroupCounts { int n[GROUP_MAX_MEMBERS]; };
+__global__ void group_scatter_kernel(double *__restrict__ vp, const double *__restrict__ gathered, GroupCounts cnt, int n_members,
+                                     int self, int width, int row) {
+    const int j = blockIdx.y, i = blockIdx.x, k = threadIdx.x;
+    if (j == self || j >= n_members || i >= cnt.n[j] || k >= CEL_P) return;
+    const double *in = gathered + ((size_t)j * width + i) * row;
+    const int t = (int)in[0];
+    vp[(size_t)t * CEL_P + k] = in[row - CEL_P + k];
+}
+
+struct GroupMember {
+    int index = 0, device = 0;
+    celeste_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;             // the catalog gather of sweep k overlaps the kernels of sweep k + 1
+    hipEvent_t done[2] = {}, buf_free[2] = {}, t0 = nullptr, t1 = nullptr, t2 = nullptr;
+    // device
+    double *d_vp = nullptr, *d_vp_nbr = nullptr, *d_entry = nullptr;   // S x 44 tables
+    int32_t *d_targets = nullptr;
+    double *d_pos = nullptr;
+    int32_t *d_it = nullptr, *d_ev = nullptr, *d_st = nullptr;
+    double *d_el = nullptr;
+    size_t tgt_cap = 0;
+    double *d_block[2] = {nullptr, nullptr}, *d_gathered = nullptr, *d_h = nullptr;
+    size_t block_cap = 0, gathered_cap = 0, h_cap = 0;
+    // page-locked host
+    double *p_gathered = nullptr, *p_h = nullptr;
+    size_t p_gathered_cap = 0, p_h_cap = 0;
+    // this call's shard
+    std::vector<int32_t> idx;        // positions in the caller's target list, ascending
+    std::vector<int32_t> tg;         // the targets themselves
+    int64_t n_chunks = 0;
+    // worker thread
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> task;
+    bool has_task = false, busy = false, quit = false;
+    int result = CELESTE_OK;
+};
+
+struct celeste_group {
+    int n = 0, n_devices = 0, exchange = 0, rccl_ranks = 0;
+    int S = 0;
+    std::vector<GroupMember *> mem;
+    std::vector<celeste_images *> images;      // one handle per distinct device
+    std::vector<int64_t> cost;                 // per source: estimate_time
+    double *p_vp = nullptr, *p_vp_nbr = nullptr;   // page-locked S x 44 (portable: every member DMAs from it)
+    bool threads = false;
+    // peer-mode barrier
+    std::mutex bmu; std::condition_variable bcv; int b_count = 0; uint64_t b_gen = 0;
+    // the planned sweep
+    int32_t plan_n = 0; uint32_t plan_flags = 0; int plan_width = 0; size_t plan_blk = 0; uint64_t sweep_k = 0; bool planned = false;
+    bool timing = false;
+    std::atomic<int> abort_rc{0};              // joint inference: a member's launch failed -- every member leaves after the exchange
+    std::mutex call_mu;                        // one call per group at a time
+};
+
+static void group_barrier(celeste_group *g) {
+    if (g->n <= 1) return;
+    std::unique_lock<std::mutex> lk(g->bmu);
+    const uint64_t gen = g->b_gen;
+    if (++g->b_count == g->n) { g->b_count = 0; ++g->b_gen; g->bcv.notify_all(); }
+    else g->bcv.wait(lk, [&] { return g->b_gen != gen; });
+}
+
+static void group_worker(GroupMember *m) {
+    (void)hipSetDevice(m->device);
+    std::unique_lock<std::mutex> lk(m->mu);
+    for (;;) {
+        m->cv.wait(lk, [&] { return m->has_task || m->quit; });
+        if (m->quit) return;
+        std::function<int()> fn = std::move(m->task);
+        m->has_task = false;
+        lk.unlock();
+        const int r = fn();
+        lk.lock();
+        if (m->result == CELESTE_OK) m->result = r;      // (sticky until the next join: sweeps are dispatched back to back)
+        m->busy = false;
+        m->cv.notify_all();
+    }
+}
+
+// fn(member) on every member, concurrently; dispatch returns at once, join returns the first non-OK status
+static void group_dispatch(celeste_group *g, const std::function<int(GroupMember *)> &fn) {
+    for (GroupMember *m : g->mem) {
+        if (!g->threads) { (void)hipSetDevice(m->device); const int r = fn(m); if (m->result == CELESTE_OK) m->result = r; continue; }
+        std::unique_lock<std::mutex> lk(m->mu);
+        m->cv.wait(lk, [&] { return !m->busy; });
+        m->task = [fn, m] { return fn(m); };
+        m->has_task = true; m->busy = true;
+        m->cv.notify_all();
+    }
+}
+static int group_join(celeste_group *g) {
+    int rc = CELESTE_OK;
+    for (GroupMember *m : g->mem) {
+        if (g->threads) { std::unique_lock<std::mutex> lk(m->mu); m->cv.wait(lk, [&] { return !m->busy; }); }
+        if (m->result != CELESTE_OK && rc == CELESTE_OK) rc = m->result;
+        m->result = CELESTE_OK;
+    }
+    return rc;
+}
+static int group_run(celeste_group *g, const std::function<int(GroupMember *)> &fn) { group_dispatch(g, fn); return group_join(g); }
+
+#define NCCL_TRY(expr)                                                                                                   \
+    do {                                                                                                                 \
+        ncclResult_t r__ = (expr);                                                                                       \
+        if (r__ != ncclSuccess) {                                                                                        \
+            fprintf(stderr, "celeste_mi355x: %s failed: %s (%s:%d)\n", #expr, ncclGetErrorString(r__), __FILE__, __LINE__); \
+            return CELESTE_ERR_HIP;                                                                                      \
+        }                                                                                                                \
+    } while (0)
+
+template <class T>
+static int group_grow(T **p, size_t *cap, size_t n, hipStream_t drain) {
+    if (n <= *cap && *p) return CELESTE_OK;
+    if (*p) { if (drain) HIP_TRY(hipStreamSynchronize(drain)); (void)hipFree(*p); *p = nullptr; }
+    *cap = 0;
+    HIP_TRY(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    *cap = std::max<size_t>(n, 1);
+    return CELESTE_OK;
+}
+template <class T>
+static int group_grow_pinned(T **p, size_t *cap, size_t n) {
+    if (n <= *cap && *p) return CELESTE_OK;
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; }
+    *cap = 0;
+    HIP_TRY(hipHostMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocPortable));
+    *cap = std::max<size_t>(n, 1);
+    return CELESTE_OK;
+}
+
+// the member's block (count doubles at `send`) to slot `index` of every member's gathered buffer, on `stream`
+static int group_exchange(celeste_group *g, GroupMember *m, const double *send, size_t count, hipStream_t stream) {
+    if (g->exchange == GROUP_EXCHANGE_RCCL) {
+        NCCL_TRY(ncclAllGather(send, m->d_gathered, count, ncclDouble, m->comm, stream));
+        return CELESTE_OK;
+    }
+    for (GroupMember *o : g->mem)
+        HIP_TRY(hipMemcpyAsync(o->d_gathered + (size_t)m->index * count, send, count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    return CELESTE_OK;
+}
+
+extern "C" void celeste_group_destroy(celeste_group_t *g) {
+    if (!g) return;
+    for (GroupMember *m : g->mem) {
+        if (!m) continue;
+        if (m->th.joinable()) {
+            { std::unique_lock<std::mutex> lk(m->mu); m->cv.wait(lk, [&] { return !m->busy; }); m->quit = true; m->cv.notify_all(); }
+            m->th.join();
+        }
+        (void)hipSetDevice(m->device);
+        if (m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
+        if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
+        if (m->comm) (void)ncclCommDestroy(m->comm);
+        void *dp[] = {m->d_vp, m->d_vp_nbr, m->d_entry, m->d_targets, m->d_pos, m->d_it, m->d_ev, m->d_st, m->d_el, m->d_block[0], m->d_block[1],
+                      m->d_gathered, m->d_h};
+        for (void *p : dp) if (p) (void)hipFree(p);
+        if (m->p_gathered) (void)hipHostFree(m->p_gathered);
+        if (m->p_h) (void)hipHostFree(m->p_h);
+        hipEvent_t evs[] = {m->done[0], m->done[1], m->buf_free[0], m->buf_free[1], m->t0, m->t1, m->t2};
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+        if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
+        if (m->ctx) celeste_ctx_destroy(m->ctx);
+        delete m;
+    }
+    for (celeste_images *im : g->images) images_release(im);
+    if (g->p_vp) (void)hipHostFree(g->p_vp);
+    if (g->p_vp_nbr) (void)hipHostFree(g->p_vp_nbr);
+    delete g;
+}
+
+extern "C" int celeste_group_create(const celeste_problem_t *pr, int32_t n_members, const int32_t *devices, celeste_group_t **out) {
+    if (!pr || !out || n_members < 1 || n_members > GROUP_MAX_MEMBERS) return CELESTE_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return CELESTE_ERR_NO_DEVICE; }
+    std::vector<int> dev((size_t)n_members);
+    for (int r = 0; r < n_members; ++r) {
+        dev[r] = devices ? devices[r] : r;
+        if (dev[r] < 0 || dev[r] >= count) return CELESTE_ERR_INVALID_ARG;
+    }
+    celeste_group *g = new (std::nothrow) celeste_group();
+    if (!g) return CELESTE_ERR_ALLOC;
+    g->n = n_members; g->S = pr->n_sources;
+    std::vector<int> distinct;
+    for (int d : dev) if (std::find(distinct.begin(), distinct.end(), d) == distinct.end()) distinct.push_back(d);
+    g->n_devices = (int)distinct.size();
+    g->exchange = g->n_devices == g->n ? GROUP_EXCHANGE_RCCL : GROUP_EXCHANGE_PEER;
+    if (const char *e = getenv("CELESTE_GROUP_EXCHANGE")) {   // "peer": hipMemcpyAsync between the members instead of RCCL (A/B, debugging)
+        if (strcmp(e, "peer") == 0) g->exchange = GROUP_EXCHANGE_PEER;
+    }
+    g->threads = g->n > 1 || (getenv("CELESTE_GROUP_THREADS") && atoi(getenv("CELESTE_GROUP_THREADS")) == 1);
+#define GR_TRY(expr) do { int s__ = (expr); if (s__ != CELESTE_OK) { celeste_group_destroy(g); return s__; } } while (0)
+#define GR_HIP(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); celeste_group_destroy(g); return CELESTE_ERR_HIP; } } while (0)
+    // the planes once per distinct device; every member gets its own context (tables, scratch, stream) on them
+    for (int d : distinct) {
+        celeste_images *im = nullptr;
+        GR_TRY(celeste_images_create(pr->n_images, pr->images, d, &im));
+        g->images.push_back(im);
+    }
+    for (int r = 0; r < g->n; ++r) {
+        GroupMember *m = new (std::nothrow) GroupMember();
+        if (!m) { celeste_group_destroy(g); return CELESTE_ERR_ALLOC; }
+        m->index = r; m->device = dev[r];
+        g->mem.push_back(m);
+    }
+    if (g->threads) for (GroupMember *m : g->mem) m->th = std::thread(group_worker, m);
+    {
+        // the contexts in parallel (spline prefilter, work-item lists: host time per member)
+        int rc = group_run(g, [&](GroupMember *m) -> int {
+            const size_t k = (size_t)(std::find(distinct.begin(), distinct.end(), m->device) - distinct.begin());
+            int st = celeste_ctx_create_on(g->images[k], pr, &m->ctx);
+            if (st != CELESTE_OK) return st;
+            HIP_TRY(hipSetDevice(m->device));
+            HIP_TRY(hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
+            for (int k2 = 0; k2 < 2; ++k2) {
+                HIP_TRY(hipEventCreateWithFlags(&m->done[k2], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&m->buf_free[k2], hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventCreate(&m->t0)); HIP_TRY(hipEventCreate(&m->t1)); HIP_TRY(hipEventCreate(&m->t2));
+            const size_t tb = (size_t)m->ctx->S * CEL_P * sizeof(double);
+            HIP_TRY(hipMalloc((void **)&m->d_vp, tb));
+            HIP_TRY(hipMalloc((void **)&m->d_vp_nbr, tb));
+            HIP_TRY(hipMalloc((void **)&m->d_entry, tb));
+            return CELESTE_OK;
+        });
+        if (rc != CELESTE_OK) { celeste_group_destroy(g); return rc; }
+    }
+    if (g->exchange == GROUP_EXCHANGE_RCCL) {
+        std::vector<ncclComm_t> comms((size_t)g->n);
+        ncclResult_t r = ncclCommInitAll(comms.data(), g->n, dev.data());
+        if (r != ncclSuccess) {
+            fprintf(stderr, "celeste_mi355x: ncclCommInitAll over %d device(s) failed: %s\n", g->n, ncclGetErrorString(r));
+            celeste_group_destroy(g); return CELESTE_ERR_HIP;
+        }
+        for (int k = 0; k < g->n; ++k) g->mem[k]->comm = comms[k];
+        if (ncclCommCount(comms[0], &g->rccl_ranks) != ncclSuccess) g->rccl_ranks = 0;
+    } else if (g->n_devices > 1) {
+        for (GroupMember *m : g->mem) {   // PEER between distinct devices: direct access where the fabric offers it
+            GR_HIP(hipSetDevice(m->device));
+            for (int d : distinct) if (d != m->device) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->device, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0); (void)hipGetLastError(); }
+        }
+    }
+    // estimate_time per source (ParallelRun.jl:45-47): the pixels of its patches
+    {
+        const celeste_ctx *c = g->mem[0]->ctx;
+        g->cost.assign((size_t)c->S, 0);
+        for (int s = 0; s < c->S; ++s)
+            for (int v = c->h_vis_off[s]; v < c->h_vis_off[s + 1]; ++v) g->cost[s] += (int64_t)c->h_patches[v].H2 * c->h_patches[v].W2;
+    }
+    const size_t tn = (size_t)g->S * CEL_P;
+    GR_HIP(hipHostMalloc((void **)&g->p_vp, tn * sizeof(double), hipHostMallocPortable));
+    GR_HIP(hipHostMalloc((void **)&g->p_vp_nbr, tn * sizeof(double), hipHostMallocPortable));
+#undef GR_TRY
+#undef GR_HIP
+    *out = g;
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_group_info(celeste_group_t *g, celeste_group_info_t *out) {
+    if (!g || !out) return CELESTE_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    out->n_members = g->n; out->n_devices = g->n_devices; out->exchange = g->exchange; out->rccl_ranks = g->rccl_ranks;
+    for (int r = 0; r < g->n; ++r) out->devices[r] = g->mem[r]->device;
+    return CELESTE_OK;
+}
+
+// ---- sharding: longest processing time first onto the least loaded member (partition.shard_targets) ----------------
+// weight[i] of unit i; returns for every member the ascending list of unit indices
+static void group_lpt(int n_members, const std::vector<int64_t> &weight, std::vector<std::vector<int32_t>> &shards) {
+    const size_t n = weight.size();
+    std::vector<int32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return weight[a] > weight[b]; });
+    std::vector<int64_t> load((size_t)n_members, 0);
+    shards.assign((size_t)n_members, {});
+    for (int32_t i : order) {
+        int k = 0;
+        for (int p = 1; p < n_members; ++p) if (load[p] < load[k]) k = p;
+        shards[k].push_back(i);
+        load[k] += weight[i];
+    }
+    for (auto &s : shards) std::sort(s.begin(), s.end());
+}
+
+static int group_check_targets(celeste_group *g, int32_t n, const int32_t *targets) {
+    if (n < 0 || (n > 0 && !targets)) return CELESTE_ERR_INVALID_ARG;
+    for (int t = 0; t < n; ++t) if (targets[t] < 0 || targets[t] >= g->S) return CELESTE_ERR_INVALID_ARG;
+    return CELESTE_OK;
+}
+
+static void group_shard(celeste_group *g, int32_t n, const int32_t *targets) {
+    std::vector<int64_t> w((size_t)n);
+    for (int t = 0; t < n; ++t) w[t] = g->cost[targets[t]];
+    std::vector<std::vector<int32_t>> shards;
+    group_lpt(g->n, w, shards);
+    for (int r = 0; r < g->n; ++r) {
+        GroupMember *m = g->mem[r];
+        m->idx.swap(shards[r]);
+        m->tg.resize(m->idx.size());
+        m->n_chunks = 0;
+        for (size_t i = 0; i < m->idx.size(); ++i) { m->tg[i] = targets[m->idx[i]]; m->n_chunks += m->ctx->h_src_chunks[m->tg[i]]; }
+    }
+}
+
+// per-target device buffers of a member at capacity >= n
+static int group_target_buffers(GroupMember *m, size_t n) {
+    if (n <= m->tgt_cap && m->d_targets) return CELESTE_OK;
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(m->comm_stream));
+    void **ps[] = {(void **)&m->d_targets, (void **)&m->d_pos, (void **)&m->d_it, (void **)&m->d_ev, (void **)&m->d_st, (void **)&m->d_el};
+    const size_t by[] = {sizeof(int32_t), 2 * sizeof(double), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t), sizeof(double)};
+    m->tgt_cap = 0;
+    for (int k = 0; k < 6; ++k) {
+        if (*ps[k]) { (void)hipFree(*ps[k]); *ps[k] = nullptr; }
+        HIP_TRY(hipMalloc(ps[k], std::max<size_t>(n, 1) * by[k]));
+    }
+    m->tgt_cap = std::max<size_t>(n, 1);
+    return CELESTE_OK;
+}
+
+// ---- the sweep: every member evaluates its shard, then the catalog gather ------------------------------------------
+// block of a member, width W: v[W] | d[W x 44] | counters[W x 2] (int64) | status[W] (int32, padded to doubles)
+static inline size_t sweep_block_doubles(int W) { return (size_t)W * (1 + CEL_P + 2) + ((size_t)W + 1) / 2; }
+
+// nothing of an earlier call is in flight on any member
+static int group_quiesce(celeste_group *g) {
+    int rc = group_join(g);
+    for (GroupMember *m : g->mem) {
+        if (!m->ctx) continue;
+        if (hipSetDevice(m->device) != hipSuccess || hipStreamSynchronize(m->ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(m->comm_stream) != hipSuccess) { (void)hipGetLastError(); if (rc == CELESTE_OK) rc = CELESTE_ERR_HIP; }
+    }
+    return rc;
+}
+
+extern "C" int celeste_group_sweep_plan(celeste_group_t *g, const double *vp, int32_t n_targets, const int32_t *targets,
+                                        uint32_t flags) {
+    if (!g || !vp || n_targets < 1 || (flags & (CELESTE_FLAG_SPLIT))) return CELESTE_ERR_INVALID_ARG;
+    if (group_check_targets(g, n_targets, targets) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    g->planned = false;
+    (void)group_quiesce(g);     // (sweeps of an earlier plan may still be in flight: their buffers are about to move)
+    group_shard(g, n_targets, targets);
+    int W = 1;
+    for (GroupMember *m : g->mem) W = std::max(W, (int)m->idx.size());
+    g->plan_n = n_targets; g->plan_flags = flags; g->plan_width = W; g->plan_blk = sweep_block_doubles(W); g->sweep_k = 0;
+    memcpy(g->p_vp, vp, (size_t)g->S * CEL_P * sizeof(double));
+    const bool want_h = (flags & CELESTE_FLAG_HESS) != 0;
+    const size_t HS = (flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;
+    int rc = group_run(g, [&](GroupMember *m) -> int {
+        HIP_TRY(hipSetDevice(m->device));
+        hipStream_t st = m->ctx->stream;
+        int s1 = group_target_buffers(m, m->tg.size());
+        if (s1 != CELESTE_OK) return s1;
+        const size_t blk = g->plan_blk;
+        if (blk > m->block_cap) {
+            HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipStreamSynchronize(m->comm_stream));
+            for (int k = 0; k < 2; ++k) { if (m->d_block[k]) (void)hipFree(m->d_block[k]); m->d_block[k] = nullptr; }
+            m->block_cap = 0;
+            for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void **)&m->d_block[k], blk * sizeof(double)));
+            m->block_cap = blk;
+        }
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipMemsetAsync(m->d_block[k], 0, blk * sizeof(double), st));
+        s1 = group_grow(&m->d_gathered, &m->gathered_cap, blk * g->n, m->comm_stream);
+        if (s1 == CELESTE_OK && want_h) s1 = group_grow(&m->d_h, &m->h_cap, std::max<size_t>(m->tg.size(), 1) * HS, st);
+        if (s1 != CELESTE_OK) return s1;
+        HIP_TRY(hipMemcpyAsync(m->d_vp, g->p_vp, (size_t)g->S * CEL_P * sizeof(double), hipMemcpyHostToDevice, st));
+        if (!m->tg.empty())
+            HIP_TRY(hipMemcpyAsync(m->d_targets, m->tg.data(), m->tg.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipEventRecord(m->buf_free[k], st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return CELESTE_OK;
+    });
+    g->planned = rc == CELESTE_OK;
+    return rc;
+}
+
+static int group_sweep_member(celeste_group *g, GroupMember *m, int k) {
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = m->ctx->stream;
+    const int W = g->plan_width;
+    double *blk = m->d_block[k];
+    HIP_TRY(hipStreamWaitEvent(st, m->buf_free[k], 0));      // the gather that last read this block is through
+    if (g->timing) HIP_TRY(hipEventRecord(m->t0, st));
+    if (!m->tg.empty()) {
+        int rc = launch_eval(m->ctx, m->d_vp, (int32_t)m->tg.size(), m->d_targets, g->plan_flags, blk, blk + W, m->d_h,
+                             reinterpret_cast<int64_t *>(blk + (size_t)W * (1 + CEL_P)),
+                             reinterpret_cast<int32_t *>(blk + (size_t)W * (1 + CEL_P + 2)), st, true, nullptr, m->n_chunks);
+        if (rc != CELESTE_OK) return rc;
+    }
+    if (g->timing) HIP_TRY(hipEventRecord(m->t1, st));
+    HIP_TRY(hipEventRecord(m->done[k], st));
+    HIP_TRY(hipStreamWaitEvent(m->comm_stream, m->done[k], 0));
+    int rc = group_exchange(g, m, blk, g->plan_blk, m->comm_stream);
+    if (rc != CELESTE_OK) return rc;
+    HIP_TRY(hipEventRecord(m->buf_free[k], m->comm_stream));
+    if (g->timing) HIP_TRY(hipEventRecord(m->t2, m->comm_stream));
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_group_sweep(celeste_group_t *g) {
+    if (!g || !g->planned) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    const int k = (int)(g->sweep_k++ & 1);
+    group_dispatch(g, [g, k](GroupMember *m) -> int { return group_sweep_member(g, m, k); });
+    if (!g->threads) return group_join(g);
+    return CELESTE_OK;     // (errors of the workers surface in celeste_group_sweep_wait)
+}
+
+extern "C" int celeste_group_sweep_wait(celeste_group_t *g) {
+    if (!g) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    // every member's kernels and copies: in PEER mode a member's gathered buffer is written by the OTHER members' streams
+    return group_quiesce(g);
+}
+
+extern "C" int celeste_group_sweep_results(celeste_group_t *g, double *v, double *d, double *h, int64_t *counters, int32_t *status) {
+    if (!g || !g->planned || g->sweep_k == 0) return CELESTE_ERR_INVALID_ARG;
+    int rc = celeste_group_sweep_wait(g);
+    if (rc != CELESTE_OK) return rc;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    const int W = g->plan_width;
+    const size_t blk = g->plan_blk;
+    const uint32_t flags = g->plan_flags;
+    const bool want_h = h && (flags & CELESTE_FLAG_HESS), want_d = d && (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS));
+    const size_t HS = (flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;
+    std::vector<int> worst((size_t)g->n, CELESTE_OK);
+    rc = group_run(g, [&](GroupMember *m) -> int {
+        HIP_TRY(hipSetDevice(m->device));
+        hipStream_t st = m->ctx->stream;
+        // the catalog (values, gradients, counters, status of ALL targets) is on every member: member 0 hands it to the host;
+        // Hessians stay with the member that owns the target and come down from there, all members at once
+        if (m->index == 0) {
+            int s1 = group_grow_pinned(&m->p_gathered, &m->p_gathered_cap, blk * g->n);
+            if (s1 != CELESTE_OK) return s1;
+            HIP_TRY(hipMemcpyAsync(m->p_gathered, m->d_gathered, blk * g->n * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+        const size_t nr = m->tg.size();
+        if (want_h && nr > 0) {
+            int s1 = group_grow_pinned(&m->p_h, &m->p_h_cap, nr * HS);
+            if (s1 != CELESTE_OK) return s1;
+            HIP_TRY(hipMemcpyAsync(m->p_h, m->d_h, nr * HS * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        if (want_h) for (size_t i = 0; i < nr; ++i) memcpy(h + (size_t)m->idx[i] * HS, m->p_h + i * HS, HS * sizeof(double));
+        if (m->index == 0) {
+            for (int r = 0; r < g->n; ++r) {
+                const GroupMember *o = g->mem[r];
+                const double *b = m->p_gathered + (size_t)r * blk;
+                const int64_t *bc = reinterpret_cast<const int64_t *>(b + (size_t)W * (1 + CEL_P));
+                const int32_t *bs = reinterpret_cast<const int32_t *>(b + (size_t)W * (1 + CEL_P + 2));
+                for (size_t i = 0; i < o->idx.size(); ++i) {
+                    const size_t q = (size_t)o->idx[i];
+                    if (v) v[q] = b[i];
+                    if (want_d) memcpy(d + q * CEL_P, b + W + i * CEL_P, CEL_P * sizeof(double));
+                    if (counters) { counters[2 * q] = bc[2 * i]; counters[2 * q + 1] = bc[2 * i + 1]; }
+                    if (status) status[q] = bs[i];
+                    if (bs[i] != CELESTE_OK && worst[0] == CELESTE_OK) worst[0] = bs[i];
+                }
+            }
+        }
+        return CELESTE_OK;
+    });
+    return rc != CELESTE_OK ? rc : worst[0];
+}
+
+extern "C" int celeste_group_enable_timing(celeste_group_t *g, int enable) {
+    if (!g) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    (void)group_quiesce(g);
+    g->timing = enable != 0;
+    for (GroupMember *m : g->mem) (void)celeste_ctx_enable_timing(m->ctx, enable);
+    return CELESTE_OK;
+}
+
+// celeste_ctx_last_kernel_ms of one member's last launch chain (prep / pixel / lift)
+extern "C" int celeste_group_last_kernel_ms(celeste_group_t *g, int32_t member, float ms[3]) {
+    if (!g || member < 0 || member >= g->n || !ms) return CELESTE_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(g->mem[member]->device));
+    return celeste_ctx_last_kernel_ms(g->mem[member]->ctx, ms);
+}
+
+// HIP-event durations of the last sweep, per member: eval_ms[r] = the member's launch chain (its shard), gather_ms[r] = from
+// the end of its chain to the end of its catalog gather.  After celeste_group_sweep_wait.
+extern "C" int celeste_group_last_sweep_ms(celeste_group_t *g, float *eval_ms, float *gather_ms) {
+    if (!g || !g->timing || g->sweep_k == 0) return CELESTE_ERR_INVALID_ARG;
+    for (int r = 0; r < g->n; ++r) {
+        GroupMember *m = g->mem[r];
+        HIP_TRY(hipSetDevice(m->device));
+        float a = 0, b = 0;
+        HIP_TRY(hipEventSynchronize(m->t2));
+        HIP_TRY(hipEventElapsedTime(&a, m->t0, m->t1));
+        HIP_TRY(hipEventElapsedTime(&b, m->t1, m->t2));
+        if (eval_ms) eval_ms[r] = a;
+        if (gather_ms) gather_ms[r] = b;
+    }
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_group_shard_sizes(celeste_group_t *g, int32_t *sizes, int64_t *costs) {
+    if (!g || !g->planned) return CELESTE_ERR_INVALID_ARG;
+    for (int r = 0; r < g->n; ++r) {
+        if (sizes) sizes[r] = (int32_t)g->mem[r]->idx.size();
+        if (costs) { costs[r] = 0; for (int32_t t : g->mem[r]->tg) costs[r] += g->cost[t]; }
+    }
+    return CELESTE_OK;
+}
+
+// elbo() for a batch of targets over all members (the drop-in call): plan + one sweep + results
+extern "C" int celeste_group_elbo_eval_batch(celeste_group_t *g, const double *vp, int32_t n_targets, const int32_t *targets,
+                                             uint32_t flags, double *v, double *d, double *h, int64_t *counters, int32_t *status) {
+    if (!g || !vp || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
+    if (n_targets == 0) return CELESTE_OK;
+    int rc = celeste_group_sweep_plan(g, vp, n_targets, targets, flags);
+    if (rc == CELESTE_OK) rc = celeste_group_sweep(g);
+    if (rc == CELESTE_OK) rc = celeste_group_sweep_results(g, v, d, h, counters, status);
+    else (void)celeste_group_sweep_wait(g);
+    return rc;
+}
+
+// ---- maximize! over the members (one_node_single_infer, ParallelRun.jl:546-607) ------------------------------------
+// after the members' optimisations: pack the updated rows, exchange them, bring every member's table up to date
+static int group_exchange_rows(celeste_group *g, GroupMember *m, double *d_table, int n_own, const int32_t *d_own_targets,
+                               const int32_t *d_it, const int32_t *d_ev, const double *d_el, const int32_t *d_st, int width, int row,
+                               const GroupCounts &cnt) {
+    hipStream_t st = m->ctx->stream;
+    const size_t blk = (size_t)width * row;
+    if (blk > m->block_cap) {
+        HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipStreamSynchronize(m->comm_stream));
+        for (int k = 0; k < 2; ++k) { if (m->d_block[k]) (void)hipFree(m->d_block[k]); m->d_block[k] = nullptr; }
+        m->block_cap = 0;
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void **)&m->d_block[k], blk * sizeof(double)));
+        m->block_cap = blk;
+    }
+    int s1 = group_grow(&m->d_gathered, &m->gathered_cap, blk * g->n, st);
+    if (s1 != CELESTE_OK) return s1;
+    // PEER mode: the other members copy into d_gathered; it must exist on every member before anyone copies
+    if (g->exchange == GROUP_EXCHANGE_PEER) group_barrier(g);
+    HIP_TRY(hipMemsetAsync(m->d_block[0], 0, blk * sizeof(double), st));
+    if (n_own > 0)
+        hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)n_own), dim3(64), 0, st, d_table, d_own_targets, n_own, d_it, d_ev, d_el, d_st,
+                           m->d_block[0], row);
+    s1 = group_exchange(g, m, m->d_block[0], blk, st);
+    if (s1 != CELESTE_OK) return s1;
+    if (g->exchange == GROUP_EXCHANGE_PEER) {    // every member's copies have landed before anyone reads its gathered buffer
+        HIP_TRY(hipStreamSynchronize(st));
+        group_barrier(g);
+    }
+    if (g->n > 1)
+        hipLaunchKernelGGL(group_scatter_kernel, dim3((unsigned)width, (unsigned)g->n), dim3(64), 0, st, d_table, m->d_gathered, cnt,
+                           g->n, m->index, width, row);
+    HIP_TRY(hipGetLastError());
+    return CELESTE_OK;
+}
+
+extern "C" int celeste_group_maximize_batch(celeste_group_t *g, double *vp, const double *vp_neighbors, const double *pos_centers,
+                                            int32_t n_targets, const int32_t *targets, const celeste_optim_config_t *cfg,
+                                            int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status) {
+    if (!g || !vp || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
+    if (n_targets == 0) return CELESTE_OK;
+    if (group_check_targets(g, n_targets, targets) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
+    {
+        std::vector<uint8_t> seen;
+        if (check_distinct_targets(g->mem[0]->ctx, n_targets, targets, seen) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
+        OptParams op; uint32_t fl;
+        if (optim_config(cfg, &op, &fl) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    g->planned = false;
+    (void)group_quiesce(g);
+    group_shard(g, n_targets, targets);
+    int W = 1;
+    GroupCounts cnt; memset(&cnt, 0, sizeof cnt);
+    for (GroupMember *m : g->mem) { W = std::max(W, (int)m->idx.size()); cnt.n[m->index] = (int)m->idx.size(); }
+    const size_t tb = (size_t)g->S * CEL_P * sizeof(double);
+    memcpy(g->p_vp, vp, tb);
+    if (vp_neighbors) memcpy(g->p_vp_nbr, vp_neighbors, tb);
+    const size_t blk = (size_t)W * GROUP_ROW;
+    int rc = group_run(g, [&](GroupMember *m) -> int {
+        HIP_TRY(hipSetDevice(m->device));
+        hipStream_t st = m->ctx->stream;
+        const size_t nr = m->tg.size();
+        int s1 = group_target_buffers(m, nr);
+        if (s1 != CELESTE_OK) return s1;
+        HIP_TRY(hipMemcpyAsync(m->d_vp, g->p_vp, tb, hipMemcpyHostToDevice, st));
+        if (vp_neighbors) HIP_TRY(hipMemcpyAsync(m->d_vp_nbr, g->p_vp_nbr, tb, hipMemcpyHostToDevice, st));
+        int own_rc = CELESTE_OK;
+        if (nr > 0) {
+            HIP_TRY(hipMemcpyAsync(m->d_targets, m->tg.data(), nr * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            if (pos_centers) {
+                std::vector<double> pc(nr * 2);
+                for (size_t i = 0; i < nr; ++i) { pc[2 * i] = pos_centers[2 * (size_t)m->idx[i]]; pc[2 * i + 1] = pos_centers[2 * (size_t)m->idx[i] + 1]; }
+                HIP_TRY(hipMemcpyAsync(m->d_pos, pc.data(), nr * 2 * sizeof(double), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));   // (pc is a local)
+            }
+            own_rc = celeste_maximize_batch_device(m->ctx, m->d_vp, vp_neighbors ? m->d_vp_nbr : nullptr, pos_centers ? m->d_pos : nullptr,
+                                                   (int32_t)nr, m->d_targets, cfg, m->d_it, m->d_ev, m->d_el, m->d_st, st);
+        }
+        // (a member whose launch failed still takes part in the exchange: the collective needs every rank)
+        s1 = group_exchange_rows(g, m, m->d_vp, own_rc == CELESTE_OK ? (int)nr : 0, m->d_targets, m->d_it, m->d_ev, m->d_el, m->d_st, W,
+                                 GROUP_ROW, cnt);
+        if (s1 != CELESTE_OK) return s1;
+        if (m->index == 0) {
+            s1 = group_grow_pinned(&m->p_gathered, &m->p_gathered_cap, blk * g->n);
+            if (s1 != CELESTE_OK) return s1;
+            HIP_TRY(hipMemcpyAsync(m->p_gathered, m->d_gathered, blk * g->n * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        return own_rc;      // (a fused launch that gave up shows as CELESTE_ERR_HIP in its targets' status: optim_finalize_kernel)
+    });
+    if (rc != CELESTE_OK) return rc;
+    int worst = CELESTE_OK;
+    const double *gp = g->mem[0]->p_gathered;
+    for (int r = 0; r < g->n; ++r) {
+        const GroupMember *o = g->mem[r];
+        for (size_t i = 0; i < o->idx.size(); ++i) {
+            const double *row = gp + ((size_t)r * W + i) * GROUP_ROW;
+            const size_t q = (size_t)o->idx[i];
+            const int t = (int)row[0], st1 = (int)row[4];
+            if (t != o->tg[i]) return CELESTE_ERR_HIP;            // the exchange lost a row
+            memcpy(vp + (size_t)t * CEL_P, row + 5, CEL_P * sizeof(double));   // (a failed target carries its input row)
+            if (iterations) iterations[q] = (int32_t)row[1];
+            if (f_evals) f_evals[q] = (int32_t)row[2];
+            if (elbo) elbo[q] = row[3];
+            if (status) status[q] = st1;
+            if (st1 != CELESTE_OK && worst == CELESTE_OK) worst = st1;
+        }
+    }
+    return worst;
+}
+
+// ---- joint inference over the members (one_node_joint_infer, ParallelRun.jl:135-196, 302-397) -----------------------
+// The connected components of a Cyclades batch never conflict (partition.jl:173-236): they are sharded over the members by
+// cost, every member runs its components' sources one after another against ITS table (celeste_joint_infer's schedule: layer
+// j = the j-th sources of its components), and the rows the batch updated are exchanged ONCE per batch -- not per layer.
+extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t n_sweeps, int32_t n_batches, const int64_t *batch_offsets,
+                                         const int64_t *comp_offsets, const int32_t *comp_targets, const double *pos_centers,
+                                         const celeste_optim_config_t *cfg, int32_t *iterations, int32_t *f_evals, double *elbo,
+                                         int32_t *status, int64_t *n_exchanges) {
+    if (!g || !vp || n_sweeps < 0 || n_batches < 0 || (n_batches > 0 && (!batch_offsets || !comp_offsets || !comp_targets)))
+        return CELESTE_ERR_INVALID_ARG;
+    if (n_exchanges) *n_exchanges = 0;
+    if (n_batches == 0 || n_sweeps == 0) return CELESTE_OK;
+    if (batch_offsets[0] != 0 || comp_offsets[0] != 0) return CELESTE_ERR_INVALID_ARG;
+    const int64_t n_comps = batch_offsets[n_batches];
+    if (n_comps < 0) return CELESTE_ERR_INVALID_ARG;
+    for (int64_t k = 0; k < n_comps; ++k) if (comp_offsets[k + 1] < comp_offsets[k]) return CELESTE_ERR_INVALID_ARG;
+    const int64_t E = comp_offsets[n_comps];
+    if (E > 0x7fffffff || group_check_targets(g, (int32_t)E, comp_targets) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
+    const celeste_ctx *c0 = g->mem[0]->ctx;
+    // a batch: every source at most once, no neighbours across components
+    {
+        std::vector<int32_t> comp_of((size_t)g->S);
+        for (int b = 0; b < n_batches; ++b) {
+            if (batch_offsets[b + 1] < batch_offsets[b]) return CELESTE_ERR_INVALID_ARG;
+            std::fill(comp_of.begin(), comp_of.end(), -1);
+            for (int64_t k = batch_offsets[b]; k < batch_offsets[b + 1]; ++k)
+                for (int64_t e = comp_offsets[k]; e < comp_offsets[k + 1]; ++e) {
+                    if (comp_of[comp_targets[e]] >= 0) return CELESTE_ERR_INVALID_ARG;
+                    comp_of[comp_targets[e]] = (int32_t)(k - batch_offsets[b]);
+                }
+            for (int64_t k = batch_offsets[b]; k < batch_offsets[b + 1]; ++k)
+                for (int64_t e = comp_offsets[k]; e < comp_offsets[k + 1]; ++e) {
+                    const int t = comp_targets[e];
+                    for (int64_t q = c0->h_nbr_off[t]; q < c0->h_nbr_off[t + 1]; ++q) {
+                        const int32_t oc = comp_of[c0->h_nbr_idx[q]];
+                        if (oc >= 0 && oc != (int32_t)(k - batch_offsets[b])) return CELESTE_ERR_INVALID_ARG;
+                    }
+                }
+        }
+    }
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    g->planned = false;
+    (void)group_quiesce(g);
+    g->abort_rc.store(0);
+    const size_t tb = (size_t)g->S * CEL_P * sizeof(double);
+    memcpy(g->p_vp, vp, tb);
+    // per batch and member: its components (cost = the chunks of their sources), flattened into layers
+    struct Part { std::vector<int64_t> off; std::vector<int32_t> tg; std::vector<int64_t> entry; std::vector<double> pos; std::vector<int32_t> rows; };
+    std::vector<std::vector<Part>> parts((size_t)n_batches, std::vector<Part>((size_t)g->n));
+    std::vector<int> widths((size_t)n_batches, 1);
+    for (int b = 0; b < n_batches; ++b) {
+        const int64_t k0 = batch_offsets[b], nk = batch_offsets[b + 1] - k0;
+        std::vector<int64_t> w((size_t)nk, 0);
+        for (int64_t k = 0; k < nk; ++k)
+            for (int64_t e = comp_offsets[k0 + k]; e < comp_offsets[k0 + k + 1]; ++e) w[k] += c0->h_src_chunks[comp_targets[e]];
+        std::vector<std::vector<int32_t>> shards;
+        group_lpt(g->n, w, shards);
+        for (int r = 0; r < g->n; ++r) {
+            Part &p = parts[b][r];
+            size_t depth = 0;
+            for (int32_t k : shards[r]) depth = std::max(depth, (size_t)(comp_offsets[k0 + k + 1] - comp_offsets[k0 + k]));
+            p.off.push_back(0);
+            for (size_t j = 0; j < depth; ++j) {
+                for (int32_t k : shards[r]) {
+                    const int64_t lo = comp_offsets[k0 + k], len = comp_offsets[k0 + k + 1] - lo;
+                    if ((int64_t)j >= len) continue;
+                    p.tg.push_back(comp_targets[lo + j]);
+                    p.entry.push_back(lo + (int64_t)j);
+                    if (pos_centers) { p.pos.push_back(pos_centers[2 * (lo + j)]); p.pos.push_back(pos_centers[2 * (lo + j) + 1]); }
+                }
+                p.off.push_back((int64_t)p.tg.size());
+            }
+            p.rows = p.tg;     // every source of a batch appears once: the rows this member updates
+            widths[b] = std::max(widths[b], (int)p.rows.size());
+        }
+    }
+    std::atomic<int64_t> exchanges{0};
+    int rc = group_run(g, [&](GroupMember *m) -> int {
+        HIP_TRY(hipSetDevice(m->device));
+        hipStream_t st = m->ctx->stream;
+        HIP_TRY(hipMemcpyAsync(m->d_vp, g->p_vp, tb, hipMemcpyHostToDevice, st));
+        int worst = CELESTE_OK;
+        for (int sw = 0; sw < n_sweeps; ++sw)
+            for (int b = 0; b < n_batches; ++b) {
+                const Part &p = parts[b][(size_t)m->index];
+                const size_t ne = p.tg.size();
+                int own_rc = CELESTE_OK;
+                if (ne > 0) {
+                    std::vector<int32_t> it(ne), ev(ne), stt(ne);
+                    std::vector<double> el(ne);
+                    // (the entry state of the table, should the dataflow launch hand the schedule to the layered driver)
+                    HIP_TRY(hipMemcpyAsync(m->d_entry, m->d_vp, tb, hipMemcpyDeviceToDevice, st));
+                    own_rc = joint_run(m->ctx, m->d_vp, m->d_entry, (int32_t)(p.off.size() - 1), p.off.data(), p.tg.data(),
+                                       pos_centers ? p.pos.data() : nullptr, cfg, it.data(), ev.data(), el.data(), stt.data(), false);
+                    for (size_t i = 0; i < ne; ++i) {
+                        const size_t q = (size_t)sw * (size_t)E + (size_t)p.entry[i];
+                        if (iterations) iterations[q] = it[i];
+                        if (f_evals) f_evals[q] = ev[i];
+                        if (elbo) elbo[q] = el[i];
+                        if (status) status[q] = stt[i];
+                    }
+                    if (own_rc == CELESTE_ERR_NONFINITE_INPUT || own_rc == CELESTE_ERR_NONFINITE_RESULT) { if (worst == CELESTE_OK) worst = own_rc; own_rc = CELESTE_OK; }
+                    // a launch that failed: the others would wait for this member at the next exchange -- tell them before this one
+                    if (own_rc != CELESTE_OK) { int z = 0; g->abort_rc.compare_exchange_strong(z, own_rc); }
+                }
+                int s1 = group_target_buffers(m, p.rows.size());
+                if (s1 != CELESTE_OK) return s1;
+                if (!p.rows.empty()) HIP_TRY(hipMemcpyAsync(m->d_targets, p.rows.data(), p.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                GroupCounts cnt; memset(&cnt, 0, sizeof cnt);
+                for (int r = 0; r < g->n; ++r) cnt.n[r] = (int)parts[b][r].rows.size();
+                s1 = group_exchange_rows(g, m, m->d_vp, (int)p.rows.size(), m->d_targets, nullptr, nullptr, nullptr, nullptr, widths[b],
+                                         GROUP_JROW, cnt);
+                if (s1 != CELESTE_OK) return s1;
+                HIP_TRY(hipStreamSynchronize(st));
+                if (m->index == 0) exchanges.fetch_add(1);
+                // (the exchange needed every member's enqueue, and a failing member raised the flag before its own)
+                if (g->exchange == GROUP_EXCHANGE_PEER) group_barrier(g);
+                if (const int a = g->abort_rc.load()) return a;
+            }
+        if (m->index == 0) {
+            HIP_TRY(hipMemcpyAsync(g->p_vp_nbr, m->d_vp, tb, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        return worst;
+    });
+    if (n_exchanges) *n_exchanges = exchanges.load();
+    if (rc == CELESTE_OK || rc == CELESTE_ERR_NONFINITE_INPUT || rc == CELESTE_ERR_NONFINITE_RESULT) memcpy(vp, g->p_vp_nbr, tb);
+    return rc;
+}

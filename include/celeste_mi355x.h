@@ -167,8 +167,9 @@ typedef struct celeste_work_stats_t {
 
 /* ABI version: major * 100 + minor.  200: celeste_optim_config_t carries tr_secular_iters (round 2 grew the struct by 8
  * bytes without bumping the version); celeste_maximize_batch_device and celeste_joint_infer exist.  Bindings check it
- * (cabi.load_library, shim/CelesteMI355X.jl): a caller built against another major version must not pass structs. */
-#define CELESTE_ABI_VERSION 200
+ * (cabi.load_library, shim/CelesteMI355X.jl): a caller built against another major version must not pass structs.
+ * 210: the celeste_group_* entry points (one process, N devices). */
+#define CELESTE_ABI_VERSION 210
 int celeste_version(void);
 const char *celeste_strerror(int status);
 
@@ -360,6 +361,79 @@ int celeste_tr_solve_batch(int device, int32_t n, const double *H, const double 
  * (every source contributes on its own patch, last column and inactive pixels excluded).  out: H x W doubles,
  * column-major, host. */
 int celeste_render_expected(celeste_ctx_t *ctx, const double *vp, int32_t image, double *out_plane);
+
+/* ---- one process, N devices: the source-partition loop --------------------------
+ * The reference drains one source list with N workers inside ONE process (one_node_single_infer, ParallelRun.jl:546-607;
+ * process_sources_dynamic!, ParallelRun.jl:302-369; its Julia caller is the only caller it has).  A group is that loop over
+ * the HIP devices of a node: the images are replicated on every member device, the targets of a call are sharded over the
+ * members by cost (estimate_time = the pixels of a source's patches, ParallelRun.jl:45-56; longest first onto the least
+ * loaded member, ties by index -- deterministic), every member runs its shard on its own worker thread and stream, and the
+ * per-source results are exchanged with ONE ncclAllGather (RCCL over xGMI; communicators from ncclCommInitAll) -- the
+ * catalog gather, the only exchange of the path.  Results are those of the one-device entry points, bit for bit: a
+ * target's evaluation / optimisation does not depend on what else is in its launch.
+ *
+ * devices[n_members]: HIP device ordinals (NULL = 0 .. n_members - 1).  Distinct devices exchange over RCCL -- a group of
+ * one included (the collective then runs with one rank).  A device that appears more than once makes the group exchange
+ * by plain device-to-device copies instead (RCCL refuses duplicate devices in a communicator): two members on one GPU
+ * exercise the shard / gather bookkeeping on a one-GPU box; it is a test configuration, not a fast one.
+ * At most 16 members.  One call per group at a time (the entry points serialise themselves). */
+typedef struct celeste_group celeste_group_t;
+enum { CELESTE_EXCHANGE_RCCL = 1, CELESTE_EXCHANGE_PEER_COPY = 2 };
+typedef struct celeste_group_info_t {
+    int32_t n_members;
+    int32_t n_devices;      /* distinct devices */
+    int32_t exchange;       /* CELESTE_EXCHANGE_* */
+    int32_t rccl_ranks;     /* ncclCommCount of the group's communicator (0 without RCCL) */
+    int32_t devices[16];
+} celeste_group_info_t;
+int celeste_group_create(const celeste_problem_t *problem, int32_t n_members, const int32_t *devices, celeste_group_t **out);
+void celeste_group_destroy(celeste_group_t *group);
+int celeste_group_info(celeste_group_t *group, celeste_group_info_t *out);
+
+/* celeste_elbo_eval_batch over the members: same arguments, same outputs in the caller's order.  v / d / counters / status
+ * of every target are all-gathered to every member (member 0 hands them to the host); Hessians come down from the member
+ * that owns the target, all members at once.  CELESTE_FLAG_SPLIT is not supported here. */
+int celeste_group_elbo_eval_batch(celeste_group_t *group, const double *vp, int32_t n_targets, const int32_t *targets,
+                                  uint32_t flags, double *v, double *d, double *h, int64_t *counters, int32_t *status);
+
+/* The same sweep with everything resident in HBM (what an optimiser loop or a benchmark repeats): _plan shards the targets
+ * and uploads the table and the shards; _sweep starts one evaluation of every shard + its catalog gather and returns (the
+ * gather of sweep k overlaps the kernels of sweep k + 1 on a second stream; two gather blocks alternate); _wait returns when
+ * every started sweep and gather is complete; _results hands out the last sweep (any pointer may be NULL). */
+int celeste_group_sweep_plan(celeste_group_t *group, const double *vp, int32_t n_targets, const int32_t *targets, uint32_t flags);
+int celeste_group_sweep(celeste_group_t *group);
+int celeste_group_sweep_wait(celeste_group_t *group);
+int celeste_group_sweep_results(celeste_group_t *group, double *v, double *d, double *h, int64_t *counters, int32_t *status);
+/* sizes[n_members] / costs[n_members] (either may be NULL) of the planned shards */
+int celeste_group_shard_sizes(celeste_group_t *group, int32_t *sizes, int64_t *costs);
+/* HIP-event durations of the last sweep per member: eval_ms[r] = its launch chain, gather_ms[r] = from the end of the chain to
+ * the end of its catalog gather.  Enable before the sweep; read after _wait. */
+int celeste_group_enable_timing(celeste_group_t *group, int enable);
+int celeste_group_last_sweep_ms(celeste_group_t *group, float *eval_ms, float *gather_ms);
+/* celeste_ctx_last_kernel_ms of one member's last launch chain: ms[0] preparation, ms[1] pixel kernel, ms[2] lift */
+int celeste_group_last_kernel_ms(celeste_group_t *group, int32_t member, float ms[3]);
+
+/* celeste_maximize_batch over the members (one_node_single_infer, ParallelRun.jl:546-607): every member optimises its shard
+ * against its copy of the table (neighbours frozen, so shards are independent), then the optimised rows + per-target outputs
+ * are all-gathered and every member's table brought up to date.  Arguments and outputs as celeste_maximize_batch. */
+int celeste_group_maximize_batch(celeste_group_t *group, double *vp, const double *vp_neighbors, const double *pos_centers,
+                                 int32_t n_targets, const int32_t *targets, const celeste_optim_config_t *cfg,
+                                 int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status);
+
+/* one_node_joint_infer (ParallelRun.jl:135-196, 302-397) over the members.  The schedule is given as the reference has it:
+ * n_batches Cyclades batches (partition.jl:173-236), batch b = the connected components batch_offsets[b] .. batch_offsets[b+1],
+ * component k = the sources comp_targets[comp_offsets[k] .. comp_offsets[k+1]) in the order they are optimised.  Components of
+ * a batch never conflict (checked: CELESTE_ERR_INVALID_ARG if a source appears twice in a batch or has a neighbour in another
+ * component of it), so they are sharded over the members by cost; a member optimises the sources of its components one
+ * after another against its table (celeste_joint_infer's schedule), and the rows a batch updated are exchanged ONCE per
+ * batch -- n_batches exchanges per sweep, not one per layer.  The batches are repeated n_sweeps times
+ * (Config.num_joint_vi_iters).  pos_centers: 2 doubles per entry of comp_targets (may be NULL), the same in every sweep
+ * (ParallelRun.jl:96-100).  Per-entry outputs (may be NULL): [sweep * n_entries + entry].  *n_exchanges (may be NULL)
+ * receives the number of exchanges made.  Equals celeste_joint_infer on the flattened schedule bit for bit. */
+int celeste_group_joint_infer(celeste_group_t *group, double *vp, int32_t n_sweeps, int32_t n_batches,
+                              const int64_t *batch_offsets, const int64_t *comp_offsets, const int32_t *comp_targets,
+                              const double *pos_centers, const celeste_optim_config_t *cfg, int32_t *iterations,
+                              int32_t *f_evals, double *elbo, int32_t *status, int64_t *n_exchanges);
 
 #ifdef __cplusplus
 }

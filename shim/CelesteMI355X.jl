@@ -128,13 +128,43 @@ end
 # -- vp::VariationalParams{Float64} against the reference's VariationalParams{T} -- evaluate on the device; an ElboArgs
 # without a context, and every non-Float64 element type (the ForwardDiff.Dual calls of test/test_elbo.jl:232-237), falls
 # through to the reference's method (elbo_objective.jl:482-492) via `invoke`.
+# Threading contract: process_source runs inside `Threads.@threads` loops (ParallelRun.jl:285, :330), so registrations,
+# releases and the look-up of the 4-argument `elbo` below race on this table -- a rehash under a concurrent `get` can miss
+# (silently falling back to the CPU `elbo`) or corrupt the table.  Every access takes MI355X_CONTEXTS_LOCK (a spin lock:
+# the critical sections are a dictionary operation; the device call itself runs outside the lock).  A context belongs to the
+# thread that evaluates its ElboArgs: at most one call per context at a time (header: "Concurrency contract").
 const MI355X_CONTEXTS = ObjectIdDict()                   # ElboArgs => MI355XContext (identity keyed; Julia 0.6: ObjectIdDict)
-register_context!(ea::ElboArgs, imgs::MI355XImages) = (MI355X_CONTEXTS[ea] = MI355XContext(ea, imgs))
-release_context!(ea::ElboArgs) = delete!(MI355X_CONTEXTS, ea)      # the context's finalizer frees the device tables
+const MI355X_CONTEXTS_LOCK = Threads.SpinLock()
+function register_context!(ea::ElboArgs, imgs::MI355XImages)
+    ctx = MI355XContext(ea, imgs)                        # (the upload happens outside the lock)
+    lock(MI355X_CONTEXTS_LOCK)
+    try
+        MI355X_CONTEXTS[ea] = ctx
+    finally
+        unlock(MI355X_CONTEXTS_LOCK)
+    end
+    ctx
+end
+function release_context!(ea::ElboArgs)                   # the context's finalizer frees the device tables
+    lock(MI355X_CONTEXTS_LOCK)
+    try
+        delete!(MI355X_CONTEXTS, ea)
+    finally
+        unlock(MI355X_CONTEXTS_LOCK)
+    end
+end
+function lookup_context(ea::ElboArgs)
+    lock(MI355X_CONTEXTS_LOCK)
+    try
+        return get(MI355X_CONTEXTS, ea, nothing)
+    finally
+        unlock(MI355X_CONTEXTS_LOCK)
+    end
+end
 
 function elbo(ea::ElboArgs, vp::VariationalParams{Float64}, elbo_vars::ElboIntermediateVariables{Float64},
               bvn_bundle::BvnBundle{Float64})
-    ctx = get(MI355X_CONTEXTS, ea, nothing)
+    ctx = lookup_context(ea)
     if ctx === nothing || ea.Sa != 1 || ea.active_sources != [1]
         return invoke(elbo, Tuple{ElboArgs, VariationalParams, ElboIntermediateVariables, BvnBundle}, ea, vp, elbo_vars, bvn_bundle)
     end
@@ -238,4 +268,85 @@ function tr_solve_batch(H::Array{Float64,3}, g::Matrix{Float64}, delta::Vector{F
                  Ptr{Int32}, Ptr{Int32}),
                 device, n, H, g, delta, solver, 0, p, m, interior, fell_back))
     p, m, interior, fell_back
+end
+
+
+# ---- one process, N devices: the N workers of one_node_single_infer / one_node_joint_infer (ParallelRun.jl:546-607, 302-397)
+# behind ONE handle.  The library replicates the images on every member device, shards a call's targets by estimate_time,
+# runs every member on its own worker thread and exchanges the per-source results with one ncclAllGather (RCCL over xGMI):
+# a Julia caller reaches all the GPUs of the node through these three calls, no Distributed / MPI on the Julia side.
+
+struct CGroupInfo                  # celeste_group_info_t
+    n_members::Int32; n_devices::Int32; exchange::Int32; rccl_ranks::Int32
+    devices::NTuple{16,Int32}
+end
+
+mutable struct MI355XGroup
+    handle::Ptr{Void}
+    n_members::Int
+end
+
+"""A device group over the whole box: `prob` is the celeste_problem_t of every catalogued source (the whole-box context of the
+section above), `devices` the 0-based HIP ordinals (default: 0 .. n - 1)."""
+function MI355XGroup(prob::CProblem, devices::Vector{Int32})
+    check_abi()
+    h = Ref{Ptr{Void}}(C_NULL)
+    check(ccall((:celeste_group_create, libceleste), Cint, (Ref{CProblem}, Int32, Ptr{Int32}, Ref{Ptr{Void}}),
+                prob, length(devices), devices, h))
+    g = MI355XGroup(h[], length(devices))
+    finalizer(g, x -> ccall((:celeste_group_destroy, libceleste), Void, (Ptr{Void},), x.handle))
+    g
+end
+
+function group_info(g::MI355XGroup)
+    gi = Ref(CGroupInfo(0, 0, 0, 0, ntuple(i -> Int32(0), 16)))
+    check(ccall((:celeste_group_info, libceleste), Cint, (Ptr{Void}, Ref{CGroupInfo}), g.handle, gi))
+    gi[]
+end
+
+"""elbo_batch! over every device of the group: same arguments, same outputs (in the order of `targets0`)."""
+function elbo_batch!(out::PinnedOutputs, g::MI355XGroup, vp_all::Matrix{Float64}, targets0::Vector{Int32};
+                     flags::UInt32 = UInt32(7 | 32))
+    ccall((:celeste_group_elbo_eval_batch, libceleste), Cint,
+          (Ptr{Void}, Ptr{Float64}, Int32, Ptr{Int32}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int32}),
+          g.handle, vp_all, length(targets0), targets0, flags, out.v, out.d, out.h, out.counters, out.status)
+end
+
+"""one_node_single_infer's loop over every device of the group (ParallelRun.jl:546-607)."""
+function maximize_batch!(g::MI355XGroup, vp_all::Matrix{Float64}, targets0::Vector{Int32};
+                         vp_frozen_neighbors = C_NULL, box_centres = C_NULL, include_kl::Bool = true,
+                         tr_secular_iters::Int = 5)
+    n = length(targets0)
+    iterations = zeros(Int32, n); f_calls = zeros(Int32, n); max_values = zeros(n); status = zeros(Int32, n)
+    cfgc = Ref(COptimConfig(1e-4, 1.0, 50, include_kl, 1e-7, 1e-6, 1e-8, 1.0, 1e9, tr_secular_iters, 0))
+    st = ccall((:celeste_group_maximize_batch, libceleste), Cint,
+               (Ptr{Void}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Int32}, Ref{COptimConfig},
+                Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}),
+               g.handle, vp_all, vp_frozen_neighbors, box_centres, n, targets0, cfgc, iterations, f_calls, max_values, status)
+    return st, iterations, f_calls, max_values, status
+end
+
+"""
+one_node_joint_infer over every device of the group.  `batches` is partition_cyclades_dynamic's result as the reference has
+it (partition.jl:173-236): batches[b][k] = the 0-based source ids of connected component k of batch b, in the order they are
+optimised.  The components of a batch are sharded over the devices; the rows a batch updated are exchanged once per batch.
+box_centres: 2 x (number of entries), a column per entry of vcat(vcat(batches...)...).  Per-entry outputs: entry fastest, then
+sweep.
+"""
+function joint_infer!(g::MI355XGroup, vp_all::Matrix{Float64}, batches::Vector{Vector{Vector{Int32}}};
+                      n_sweeps::Int = 3, box_centres = C_NULL, include_kl::Bool = true, tr_secular_iters::Int = 5)
+    comps = vcat(batches...)
+    batch_offsets = Int64[0; cumsum(map(length, batches))]
+    comp_offsets = Int64[0; cumsum(map(length, comps))]
+    flat = vcat(comps...)
+    total = length(flat) * n_sweeps
+    iterations = zeros(Int32, total); f_calls = zeros(Int32, total); max_values = zeros(total); status = zeros(Int32, total)
+    exchanges = Ref{Int64}(0)
+    cfgc = Ref(COptimConfig(1e-4, 1.0, 50, include_kl, 1e-7, 1e-6, 1e-8, 1.0, 1e9, tr_secular_iters, 0))
+    st = ccall((:celeste_group_joint_infer, libceleste), Cint,
+               (Ptr{Void}, Ptr{Float64}, Int32, Int32, Ptr{Int64}, Ptr{Int64}, Ptr{Int32}, Ptr{Float64}, Ref{COptimConfig},
+                Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}, Ref{Int64}),
+               g.handle, vp_all, n_sweeps, length(batches), batch_offsets, comp_offsets, flat, box_centres, cfgc,
+               iterations, f_calls, max_values, status, exchanges)
+    return st, iterations, f_calls, max_values, status, exchanges[]
 end

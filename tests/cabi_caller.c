@@ -6,7 +6,10 @@
  * src/ParallelRun.jl:302-397): it fills celeste_problem_t / celeste_image_t / celeste_patch_t the way the header
  * documents them, with the compiler -- not a ctypes mirror -- laying out the structs, and calls
  *     celeste_ctx_create, celeste_elbo_eval (one call per source), celeste_elbo_eval_batch,
- *     celeste_maximize_batch, celeste_joint_infer, celeste_ctx_destroy.
+ *     celeste_maximize_batch, celeste_joint_infer, celeste_ctx_destroy,
+ * and the same three computations through a device group (one process, N devices: the N workers of
+ * src/ParallelRun.jl:546-607): celeste_group_create, celeste_group_elbo_eval_batch, celeste_group_maximize_batch,
+ * celeste_group_joint_infer, celeste_group_destroy.
  * Input: a fixture of tests/golden/export_raw.py (tests/golden/raw/<name>.txt manifest + <name>.bin, little-endian,
  * matrices column-major).  Output on stdout, one record per line, every double as %.17g:
  *     elbo <s> <v> <n_active_px> <n_inactive_px>
@@ -16,6 +19,10 @@
  *     maximize <s> <iterations> <f_evals> <status> <elbo> <44 optimised parameters>
  *     joint <entry> <source> <iterations> <f_evals> <status> <elbo>
  *     joint_vp <s> <44 parameters>
+ *     group <n_members> <exchange> <rccl_ranks>
+ *     group_equal <eval 0|1> <maximize 0|1> <joint 0|1> <exchanges>
+ *                                            (celeste_group_* over `members` members on `device` returned the one-device
+ *                                            calls' numbers, bit for bit; one exchange per batch and sweep)
  * tests/test_cabi_caller.py builds it with `gcc -std=c99`, runs it on the GPU box and compares with the committed
  * golden (tests/golden/<name>.npz) at the 1e-8 of BASELINE.json, and with the ctypes binding's results bit for bit.
  *
@@ -57,6 +64,12 @@ _Static_assert(offsetof(celeste_prior_t, color_mean) == 176, "celeste_prior_t.co
 _Static_assert(offsetof(celeste_prior_t, color_cov) == 688, "celeste_prior_t.color_cov");
 _Static_assert(offsetof(celeste_prior_t, gal_radius_px_mean) == 2736, "celeste_prior_t.gal_radius_px_mean");
 _Static_assert(offsetof(celeste_prior_t, gal_radius_px_var) == 2744, "celeste_prior_t.gal_radius_px_var");
+_Static_assert(sizeof(celeste_group_info_t) == 80, "celeste_group_info_t");
+_Static_assert(offsetof(celeste_group_info_t, n_members) == 0, "celeste_group_info_t.n_members");
+_Static_assert(offsetof(celeste_group_info_t, n_devices) == 4, "celeste_group_info_t.n_devices");
+_Static_assert(offsetof(celeste_group_info_t, exchange) == 8, "celeste_group_info_t.exchange");
+_Static_assert(offsetof(celeste_group_info_t, rccl_ranks) == 12, "celeste_group_info_t.rccl_ranks");
+_Static_assert(offsetof(celeste_group_info_t, devices) == 16, "celeste_group_info_t.devices");
 _Static_assert(sizeof(celeste_problem_t) == 88, "celeste_problem_t");
 _Static_assert(offsetof(celeste_problem_t, n_images) == 0, "celeste_problem_t.n_images");
 _Static_assert(offsetof(celeste_problem_t, n_sources) == 4, "celeste_problem_t.n_sources");
@@ -161,7 +174,7 @@ static void print_row(const char *tag, int s, const double *x, int n) {
 }
 
 int main(int argc, char **argv) {
-    int N, S, n, s, k, device = 0;
+    int N, S, n, s, k, device = 0, members = 1;
     celeste_image_t *images;
     celeste_patch_t *patches;
     double *stamps;
@@ -171,8 +184,10 @@ int main(int argc, char **argv) {
     celeste_problem_t prob;
     celeste_ctx_t *ctx = NULL;
 
-    if (argc < 2) die("usage: cabi_caller <fixture stem, e.g. tests/golden/raw/sample_two_body> [device]");
+    if (argc < 2) die("usage: cabi_caller <fixture stem, e.g. tests/golden/raw/sample_two_body> [device [group members]]");
     if (argc > 2) device = atoi(argv[2]);
+    if (argc > 3) members = atoi(argv[3]);
+    if (members < 1 || members > 16) die("group members: 1 .. 16");
     if (celeste_version() / 100 != CELESTE_ABI_VERSION / 100) die("library / header ABI version mismatch");
     load_fixture(argv[1]);
     N = (int)*(const int64_t *)arr("n_images", "int64");
@@ -278,6 +293,57 @@ int main(int argc, char **argv) {
         check(celeste_joint_infer(ctx, vp, 2 * S, off, tg, NULL, &cfg, it, ev, el, st), "celeste_joint_infer");
         for (k = 0; k < 2 * S; ++k) printf("joint %d %d %d %d %d %.17g\n", k, (int)tg[k], (int)it[k], (int)ev[k], (int)st[k], el[k]);
         for (s = 0; s < S; ++s) print_row("joint_vp", s, vp + (size_t)s * P, P);
+    }
+    {   /* the same three computations through a device group: `members` members, all on `device` (one member: RCCL with one
+           rank; several on one device: device-to-device copies -- see the header) */
+        const uint32_t flags = CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS | CELESTE_FLAG_KL;
+        celeste_group_t *grp = NULL;
+        celeste_group_info_t gi;
+        celeste_optim_config_t cfg;
+        int32_t devs[16];
+        const size_t nv = (size_t)S, nd = (size_t)S * P, nh = (size_t)S * P * P;
+        double *v[2], *d[2], *h[2], *vp[2], *el[2];
+        int64_t *cnt[2], *off = (int64_t *)malloc((size_t)(2 * S + 1) * sizeof(int64_t)), n_exch = -1;
+        int32_t *st[2], *it[2], *ev[2], *tg = (int32_t *)malloc((size_t)2 * S * sizeof(int32_t));
+        int q, eq_eval, eq_max, eq_joint;
+        for (q = 0; q < members; ++q) devs[q] = device;
+        for (q = 0; q < 2; ++q) {
+            v[q] = (double *)calloc(nv, sizeof(double)); d[q] = (double *)calloc(nd, sizeof(double)); h[q] = (double *)calloc(nh, sizeof(double));
+            vp[q] = (double *)malloc(nd * sizeof(double)); el[q] = (double *)calloc(2 * nv, sizeof(double));
+            cnt[q] = (int64_t *)calloc(2 * nv, sizeof(int64_t)); st[q] = (int32_t *)calloc(2 * nv, sizeof(int32_t));
+            it[q] = (int32_t *)calloc(2 * nv, sizeof(int32_t)); ev[q] = (int32_t *)calloc(2 * nv, sizeof(int32_t));
+        }
+        memset(&cfg, 0, sizeof cfg);
+        cfg.loc_width = 1e-4; cfg.loc_scale = 1.0; cfg.max_iters = 4; cfg.include_kl = 1; cfg.xtol_abs = 1e-7;
+        cfg.ftol_rel = 1e-6; cfg.gtol = 1e-8; cfg.initial_delta = 1.0; cfg.delta_hat = 1e9; cfg.tr_secular_iters = 0;
+        check(celeste_group_create(&prob, members, devs, &grp), "celeste_group_create");
+        check(celeste_group_info(grp, &gi), "celeste_group_info");
+        printf("group %d %d %d\n", (int)gi.n_members, (int)gi.exchange, (int)gi.rccl_ranks);
+        for (s = 0; s < S; ++s) tg[s] = s;
+        check(celeste_elbo_eval_batch(ctx, vp_in, S, tg, flags, v[0], d[0], h[0], cnt[0], st[0]), "celeste_elbo_eval_batch");
+        check(celeste_group_elbo_eval_batch(grp, vp_in, S, tg, flags, v[1], d[1], h[1], cnt[1], st[1]), "celeste_group_elbo_eval_batch");
+        eq_eval = memcmp(v[0], v[1], nv * sizeof(double)) == 0 && memcmp(d[0], d[1], nd * sizeof(double)) == 0 &&
+                  memcmp(h[0], h[1], nh * sizeof(double)) == 0 && memcmp(cnt[0], cnt[1], 2 * nv * sizeof(int64_t)) == 0 &&
+                  memcmp(st[0], st[1], nv * sizeof(int32_t)) == 0;
+        memcpy(vp[0], vp_in, nd * sizeof(double)); memcpy(vp[1], vp_in, nd * sizeof(double));
+        check(celeste_maximize_batch(ctx, vp[0], NULL, NULL, S, tg, &cfg, it[0], ev[0], el[0], st[0]), "celeste_maximize_batch");
+        check(celeste_group_maximize_batch(grp, vp[1], NULL, NULL, S, tg, &cfg, it[1], ev[1], el[1], st[1]), "celeste_group_maximize_batch");
+        eq_max = memcmp(vp[0], vp[1], nd * sizeof(double)) == 0 && memcmp(it[0], it[1], nv * sizeof(int32_t)) == 0 &&
+                 memcmp(ev[0], ev[1], nv * sizeof(int32_t)) == 0 && memcmp(el[0], el[1], nv * sizeof(double)) == 0 &&
+                 memcmp(st[0], st[1], nv * sizeof(int32_t)) == 0;
+        /* joint inference, two sweeps: every source a batch of its own with one one-source component (the sources of these
+           fixtures are neighbours) == every source a layer of its own, twice */
+        memcpy(vp[0], vp_in, nd * sizeof(double)); memcpy(vp[1], vp_in, nd * sizeof(double));
+        for (k = 0; k < 2 * S; ++k) { tg[k] = k % S; off[k] = k; }
+        off[2 * S] = 2 * S;
+        check(celeste_joint_infer(ctx, vp[0], 2 * S, off, tg, NULL, &cfg, it[0], ev[0], el[0], st[0]), "celeste_joint_infer");
+        check(celeste_group_joint_infer(grp, vp[1], 2, S, off, off, tg, NULL, &cfg, it[1], ev[1], el[1], st[1], &n_exch),
+              "celeste_group_joint_infer");
+        eq_joint = memcmp(vp[0], vp[1], nd * sizeof(double)) == 0 && memcmp(it[0], it[1], 2 * nv * sizeof(int32_t)) == 0 &&
+                   memcmp(ev[0], ev[1], 2 * nv * sizeof(int32_t)) == 0 && memcmp(el[0], el[1], 2 * nv * sizeof(double)) == 0 &&
+                   memcmp(st[0], st[1], 2 * nv * sizeof(int32_t)) == 0;
+        printf("group_equal %d %d %d %lld\n", eq_eval, eq_max, eq_joint, (long long)n_exch);
+        celeste_group_destroy(grp);
     }
     celeste_ctx_destroy(ctx);
     return 0;

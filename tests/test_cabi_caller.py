@@ -46,7 +46,7 @@ def test_ctypes_mirrors_have_the_offsets_the_compiler_checked():
     from celeste_jl_amd import cabi
     mirror = {"celeste_image_t": cabi.ImageT, "celeste_patch_t": cabi.PatchT, "celeste_prior_t": cabi.PriorT,
               "celeste_problem_t": cabi.ProblemT, "celeste_work_stats_t": cabi.WorkStatsT,
-              "celeste_optim_config_t": cabi.OptimConfigT}
+              "celeste_optim_config_t": cabi.OptimConfigT, "celeste_group_info_t": cabi.GroupInfoT}
     txt = open(SRC).read()
     offs = re.findall(r"_Static_assert\(offsetof\((\w+), (\w+)\) == (\d+)", txt)
     sizes = re.findall(r"_Static_assert\(sizeof\((\w+)\) == (\d+)", txt)
@@ -72,6 +72,8 @@ def _parse(out):
         tok = ln.split()
         if tok[0] == "batch_equal":
             rec["batch_equal"] = int(tok[1])
+        elif tok[0] in ("group", "group_equal"):
+            rec[tok[0]] = [int(x) for x in tok[1:]]
         elif tok[0] == "elbo":
             rec["elbo"][int(tok[1])] = (float(tok[2]), int(tok[3]), int(tok[4]))
         elif tok[0] in ("d", "h", "joint_vp"):
@@ -87,6 +89,7 @@ def _parse(out):
 @pytest.mark.parametrize("name", ["sample_star", "sample_galaxy", "sample_two_body"])
 def test_c_caller_reproduces_the_golden_and_the_ctypes_binding(exe, name):
     import celeste_jl_amd as cel
+    from celeste_jl_amd import cabi
     r = subprocess.run([exe, os.path.join(RAW, name)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     got = _parse(r.stdout)
@@ -117,3 +120,15 @@ def test_c_caller_reproduces_the_golden_and_the_ctypes_binding(exe, name):
         assert (src, it, ev, stt) == (k % S, jit[k], jev[k], jst[k]) and e == jel[k]
     for s in range(S):
         assert np.array_equal(got["joint_vp"][s], jvp[s])
+    # ... and through a device group of one member (RCCL: ncclCommInitAll over one device, one rank), the one-device numbers
+    assert got["group"] == [1, cabi.EXCHANGE_RCCL, 1] and got["group_equal"] == [1, 1, 1, 2 * S]
+
+
+@pytest.mark.gpu
+def test_c_caller_drives_two_group_members_on_one_device(exe):
+    """two members sharing the device (worker threads, shards, device-to-device exchange): still the one-device numbers"""
+    from celeste_jl_amd import cabi
+    r = subprocess.run([exe, os.path.join(RAW, "sample_two_body"), "0", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = _parse(r.stdout)
+    assert got["group"] == [2, cabi.EXCHANGE_PEER_COPY, 0] and got["group_equal"] == [1, 1, 1, 4]

@@ -1,0 +1,238 @@
+"""-m gpu: one process, N devices behind the C ABI (celeste_group_*, csrc/group.h).
+
+The group entry points must return what the one-device entry points return, BIT FOR BIT, whatever the number of members:
+a target's evaluation / optimisation does not depend on what else is in its launch, and the exchange only moves bytes.
+On a one-GPU box the members are
+  * one member on device 0 -- the RCCL path (ncclCommInitAll over one device, ncclAllGather with one rank), and
+  * two / three members that share device 0 -- worker threads, cost-sharding, the gather layout and the table updates, with
+    plain device-to-device copies standing in for RCCL (which refuses duplicate devices).
+The >= 2-device tests at the end arm themselves on a node that has the devices (RCCL between real ranks)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _n_devices():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.fixture(scope="module")
+def crowded():
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(220, 240, 40, seed=23, margin=30)
+    return f, cel.FieldContext(f.images, f.patches, f.neighbors)
+
+
+def _group(f, devices):
+    from celeste_jl_amd.group import FieldGroup
+    return FieldGroup(f.images, f.patches, f.neighbors, devices=devices)
+
+
+def _same(a, b, what):
+    for x, y, n in zip(a, b, ("v / table", "d / iterations", "h / f_evals", "counters / elbo", "status")):
+        if x is None and y is None:
+            continue
+        assert np.array_equal(x, y, equal_nan=True), "%s: output %s differs (max |diff| %.3e)" % (
+            what, n, np.nanmax(np.abs(np.asarray(x, dtype=np.float64) - np.asarray(y, dtype=np.float64))))
+
+
+MEMBERS = [[0], [0, 0], [0, 0, 0]]
+
+
+@pytest.mark.parametrize("devices", MEMBERS, ids=lambda d: "%d_member%s" % (len(d), "s" if len(d) > 1 else ""))
+def test_group_eval_equals_the_one_device_entry_bit_for_bit(crowded, devices):
+    from celeste_jl_amd import cabi
+    from celeste_jl_amd.partition import shard_targets
+    f, ctx = crowded
+    S = len(f.catalog)
+    g = _group(f, devices)
+    info = g.info()
+    assert info["n_members"] == len(devices) and info["devices"] == devices and info["n_devices"] == 1
+    if len(devices) == 1:
+        assert info["exchange"] == "rccl" and info["rccl_ranks"] == 1          # ncclCommCount of the group's communicator
+    else:
+        assert info["exchange"] == "peer_copy" and info["rccl_ranks"] == 0
+    rng = np.random.default_rng(11)
+    cases = [("every source", list(range(S)), cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL),
+             ("shuffled, repeated", [int(t) for t in rng.integers(0, S, 57)], cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL),
+             ("gradient only, no KL", list(range(0, S, 2)), cabi.FLAG_GRAD),
+             ("value only", [5, 1, 9], 0),
+             ("packed Hessians", list(range(S)), cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL | cabi.FLAG_PACKED_HESS),
+             ("fewer targets than members", [7], cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL),
+             ("single precision", list(range(S)), cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL | cabi.FLAG_FP32)]
+    for what, tg, flags in cases:
+        ref = ctx.eval_batch(f.vp, tg, flags)
+        got = g.eval_batch(f.vp, tg, flags)
+        assert (ref[4] == 0).all()
+        _same(ref, got, "%s, %d member(s)" % (what, len(devices)))
+        # the shards: the reference's estimate_time, longest first onto the least loaded member (partition.shard_targets)
+        sizes, costs = g.shard_sizes()
+        assert sum(sizes) == len(tg)
+        cost = [sum(int(p.active_pixel_bitmap.size) for p in f.patches[t]) for t in tg]
+        expect = shard_targets(cost, len(devices))
+        assert sizes == [len(s) for s in expect] and costs == [sum(cost[i] for i in s) for s in expect]
+    # a non-finite source: its status, everyone else's result
+    vp = f.vp.copy()
+    vp[3, 7] = np.nan
+    ref = ctx.eval_batch(vp, list(range(S)), raise_on_error=False)
+    got = g.eval_batch(vp, list(range(S)), raise_on_error=False)
+    assert (ref[4] != 0).any() and (ref[4] == 0).any()
+    _same(ref, got, "a failing source")
+    with pytest.raises(AssertionError):
+        g.eval_batch(vp, list(range(S)))
+    with pytest.raises(cabi.CelesteError):
+        g.eval_batch(f.vp, [S])                     # out of range
+    g.close()
+
+
+def test_group_resident_sweeps_track_the_table_and_overlap_their_gathers(crowded):
+    """plan once, sweep many times (the gather of sweep k runs while sweep k + 1 computes; two blocks alternate): the last
+    sweep's results are the one-device results; a new plan with another table and other targets replaces the first"""
+    f, ctx = crowded
+    S = len(f.catalog)
+    for devices in ([0], [0, 0]):
+        g = _group(f, devices)
+        g.enable_timing(True)
+        for tg, scale in ((list(range(S)), 1.0), (list(range(1, S, 3)), 1.0 + 1e-3)):
+            vp = f.vp.copy()
+            vp[:, 6:] *= scale
+            g.plan(vp, tg)
+            for _ in range(5):
+                g.sweep()
+            g.wait()
+            ref = ctx.eval_batch(vp, tg)
+            _same(ref, g.results(), "resident sweeps, %d member(s)" % len(devices))
+            ev, ga = g.last_sweep_ms()
+            assert len(ev) == len(devices) and all(x > 0 for x in ev) and all(x >= 0 for x in ga)
+        g.close()
+
+
+def test_group_maximize_equals_the_one_device_entry_bit_for_bit(crowded):
+    import celeste_jl_amd as cel
+    f, ctx = crowded
+    S = len(f.catalog)
+    rng = np.random.default_rng(5)
+    cases = [("every source", list(range(S)), cel.ElboConfig(max_iters=9), {}),
+             ("shuffled, pinned centres", [int(t) for t in rng.permutation(S)][:23], cel.ElboConfig(max_iters=6, loc_width=0.5),
+              {"pos_centers": None}),
+             ("frozen neighbours from another table", list(range(1, S, 3)), cel.ElboConfig(max_iters=5),
+              {"vp_neighbors": f.vp * (1.0 + 1e-3 * rng.standard_normal(f.vp.shape) * (np.arange(44) >= 6))})]
+    for devices in MEMBERS:
+        g = _group(f, devices)
+        for what, tg, cfg, kw in cases:
+            kw = dict(kw)
+            if "pos_centers" in kw:
+                kw["pos_centers"] = f.vp[tg, 0:2] + 0.01
+            ref = ctx.maximize_batch(f.vp, tg, cfg, **kw)
+            got = g.maximize_batch(f.vp, tg, cfg, **kw)
+            assert (ref[4] == 0).all() and ref[1].max() >= 5
+            _same(ref, got, "%s, %d member(s)" % (what, len(devices)))
+        # a failing target keeps its row, the others are optimised
+        vp = f.vp.copy()
+        vp[4, 10] = np.nan
+        tg = [t for t in range(S) if t != 4 and 4 in f.neighbors[t]] + [t for t in range(S) if 4 not in f.neighbors[t] and t != 4][:6]
+        ref = ctx.maximize_batch(vp, tg, cel.ElboConfig(max_iters=4), raise_on_error=False)
+        got = g.maximize_batch(vp, tg, cel.ElboConfig(max_iters=4), raise_on_error=False)
+        assert (ref[4] != 0).any() and (ref[4] == 0).any()
+        _same(ref, got, "failing targets, %d member(s)" % len(devices))
+        from celeste_jl_amd import cabi
+        with pytest.raises(cabi.CelesteError):
+            g.maximize_batch(f.vp, [1, 2, 1])           # duplicates
+        g.close()
+
+
+def test_group_joint_inference_shards_components_and_exchanges_once_per_batch(crowded):
+    """celeste_group_joint_infer: the connected components of every Cyclades batch sharded over the members, one exchange
+    per batch -- and the table, the per-entry iterations / evaluations / ELBO values / statuses of celeste_joint_infer on the
+    flattened schedule, bit for bit"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd.group import cyclades_schedule, schedule_layers
+    from celeste_jl_amd.params import catalog_init_source, generic_init_source
+    f, ctx = crowded
+    S = len(f.catalog)
+    targets = [s for s in range(S) if s % 7 != 3]
+    vp0 = np.stack([catalog_init_source(ce) for ce in f.catalog])
+    for t in targets:
+        vp0[t] = generic_init_source(f.catalog[t].pos)
+    n_sweeps = 2
+    b_off, c_off, flat = cyclades_schedule(targets, f.neighbors, batch_size=12, rng=np.random.default_rng(3))
+    n_batches = len(b_off) - 1
+    assert n_batches == 3 and sorted(flat.tolist()) == sorted(targets) and (np.diff(c_off) > 1).any()
+    pos = vp0[flat, 0:2].copy()
+    layers, entries = schedule_layers(b_off, c_off, flat, n_sweeps)
+    cfg = cel.ElboConfig(max_iters=6)
+    ref = ctx.joint_infer(vp0, layers, cfg, pos_centers=[pos[e] for e in entries])
+    assert (ref[4] == 0).all() and ref[1].max() == 6
+    flat_entry = np.concatenate([np.asarray(e) + (k // (len(layers) // n_sweeps)) * len(flat) for k, e in enumerate(entries)])
+    for devices in MEMBERS:
+        g = _group(f, devices)
+        for dataflow in (None, 0):
+            os.environ.pop("CELESTE_JOINT_DATAFLOW", None)
+            if dataflow is not None:
+                os.environ["CELESTE_JOINT_DATAFLOW"] = str(dataflow)
+            try:
+                new, its, evals, el, st, nx = g.joint_infer(vp0, b_off, c_off, flat, n_sweeps, cfg, pos_centers=pos)
+            finally:
+                os.environ.pop("CELESTE_JOINT_DATAFLOW", None)
+            assert nx == n_sweeps * n_batches                    # exchanges: one per batch, not one per layer
+            assert np.array_equal(new, ref[0]), (devices, np.abs(new - ref[0]).max())
+            for got, want, what in ((its, ref[1], "iterations"), (evals, ref[2], "f_evals"), (el, ref[3], "elbo"), (st, ref[4], "status")):
+                assert np.array_equal(got.reshape(-1)[flat_entry], want), (devices, what)
+        # a batch whose components conflict is refused
+        from celeste_jl_amd import cabi
+        a = next(s for s in targets if any(n in targets for n in f.neighbors[s]))
+        b = next(n for n in f.neighbors[a] if n in targets)
+        with pytest.raises(cabi.CelesteError):
+            g.joint_infer(vp0, [0, 2], [0, 1, 2], [a, b], 1, cfg)
+        g.close()
+
+
+def test_group_on_the_bench_field_two_members_one_device():
+    """config 3 at full size: 2000 targets, two members -- the sweep and one batch of joint inference"""
+    import celeste_jl_amd as cel
+    import bench
+    from celeste_jl_amd.group import FieldGroup
+    fld = bench.build_field(2048, 1489, 2000, 3)
+    ctx = cel.FieldContext(fld.images, fld.patches, fld.neighbors)
+    g = FieldGroup(fld.images, fld.patches, fld.neighbors, devices=[0, 0])
+    tg = list(range(len(fld.catalog)))
+    ref = ctx.eval_batch(fld.vp, tg)
+    _same(ref, g.eval_batch(fld.vp, tg), "bench field")
+    sizes, costs = g.shard_sizes()
+    assert sum(sizes) == 2000 and abs(costs[0] - costs[1]) <= 0.002 * sum(costs)
+    g.close()
+    ctx.close()
+
+
+# ---- real devices: these arm themselves on a node that has them -------------------------------------------------------
+@pytest.mark.skipif(_n_devices() < 2, reason="needs >= 2 HIP devices (RCCL between real ranks)")
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_group_over_real_devices_rccl(crowded, n):
+    if _n_devices() < n:
+        pytest.skip("needs %d devices" % n)
+    import celeste_jl_amd as cel
+    from celeste_jl_amd.group import cyclades_schedule, schedule_layers
+    f, ctx = crowded
+    S = len(f.catalog)
+    g = _group(f, list(range(n)))
+    info = g.info()
+    assert info["exchange"] == "rccl" and info["rccl_ranks"] == n and info["n_devices"] == n
+    tg = list(range(S))
+    _same(ctx.eval_batch(f.vp, tg), g.eval_batch(f.vp, tg), "eval over %d devices" % n)
+    cfg = cel.ElboConfig(max_iters=6)
+    _same(ctx.maximize_batch(f.vp, tg, cfg), g.maximize_batch(f.vp, tg, cfg), "maximize over %d devices" % n)
+    b_off, c_off, flat = cyclades_schedule(tg, f.neighbors, batch_size=12, rng=np.random.default_rng(3))
+    layers, entries = schedule_layers(b_off, c_off, flat, 2)
+    pos = f.vp[flat, 0:2].copy()
+    ref = ctx.joint_infer(f.vp, layers, cfg, pos_centers=[pos[e] for e in entries])
+    new, _, _, _, st, nx = g.joint_infer(f.vp, b_off, c_off, flat, 2, cfg, pos_centers=pos)
+    assert nx == 2 * (len(b_off) - 1) and np.array_equal(new, ref[0])
+    g.close()

@@ -55,7 +55,7 @@ def _header_prototypes():
 
 def test_every_ccall_of_the_julia_shim_matches_the_header():
     protos = _header_prototypes()
-    assert len(protos) == 27
+    assert len(protos) == 41
     jl = open(os.path.join(ROOT, "shim", "CelesteMI355X.jl")).read()
     calls = re.findall(r"ccall\(\(:(celeste_[a-z_0-9]+),\s*libceleste\),\s*([A-Za-z{}0-9]+),\s*\(", jl)
     assert len(calls) >= 14
@@ -75,7 +75,9 @@ def test_every_ccall_of_the_julia_shim_matches_the_header():
         seen.add(name)
     # the entry points a maintainer needs are all bound
     for need in ("celeste_images_create", "celeste_ctx_create_on", "celeste_elbo_eval", "celeste_elbo_eval_batch",
-                 "celeste_maximize_batch", "celeste_joint_infer", "celeste_tr_solve_batch", "celeste_host_alloc", "celeste_version"):
+                 "celeste_maximize_batch", "celeste_joint_infer", "celeste_tr_solve_batch", "celeste_host_alloc", "celeste_version",
+                 "celeste_group_create", "celeste_group_destroy", "celeste_group_info", "celeste_group_elbo_eval_batch",
+                 "celeste_group_maximize_batch", "celeste_group_joint_infer"):
         assert need in seen, need
 
 
@@ -83,7 +85,7 @@ def test_julia_struct_mirrors_list_the_header_fields_in_order():
     hdr = open(os.path.join(ROOT, "include", "celeste_mi355x.h")).read()
     jl = open(os.path.join(ROOT, "shim", "CelesteMI355X.jl")).read()
     for jname, cname in (("CImage", "celeste_image_t"), ("CPatch", "celeste_patch_t"), ("CProblem", "celeste_problem_t"),
-                         ("COptimConfig", "celeste_optim_config_t")):
+                         ("COptimConfig", "celeste_optim_config_t"), ("CGroupInfo", "celeste_group_info_t")):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         cfields = [re.sub(r"\[.*", "", d.strip().split()[-1].lstrip("*")) for d in body.split(";") if d.strip()]
@@ -91,3 +93,17 @@ def test_julia_struct_mirrors_list_the_header_fields_in_order():
         jbody = re.sub(r"#.*", "", jbody)
         jfields = re.findall(r"\b([a-zA-Z_0-9]+)::", jbody)
         assert jfields == cfields, (jname, jfields, cfields)
+
+
+def test_the_context_table_of_the_shim_is_only_touched_under_its_lock():
+    """process_source runs under Threads.@threads (ParallelRun.jl:285, :330): every use of MI355X_CONTEXTS sits between
+    lock(MI355X_CONTEXTS_LOCK) and its `finally unlock`"""
+    jl = open(os.path.join(ROOT, "shim", "CelesteMI355X.jl")).read()
+    code = "\n".join(ln.split("#")[0] for ln in jl.splitlines())
+    uses = [m.start() for m in re.finditer(r"MI355X_CONTEXTS\b(?!_LOCK)", code)]
+    assert len(uses) >= 4                                  # the declaration, register, release, look-up
+    for pos in uses[1:]:
+        before = code[:pos]
+        locks = [m.start() for m in re.finditer(r"(?<!un)lock\(MI355X_CONTEXTS_LOCK\)", before)]
+        assert locks and locks[-1] > before.rfind("unlock(MI355X_CONTEXTS_LOCK)"), code[pos - 80:pos + 40]
+        assert code.find("unlock(MI355X_CONTEXTS_LOCK)", pos) > 0
