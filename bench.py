@@ -193,19 +193,24 @@ def cpu_baseline(problem, vp, targets, seconds_target=15.0):
 
 
 def self_launch(n):
-    """Re-run this command line as n ranks under torch.distributed.run on this node (rendezvous on 127.0.0.1, a free
-    port); returns the launcher's exit code.  stdout is inherited: rank 0's JSON line is this process's output."""
-    import socket
+    """Re-run this command line as n ranks under torch.distributed.run on this node; returns the launcher's exit code.
+    --standalone: the launcher itself binds a free port for the rendezvous (no bind-and-release race), on 127.0.0.1 (the
+    container's hostname may not resolve).  stdout is inherited: rank 0's JSON line is this process's output."""
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     return subprocess.call(cmd, env=env)
+
+
+def parity_pin_status():
+    """Has the oracle been pinned by numbers the reference itself produced?  tools/reference_golden.jl writes them to
+    tests/golden/ref/*.txt (one command, needs Julia 0.6 + the reference's packages: not in this image);
+    tests/test_reference_outputs.py arms itself on them."""
+    import glob
+    return "present" if glob.glob(os.path.join(ROOT, "tests", "golden", "ref", "*.txt")) else "absent"
 
 
 def main():
@@ -238,6 +243,9 @@ def main():
     ap.add_argument("--kernels-in-pass", action="store_true",
                     help="record the kernels' HIP-event durations inside the timed steps themselves (one synchronisation per "
                          "step) instead of in a pass of their own: kernels_ms then sums to at most ms_per_step by construction")
+    ap.add_argument("--shard-projection", action="store_true",
+                    help="one GPU: sweep rank 0's cost-balanced shard of this workload for N = 1, 2, 4, 8 ranks (fp32 and fp64) -- "
+                         "a one-GPU bound on the strong-scaling efficiency (used for the config5 sub-record)")
     ap.add_argument("--check-dir", default=None,
                     help="every rank writes its gathered (v, d) of the last sweep to <dir>/rank<r>.npz (tests)")
     args = ap.parse_args()
@@ -265,7 +273,7 @@ def main():
     if args.dtype is None:
         args.dtype = "f32" if args.config == 5 else "f64"
     if args.steps is None:
-        args.steps = 50 if args.config == 3 else 10
+        args.steps = 200 if args.config == 3 else 10   # (config 3: a 0.7 ms step -- 50 steps gave 4 % box-to-box noise)
     if args.sources is None:
         args.sources = 2000 if args.config == 3 else 30000
     if args.seed is None:
@@ -486,6 +494,11 @@ def main():
         out_extra["fp32_speedup_over_fp64_pixel_kernel"] = float(np.mean(k64[1:]) / kms[1])
         del d_h64
 
+    if args.shard_projection and world == 1:
+        out_extra["shard_projection"] = shard_projection(ctx, fld, targets, costs, d_vp, dev,
+                                                         (("f32", FLAGS_ALL | cabi.FLAG_FP32), ("f64", FLAGS_ALL)) if args.config == 5
+                                                         else (("f64", FLAGS_ALL),))
+
     # split variant: per-pixel records to HBM, then the streaming per-patch sum -- the one
     # HBM-bound kernel of the path; a measurement aid next to the fused throughput configuration
     split = None
@@ -579,11 +592,12 @@ def main():
                          "traffic_source": facts.get("source"), "traffic_measured_in_this_run": bool(pmc_live),
                          "kernel": kname, "kernel_ms": float(kms[1]),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu_utilization": facts.get("pixel_kernel_valu_utilization") if args.dtype == "f64" else None,
-                         "note": "the fused kernel is FP64-VALU bound, not HBM- or MFMA-bound (SURVEY.md F8, DESIGN.md 4.3): "
-                                 "valu_utilization = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles (traffic_source says where the "
-                                 "counters come from); "
-                                 "the HBM-bound kernel of the path is split_variant.kernel; figures are rank 0's launch"},
+                         "valu_utilization": facts.get("pixel_kernel_valu_utilization") if args.dtype == "f64" else None},
+            "timing_method": ("value / ms_per_step: wall clock around K sweeps (launch chain + catalog gather) between two device "
+                              "synchronisations + barriers, max over ranks; kernels_ms / roofline.kernel_ms: HIP events recorded by "
+                              "the library on the launch stream, " + ("inside the timed steps (one synchronisation per step)"
+                                                                     if args.kernels_in_pass else "in a pass of their own after the timed region")),
+            "parity_pin": parity_pin_status(),
             "kernels_ms": {"prep": float(kms[0]), "pixel": float(kms[1]), "lift": float(kms[2])},
             "pixel_visits_per_sec_rank0": pixel_visits_local / (kms[1] * 1e-3),
         }
@@ -592,15 +606,29 @@ def main():
             # not the patches' areas, which include the last-column pixels that skip the component loop
             fl = fpp * pixel_visits_local / (kms[1] * 1e-3) / 1e12
             sus = FP32_SUSTAINED_FMA_TFLOPS if args.dtype == "f32" else FP64_SUSTAINED_FMA_TFLOPS
-            out["roofline"]["valu"] = {"achieved": fl, "peak": peak_fl, "unit": "TFLOP/s", "frac": fl / peak_fl,
-                                       "sustained_fma_peak": sus, "frac_of_sustained": fl / sus,
-                                       "sustained_source": "profiles/r04_fp64_issue_rates.txt: independent FMAs issue every "
-                                                           "4.9 cycles per SIMD at the clock the chip holds under them, "
-                                                           "0.70 (fp64) / 0.80 (packed fp32) of the nominal peak",
-                                       "flops_per_pixel_visit": fpp, "pixel_visits": pixel_visits_local, "dtype": args.dtype,
-                                       "instruction_mix": facts.get("instruction_mix_f32" if args.dtype == "f32" else "instruction_mix")}
-            if args.dtype == "f64":
-                out["roofline"]["fp64"] = out["roofline"]["valu"]
+            hbm = out["roofline"]
+            # the binding roofline on top: the fused kernel is vector-ALU bound, so `frac` is
+            # the executed-flop fraction of the nominal vector peak; the HBM figures the metric's text asks for sit in `hbm`
+            out["roofline"] = {"bound": "fp32_valu" if args.dtype == "f32" else "fp64_valu",
+                               "achieved": fl, "peak": peak_fl, "unit": "TFLOP/s", "frac": fl / peak_fl,
+                               "traffic": hbm["traffic"], "kernel": kname, "kernel_ms": float(kms[1]),
+                               "sustained_fma_peak": sus, "frac_of_sustained": fl / sus,
+                               "sustained_source": "profiles/r04_fp64_issue_rates.txt: independent FMAs issue every 4.9 cycles per "
+                                                   "SIMD at the clock the chip holds under them, 0.70 (fp64) / 0.80 (packed fp32) of "
+                                                   "the nominal peak (self-measured: `frac` against the nominal peak is the figure "
+                                                   "of record)",
+                               "flops_per_pixel_visit": fpp, "pixel_visits": pixel_visits_local, "dtype": args.dtype,
+                               "flops_source": "tools/count_flops.py on the compiled ISA (profiles/hbm_traffic.json; "
+                                               "tests/test_dpp_hazard.py holds the file to the tree)",
+                               "instruction_mix": facts.get("instruction_mix_f32" if args.dtype == "f32" else "instruction_mix"),
+                               "valu_utilization": hbm["valu_utilization"],
+                               "hbm": hbm,
+                               "note": "valu_utilization = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles (hbm.traffic_source says where the "
+                                       "counters come from); the HBM-bound kernel of the path is split_variant.kernel; figures are "
+                                       "rank 0's launch"}
+            out["roofline"]["valu"] = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "sustained_fma_peak",
+                                                                       "frac_of_sustained", "flops_per_pixel_visit", "pixel_visits",
+                                                                       "dtype", "instruction_mix")}   # (the rounds-1..4 location)
         if sweep_only_ms is not None:
             out["config"]["sweep_ms_without_gather_per_rank"] = sweep_only_ms
             out["config"]["gather_and_imbalance_ms"] = ms_per_step - max(sweep_only_ms)
@@ -846,30 +874,42 @@ def secondary_figures(ctx, fld, targets, args, costs):
                           "c_call_seconds": dt_jcall, "elbo_evaluations": int(jevals.sum()),
                           "evals_per_sec": float(jevals.sum()) / dt_jcall}
     # rank 0's cost-balanced shard of THIS field for N ranks, swept on this GPU by the driver the ranks run
-    # (parallel.DeviceShardedSweep, no gather)
-    from celeste_jl_amd.parallel import DeviceShardedSweep
     dev = torch.device("cuda", ctx.device)
     d_vp = torch.tensor(fld.vp, dtype=torch.float64, device=dev)
+    sp = shard_projection(ctx, fld, targets, costs, d_vp, dev, (("f64", FLAGS_ALL),), K=20)
+    out["shard_projection"] = dict(sp["f64"], note=sp["note"])
+    return out
+
+
+def shard_projection(ctx, fld, targets, costs, d_vp, dev, modes, K=10):
+    """rank 0's cost-balanced shard of the workload for N = 1, 2, 4, 8 ranks, swept on THIS GPU by the driver the ranks run
+    (parallel.DeviceShardedSweep, no gather): the strong-scaling efficiency the kernels allow if the catalog gather hides
+    under the next sweep.  Not a multi-GPU measurement."""
+    import torch
+    from celeste_jl_amd.parallel import DeviceShardedSweep
+    from celeste_jl_amd.partition import shard_targets
     stream = torch.cuda.current_stream(dev)
-    proj = {}
-    for world in (1, 2, 4, 8):
-        sw = DeviceShardedSweep(ctx, targets, costs, 0, 1, FLAGS_ALL, shards=[shard_targets(costs, world)[0]])
-        for _ in range(3):
-            sw.step(d_vp.data_ptr())
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        K = 20
-        e0.record(stream)
-        for _ in range(K):
-            sw.step(d_vp.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize(dev)
-        proj[str(world)] = {"targets_rank0": sw.n, "ms_per_sweep": e0.elapsed_time(e1) / K}
-    for world in (2, 4, 8):
-        proj[str(world)]["compute_bound_efficiency"] = proj["1"]["ms_per_sweep"] / (world * proj[str(world)]["ms_per_sweep"])
-    out["shard_projection"] = dict(proj, note="rank 0's shard of this field for N ranks, swept on ONE GPU: the strong-scaling "
-                                   "efficiency the kernels allow if the catalog gather hides under the next sweep; not a "
-                                   "multi-GPU measurement")
+    out = {}
+    for name, fl in modes:
+        proj = {}
+        for world in (1, 2, 4, 8):
+            sw = DeviceShardedSweep(ctx, targets, costs, 0, 1, fl, shards=[shard_targets(costs, world)[0]])
+            for _ in range(3):
+                sw.step(d_vp.data_ptr())
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(K):
+                sw.step(d_vp.data_ptr())
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            proj[str(world)] = {"targets_rank0": sw.n, "ms_per_sweep": e0.elapsed_time(e1) / K}
+            del sw
+        for world in (2, 4, 8):
+            proj[str(world)]["compute_bound_efficiency"] = proj["1"]["ms_per_sweep"] / (world * proj[str(world)]["ms_per_sweep"])
+        out[name] = proj
+    out["note"] = ("rank 0's shard of this workload for N ranks, swept on ONE GPU: the strong-scaling efficiency the kernels allow "
+                   "if the catalog gather hides under the next sweep; not a multi-GPU measurement")
     return out
 
 
@@ -878,7 +918,8 @@ def config5_record(args):
     80 images, 30 000 sources): throughput, the fp32-vs-fp64 check on every source, the fp32 kernel's VALU roofline."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--config", "5", "--dtype", "f32", "--steps", "10", "--warmup", "2",
-           "--kernels-in-pass", "--no-cpu-baseline", "--no-extras", "--height", str(args.height), "--width", str(args.width)]
+           "--kernels-in-pass", "--no-cpu-baseline", "--no-extras", "--shard-projection", "--height", str(args.height),
+           "--width", str(args.width)]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -897,7 +938,9 @@ def config5_record(args):
     keep["sources_per_step"] = d["config"]["sources_per_step"]
     keep["pixel_visits_per_sweep"] = d["config"]["pixel_visits_per_sweep"]
     keep["roofline_valu"] = d["roofline"].get("valu")
-    keep["roofline_hbm_frac"] = d["roofline"]["frac"]
+    keep["roofline_hbm_frac"] = d["roofline"].get("hbm", d["roofline"])["frac"]
+    if "shard_projection" in d:
+        keep["shard_projection"] = d["shard_projection"]
     keep["wall_s_including_field_generation"] = time.time() - t0
     return keep
 

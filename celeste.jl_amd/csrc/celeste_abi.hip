@@ -760,7 +760,9 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     }
     // a workgroup handles a group of up to G consecutive chunks of a patch (results do not depend on G, see
     // visit_chunks): 4 for large sweeps, 1 for small batches whose critical path is one patch
-    int G = n_targets >= 1536 ? 4 : n_targets >= 768 ? 2 : 1;   // (measured on the bench field's shards: 1000 targets 0.287 ms with 2, 0.315 with 4)
+    // (measured, round 5: the 2000-target sweep of the bench field 0.499 ms with 2, 0.503 with 1, 0.502 with 3, 0.512 with 4;
+    // config 5's 30 000 targets 5.31 ms with 4, 5.45 with 2, 5.30 with 8; a 1000-target shard 0.287 ms with 2, 0.315 with 4)
+    int G = n_targets >= 8192 ? 4 : n_targets >= 768 ? 2 : 1;
     if (const char *e = getenv("CELESTE_CHUNK_GROUP")) if (atoi(e) >= 1 && atoi(e) <= 16) G = atoi(e);
     // small Hessian-mode fp64 batches: eval_fused_kernel instead of pixel_kernel + lift_kernel (below)
     bool eval_fused = !render_only && (flags & CELESTE_FLAG_HESS) && !(flags & (CELESTE_FLAG_FP32 | CELESTE_FLAG_SPLIT)) &&

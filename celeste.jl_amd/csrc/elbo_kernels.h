@@ -1143,7 +1143,7 @@ template <> __device__ __forceinline__ float fma_r<float>(float a, float b, floa
 // weighted sum over components of spatial derivatives up to order 4 (24 sums instead of 1+6+21,
 // and no 3x3 transforms inside the loop).  Weights: w0 = z theta_i, wd = +-z, and their products with
 // nu, nu^2.  (dx, dy) = pixel - m_pos.  Returns sum f; fills the S* members of T.
-// ---- explicit LDS reads of a component record (PIXEL_LDS_PINGPONG) -------------------------------------------
+// ---- explicit LDS reads of a component record (two register sets, ping-pong) -------------------------------------------
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 struct LdsComp { dbl2 a, b, c, d, e, f; };   // {p11, p12} {p22, w0} {wd, nu} | {-2 p12, -3 p11} {-3 p12, -3 p22} {-4 p12, -2 p12^2}
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
@@ -1176,25 +1176,10 @@ __device__ __forceinline__ void comp_extra(const Comp &k, double *__restrict__ x
     x[0] = -2.0 * k.p12; x[1] = -3.0 * k.p11; x[2] = -3.0 * k.p12; x[3] = -3.0 * k.p22;
     x[4] = -4.0 * k.p12; x[5] = -2.0 * (k.p12 * k.p12);
 }
-#ifndef PIXEL_LDS_PINGPONG
-#define PIXEL_LDS_PINGPONG 1
-#endif
-#ifndef PIXEL_SCHED_BARRIER
-#define PIXEL_SCHED_BARRIER 1
-#endif
-// PX_HALF_D: the quadratic form as hd1 u + hd2 v with hd = -d / 2 formed once per run of prototypes (one multiply per
-// component less, same bits: a factor 1/2 commutes with rounding).  PX_IMM_OFF: the runs of 8 / 6 prototypes fully unrolled,
+// The quadratic form is hd1 u + hd2 v with hd = -d / 2 formed once per run of prototypes (one multiply per
+// component less, same bits: a factor 1/2 commutes with rounding); the runs of 8 / 6 prototypes are fully unrolled,
 // records read at immediate offsets from the run's base (two v_mov and the scalar address arithmetic per component less).
 // Together 138 -> 132 VALU per two components, 0.543 -> 0.531 ms on the bench field.
-#ifndef PX_HALF_D
-#define PX_HALF_D 1
-#endif
-#ifndef PX_IMM_OFF
-#define PX_IMM_OFF 1
-#endif
-#ifndef F32_ROW_FOLD
-#define F32_ROW_FOLD 1
-#endif
 
 template <int MODE, typename R>
 __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int nc, R dx, R dy, R dev, const double *etab,
@@ -1207,7 +1192,7 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
         // 18 accumulations per component instead of 24.
         R U0[6] = {0, 0, 0, 0, 0, 0}, U1[6] = {0, 0, 0, 0, 0, 0};
         R S2a = 0, S2b = 0, S2c = 0, S3a = 0, S3b = 0, S3c = 0, S3d = 0, S4a = 0, S4b = 0, S4c = 0, S4d = 0, S4e = 0;
-        R hd1 = 0, hd2 = 0;   // -d / 2 of the current run of prototypes (PX_HALF_D)
+        R hd1 = 0, hd2 = 0;   // -d / 2 of the current run of prototypes
         (void)hd1; (void)hd2;
         // GW (a std::integral_constant<bool>): the sums of orders 2 .. 4 are accumulated with the d-weights g = wd e as well
         // (the de Vaucouleurs loop: f = theta_0 g there, applied ONCE to the twelve sums when the loop ends -- three weight
@@ -1222,11 +1207,7 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             R xr, tj = 0, pe = 0;
             int ni = 0;
             if constexpr (sizeof(R) == 8) {
-#if PX_HALF_D
                 double x = __builtin_fma(hd1, u, hd2 * v);        // hd = -d / 2, formed once per run of prototypes
-#else
-                double x = -0.5 * (d1 * u + d2 * v);
-#endif
                 // (v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64 issue FASTER than v_fma_f64 on this chip -- 4.6 / 4.7 / 5.1 against
                 // 5.7 cycles per wave instruction, tools/fp64_rate_probe.hip -- so the magic-number rounding and exponent
                 // arithmetic that replace them with fp64 adds and 32-bit integer operations lost 2 %: measured, removed)
@@ -1254,9 +1235,7 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             R e;
             if constexpr (sizeof(R) == 8) {
                 pe = exp_poly(xr);
-#if PIXEL_SCHED_BARRIER
                 __builtin_amdgcn_sched_barrier(0);   // nothing that needs the table entry moves above this point
-#endif
                 e = ldexp(pe * tj, ni >> EXP_TAB_LOG2);   // eval_bvn_pdf!
             } else e = exp_np<R>(xr, etab);
             const R g = k.wd * e, gn = g * k.nu;
@@ -1284,7 +1263,6 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
         };
         (void)scale_dev;
         // runs of 8 (de Vaucouleurs) / 6 (exponential) prototypes share a PSF component, i.e. the offset xiBar_k
-#if PIXEL_LDS_PINGPONG
         if constexpr (sizeof(R) == 8) {
             // The record of component c + 1 is requested while component c is computed (two register sets, the loop
             // unrolled by two): the compiler neither rotates the loop nor leaves a hand-hoisted load where it is put,
@@ -1293,14 +1271,6 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
             const unsigned base = lds_addr(tc), basex = lds_addr(tcx);
             LdsComp ra, rb;
             lds_issue_comp(ra, base, basex);
-            auto half = [&](LdsComp &k, LdsComp &nxt, int c_next, R (&U)[6], R d1, R d2, auto GW) {
-                lds_wait_comp(k);
-                body_regs(k.a.x, k.a.y, k.b.x, k.b.y, k.c.x, k.c.y, k.d.x, k.d.y, k.e.x, k.e.y, k.f.x, k.f.y, U, d1, d2, GW, [&]() {
-                    const unsigned cn = (unsigned)(c_next < nc ? c_next : nc - 1);
-                    lds_issue_comp(nxt, base + 64u * cn, basex + (unsigned)(COMPX * 8) * cn);
-                });
-            };
-#if PX_IMM_OFF
             // runs of 8 / 6 prototypes fully unrolled: component j of a run is read at (run base) + 64 j, an immediate; the
             // request that follows a run's last component lands on the next run's first record (or, after the very last
             // run, on the 96 bytes behind the tables -- inside the workgroup's LDS, never used)
@@ -1333,22 +1303,8 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
                 half_imm(ra, rb, IC(5), vb, vbx, U1, d1, d2, GWF); half_imm(rb, ra, IC(6), vb, vbx, U1, d1, d2, GWF);
             }
 #undef IC
-#else
-            for (int c0 = 0; c0 < n_dev; c0 += 8) {
-                const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
-                hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
-                for (int c = c0; c < c0 + 8; c += 2) { half(ra, rb, c + 1, U0, d1, d2, std::true_type()); half(rb, ra, c + 2, U0, d1, d2, std::true_type()); }
-            }
-            scale_dev(dev);
-            for (int c0 = n_dev; c0 < nc; c0 += 6) {
-                const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
-                hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
-                for (int c = c0; c < c0 + 6; c += 2) { half(ra, rb, c + 1, U1, d1, d2, std::false_type()); half(rb, ra, c + 2, U1, d1, d2, std::false_type()); }
-            }
-#endif
             lds_wait_comp(ra);   // the last (unused) request must land before its registers are reused
         } else
-#endif
         {
         for (int c0 = 0; c0 < n_dev; c0 += 8) {
             const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
@@ -1505,9 +1461,6 @@ __device__ __forceinline__ PixelInputs load_pixel_inputs(
     bool dup = false;
 
     // ---- neighbours: gather their pre-rendered (E_G_s.v, var_G_s.v) ----
-#ifdef PIXEL_EXP_NO_NEIGHBORS   // (timing experiment, wrong results: what the gather costs)
-    nb1 = nb0;
-#endif
     for (int64_t q = nb0; q < nb1; ++q) {
         const int s2 = nbr_idx[q];
         const int v2 = nv ? nv[q - nb0] : s2 * N + n;    // the neighbour's table entry for this image (visit lists: -1 = none)
@@ -1542,9 +1495,6 @@ __device__ __forceinline__ PixelInputs load_pixel_inputs(
 
 // MODE 0: value only; MODE 1: value + gradient sums; MODE 2: value + gradient + Hessian sums;
 // MODE 3: as MODE 2 but the per-pixel records are written to HBM for record_sum_kernel (split variant)
-#ifndef PIXEL_LOADS_FIRST
-#define PIXEL_LOADS_FIRST 0
-#endif
 #ifndef PIXEL_WAVES
 #define PIXEL_WAVES 2  // waves per SIMD the register allocator must allow (256 VGPRs, no scratch; 3 waves with a dozen
                        // loop invariants in scratch measured 3 % slower)
@@ -1627,21 +1577,14 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
         T.S0d = 0; T.S1x = 0; T.S1y = 0; T.S1xd = 0; T.S1yd = 0;
         T.S2a = 0; T.S2b = 0; T.S2c = 0; T.S2an = 0; T.S2bn = 0; T.S2cn = 0; T.S2ad = 0; T.S2bd = 0; T.S2cd = 0;
         T.S3a = 0; T.S3b = 0; T.S3c = 0; T.S3d = 0; T.S4a = 0; T.S4b = 0; T.S4c = 0; T.S4d = 0; T.S4e = 0;
-#if PIXEL_LOADS_FIRST
-        const PixelInputs I = LOAD_PIXEL_INPUTS();
-        if (I.valid && own_geo) {
-#else
         // The component loop runs before the pixel's inputs are fetched: the loop needs only the pixel's coordinates,
         // and every double that is not live across it is a register the loop does not have to share (a masked pixel
         // inside the patch costs one wasted evaluation; its record entries are zeroed by the weights below).
         if (own_geo) {
-#endif
             if constexpr (sizeof(R) == 4) S0 = galaxy_sums_pk<GM>(W.tcr, 8 * (NC / 14), NC, (float)(hh - si.m1), (float)(ww - si.m2), (float)si.dev, T);
             else S0 = galaxy_sums<GM, R>(W.tcr, 8 * (NC / 14), NC, (R)(hh - si.m1), (R)(ww - si.m2), (R)si.dev, etab, T, W.tcx);
         }
-#if !PIXEL_LOADS_FIRST
         const PixelInputs I = LOAD_PIXEL_INPUTS();
-#endif
 #undef LOAD_PIXEL_INPUTS
         const bool valid = I.valid, dup = I.dup, own = valid && own_geo;
         const S x = (S)I.x, Ebar = (S)I.Ebar, Vbar = (S)I.Vbar, lgx = (S)I.lgx, iota = (S)I.iota, log_iota = (S)I.log_iota;
@@ -1651,11 +1594,7 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
 
         // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
         T.f0 = 0; T.f0g0 = 0; T.f0g1 = 0; T.f0h0 = 0; T.f0h1 = 0; T.f0h2 = 0;
-#ifdef PIXEL_EXP_NO_STAR        // (timing experiment, wrong results: what the star spline costs)
-        if (own && hh < -1e30) {
-#else
         if (own) {
-#endif
             const double xh = hh + sh0, xw = ww + sw0;     // (the cell index and the offset inside the cell from fp64 coordinates)
             int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
             int iy = (int)floor(xw); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
@@ -1738,15 +1677,248 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
             add_entries<MODE, 0>(ent, slot_s);
         } else {
             gate();
-#if F32_ROW_FOLD
             if constexpr (sizeof(S) == 4) {
                 static_assert(ACC_N % 4 == 0, "entries are added four at a time");
                 accum_entries_rows<MODE, 0>(T, slot_s + ACC_SLOTS * (lane >> 4));
             } else
-#endif
             accum_entries<MODE, 0>(T, slot_s);
         }
     }
+}
+
+// ---- single-precision mode, TWO pixels per lane (pixel_kernel<1 | 2, float>) -------------------------------------------------
+// The lane's pixels idx = base + lane and base + 64 + lane sit in the two halves of float2 values, so that EVERYTHING per
+// pixel -- the component loop, the star spline, the per-pixel term, the 65 record entries -- runs on v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32 (round 4 packed two COMPONENTS per instruction: the 41 % of the kernel's VALU instructions
+// outside the component loop stayed scalar).  The component records keep their pair-interleaved LDS layout; component c of a
+// pair is the low half of every slot, c + 1 the high half, broadcast to both pixels by the instruction's op_sel bits.  The
+// two pixels' record entries are added before they go to the chunk's slots: half the LDS adds per pixel.  Same arithmetic per
+// pixel as pixel_iter<MODE, float>; sums are formed in another (fixed) order.
+template <int MODE, class TT>
+__device__ __forceinline__ f2v galaxy_sums_px2(const f2v *tp, int n_dev, int nc, f2v dx, f2v dy, float dev, TT &T) {
+    const f2v z = (f2v)(0.0f);
+    if constexpr (MODE == 2) {
+        // as in galaxy_sums: the six sums that exist f-weighted and d-weighted are accumulated once, d-weighted, per profile
+        // type (U0: de Vaucouleurs, U1: exponential, carrying wd's minus sign)
+        f2v U0[6] = {z, z, z, z, z, z}, U1[6] = {z, z, z, z, z, z};
+        f2v S2a = z, S2b = z, S2c = z, S3a = z, S3b = z, S3c = z, S3d = z, S4a = z, S4b = z, S4c = z, S4d = z, S4e = z;
+        // GW (std::true_type): the sums of orders 2 .. 4 are accumulated with the d-weights g = wd e as well (the de Vaucouleurs
+        // loop: f = theta_0 g there, applied once to the twelve sums when the loop ends -- three weight products per component
+        // instead of five, as in galaxy_sums).  The exponential is v_exp_f32 on the quadratic form scaled by log2(e) / -2 in ONE
+        // multiply (no separate conversion to base 2).
+        auto comp = [&](auto HI, auto GW, const f2v *k, f2v (&U)[6]) {
+            constexpr bool hi = decltype(HI)::value, gw = decltype(GW)::value;
+#define PXB(i) (hi ? k[i].yy : k[i].xx)
+            const f2v p11 = PXB(0), p12 = PXB(1), p22 = PXB(2), w0 = PXB(3), wd = PXB(4), nu = PXB(5), xi1 = PXB(6), xi2 = PXB(7);
+            const f2v m2p12 = PXB(8), m3p11 = PXB(9), m3p12 = PXB(10), m3p22 = PXB(11);
+#undef PXB
+            const f2v d1 = dx - xi1, d2 = dy - xi2;
+            const f2v u = p11 * d1 + p12 * d2, v = p12 * d1 + p22 * d2;
+            const f2v q2 = -0.72134752044448170368f * (d1 * u + d2 * v);      // log2(e) x (-1/2) d' P d
+            const f2v e = {__builtin_amdgcn_exp2f(q2.x), __builtin_amdgcn_exp2f(q2.y)};
+            const f2v g = wd * e, gn = g * nu;
+            f2v f, fn, fnn;
+            if constexpr (gw) { f = g; fn = gn; fnn = gn * nu; }
+            else { f = w0 * e; fn = f * nu; fnn = fn * nu; }
+            const f2v ha = u * u - p11, hb = u * v - p12, hc = v * v - p22;
+            U[0] += g; U[1] += u * g; U[2] += v * g;
+            U[3] += ha * gn; U[4] += hb * gn; U[5] += hc * gn;
+            S2a += ha * f; S2b += hb * f; S2c += hc * f;
+            const f2v h3a = u * (ha - 2.0f * p11), h3b = v * ha + u * m2p12, h3c = u * hc + v * m2p12, h3d = v * (hc - 2.0f * p22);
+            S3a += h3a * fn; S3b += h3b * fn; S3c += h3c * fn; S3d += h3d * fn;
+            const f2v h4a = u * h3a + ha * m3p11, h4b = v * h3a + ha * m3p12, h4c = u * h3c + (hb * m2p12 - hc * p11),
+                      h4d = u * h3d + hc * m3p12, h4e = v * h3d + hc * m3p22;
+            S4a += h4a * fnn; S4b += h4b * fnn; S4c += h4c * fnn; S4d += h4d * fnn; S4e += h4e * fnn;
+        };
+        const f2v th0 = (f2v)(dev), th1 = (f2v)(1.0f - dev);
+        for (int c = 0; c < n_dev; c += 2) {
+            const f2v *k = tp + (PKSLOTS / 2) * c;
+            comp(std::false_type(), std::true_type(), k, U0); comp(std::true_type(), std::true_type(), k, U0);
+        }
+        S2a *= th0; S2b *= th0; S2c *= th0; S3a *= th0; S3b *= th0; S3c *= th0; S3d *= th0;
+        S4a *= th0; S4b *= th0; S4c *= th0; S4d *= th0; S4e *= th0;
+        for (int c = n_dev; c < nc; c += 2) {
+            const f2v *k = tp + (PKSLOTS / 2) * c;
+            comp(std::false_type(), std::false_type(), k, U1); comp(std::true_type(), std::false_type(), k, U1);
+        }
+        T.S0d = U0[0] + U1[0]; T.S1xd = U0[1] + U1[1]; T.S1yd = U0[2] + U1[2];
+        T.S2ad = U0[3] + U1[3]; T.S2bd = U0[4] + U1[4]; T.S2cd = U0[5] + U1[5];
+        T.S1x = th0 * U0[1] - th1 * U1[1]; T.S1y = th0 * U0[2] - th1 * U1[2];
+        T.S2an = th0 * U0[3] - th1 * U1[3]; T.S2bn = th0 * U0[4] - th1 * U1[4]; T.S2cn = th0 * U0[5] - th1 * U1[5];
+        T.S2a = S2a; T.S2b = S2b; T.S2c = S2c; T.S3a = S3a; T.S3b = S3b; T.S3c = S3c; T.S3d = S3d;
+        T.S4a = S4a; T.S4b = S4b; T.S4c = S4c; T.S4d = S4d; T.S4e = S4e;
+        return th0 * U0[0] - th1 * U1[0];
+    } else {
+        f2v S0 = z, S0d = z, S1x = z, S1y = z, S2an = z, S2bn = z, S2cn = z;
+        auto comp = [&](auto HI, const f2v *k) {
+            constexpr bool hi = decltype(HI)::value;
+#define PXB(i) (hi ? k[i].yy : k[i].xx)
+            const f2v p11 = PXB(0), p12 = PXB(1), p22 = PXB(2), w0 = PXB(3), wd = PXB(4), nu = PXB(5), xi1 = PXB(6), xi2 = PXB(7);
+#undef PXB
+            const f2v d1 = dx - xi1, d2 = dy - xi2;
+            const f2v u = p11 * d1 + p12 * d2, v = p12 * d1 + p22 * d2;
+            const f2v q2 = -0.72134752044448170368f * (d1 * u + d2 * v);      // log2(e) x (-1/2) d' P d
+            const f2v e = {__builtin_amdgcn_exp2f(q2.x), __builtin_amdgcn_exp2f(q2.y)};
+            const f2v f = w0 * e, fd = wd * e, fn = f * nu;
+            const f2v ha = u * u - p11, hb = u * v - p12, hc = v * v - p22;
+            S0 += f; S0d += fd;
+            S1x += u * f; S1y += v * f;
+            S2an += ha * fn; S2bn += hb * fn; S2cn += hc * fn;
+        };
+        for (int c = 0; c < nc; c += 2) { const f2v *k = tp + (PKSLOTS / 2) * c; comp(std::false_type(), k); comp(std::true_type(), k); }
+        T.S0d = S0d; T.S1x = S1x; T.S1y = S1y; T.S2an = S2an; T.S2bn = S2bn; T.S2cn = S2cn;
+        return S0;
+    }
+}
+
+// entries E .. E + 3 of the two pixels of every lane -> the chunk's slots: the pixels' entries are added, then
+// accum_entries_rows' fold over the four rows of 16 lanes (17 conflict-free LDS adds per 128 pixels)
+template <int MODE, int E, class TT>
+__device__ __forceinline__ float entry2_or_zero(const TT &T) {
+    constexpr bool hess_only = E > ZV && E < ACC_CNT;
+    if constexpr (E >= ACC_N || (MODE == 1 && hess_only) || entry_is_zero<E < ACC_N ? E : 0>()) return 0.0f;
+    else { const f2v e = record_entry<E>(T); return e.x + e.y; }
+}
+template <int MODE, int E, class TT>
+__device__ __forceinline__ void accum_entries_rows2(const TT &T, double *__restrict__ slot_row) {
+    if constexpr (!group_is_empty<MODE, E>()) {
+        const float s01 = fold_rows_pair16(entry2_or_zero<MODE, E>(T), entry2_or_zero<MODE, E + 1>(T));
+        const float s23 = fold_rows_pair16(entry2_or_zero<MODE, E + 2>(T), entry2_or_zero<MODE, E + 3>(T));
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+        const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // row r: entry E + r, slot lane & 15
+        __hip_atomic_fetch_add(slot_row + ACC_SLOTS * E, (double)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if constexpr (E + 4 < ACC_N) accum_entries_rows2<MODE, E + 4>(T, slot_row);
+}
+
+// one iteration of the single-precision pixel loop: 128 pixels, lanes = the pixels base + lane and base + 64 + lane
+template <int MODE>
+__device__ __forceinline__ void pixel_iter_px2(const PixWork<float> &W, int base, int p1, int lane, double *__restrict__ slot) {
+    static_assert(MODE == 1 || MODE == 2, "derivative modes only");
+    typedef f2v S;
+    const DevImage &img = *W.img;
+    const DevPatch &P = *W.P;
+    const SrcImg &si = W.si;
+    const int H2 = P.H2, W2 = P.W2, NC = W.NC;
+    const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
+    const double *__restrict__ tcoef = W.tcoef;
+#define PK2(a, b) ((S){(float)(a), (float)(b)})
+    int h[2], w[2], h2[2], w2[2];
+    bool in_range[2], own_geo[2];
+    double hh[2], ww[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = base + 64 * q + lane;
+        const int idx = min(i, p1 - 1);                   // clamped: every lane stays in the loop body
+        in_range[q] = i < p1;
+        w2[q] = idx / H2; h2[q] = idx - w2[q] * H2;       // 0-based patch coordinates, h fastest
+        h[q] = P.off_h + h2[q] + 1; w[q] = P.off_w + w2[q] + 1;
+        hh[q] = (double)h[q]; ww[q] = (double)w[q];
+        own_geo[q] = in_range[q] && (w2[q] < W2 - 1);     // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
+    }
+    PixelTermsT<S> T;
+    const S z = (S)(0.0f);
+    S S0 = z;
+    T.S0d = z; T.S1x = z; T.S1y = z; T.S1xd = z; T.S1yd = z;
+    T.S2a = z; T.S2b = z; T.S2c = z; T.S2an = z; T.S2bn = z; T.S2cn = z; T.S2ad = z; T.S2bd = z; T.S2cd = z;
+    T.S3a = z; T.S3b = z; T.S3c = z; T.S3d = z; T.S4a = z; T.S4b = z; T.S4c = z; T.S4d = z; T.S4e = z;
+    // the component loop runs before the pixels' inputs are fetched (it needs only their coordinates)
+    if (own_geo[0] || own_geo[1])
+        S0 = galaxy_sums_px2<MODE>(reinterpret_cast<const f2v *>(W.tcr), 8 * (NC / 14), NC, PK2(hh[0] - si.m1, hh[1] - si.m1),
+                                   PK2(ww[0] - si.m2, ww[1] - si.m2), (float)si.dev, T);
+    // (one gather loop over the neighbours for both pixels -- their dependent loads issued together -- measured no faster:
+    // 5.30 against 5.27 ms on config 5, three wavefronts per SIMD hide the chains)
+    const PixelInputs I0 = load_pixel_inputs<false, false>(img, P, W.patches, W.bitmaps, W.nbr_idx, W.nv, W.nb0, W.nb1, W.val_off, W.val,
+                                                          W.active_rank, W.my_rank, W.N, W.n, H2, h[0], w[0], h2[0], w2[0], in_range[0]);
+    const PixelInputs I1 = load_pixel_inputs<false, false>(img, P, W.patches, W.bitmaps, W.nbr_idx, W.nv, W.nb0, W.nb1, W.val_off, W.val,
+                                                          W.active_rank, W.my_rank, W.N, W.n, H2, h[1], w[1], h2[1], w2[1], in_range[1]);
+    const bool valid[2] = {I0.valid, I1.valid};
+    const bool own[2] = {valid[0] && own_geo[0], valid[1] && own_geo[1]};
+    auto sel = [](const bool (&m)[2], S v) -> S { return (S){m[0] ? v.x : 0.0f, m[1] ? v.y : 0.0f}; };
+    const S x = PK2(I0.x, I1.x), Ebar = PK2(I0.Ebar, I1.Ebar), Vbar = PK2(I0.Vbar, I1.Vbar), lgx = PK2(I0.lgx, I1.lgx);
+    const S iota = PK2(I0.iota, I1.iota), log_iota = PK2(I0.log_iota, I1.log_iota);
+    const S c0 = (S)((float)si.c0), c1 = (S)((float)si.c1), q0 = (S)((float)si.q0), q1 = (S)((float)si.q1);
+    T.f1 = sel(own, S0);
+
+    // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
+    T.f0 = z; T.f0g0 = z; T.f0g1 = z; T.f0h0 = z; T.f0h1 = z; T.f0h2 = z;
+    if (own[0] || own[1]) {
+        const double *cc[2];
+        float fxs[2], fys[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const double xh = hh[q] + sh0, xw = ww[q] + sw0;   // (the cell index and the offset inside the cell from fp64 coordinates)
+            int ix = (int)floor(xh); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
+            int iy = (int)floor(xw); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
+            cc[q] = tcoef + (ix - 1) + CEL_COEF * (iy - 1);
+            fxs[q] = (float)(xh - ix); fys[q] = (float)(xw - iy);
+        }
+        const S fx = PK2(fxs[0], fxs[1]), fy = PK2(fys[0], fys[1]);
+        S wx[4], wy[4], dwx[4], ddwx[4], dwy[4], ddwy[4];
+        bspline_w(fx, wx); bspline_w(fy, wy);
+        bspline_dw(fx, dwx, ddwx); bspline_dw(fy, dwy, ddwy);
+        S y = z, yx = z, yy = z, yxx = z, yxy = z, yyy = z;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const double *ca = cc[0] + CEL_COEF * b, *cb = cc[1] + CEL_COEF * b;
+            const S k0 = PK2(ca[0], cb[0]), k1 = PK2(ca[1], cb[1]), k2 = PK2(ca[2], cb[2]), k3 = PK2(ca[3], cb[3]);
+            const S r = k0 * wx[0] + k1 * wx[1] + k2 * wx[2] + k3 * wx[3];
+            const S rx = k0 * dwx[0] + k1 * dwx[1] + k2 * dwx[2] + k3 * dwx[3];
+            const S rxx = k0 * ddwx[0] + k1 * ddwx[1] + k2 * ddwx[2] + k3 * ddwx[3];
+            y += r * wy[b]; yx += rx * wy[b]; yxx += rxx * wy[b];
+            yy += r * dwy[b]; yxy += rx * dwy[b]; yyy += r * ddwy[b];
+        }
+        // softpluslikeinv and its derivatives; not C2 at 0, branch exactly (fsm_util.jl:222) -- per pixel
+        const bool neg[2] = {y.x < 0.0f, y.y < 0.0f};
+        const S ey = (S){1e-3f * exp_s(y.x), 1e-3f * exp_s(y.y)}, lin = 1e-3f * (y + 1.0f);
+        const S gv = (S){neg[0] ? ey.x : lin.x, neg[1] ? ey.y : lin.y};
+        const S gp = (S){neg[0] ? ey.x : 1e-3f, neg[1] ? ey.y : 1e-3f};
+        const S gpp = sel(neg, ey);
+        const S ym1 = -yx, ym2 = -yy;  // d(index)/dm = -1
+        T.f0 = sel(own, gv);
+        T.f0g0 = sel(own, gp * ym1); T.f0g1 = sel(own, gp * ym2);
+        T.f0h0 = sel(own, gpp * ym1 * ym1 + gp * yxx);
+        T.f0h1 = sel(own, gpp * ym1 * ym2 + gp * yxy);
+        T.f0h2 = sel(own, gpp * ym2 * ym2 + gp * yyy);
+    }
+
+    // ---- per-pixel term (add_pixel_term!, add_elbo_log_term!) ----
+    {
+        const S A = c0 * T.f0 + c1 * T.f1;                       // E_G_s.v
+        const S B = q0 * (T.f0 * T.f0) + q1 * (T.f1 * T.f1);     // E_G2_s.v
+        const S EA = Ebar + A;
+        const S E = (S){valid[0] ? EA.x : 1.0f, valid[1] ? EA.y : 1.0f};   // E_G.v
+        const S V = Vbar + (B - A * A);                          // var_G.v
+        const S iE = (S){1.0f / E.x, 1.0f / E.y}, logE = (S){log_s(E.x), log_s(E.y)};
+        const S iE2 = iE * iE, iE3 = iE2 * iE;
+        T.vterm = sel(valid, x * (log_iota + (logE - V * (0.5f * iE2))) - iota * E - lgx);
+        T.cnt_act = (S){own[0] ? 1.0f : 0.0f, own[1] ? 1.0f : 0.0f};
+        T.cnt_inact = PK2(I0.n_inact, I1.n_inact);
+        // derivative weights are zero unless the active source covers the pixel, which zeroes every derivative entry
+        const S xo = sel(own, x), io = sel(own, iota);
+        const S w1 = xo * (iE + V * iE3) - io;                   // dT/dE
+        T.w2 = -0.5f * xo * iE2;                                 // dT/dVar
+        const S w11 = -xo * (iE2 + 3.0f * V * iE2 * iE2);        // d2T/dE2
+        T.w12 = xo * iE3;                                        // d2T/dE dVar
+        T.alpha = w1 - 2.0f * A * T.w2;
+        T.beta = w11 - 2.0f * T.w2 - 4.0f * A * T.w12;
+        T.k1 = T.alpha * c1 + 2.0f * T.w2 * q1 * T.f1;           // multiplies d2 f1
+        T.k0 = T.alpha * c0 + 2.0f * T.w2 * q0 * T.f0;           // multiplies d2 f0
+        {
+            const S t0 = 2.0f * T.w12 * q0 * T.f0, t1 = 2.0f * T.w12 * q1 * T.f1;
+            const S P0 = T.beta * c0 + t0, P1 = T.beta * c1 + t1;      // beta dA + w12 dB = P0 ds + P1 dg
+            T.C0s = T.alpha + T.f0 * P0; T.C0g = T.f0 * P1;
+            T.C1s = T.f1 * P0; T.C1g = T.alpha + T.f1 * P1;
+            const S v0 = T.w12 * (T.f0 * T.f0), v1 = T.w12 * (T.f1 * T.f1), u0 = 2.0f * T.w2 * T.f0, u1 = 2.0f * T.w2 * T.f1;
+            T.Q0s = u0 + v0 * c0; T.Q0g = v0 * c1;                          // 2 w2 f0 ds + w12 f0^2 dA
+            T.Q1s = v1 * c0; T.Q1g = u1 + v1 * c1;
+            T.Wgg = 2.0f * T.w2 * q1 + c1 * (P1 + t1);
+            T.Wss = 2.0f * T.w2 * q0 + c0 * (P0 + t0);
+            T.Wsg = c0 * P1 + c1 * t0;
+        }
+    }
+#undef PK2
+    accum_entries_rows2<MODE, 0>(T, slot + ACC_SLOTS * (lane >> 4));
 }
 
 // lane e sums the 16 slots of entry e (rotated start: 4-way instead of 64-way bank conflicts; the order of the additions
@@ -1767,7 +1939,10 @@ __device__ __forceinline__ void fold_record_slots(const S *__restrict__ sacc, in
 // MULTI: several active sources (celeste_elbo_eval_multi) -- compiled separately so that the production
 // instantiation carries none of its per-neighbour bookkeeping
 template <int MODE, typename R, bool MULTI = false>
-__global__ void __launch_bounds__(64, sizeof(R) == 4 ? 3 : PIXEL_WAVES)   // the single-precision kernels fit three waves per SIMD
+#ifndef PIXEL_F32_WAVES
+#define PIXEL_F32_WAVES 3   // (measured, config 5: 5.37 ms with three waves per SIMD and 76 B of scratch outside the pixel loop, 5.72 ms with two and none)
+#endif
+__global__ void __launch_bounds__(64, sizeof(R) == 4 ? (MODE == 3 ? 3 : PIXEL_F32_WAVES) : PIXEL_WAVES)
 pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ patches,
              const double *__restrict__ coefs, const uint8_t *__restrict__ bitmaps,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
@@ -1865,6 +2040,9 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     }
     double a[3] = {0.0, 0.0, 0.0};
 
+    if constexpr (sizeof(R) == 4 && (MODE == 1 || MODE == 2) && !MULTI) {
+        for (int base = p0; base < p1; base += 128) pixel_iter_px2<MODE>(W, base, p1, lane, slot);
+    } else
     for (int base = p0; base < p1; base += 64) pixel_iter<MODE, R, MULTI>(W, base, p1, lane, slot, a, []() {});
     if (MODE == 3) continue;
 
@@ -2100,6 +2278,7 @@ __device__ const __attribute__((aligned(16))) LiftTables c_lift = make_lift_tabl
 struct KLShared {
     double t[16], m[16], Ld[16][4], ml[16][4];  // per (type, colour component)
     double ta[2], g[2], g_r[2], g_v[2], ck[2], cm[2];
+    double rad;                                  // log p(radius) (elbo_kl.jl:130-137)
 };
 
 // Hessian entry (p1 <= p2) of subtract_kl; vs = the target's parameters
@@ -2284,6 +2463,13 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
         K.g_r[i] = (mu1 - mu2) / var2;
         K.g_v[i] = .5 * (-1.0 / var1 + 1.0 / var2);
     }
+    // (the radius prior here, not in kl_value: that lambda runs inside the image loop, and the constants of its library
+    // logarithms -- hoisted out of the loop -- were what lift_kernel spilled: 88 B of scratch per thread, stored by EVERY
+    // thread, 45 MB of HBM writes per 2000-target sweep next to 31 MB of Hessians)
+    if (want_kl && tid == 237) {
+        const double x = vs[5], mu = prior->p.gal_radius_px_mean, s2 = prior->p.gal_radius_px_var;
+        K.rad = -0.5 * (log(2.0 * M_PI) + log(s2) + (x - mu) * (x - mu) / s2);
+    }
     // ---- KL value (elbo_kl.jl:140-154): by the same wavefront, while the others are in the second pass ----
     auto kl_value = [&]() {
         if (want_kl && tid >= 192 && tid < 256) {
@@ -2298,8 +2484,7 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
             if (tid == 238) {
                 double kl = 0;
                 for (int i = 0; i < 2; ++i) kl -= vs[26 + i] * (K.ta[i] + K.ck[i] + K.g[i] + K.cm[i]);
-                const double x = vs[5], mu = prior->p.gal_radius_px_mean, s2 = prior->p.gal_radius_px_var;
-                kl += -0.5 * (log(2.0 * M_PI) + log(s2) + (x - mu) * (x - mu) / s2);
+                kl += K.rad;
                 L.klv = kl;
             }
         }

@@ -29,6 +29,18 @@ def test_the_checker_sees_a_hazard_when_there_is_one():
     sw = ["f:", "\tv_permlane32_swap_b32_e32 v7, v4", "\tv_add_f64 v[10:11], v[12:13], v[14:15]",
           "\tv_fmac_f64_dpp v[0:1], v[4:5], v[2:3] row_newbcast:0 row_mask:0xf bank_mask:0xf"]
     assert len(chk.check(sw)[1]) == 1
+    # a block boundary is not safe: the write at the end of the predecessor block, and the one in front of a branch into it
+    dpp = "\tv_fmac_f64_dpp v[0:1], v[4:5], v[2:3] row_newbcast:3 row_mask:0xf bank_mask:0xf"
+    fall = ["f:", "\tv_mov_b64_e32 v[4:5], v[8:9]", ".LBB0_1:", dpp]
+    assert len(chk.check(fall)[1]) == 1
+    jump = ["f:", "\tv_mov_b64_e32 v[4:5], v[8:9]", "\ts_cbranch_vccz .LBB0_2", "\ts_nop 3", "\ts_branch .LBB0_3", ".LBB0_2:", dpp, ".LBB0_3:"]
+    assert len(chk.check(jump)[1]) == 1              # (the branch itself is one wait state: one short)
+    safe = ["f:", "\tv_mov_b64_e32 v[4:5], v[8:9]", "\ts_nop 0", "\ts_cbranch_vccz .LBB0_2", "\ts_branch .LBB0_3", ".LBB0_2:", dpp, ".LBB0_3:"]
+    assert chk.check(safe) == (1, [])
+    # a VALU write of EXEC needs five wait states before a DPP instruction
+    ex = ["f:", "\tv_cmpx_lt_f64_e32 v[8:9], v[10:11]", "\ts_nop 2", dpp]
+    assert len(chk.check(ex)[1]) == 1 and chk.check(ex)[1][0][2] == "exec"
+    assert chk.check(["f:", "\tv_cmpx_lt_f64_e32 v[8:9], v[10:11]", "\ts_nop 4", dpp]) == (1, [])
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
@@ -68,8 +80,10 @@ def test_register_and_scratch_budgets_of_the_hot_kernels():
         return hits[0]
     v, s, l = one("_Z12pixel_kernelILi2EdLb0EE")
     assert s == 0 and v <= 256 and l <= 16 * 1024
+    # single precision, two pixels per lane: three waves per SIMD (168 VGPRs) with a few spills OUTSIDE the pixel loop
+    # (measured faster than two waves and none: 5.37 against 5.72 ms on config 5)
     v, s, l = one("_Z12pixel_kernelILi2EfLb0EE")
-    assert s == 0 and v <= 168
+    assert s <= 96 and v <= 168
     for k in ("_Z18optim_fused_kernelILb0EE", "_Z18optim_fused_kernelILb1EE"):
         v, s, l = one(k)
         assert s <= 128 and v <= 256 and 2 * l <= 160 * 1024, (k, v, s, l)
@@ -77,3 +91,22 @@ def test_register_and_scratch_budgets_of_the_hot_kernels():
     assert s <= 96 and v <= 256 and 8 * l <= 160 * 1024
     v, s, l = one("_Z17eval_fused_kernel")
     assert s == 0
+    # the lift: 8 workgroups of 256 threads per CU (64 VGPRs); its spill is stored by every thread, i.e. it is HBM traffic
+    # (88 B per thread = 45 MB per 2000-target sweep before round 5 moved the radius prior's logarithms out of the image loop)
+    v, s, l = one("_Z11lift_kernel")
+    assert s <= 40 and v <= 64 and 8 * l <= 160 * 1024
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_the_flop_counts_bench_reports_are_those_of_this_tree():
+    """bench.py's roofline numerator (flops per pixel visit, instruction mix) is read from profiles/hbm_traffic.json; a kernel
+    edit without `python tools/count_flops.py --write` would leave it stale -- the fresh count of the compiled listing must
+    equal the committed one, fp64 and fp32"""
+    import json
+    import count_flops as cf
+    txt = "\n".join(compiled_listing())
+    committed = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    for key, sym in (("", "_Z12pixel_kernelILi2EdLb0EEv"), ("_f32", "_Z12pixel_kernelILi2EfLb0EEv")):
+        flops, mix, _ = cf.analyse(txt, sym, pixels_per_lane=cf.PIXELS_PER_LANE[key])
+        assert flops == committed["flops_per_pixel_visit" + key], (key, flops, committed["flops_per_pixel_visit" + key])
+        assert mix == committed["instruction_mix" + key], (key, mix, committed["instruction_mix" + key])

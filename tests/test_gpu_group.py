@@ -137,8 +137,9 @@ def test_group_maximize_equals_the_one_device_entry_bit_for_bit(crowded):
             _same(ref, got, "%s, %d member(s)" % (what, len(devices)))
         # a failing target keeps its row, the others are optimised
         vp = f.vp.copy()
-        vp[4, 10] = np.nan
-        tg = [t for t in range(S) if t != 4 and 4 in f.neighbors[t]] + [t for t in range(S) if 4 not in f.neighbors[t] and t != 4][:6]
+        bad = int(np.argmax([len(n) for n in f.neighbors]))     # NaN in the most connected source: it and its neighbours fail
+        vp[bad, 10] = np.nan
+        tg = list(range(S))
         ref = ctx.maximize_batch(vp, tg, cel.ElboConfig(max_iters=4), raise_on_error=False)
         got = g.maximize_batch(vp, tg, cel.ElboConfig(max_iters=4), raise_on_error=False)
         assert (ref[4] != 0).any() and (ref[4] == 0).any()

@@ -27,39 +27,77 @@ def vregs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def check(lines):
-    """(number of DPP instructions, list of (line number, text, register, wait states seen))"""
-    n, bad, hist = 0, [], []   # hist: (wait states the instruction provides, VGPRs it writes; None = block boundary)
+def _parse(lines):
+    """instructions of the listing: (line number, text, opcode, VGPRs written, wait states it provides, DPP source or None,
+    VALU write of EXEC), labels -> instruction index, branch sites per label"""
+    ins, label_at, branches = [], {}, {}
     for no, line in enumerate(lines, 1):
         t = line.split(";")[0].strip()
-        if not t or t.startswith("."):
+        if t.endswith(":") and " " not in t:
+            label_at[t[:-1]] = len(ins)
             continue
-        if t.endswith(":"):
-            hist = [(0, None)]
+        if not t or t.startswith("."):
             continue
         parts = t.replace(",", " ").split()
         op = parts[0]
+        wr, ws, src, wexec = set(), 1, None, False
         if any(w in t for w in DPP_WORDS):
-            n += 1
             src = vregs(parts[2]) if len(parts) > 2 else set()
-            ws = 0
-            for w, wr in reversed(hist):
-                if ws >= 2 or wr is None:
-                    break
-                if wr & src:
-                    bad.append((no, t, sorted(wr & src), ws))
-                    break
-                ws += w
         if op.startswith("s_nop"):
-            hist.append((int(parts[1]) + 1 if len(parts) > 1 else 1, set()))
+            ws = int(parts[1]) + 1 if len(parts) > 1 else 1
         elif op.startswith("v_"):
             wr = vregs(parts[1]) if len(parts) > 1 else set()
             if "swap" in op and len(parts) > 2:
                 wr |= vregs(parts[2])
-            hist.append((1, wr))
-        else:
-            hist.append((1, set()))
-        hist = hist[-8:]
+            # a VALU write of EXEC: v_cmpx*, or any VALU instruction whose destination is exec
+            wexec = op.startswith("v_cmpx") or (len(parts) > 1 and parts[1].startswith("exec"))
+        if op.startswith(("s_cbranch", "s_branch")) and len(parts) > 1:
+            branches.setdefault(parts[-1], []).append(len(ins))
+        ins.append((no, t, op, wr, ws, src, wexec))
+    return ins, label_at, branches
+
+
+def check(lines):
+    """(number of DPP instructions, list of (line number, text, register, wait states seen)).  A DPP instruction needs two
+    wait states behind a VALU write of its source and five behind a VALU write of EXEC.  Basic-block boundaries are NOT taken
+    as safe: the walk back from a DPP instruction continues through the fall-through predecessor and through every branch
+    that targets the block (the static_for bodies of the solver sit inside `if` regions, so a write at the end of a
+    predecessor block can sit right in front of a DPP that opens the next one)."""
+    ins, label_at, branches = _parse(lines)
+    starts = {}
+    for lab, idx in label_at.items():
+        starts.setdefault(idx, []).append(lab)
+    bad, n = [], 0
+
+    def walk(i, ws, src, need, depth, seen):
+        """instructions before index i, `ws` wait states already between them and the DPP; True if a hazard is found"""
+        while i >= 0 and ws < need:
+            if i + 1 in starts and depth < 4:           # instruction i + 1 opens a block: the branches that target it
+                for lab in starts[i + 1]:
+                    for b in branches.get(lab, ()):
+                        if (b, ws) not in seen:
+                            seen.add((b, ws))
+                            hit = walk(b, ws, src, need, depth + 1, seen)
+                            if hit:
+                                return hit
+                if ins[i][2].startswith(("s_branch", "s_endpgm", "s_setpc")):
+                    return False                         # no fall-through into the block
+            no, t, op, wr, w, _, wexec = ins[i]
+            if ws < 2 and wr & src:
+                return (no, t, sorted(wr & src), ws)
+            if wexec and ws < 5:
+                return (no, t, "exec", ws)
+            ws += w
+            i -= 1
+        return False
+
+    for i, (no, t, op, wr, w, src, wexec) in enumerate(ins):
+        if src is None:
+            continue
+        n += 1
+        hit = walk(i - 1, 0, src, 5, 0, set())
+        if hit:
+            bad.append((no, t, hit[2], hit[3]))
     return n, bad
 
 

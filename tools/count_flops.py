@@ -54,7 +54,9 @@ def loops_of(lines):
     return out
 
 
-def analyse(txt, symbol, psf_k=2):
+def analyse(txt, symbol, psf_k=2, pixels_per_lane=1):
+    """pixels_per_lane: pixels a lane handles per trip of the pixel loop -- 2 in the single-precision kernel (pixel_iter_px2:
+    two pixels in the halves of every float2), so its per-trip counts are halved to give per-pixel-visit figures"""
     i = txt.index(symbol)
     i = txt.index(":\n", i)
     lines = txt[i:txt.index("s_endpgm", i)].split("\n")
@@ -81,10 +83,17 @@ def analyse(txt, symbol, psf_k=2):
             per_visit[k] += (trips - 1) * c[k]
     report.append("pixel loop body (one copy of each component loop inside): %d fp64 + %d fp32 flops, %d VALU" %
                   (body["f64"], body["f32"], body["valu"]))
-    mix = {"valu_per_pixel_visit": per_visit["valu"], "fp_instructions": per_visit["fp_instr"], "fma_class": per_visit["fma"],
+    if pixels_per_lane > 1:
+        report.append("a trip of the pixel loop handles %d pixels per lane: per-visit figures = per-trip / %d" % (pixels_per_lane, pixels_per_lane))
+        per_visit = {k: v / pixels_per_lane for k, v in per_visit.items()}
+    rnd = (lambda x: int(round(x))) if pixels_per_lane == 1 else (lambda x: round(x, 1))
+    mix = {"valu_per_pixel_visit": rnd(per_visit["valu"]), "fp_instructions": rnd(per_visit["fp_instr"]), "fma_class": rnd(per_visit["fma"]),
            "fma_share_of_valu": round(per_visit["fma"] / per_visit["valu"], 4),
-           "fp64_flops": per_visit["f64"], "fp32_flops": per_visit["f32"]}
-    return per_visit["f64"] + per_visit["f32"], mix, report
+           "fp64_flops": rnd(per_visit["f64"]), "fp32_flops": rnd(per_visit["f32"])}
+    return rnd(per_visit["f64"] + per_visit["f32"]), mix, report
+
+
+PIXELS_PER_LANE = {"": 1, "_f32": 2}
 
 
 def main():
@@ -96,11 +105,11 @@ def main():
     res = {}
     for key, sym, name in (("", "_Z12pixel_kernelILi2EdLb0EEv", "pixel_kernel<2, double>"),
                            ("_f32", "_Z12pixel_kernelILi2EfLb0EEv", "pixel_kernel<2, float>")):
-        flops, mix, report = analyse(txt, sym)
+        flops, mix, report = analyse(txt, sym, pixels_per_lane=PIXELS_PER_LANE[key])
         print(name)
         for r in report:
             print("  " + r)
-        print("  per pixel visit (psf_K = 2): %d flops (%d fp64 + %d fp32), %d VALU instructions, %d of them FMA-class (%.0f %%)"
+        print("  per pixel visit (psf_K = 2): %g flops (%g fp64 + %g fp32), %g VALU instructions, %g of them FMA-class (%.0f %%)"
               % (flops, mix["fp64_flops"], mix["fp32_flops"], mix["valu_per_pixel_visit"], mix["fma_class"],
                  100 * mix["fma_share_of_valu"]))
         res["flops_per_pixel_visit" + key] = flops
