@@ -17,14 +17,15 @@ def path(k):
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge     # the product's own compile and link flags (exports.map, RCCL)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc", ".map"))]
     newest = max(os.path.getmtime(s) for s in srcs)
     procs = []
     for k in MUTANTS:
         if force or not os.path.exists(path(k)) or os.path.getmtime(path(k)) < newest:
-            procs.append(subprocess.Popen([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3",
-                                           "-std=c++17", "-fPIC", "-shared", "-DCELESTE_MUTANT=%d" % k, "-o", path(k),
-                                           os.path.join(CSRC, "celeste_abi.hip")], cwd=CSRC))
+            procs.append(subprocess.Popen([ge.HIPCC] + ge.HIP_FLAGS + ["-DCELESTE_MUTANT=%d" % k, "-o", path(k),
+                                           os.path.join(CSRC, "celeste_abi.hip")] + ge.LINK_FLAGS, cwd=CSRC))
     for p in procs:
         if p.wait() != 0:
             raise SystemExit("mutant build failed")

@@ -1,11 +1,10 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c5
-B="python bench.py --config 5 --dtype f32 --steps 10 --warmup 2 --kernels-in-pass --no-cpu-baseline --no-extras"
-run() { name=$1; shift; env "$@" timeout 300 $B > gpurun_out/c5/$name.json 2> gpurun_out/c5/$name.err; python -c "import json;d=json.load(open('gpurun_out/c5/$name.json'));print('$name', round(d['value']), d['kernels_ms'], d['fp32_vs_fp64_device'])" || tail -3 gpurun_out/c5/$name.err; }
-run new X=1
-run prev CELESTE_MI355X_LIB=$GRAFT_REPO_ROOT/tools/variants/lib_prev.so
-run new_again X=1
-B3="python bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-extras"
-for e in CELESTE_CHUNK_GROUP=1 CELESTE_CHUNK_GROUP=2 CELESTE_CHUNK_GROUP=3 CELESTE_CHUNK_GROUP=4 CELESTE_CHUNK_GROUP=2; do
-  env $e timeout 300 $B3 > gpurun_out/c5/f64_$e.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/c5/f64_$e.json'));print('f64 $e', round(d['value']), d['kernels_ms'])"
-done
+mkdir -p gpurun_out/c6
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/c6/pytest_gpu.txt
+cat gpurun_out/c6/pytest_gpu.txt
+timeout 600 python bench.py --no-config5 > gpurun_out/c6/bench.json 2> gpurun_out/c6/bench.err; tail -2 gpurun_out/c6/bench.err
+python -c "
+import json;d=json.load(open('gpurun_out/c6/bench.json'))
+print(d['value'], d['ms_per_step'], d['kernels_ms'], d['roofline']['frac'], d['roofline']['bound'])
+for k in ('optimizer','joint_infer','single_call_latency_us','shard_projection','host_api_sources_per_sec'): print(k, d.get(k))
+"
