@@ -827,6 +827,9 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            c->d_nbr_off, c->d_nbr_idx, c->d_rec_off, (int)setup_blocks, c->d_images, c->K, c->d_srcimg,
                            c->d_comps, prep_all_here ? (int)c->V : 0, c->d_vis_src);
     } else {
+        // (the work-list kernels depend on nothing setup / prep / value produce; built on a second stream beside them and
+        // joined in front of the pixel kernel they measured no faster -- 0.6519 ms per sweep of the bench field either way --
+        // and a stream more per context is not free: round 5, removed)
         hipLaunchKernelGGL(setup_kernel, dim3((unsigned)((setup_threads + 63) / 64)), dim3(64), 0, stream, d_vp, geo_S,
                            c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
                            render_neighbors ? c->d_needed : nullptr, c->stamp, prep_mark, c->d_nbr_off, c->d_nbr_idx, d_live);
