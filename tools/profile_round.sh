@@ -8,8 +8,8 @@ ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $ROOT/bench.py --steps 30 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-live-pmc --no-config5 > $OUT/bench_traced.json 2> $OUT/trace.err
+python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-live-pmc --no-config5 > $OUT/bench_traced.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc --no-config5 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc --no-config5 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o sq -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc --no-config5 > /dev/null 2> $OUT/pmc_sq.err
