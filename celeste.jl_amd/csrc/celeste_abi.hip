@@ -74,6 +74,7 @@ struct celeste_ctx {
     DevImage *d_images = nullptr;        // = imgs->d_images
     DevPatch *d_patches = nullptr;
     double *d_coefs = nullptr;
+    float *d_coefs_f = nullptr;          // the spline coefficients rounded to float (single-precision mode)
     uint8_t *d_bitmaps = nullptr;
     int64_t *d_nbr_off = nullptr;
     int32_t *d_nbr_idx = nullptr;
@@ -423,6 +424,7 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
     }
     c->V = (int64_t)c->h_vis_img.size();
     if (c->V > 0x7fffffffll / std::max(c->NC, 1)) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }
+    if (c->max_npx >= (1 << 22)) { celeste_ctx_destroy(c); return CELESTE_ERR_INVALID_ARG; }   // (divmod_small: pixel indices of a patch in 22 bits)
     CTX_TRY(dev_upload(&c->d_patches, c->h_patches.data(), c->h_patches.size()));
     CTX_TRY(dev_upload(&c->d_bitmaps, pool.data(), pool.size()));
 
@@ -432,6 +434,8 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         for (int k = 0; k < c->n_stamps; ++k)
             celeste_spline_prefilter(pr->stamps + (size_t)k * CEL_STAMP * CEL_STAMP, coefs.data() + (size_t)k * CEL_COEF * CEL_COEF);
         CTX_TRY(dev_upload(&c->d_coefs, coefs.data(), coefs.size()));
+        std::vector<float> coefs_f(coefs.begin(), coefs.end());
+        CTX_TRY(dev_upload(&c->d_coefs_f, coefs_f.data(), coefs_f.size()));
     }
 
     // neighbour CSR
@@ -602,7 +606,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    void *ptrs[] = {c->d_patches, c->d_coefs, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
+    void *ptrs[] = {c->d_patches, c->d_coefs, c->d_coefs_f, c->d_bitmaps, c->d_nbr_off, c->d_nbr_idx, c->d_prior,
                     c->d_srcimg, c->d_comps, c->d_geo, c->d_val_off, c->d_val, c->d_needed, c->d_vis_off, c->d_vis_img, c->d_vis_src, c->d_value_items, c->d_vitems_src, c->d_vitem_off, c->d_prep_mark, c->d_rec_off, c->d_lg_sum, c->d_nv_base, c->d_nbr_vis, c->d_items, c->d_work, c->d_work_blk, c->d_work_total, c->d_tile_off, c->d_rec, c->d_acc_split, c->d_acc, c->d_vp, c->d_targets, c->d_v, c->d_d, c->d_h,
                     c->d_cnt, c->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -900,7 +904,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
 #define PIXEL_ARGS                                                                                                \
     c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx,       \
     c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, G, c->d_acc, c->d_tile_off, c->d_rec, \
-    d_active_rank, c->d_items, c->M, c->d_work, c->d_work_total, c->d_nv_base, c->d_nbr_vis, c->d_rec_off
+    d_active_rank, c->d_items, c->M, c->d_work, c->d_work_total, c->d_nv_base, c->d_nbr_vis, c->d_rec_off, c->d_coefs_f
 #define LAUNCH_PIXEL_T(MODE, R) hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL_M(MODE) hipLaunchKernelGGL((pixel_kernel<MODE, double, true>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL(MODE) do { if (flags & CELESTE_FLAG_FP32) LAUNCH_PIXEL_T(MODE, float); else LAUNCH_PIXEL_T(MODE, double); } while (0)

@@ -449,6 +449,16 @@ __device__ inline float galaxy_value_f(const float *tcf, int NC, float dx, float
     return v.x + v.y;
 }
 
+// idx / d and idx mod d for 0 <= idx < 2^22 and 1 <= d: one float multiply and a correction instead of the ~35 instructions of
+// a 32-bit integer division by a run-time divisor (rd = 1.0f / d, formed once per patch).  Exact: (float)idx is exact, the
+// product is within one of the true quotient, and the remainder test puts it right.
+__device__ __forceinline__ void divmod_small(int idx, int d, float rd, int &q, int &r) {
+    q = (int)((float)idx * rd);
+    r = idx - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
+
 // ---- cross-lane helpers (wave64) ----------------------------------------------------------------
 __device__ inline double wave_sum(double x) {
 #pragma unroll
@@ -814,8 +824,10 @@ __device__ __forceinline__ void value_pixels(int lane, const DevPatch &P, const 
                                              const float *__restrict__ tcf = nullptr) {
     const double *__restrict__ coef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
+    const float rRH = 1.0f / (float)RH;
     for (int idx = p0 + lane; idx < p1; idx += 64) {
-        const int rw = idx / RH, rh = idx - rw * RH;
+        int rw, rh;
+        divmod_small(idx, RH, rRH, rw, rh);
         const int h0 = h_lo + rh, w0 = w_lo + rw;  // 0-based image coordinates
         const double hh = (double)(h0 + 1), ww = (double)(w0 + 1);
         double f0, f1;
@@ -1515,6 +1527,7 @@ struct PixWork {
     const CompR<R> *tcr;             // the same in the arithmetic type of the component loop (LDS)
     const double *etab;              // 2^(j/64) table (LDS)
     const double *tcoef;             // star spline coefficients of the patch's stamp
+    const float *tcoef_f;            // the same rounded to float (single-precision mode: 4-byte loads, no conversions)
     const int64_t *tile_off; double *rec;   // split variant only
 };
 
@@ -1539,7 +1552,8 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
     {
         const int idx = min(base + lane, p1 - 1);           // clamped: every lane stays in the loop body
         const bool in_range = base + lane < p1;
-        const int w2 = idx / H2, h2 = idx - w2 * H2;        // 0-based patch coordinates, h fastest
+        int w2, h2;                                         // 0-based patch coordinates, h fastest
+        divmod_small(idx, H2, 1.0f / (float)H2, w2, h2);
         const int h = P.off_h + h2 + 1, w = P.off_w + w2 + 1;  // 1-based image coordinates
         const double hh = (double)h, ww = (double)w;
 #define LOAD_PIXEL_INPUTS() load_pixel_inputs<MULTI, COHV>(img, P, W.patches, W.bitmaps, W.nbr_idx, W.nv, W.nb0, W.nb1, W.val_off, \
@@ -1801,9 +1815,10 @@ __device__ __forceinline__ void pixel_iter_px2(const PixWork<float> &W, int base
     const SrcImg &si = W.si;
     const int H2 = P.H2, W2 = P.W2, NC = W.NC;
     const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
-    const double *__restrict__ tcoef = W.tcoef;
+    const float *__restrict__ tcoef = W.tcoef_f;
 #define PK2(a, b) ((S){(float)(a), (float)(b)})
     int h[2], w[2], h2[2], w2[2];
+    const float rH2 = 1.0f / (float)H2;
     bool in_range[2], own_geo[2];
     double hh[2], ww[2];
 #pragma unroll
@@ -1811,7 +1826,7 @@ __device__ __forceinline__ void pixel_iter_px2(const PixWork<float> &W, int base
         const int i = base + 64 * q + lane;
         const int idx = min(i, p1 - 1);                   // clamped: every lane stays in the loop body
         in_range[q] = i < p1;
-        w2[q] = idx / H2; h2[q] = idx - w2[q] * H2;       // 0-based patch coordinates, h fastest
+        divmod_small(idx, H2, rH2, w2[q], h2[q]);         // 0-based patch coordinates, h fastest
         h[q] = P.off_h + h2[q] + 1; w[q] = P.off_w + w2[q] + 1;
         hh[q] = (double)h[q]; ww[q] = (double)w[q];
         own_geo[q] = in_range[q] && (w2[q] < W2 - 1);     // 1 <= w2 < W2 (1-based), elbo_objective.jl:349
@@ -1843,7 +1858,7 @@ __device__ __forceinline__ void pixel_iter_px2(const PixWork<float> &W, int base
     // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
     T.f0 = z; T.f0g0 = z; T.f0g1 = z; T.f0h0 = z; T.f0h1 = z; T.f0h2 = z;
     if (own[0] || own[1]) {
-        const double *cc[2];
+        const float *cc[2];
         float fxs[2], fys[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -1860,7 +1875,7 @@ __device__ __forceinline__ void pixel_iter_px2(const PixWork<float> &W, int base
         S y = z, yx = z, yy = z, yxx = z, yxy = z, yyy = z;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const double *ca = cc[0] + CEL_COEF * b, *cb = cc[1] + CEL_COEF * b;
+            const float *ca = cc[0] + CEL_COEF * b, *cb = cc[1] + CEL_COEF * b;
             const S k0 = PK2(ca[0], cb[0]), k1 = PK2(ca[1], cb[1]), k2 = PK2(ca[2], cb[2]), k3 = PK2(ca[3], cb[3]);
             const S r = k0 * wx[0] + k1 * wx[1] + k2 * wx[2] + k3 * wx[3];
             const S rx = k0 * dwx[0] + k1 * dwx[1] + k2 * dwx[2] + k3 * dwx[3];
@@ -1889,7 +1904,8 @@ __device__ __forceinline__ void pixel_iter_px2(const PixWork<float> &W, int base
         const S EA = Ebar + A;
         const S E = (S){valid[0] ? EA.x : 1.0f, valid[1] ? EA.y : 1.0f};   // E_G.v
         const S V = Vbar + (B - A * A);                          // var_G.v
-        const S iE = (S){1.0f / E.x, 1.0f / E.y}, logE = (S){log_s(E.x), log_s(E.y)};
+        // (v_rcp_f32, 1 ulp, instead of the correctly rounded division's ten instructions: the mode's budget is 1e-4)
+        const S iE = (S){__builtin_amdgcn_rcpf(E.x), __builtin_amdgcn_rcpf(E.y)}, logE = (S){log_s(E.x), log_s(E.y)};
         const S iE2 = iE * iE, iE3 = iE2 * iE;
         T.vterm = sel(valid, x * (log_iota + (logE - V * (0.5f * iE2))) - iota * E - lgx);
         T.cnt_act = (S){own[0] ? 1.0f : 0.0f, own[1] ? 1.0f : 0.0f};
@@ -1953,7 +1969,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
              const int32_t *__restrict__ active_rank, const int2 *__restrict__ items, int M,
              const int32_t *__restrict__ work, const int32_t *__restrict__ work_total,
              const int64_t *__restrict__ nv_base, const int32_t *__restrict__ nbr_vis,
-             const int32_t *__restrict__ rec_off) {
+             const int32_t *__restrict__ rec_off, const float *__restrict__ coefs_f) {
     __shared__ double etab[64];
     // work list (work_fill_kernel): groups of up to G chunks that exist, longest first.  The grid is the host's bound on
     // the list's length: exact when it knows the targets, else the chunk count of the n_targets chunk-richest sources --
@@ -2025,6 +2041,7 @@ pixel_kernel(const DevImage *__restrict__ images, const DevPatch *__restrict__ p
     W.tcr = sizeof(R) == 4 ? reinterpret_cast<const CompR<R> *>(tcr_f) : reinterpret_cast<const CompR<R> *>(tc);
     W.etab = etab;
     W.tcoef = coefs + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
+    W.tcoef_f = coefs_f + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF);
     W.tile_off = tile_off; W.rec = rec;
     // the chunk's record, 16 slots per entry (accum_entries); MODE 0 keeps its three sums in registers
     __shared__ double sacc[MODE == 0 || MODE == 3 ? 1 : ACC_N * ACC_SLOTS];
