@@ -91,7 +91,7 @@ struct celeste_group {
     double *p_vp = nullptr, *p_vp_nbr = nullptr;   // page-locked S x 44 (portable: every member DMAs from it)
     bool threads = false;
     // peer-mode barrier
-    std::mutex bmu; std::condition_variable bcv; int b_count = 0; uint64_t b_gen = 0;
+    std::mutex bmu; std::condition_variable bcv; int b_count = 0; uint64_t b_gen = 0; bool b_abort = false;
     // the planned sweep
     int32_t plan_n = 0; uint32_t plan_flags = 0; int plan_width = 0; size_t plan_blk = 0; uint64_t sweep_k = 0; bool planned = false;
     bool timing = false;
@@ -99,12 +99,25 @@ struct celeste_group {
     std::mutex call_mu;                        // one call per group at a time
 };
 
-static void group_barrier(celeste_group *g) {
-    if (g->n <= 1) return;
+// All members meet here (PEER mode only: RCCL's collectives are the meeting point otherwise).  A member that leaves a call
+// with an error never arrives: group_fail wakes the ones that wait, and they leave with an error too instead of hanging.
+static bool group_barrier(celeste_group *g) {
+    if (g->n <= 1) return true;
     std::unique_lock<std::mutex> lk(g->bmu);
+    if (g->b_abort) return false;
     const uint64_t gen = g->b_gen;
     if (++g->b_count == g->n) { g->b_count = 0; ++g->b_gen; g->bcv.notify_all(); }
-    else g->bcv.wait(lk, [&] { return g->b_gen != gen; });
+    else g->bcv.wait(lk, [&] { return g->b_gen != gen || g->b_abort; });
+    return !g->b_abort;
+}
+static void group_fail(celeste_group *g) {
+    std::lock_guard<std::mutex> lk(g->bmu);
+    g->b_abort = true;
+    g->bcv.notify_all();
+}
+static void group_barrier_reset(celeste_group *g) {
+    std::lock_guard<std::mutex> lk(g->bmu);
+    g->b_abort = false; g->b_count = 0;
 }
 
 static void group_worker(GroupMember *m) {
@@ -128,9 +141,15 @@ static void group_worker(GroupMember *m) {
 static void group_dispatch(celeste_group *g, const std::function<int(GroupMember *)> &fn) {
     for (GroupMember *m : g->mem) {
         if (!g->threads) { (void)hipSetDevice(m->device); const int r = fn(m); if (m->result == CELESTE_OK) m->result = r; continue; }
+        celeste_group *const gg = g;
         std::unique_lock<std::mutex> lk(m->mu);
         m->cv.wait(lk, [&] { return !m->busy; });
-        m->task = [fn, m] { return fn(m); };
+        m->task = [fn, m, gg] {
+            const int r = fn(m);
+            // (per-source failures are statuses, not errors of the call: the other members go on)
+            if (r != CELESTE_OK && r != CELESTE_ERR_NONFINITE_INPUT && r != CELESTE_ERR_NONFINITE_RESULT) group_fail(gg);
+            return r;
+        };
         m->has_task = true; m->busy = true;
         m->cv.notify_all();
     }
@@ -181,7 +200,7 @@ static int group_exchange(celeste_group *g, GroupMember *m, const double *send, 
         return CELESTE_OK;
     }
     for (GroupMember *o : g->mem)
-        HIP_TRY(hipMemcpyAsync(o->d_gathered + (size_t)m->index * count, send, count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(o->d_gathered + (size_t)m->index * count, send, count * sizeof(double), hipMemcpyDefault, stream));
     return CELESTE_OK;
 }
 
@@ -581,7 +600,7 @@ static int group_exchange_rows(celeste_group *g, GroupMember *m, double *d_table
     int s1 = group_grow(&m->d_gathered, &m->gathered_cap, blk * g->n, st);
     if (s1 != CELESTE_OK) return s1;
     // PEER mode: the other members copy into d_gathered; it must exist on every member before anyone copies
-    if (g->exchange == GROUP_EXCHANGE_PEER) group_barrier(g);
+    if (g->exchange == GROUP_EXCHANGE_PEER && !group_barrier(g)) return CELESTE_ERR_HIP;
     HIP_TRY(hipMemsetAsync(m->d_block[0], 0, blk * sizeof(double), st));
     if (n_own > 0)
         hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)n_own), dim3(64), 0, st, d_table, d_own_targets, n_own, d_it, d_ev, d_el, d_st,
@@ -590,7 +609,7 @@ static int group_exchange_rows(celeste_group *g, GroupMember *m, double *d_table
     if (s1 != CELESTE_OK) return s1;
     if (g->exchange == GROUP_EXCHANGE_PEER) {    // every member's copies have landed before anyone reads its gathered buffer
         HIP_TRY(hipStreamSynchronize(st));
-        group_barrier(g);
+        if (!group_barrier(g)) return CELESTE_ERR_HIP;
     }
     if (g->n > 1)
         hipLaunchKernelGGL(group_scatter_kernel, dim3((unsigned)width, (unsigned)g->n), dim3(64), 0, st, d_table, m->d_gathered, cnt,
@@ -614,6 +633,7 @@ extern "C" int celeste_group_maximize_batch(celeste_group_t *g, double *vp, cons
     std::lock_guard<std::mutex> lock(g->call_mu);
     g->planned = false;
     (void)group_quiesce(g);
+    group_barrier_reset(g);
     group_shard(g, n_targets, targets);
     int W = 1;
     GroupCounts cnt; memset(&cnt, 0, sizeof cnt);
@@ -718,6 +738,7 @@ extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t
     std::lock_guard<std::mutex> lock(g->call_mu);
     g->planned = false;
     (void)group_quiesce(g);
+    group_barrier_reset(g);
     g->abort_rc.store(0);
     const size_t tb = (size_t)g->S * CEL_P * sizeof(double);
     memcpy(g->p_vp, vp, tb);
@@ -791,7 +812,7 @@ extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t
                 HIP_TRY(hipStreamSynchronize(st));
                 if (m->index == 0) exchanges.fetch_add(1);
                 // (the exchange needed every member's enqueue, and a failing member raised the flag before its own)
-                if (g->exchange == GROUP_EXCHANGE_PEER) group_barrier(g);
+                if (g->exchange == GROUP_EXCHANGE_PEER && !group_barrier(g)) return CELESTE_ERR_HIP;
                 if (const int a = g->abort_rc.load()) return a;
             }
         if (m->index == 0) {

@@ -12,7 +12,9 @@ import os
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+# (worker threads + barriers: a hang must end the process, not the GPU box's lease -- the thread method kills from outside the
+# blocked C call)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900, method="thread")]
 
 
 def _n_devices():
@@ -209,6 +211,31 @@ def test_group_on_the_bench_field_two_members_one_device():
     _same(ref, g.eval_batch(fld.vp, tg), "bench field")
     sizes, costs = g.shard_sizes()
     assert sum(sizes) == 2000 and abs(costs[0] - costs[1]) <= 0.002 * sum(costs)
+    g.close()
+    ctx.close()
+
+
+def test_group_on_overlapping_fields_with_the_sparse_patch_list():
+    """configs[4]'s shape (a source sees a few of many images: visit lists, sparse patch list) through a group of two: sweep,
+    single-precision mode, maximize! and one Cyclades batch -- the one-device results"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    from celeste_jl_amd.group import FieldGroup, cyclades_schedule, schedule_layers
+    f = synthetic.make_multifield((2, 3), 160, 160, 0.10, 70, seed=11, sparse=True)
+    S = len(f.catalog)
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    g = FieldGroup(f.images, f.patches, f.neighbors, devices=[0, 0])
+    tg = list(range(S))
+    for flags in (7, 7 | cabi.FLAG_FP32, 5):
+        _same(ctx.eval_batch(f.vp, tg, flags), g.eval_batch(f.vp, tg, flags), "sparse patch list, flags %d" % flags)
+    cfg = cel.ElboConfig(max_iters=5)
+    _same(ctx.maximize_batch(f.vp, tg, cfg), g.maximize_batch(f.vp, tg, cfg), "sparse patch list, maximize")
+    b_off, c_off, flat = cyclades_schedule(tg, f.neighbors, batch_size=30, rng=np.random.default_rng(1))
+    layers, entries = schedule_layers(b_off, c_off, flat, 1)
+    pos = f.vp[flat, 0:2].copy()
+    ref = ctx.joint_infer(f.vp, layers, cfg, pos_centers=[pos[e] for e in entries])
+    new, _, _, _, st, nx = g.joint_infer(f.vp, b_off, c_off, flat, 1, cfg, pos_centers=pos)
+    assert nx == len(b_off) - 1 and np.array_equal(new, ref[0]) and (st == 0).all()
     g.close()
     ctx.close()
 
