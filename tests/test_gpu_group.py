@@ -240,6 +240,39 @@ def test_group_on_overlapping_fields_with_the_sparse_patch_list():
     ctx.close()
 
 
+def test_bench_group_driver_prints_the_line_and_the_single_rank_catalog(tmp_path):
+    """`bench.py --driver group`: ONE process, the members behind the C ABI -- one member (RCCL, one rank: `ranks_seen` is
+    ncclCommCount) and two members on the one device; both leave the catalog the torch driver's single rank leaves"""
+    import json
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--height", "300", "--width", "260", "--sources", "60", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+    def run(extra, sub):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra + ["--check-dir", str(tmp_path / sub)],
+                             capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1                      # RCCL's banner and everything else stay off stdout
+        return json.loads(lines[0])
+    ref = run(["--no-extras"], "ranks")
+    d1 = run(["--driver", "group"], "g1")
+    d2 = run(["--driver", "group", "--gpus", "2", "--group-devices", "0,0"], "g2")
+    assert d1["n_gpus"] == 1 and d1["ranks_seen"] == 1 and d1["config"]["gather_backend"] == "rccl" and d1["config"]["shard_sizes"] == [60]
+    assert d2["config"]["members"] == 2 and d2["config"]["gather_backend"] == "peer_copy" and sum(d2["config"]["shard_sizes"]) == 60
+    for d in (d1, d2):
+        for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                    "data", "config", "roofline", "timing_method"):
+            assert key in d, key
+        assert d["value"] > 0 and d["roofline"]["bound"] == "fp64_valu" and d["unit"] == ref["unit"] and d["metric"] == ref["metric"]
+    r = np.load(tmp_path / "ranks" / "rank0.npz")
+    for sub in ("g1", "g2"):
+        g = np.load(tmp_path / sub / "group.npz")
+        assert np.array_equal(g["v"], r["v"]) and np.array_equal(g["d"], r["d"])
+
+
 # ---- real devices: these arm themselves on a node that has them -------------------------------------------------------
 @pytest.mark.skipif(_n_devices() < 2, reason="needs >= 2 HIP devices (RCCL between real ranks)")
 @pytest.mark.parametrize("n", [2, 4, 8])

@@ -427,6 +427,72 @@ def test_randomised_small_fields(oracle, seed):
     print("fuzz", seed, (H, W, S), "targets", len(tg), "flags", flags, "psf_K", psf_K, errs)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_single_precision_mode_counts_and_masks_like_the_fp64_path(seed):
+    """CELESTE_FLAG_FP32 runs its own pixel loop (two pixels per lane, pixel_iter_px2): on fields with NaN pixels, punched
+    bitmaps, a missing patch, one-column patches, tiny patches (chunks with fewer than 64 / 128 pixels) and psf_K 1 / 3 the
+    pixel COUNTERS and statuses must equal the fp64 path's exactly, values / gradients / Hessians agree at the mode's 1e-4,
+    and gradient-only equals the gradient of the Hessian mode"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic, cabi
+    rng = np.random.default_rng(7000 + seed)
+    H, W = int(rng.integers(50, 150)), int(rng.integers(50, 150))
+    S = int(rng.integers(2, 12))
+    f = synthetic.make_field(H, W, S, seed=7100 + seed, nan_fraction=float(rng.choice([0.0, 0.02, 0.08])), margin=int(rng.integers(3, 27)))
+    for s_ in range(S):
+        if rng.random() < 0.4:
+            p = f.patches[s_][int(rng.integers(5))]
+            if p.active_pixel_bitmap.size:
+                p.active_pixel_bitmap &= rng.random(p.active_pixel_bitmap.shape) > 0.25
+    if S > 2:                      # one source loses a patch (ragged visit lists), another gets one-column patches
+        p = f.patches[int(rng.integers(S))][int(rng.integers(5))]
+        (h0, h1), (w0, w1) = p.box
+        p.box = ((h0, h0 - 1), (w0, w0 - 1))
+        p.active_pixel_bitmap = np.zeros((0, 0), dtype=bool)
+        q = int(rng.integers(S))
+        for n in range(5):
+            p = f.patches[q][n]
+            if p.active_pixel_bitmap.size:
+                (h0, h1), (w0, w1) = p.box
+                keep = p.active_pixel_bitmap[:, :1].copy()
+                p.box = ((h0, h1), (w0, w0))
+                p.active_pixel_bitmap = keep
+    if seed % 3 == 0:              # tiny patches: every chunk is a partial one
+        for row in f.patches:
+            for p in row:
+                if p.active_pixel_bitmap.shape[0] > 9 and p.active_pixel_bitmap.shape[1] > 9:
+                    (h0, h1), (w0, w1) = p.box
+                    p.box = ((h0, h0 + 6), (w0, w0 + 7))
+                    p.active_pixel_bitmap = p.active_pixel_bitmap[:7, :8].copy()
+    psf_K = 2
+    if seed % 4 == 1:
+        from celeste_jl_amd.model import render_psf
+        psf_K = int(rng.choice([1, 3]))
+        for row in f.patches:
+            for p in row:
+                w = rng.dirichlet(np.ones(psf_K) * 4)
+                p.psf = np.array([[w[k], 0.2 * rng.normal(), 0.2 * rng.normal(), (1.1 + 0.8 * k) ** 2, 0.15 * rng.normal(),
+                                   (1.2 + 0.8 * k) ** 2] for k in range(psf_K)])
+                p.stamp = render_psf(p.psf)
+    from celeste_jl_amd.model import neighbor_map
+    ctx = cel.FieldContext(f.images, f.patches, neighbor_map(f.patches), psf_K=psf_K)
+    tg = rng.permutation(S).tolist()
+    v64, d64, h64, c64, s64 = ctx.eval_batch(f.vp, tg, ALL)
+    v32, d32, h32, c32, s32 = ctx.eval_batch(f.vp, tg, ALL | cabi.FLAG_FP32)
+    assert np.array_equal(c64, c32) and np.array_equal(s64, s32) and (s64 == 0).all()
+    assert c64[:, 0].sum() > 0
+    ev = float(np.max(np.abs(v32 - v64) / np.abs(v64)))
+    ed = max(np.abs(d32[k] - d64[k]).max() / np.abs(d64[k]).max() for k in range(len(tg)))
+    eh = max(np.abs(h32[k] - h64[k]).max() / np.abs(h64[k]).max() for k in range(len(tg)))
+    assert max(ev, ed, eh) <= 1e-4, (ev, ed, eh)
+    assert all(np.array_equal(h32[k], h32[k].T) for k in range(len(tg)))
+    vg, dg, _, cg, _ = ctx.eval_batch(f.vp, tg, 1 | 4 | cabi.FLAG_FP32)
+    assert np.array_equal(cg, c64)
+    assert float(np.max(np.abs(vg - v64) / np.abs(v64))) <= 1e-4
+    assert max(np.abs(dg[k] - d64[k]).max() / np.abs(d64[k]).max() for k in range(len(tg))) <= 1e-4
+    print("fp32 fuzz", seed, (H, W, S), "psf_K", psf_K, "errors", ev, ed, eh)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_randomised_multi_active(oracle, seed):
     """fuzz of celeste_elbo_eval_multi: random crowded scene with NaNs and punched bitmaps, random active subset and
