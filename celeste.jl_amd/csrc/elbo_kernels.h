@@ -1718,17 +1718,17 @@ __device__ __forceinline__ f2v galaxy_sums_px2(const f2v *tp, int n_dev, int nc,
         f2v S2a = z, S2b = z, S2c = z, S3a = z, S3b = z, S3c = z, S3d = z, S4a = z, S4b = z, S4c = z, S4d = z, S4e = z;
         // GW (std::true_type): the sums of orders 2 .. 4 are accumulated with the d-weights g = wd e as well (the de Vaucouleurs
         // loop: f = theta_0 g there, applied once to the twelve sums when the loop ends -- three weight products per component
-        // instead of five, as in galaxy_sums).  The exponential is v_exp_f32 on the quadratic form scaled by log2(e) / -2 in ONE
-        // multiply (no separate conversion to base 2).
-        auto comp = [&](auto HI, auto GW, const f2v *k, f2v (&U)[6]) {
+        // instead of five, as in galaxy_sums).  The exponential is v_exp_f32 directly (base 2).
+        // The 8 (de Vaucouleurs) / 6 (exponential) prototypes of a run share a PSF component, i.e. the offset xiBar_k: d = x - xi
+        // and hd = -log2(e)/2 d are formed once per run, and the exponent is hd' u in two instructions.
+        auto comp = [&](auto HI, auto GW, const f2v *k, f2v (&U)[6], f2v d1, f2v d2, f2v hd1, f2v hd2) {
             constexpr bool hi = decltype(HI)::value, gw = decltype(GW)::value;
 #define PXB(i) (hi ? k[i].yy : k[i].xx)
-            const f2v p11 = PXB(0), p12 = PXB(1), p22 = PXB(2), w0 = PXB(3), wd = PXB(4), nu = PXB(5), xi1 = PXB(6), xi2 = PXB(7);
+            const f2v p11 = PXB(0), p12 = PXB(1), p22 = PXB(2), w0 = PXB(3), wd = PXB(4), nu = PXB(5);
             const f2v m2p12 = PXB(8), m3p11 = PXB(9), m3p12 = PXB(10), m3p22 = PXB(11);
 #undef PXB
-            const f2v d1 = dx - xi1, d2 = dy - xi2;
             const f2v u = p11 * d1 + p12 * d2, v = p12 * d1 + p22 * d2;
-            const f2v q2 = -0.72134752044448170368f * (d1 * u + d2 * v);      // log2(e) x (-1/2) d' P d
+            const f2v q2 = hd1 * u + hd2 * v;                                  // log2(e) x (-1/2) d' P d
             const f2v e = {__builtin_amdgcn_exp2f(q2.x), __builtin_amdgcn_exp2f(q2.y)};
             const f2v g = wd * e, gn = g * nu;
             f2v f, fn, fnn;
@@ -1744,17 +1744,20 @@ __device__ __forceinline__ f2v galaxy_sums_px2(const f2v *tp, int n_dev, int nc,
                       h4d = u * h3d + hc * m3p12, h4e = v * h3d + hc * m3p22;
             S4a += h4a * fnn; S4b += h4b * fnn; S4c += h4c * fnn; S4d += h4d * fnn; S4e += h4e * fnn;
         };
+        auto run = [&](int c0, int len, auto GW, f2v (&U)[6]) {
+            const f2v *k0 = tp + (PKSLOTS / 2) * c0;
+            const f2v d1 = dx - k0[6].xx, d2 = dy - k0[7].xx;
+            const f2v hd1 = -0.72134752044448170368f * d1, hd2 = -0.72134752044448170368f * d2;
+            for (int c = c0; c < c0 + len; c += 2) {
+                const f2v *k = tp + (PKSLOTS / 2) * c;
+                comp(std::false_type(), GW, k, U, d1, d2, hd1, hd2); comp(std::true_type(), GW, k, U, d1, d2, hd1, hd2);
+            }
+        };
         const f2v th0 = (f2v)(dev), th1 = (f2v)(1.0f - dev);
-        for (int c = 0; c < n_dev; c += 2) {
-            const f2v *k = tp + (PKSLOTS / 2) * c;
-            comp(std::false_type(), std::true_type(), k, U0); comp(std::true_type(), std::true_type(), k, U0);
-        }
+        for (int c0 = 0; c0 < n_dev; c0 += 8) run(c0, 8, std::true_type(), U0);
         S2a *= th0; S2b *= th0; S2c *= th0; S3a *= th0; S3b *= th0; S3c *= th0; S3d *= th0;
         S4a *= th0; S4b *= th0; S4c *= th0; S4d *= th0; S4e *= th0;
-        for (int c = n_dev; c < nc; c += 2) {
-            const f2v *k = tp + (PKSLOTS / 2) * c;
-            comp(std::false_type(), std::false_type(), k, U1); comp(std::true_type(), std::false_type(), k, U1);
-        }
+        for (int c0 = n_dev; c0 < nc; c0 += 6) run(c0, 6, std::false_type(), U1);
         T.S0d = U0[0] + U1[0]; T.S1xd = U0[1] + U1[1]; T.S1yd = U0[2] + U1[2];
         T.S2ad = U0[3] + U1[3]; T.S2bd = U0[4] + U1[4]; T.S2cd = U0[5] + U1[5];
         T.S1x = th0 * U0[1] - th1 * U1[1]; T.S1y = th0 * U0[2] - th1 * U1[2];
@@ -1764,14 +1767,13 @@ __device__ __forceinline__ f2v galaxy_sums_px2(const f2v *tp, int n_dev, int nc,
         return th0 * U0[0] - th1 * U1[0];
     } else {
         f2v S0 = z, S0d = z, S1x = z, S1y = z, S2an = z, S2bn = z, S2cn = z;
-        auto comp = [&](auto HI, const f2v *k) {
+        auto comp = [&](auto HI, const f2v *k, f2v d1, f2v d2, f2v hd1, f2v hd2) {
             constexpr bool hi = decltype(HI)::value;
 #define PXB(i) (hi ? k[i].yy : k[i].xx)
-            const f2v p11 = PXB(0), p12 = PXB(1), p22 = PXB(2), w0 = PXB(3), wd = PXB(4), nu = PXB(5), xi1 = PXB(6), xi2 = PXB(7);
+            const f2v p11 = PXB(0), p12 = PXB(1), p22 = PXB(2), w0 = PXB(3), wd = PXB(4), nu = PXB(5);
 #undef PXB
-            const f2v d1 = dx - xi1, d2 = dy - xi2;
             const f2v u = p11 * d1 + p12 * d2, v = p12 * d1 + p22 * d2;
-            const f2v q2 = -0.72134752044448170368f * (d1 * u + d2 * v);      // log2(e) x (-1/2) d' P d
+            const f2v q2 = hd1 * u + hd2 * v;
             const f2v e = {__builtin_amdgcn_exp2f(q2.x), __builtin_amdgcn_exp2f(q2.y)};
             const f2v f = w0 * e, fd = wd * e, fn = f * nu;
             const f2v ha = u * u - p11, hb = u * v - p12, hc = v * v - p22;
@@ -1779,7 +1781,17 @@ __device__ __forceinline__ f2v galaxy_sums_px2(const f2v *tp, int n_dev, int nc,
             S1x += u * f; S1y += v * f;
             S2an += ha * fn; S2bn += hb * fn; S2cn += hc * fn;
         };
-        for (int c = 0; c < nc; c += 2) { const f2v *k = tp + (PKSLOTS / 2) * c; comp(std::false_type(), k); comp(std::true_type(), k); }
+        auto run = [&](int c0, int len) {
+            const f2v *k0 = tp + (PKSLOTS / 2) * c0;
+            const f2v d1 = dx - k0[6].xx, d2 = dy - k0[7].xx;
+            const f2v hd1 = -0.72134752044448170368f * d1, hd2 = -0.72134752044448170368f * d2;
+            for (int c = c0; c < c0 + len; c += 2) {
+                const f2v *k = tp + (PKSLOTS / 2) * c;
+                comp(std::false_type(), k, d1, d2, hd1, hd2); comp(std::true_type(), k, d1, d2, hd1, hd2);
+            }
+        };
+        for (int c0 = 0; c0 < n_dev; c0 += 8) run(c0, 8);
+        for (int c0 = n_dev; c0 < nc; c0 += 6) run(c0, 6);
         T.S0d = S0d; T.S1x = S1x; T.S1y = S1y; T.S2an = S2an; T.S2bn = S2bn; T.S2cn = S2cn;
         return S0;
     }
