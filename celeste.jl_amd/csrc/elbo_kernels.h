@@ -404,11 +404,18 @@ __device__ inline double star_value(const double *__restrict__ coef, double xh, 
 // (dx, dy) = pixel - m_pos
 __device__ inline double galaxy_value(const Comp *tc, int NC, double dx, double dy, const double *etab) {
     double v = 0;
-    for (int c = 0; c < NC; ++c) {
-        const Comp k = tc[c];
-        const double d1 = dx - k.xi1, d2 = dy - k.xi2;
-        const double u = k.p11 * d1 + k.p12 * d2, vv = k.p12 * d1 + k.p22 * d2;
-        v = __builtin_fma(k.w0, exp_nonpos(-0.5 * (d1 * u + d2 * vv), etab), v);
+    // the 8 (de Vaucouleurs) / 6 (exponential) prototypes of a run share a PSF component, i.e. the offset xiBar_k (records are
+    // ordered type, PSF component, prototype): d and -d / 2 once per run, as in the derivative loops
+    const int n_dev = 8 * (NC / 14);
+    for (int c0 = 0; c0 < NC; c0 += (c0 < n_dev ? 8 : 6)) {
+        const int len = c0 < n_dev ? 8 : 6;
+        const double d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
+        const double hd1 = -0.5 * d1, hd2 = -0.5 * d2;
+        for (int c = c0; c < c0 + len; ++c) {
+            const Comp k = tc[c];
+            const double u = k.p11 * d1 + k.p12 * d2, vv = k.p12 * d1 + k.p22 * d2;
+            v = __builtin_fma(k.w0, exp_nonpos(__builtin_fma(hd1, u, hd2 * vv), etab), v);
+        }
     }
     return v;
 }
