@@ -866,7 +866,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
 #define LAUNCH_VALUE(R, WAVES)                                                                                              \
         hipLaunchKernelGGL((value_kernel<R, WAVES>), dim3((unsigned)c->n_value_items), dim3(64 * WAVES), 0, stream,       \
                            c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_val_off,          \
-                           c->d_value_items, c->NC, c->chunk_px, c->d_val)
+                           c->d_value_items, c->NC, c->chunk_px, c->d_val, c->d_coefs_f)
         if (flags & CELESTE_FLAG_FP32) { if (wide_items) LAUNCH_VALUE(float, 4); else LAUNCH_VALUE(float, 1); }
         else { if (wide_items) LAUNCH_VALUE(double, 4); else LAUNCH_VALUE(double, 1); }
 #undef LAUNCH_VALUE

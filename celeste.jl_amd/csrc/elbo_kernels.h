@@ -855,6 +855,89 @@ __device__ __forceinline__ void value_pixels(int lane, const DevPatch &P, const 
     }
 }
 
+// value_pixels in single precision with TWO pixels per lane (idx and idx + 64 in the halves of float2 values, as in
+// pixel_iter_px2): the component records' pair-interleaved fields are broadcast to both pixels (op_sel), the offsets d = x - xi
+// and -log2(e)/2 d are formed once per run of prototypes, the spline runs packed on the float copy of the coefficients; the
+// moments E, var are formed in double per pixel as before.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void value_pixels_f2(int lane, const DevPatch &P, const SrcImg &si, int NC, const float *__restrict__ coef,
+                                                int h_lo, int w_lo, int RH, int p0, int p1, double2 *__restrict__ out,
+                                                const float *__restrict__ tcf) {
+    const double sh0 = 26.0 - si.m1, sw0 = 26.0 - si.m2;
+    const float rRH = 1.0f / (float)RH;
+    const f2v *tp = reinterpret_cast<const f2v *>(tcf);     // per pair of components: p11, p12, p22, xi1, xi2, w0
+    const int n_dev = 8 * (NC / 14);
+    for (int base = p0; base < p1; base += 128) {
+        int h0[2], w0[2];
+        bool ok[2];
+        float dxs[2], dys[2], xh[2], xw[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = base + 64 * q + lane;
+            ok[q] = i < p1;
+            int rw, rh;
+            divmod_small(min(i, p1 - 1), RH, rRH, rw, rh);
+            h0[q] = h_lo + rh; w0[q] = w_lo + rw;              // 0-based image coordinates
+            const double hh = (double)(h0[q] + 1), ww = (double)(w0[q] + 1);
+            dxs[q] = (float)(hh - si.m1); dys[q] = (float)(ww - si.m2);
+            xh[q] = (float)(hh + sh0); xw[q] = (float)(ww + sw0);
+        }
+        // galaxy density
+        const f2v dx = {dxs[0], dxs[1]}, dy = {dys[0], dys[1]};
+        f2v f1 = (f2v)(0.0f);
+        for (int c0 = 0; c0 < NC; c0 += (c0 < n_dev ? 8 : 6)) {
+            const int len = c0 < n_dev ? 8 : 6;
+            const f2v *k0 = tp + 3 * c0;
+            const f2v d1 = dx - k0[3].xx, d2 = dy - k0[4].xx;
+            const f2v hd1 = -0.72134752044448170368f * d1, hd2 = -0.72134752044448170368f * d2;
+            for (int c = c0; c < c0 + len; c += 2) {
+                const f2v *k = tp + 3 * c;
+                {
+                    const f2v p11 = k[0].xx, p12 = k[1].xx, p22 = k[2].xx, w = k[5].xx;
+                    const f2v u = p11 * d1 + p12 * d2, vv = p12 * d1 + p22 * d2;
+                    const f2v q2 = hd1 * u + hd2 * vv;
+                    f1 += w * (f2v){__builtin_amdgcn_exp2f(q2.x), __builtin_amdgcn_exp2f(q2.y)};
+                }
+                {
+                    const f2v p11 = k[0].yy, p12 = k[1].yy, p22 = k[2].yy, w = k[5].yy;
+                    const f2v u = p11 * d1 + p12 * d2, vv = p12 * d1 + p22 * d2;
+                    const f2v q2 = hd1 * u + hd2 * vv;
+                    f1 += w * (f2v){__builtin_amdgcn_exp2f(q2.x), __builtin_amdgcn_exp2f(q2.y)};
+                }
+            }
+        }
+        // star density: natural bicubic spline at (xh, xw), softpluslikeinv (fsm_util.jl:221-236)
+        const float *cc[2];
+        float fxs[2], fys[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int ix = (int)floorf(xh[q]); ix = ix < 1 ? 1 : (ix > 50 ? 50 : ix);
+            int iy = (int)floorf(xw[q]); iy = iy < 1 ? 1 : (iy > 50 ? 50 : iy);
+            cc[q] = coef + (ix - 1) + CEL_COEF * (iy - 1);
+            fxs[q] = xh[q] - (float)ix; fys[q] = xw[q] - (float)iy;
+        }
+        f2v wx[4], wy[4];
+        bspline_w((f2v){fxs[0], fxs[1]}, wx); bspline_w((f2v){fys[0], fys[1]}, wy);
+        f2v y = (f2v)(0.0f);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float *ca = cc[0] + CEL_COEF * b, *cb = cc[1] + CEL_COEF * b;
+            const f2v r = (f2v){ca[0], cb[0]} * wx[0] + (f2v){ca[1], cb[1]} * wx[1] + (f2v){ca[2], cb[2]} * wx[2] + (f2v){ca[3], cb[3]} * wx[3];
+            y += r * wy[b];
+        }
+        const float f0s[2] = {y.x < 0 ? 1e-3f * __expf(y.x) : 1e-3f * (y.x + 1.0f), y.y < 0 ? 1e-3f * __expf(y.y) : 1e-3f * (y.y + 1.0f)};
+        const float f1s[2] = {f1.x, f1.y};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!ok[q]) continue;
+            const double f0 = (double)f0s[q], g1 = (double)f1s[q];
+            const double En = si.c0 * f0 + si.c1 * g1;                      // E_G_s.v  (elbo_objective.jl:62-65)
+            const double E2n = si.q0 * (f0 * f0) + si.q1 * (g1 * g1);
+            out[(h0[q] - P.off_h) + (int64_t)P.H2 * (w0[q] - P.off_w)] = make_double2(En, E2n - En * En);   // var_G_s.v (:204)
+        }
+    }
+}
+
 // One wavefront per work item (neighbour link t -> s2, image, chunk of the overlap): renders s2's value-only
 // light on the rectangle where s2's patch (minus its last column, elbo_objective.jl:349) overlaps target t's
 // patch, into s2's own patch buffer.  The items with a non-empty overlap are listed once per context
@@ -871,7 +954,8 @@ __global__ void __launch_bounds__(64 * WAVES)
 value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
              const SrcImg *__restrict__ srcimg, const Comp *__restrict__ comps,
              const int32_t *__restrict__ is_target, int32_t stamp, const int64_t *__restrict__ val_off,
-             const int4 *__restrict__ items, int NC, int chunk_px, double2 *__restrict__ val) {
+             const int4 *__restrict__ items, int NC, int chunk_px, double2 *__restrict__ val,
+             const float *__restrict__ coefs_f) {
     __shared__ double etab[64];
 #ifdef VALUE_TIMING
     long long vts[4]; vts[0] = clock64();     // stamps only; the (contended) atomics all come at the very end
@@ -915,7 +999,10 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
         __syncthreads();
     }
     VT(1);
-    if constexpr (WAVES == 1)
+    if constexpr (WAVES == 1 && sizeof(R) == 4)
+        value_pixels_f2(threadIdx.x, P, si, NC, coefs_f + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF), h_lo, w_lo, RH,
+                        p0, p1, val + val_off[sn], tcf);
+    else if constexpr (WAVES == 1)
         value_pixels<false, R>(threadIdx.x, P, si, tc, NC, coefs, etab, h_lo, w_lo, RH, p0, p1, val + val_off[sn], tcf);
     else {
         const int q0 = p0 + 64 * (int)(threadIdx.x >> 6);
@@ -1367,7 +1454,6 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
 // components c and c + 1 sit in the two halves of float2 values, so the whole Hermite chain runs on v_pk_fma_f32 /
 // v_pk_mul_f32 (NC = 14 psf_K is even); only the exponential is evaluated per half.  The two halves of every sum are
 // added at the end.  Same arithmetic per component as galaxy_sums<MODE, float>.
-typedef float f2v __attribute__((ext_vector_type(2)));
 #define PKSLOTS 12   // 8-byte slots per PAIR of components in the fp32 record table: the eight fields of Comp, then -2 p12, -3 p11, -3 p12, -3 p22
 template <int MODE, class TT>
 __device__ __forceinline__ typename TT::scalar galaxy_sums_pk(const CompR<float> *tc, int n_dev, int nc, float dx, float dy,

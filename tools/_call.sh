@@ -1,6 +1,11 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 bash tools/profile_round.sh r05c > gpurun_out/r05c.log 2>&1; tail -1 gpurun_out/r05c.log | cut -c1-400
-timeout 600 bash tools/pmc_config5.sh r05c_c5 > gpurun_out/r05c_c5.log 2>&1
-timeout 300 python bench.py --driver group --config 5 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/r05c_group_c5.json 2> gpurun_out/r05c_group_c5.err; python -c "import json;d=json.load(open('gpurun_out/r05c_group_c5.json'));print('group c5', round(d['value']), d['ms_per_step'], d['kernels_ms'], d['config']['member_gather_ms'])" || tail -3 gpurun_out/r05c_group_c5.err
-timeout 300 python bench.py --driver group --steps 200 --no-cpu-baseline > gpurun_out/r05c_group_c3.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/r05c_group_c3.json'));print('group c3', round(d['value']), d['ms_per_step'], d['kernels_ms'], d['config']['member_gather_ms'])"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+mkdir -p gpurun_out/c18
+B="python bench.py --config 5 --dtype f32 --steps 10 --warmup 2 --kernels-in-pass --no-cpu-baseline --no-extras"
+for rep in 1 2; do
+for v in new head; do
+  if [ $v = new ]; then unset CELESTE_MI355X_LIB; else export CELESTE_MI355X_LIB=$GRAFT_REPO_ROOT/tools/variants/lib_$v.so; fi
+  timeout 300 $B > gpurun_out/c18/c5_$v.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/c18/c5_$v.json'));print('c5 $v', round(d['value']), d['ms_per_step'], d['kernels_ms'], d['fp32_vs_fp64_device'])"
+done
+done
+unset CELESTE_MI355X_LIB
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_round2.py -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3
