@@ -726,6 +726,14 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     if (n_targets == 0) return CELESTE_OK;
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(c->device));
+    // Pixel chunks of THIS launch.  Single precision: 512 pixels, i.e. four 128-pixel trips of pixel_iter_px2 per record
+    // instead of two -- half the records to zero, fold, store and lift (measured on config 5: 5.31 -> 5.20 ms; the fp64 kernel
+    // loses 3-5 % with 512, so the context's own chunk stays 256).  Everything that depends on the chunk size is per launch
+    // (work list, record offsets, pixel and lift kernels); the host's chunk counts (256-pixel chunks) remain upper bounds.
+    const bool big_chunks = (flags & CELESTE_FLAG_FP32) && !(flags & CELESTE_FLAG_SPLIT) && !d_active_rank && c->chunk_px == 256 &&
+                            !getenv("CELESTE_FP32_CHUNK_256");
+    const int chunk_px = big_chunks ? 512 : c->chunk_px;
+    const int CH = big_chunks ? std::max(1, (c->max_npx + chunk_px - 1) / chunk_px) : c->CH;
     // one 68-double record per chunk that exists (rec_off = prefix sum of the visits' chunk counts): exactly n_chunks
     // when the caller knows its targets on the host, else at most n_targets x the chunk count of the richest source
     const size_t rec_cap = n_chunks >= 0 ? (size_t)n_chunks
@@ -827,7 +835,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         hipLaunchKernelGGL(setup_worklist_kernel, dim3(1 + setup_blocks + prep_blocks), dim3(WORK1_NT),
                            0, stream, d_vp, geo_S, c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M,
                            c->dense ? nullptr : c->d_items, render_neighbors ? c->d_needed : nullptr, c->stamp, c->d_patches,
-                           c->N, c->CH, c->chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live, prep_mark,
+                           c->N, CH, chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live, prep_mark,
                            c->d_nbr_off, c->d_nbr_idx, c->d_rec_off, (int)setup_blocks, c->d_images, c->K, c->d_srcimg,
                            c->d_comps, prep_all_here ? (int)c->V : 0, c->d_vis_src);
     } else {
@@ -838,11 +846,11 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M, c->dense ? nullptr : c->d_items,
                            render_neighbors ? c->d_needed : nullptr, c->stamp, prep_mark, c->d_nbr_off, c->d_nbr_idx, d_live);
         hipLaunchKernelGGL(work_count_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
-                           c->d_vis_off, c->d_vis_img, c->N, c->M, c->chunk_px, G, (int)c->dense, c->d_work_blk, d_live);
+                           c->d_vis_off, c->d_vis_img, c->N, c->M, chunk_px, G, (int)c->dense, c->d_work_blk, d_live);
         hipLaunchKernelGGL(work_scan_kernel, dim3(1), dim3(1024), 0, stream, c->d_work_blk, n_wblk * (n_classes + 1),
                            c->d_work_total, n_wblk * n_classes);
         hipLaunchKernelGGL(work_fill_kernel, dim3(n_wblk), dim3(WORK_NT), 0, stream, d_targets, n_visits, c->d_patches,
-                           c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH, c->chunk_px, G, (int)c->dense, c->d_work_blk, c->d_work, d_live,
+                           c->d_vis_off, c->d_vis_img, c->N, c->M, CH, chunk_px, G, (int)c->dense, c->d_work_blk, c->d_work, d_live,
                            c->d_rec_off);
     }
     // per-(source, image) constants: of every source when the neighbours are (re)rendered, else of the targets only
@@ -903,7 +911,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     const dim3 grid((unsigned)std::max<size_t>(grid_need, 1));
 #define PIXEL_ARGS                                                                                                \
     c->d_images, c->d_patches, c->d_coefs, c->d_bitmaps, c->d_srcimg, c->d_comps, c->d_nbr_off, c->d_nbr_idx,       \
-    c->d_val_off, c->d_val, d_targets, c->N, c->NC, c->CH, c->chunk_px, G, c->d_acc, c->d_tile_off, c->d_rec, \
+    c->d_val_off, c->d_val, d_targets, c->N, c->NC, CH, chunk_px, G, c->d_acc, c->d_tile_off, c->d_rec, \
     d_active_rank, c->d_items, c->M, c->d_work, c->d_work_total, c->d_nv_base, c->d_nbr_vis, c->d_rec_off, c->d_coefs_f
 #define LAUNCH_PIXEL_T(MODE, R) hipLaunchKernelGGL((pixel_kernel<MODE, R>), grid, dim3(64), 0, stream, PIXEL_ARGS)
 #define LAUNCH_PIXEL_M(MODE) hipLaunchKernelGGL((pixel_kernel<MODE, double, true>), grid, dim3(64), 0, stream, PIXEL_ARGS)
@@ -940,8 +948,8 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum, nullptr);
     } else
     hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
-                       c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M, c->CH,
-                       c->chunk_px, flags,
+                       c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M, CH,
+                       chunk_px, flags,
                        d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum, c->d_rec_off);
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[3], stream)); c->ev_valid = 1; }
     HIP_TRY(hipGetLastError());
