@@ -2628,18 +2628,18 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
             const int npx = P.H2 * P.W2;
             double s = 0.0;
             const double *const r0 = acc + (rec_off ? (size_t)rec_off[ti * M + n0 + i] : (size_t)(ti * M + n0 + i) * CH) * ACC_N + e;
-            if constexpr (COH_ACC) {
-                // L1-bypassing loads, four in flight at a time; added in chunk order like the plain loop below
-                for (int c0 = 0; c0 * chunk_px < npx && c0 < CH; c0 += 4) {
-                    double v[4];
+            // four loads in flight at a time (COH_ACC: past the L1), added in chunk order -- the plain `if (exists) s += r0[..]`
+            // loop waited for every chunk's load before it asked for the next
+            for (int c0 = 0; c0 * chunk_px < npx && c0 < CH; c0 += 4) {
+                double v[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (c0 + q < CH && (c0 + q) * chunk_px < npx) ? ldc<true>(r0 + (size_t)(c0 + q) * ACC_N) : 0.0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (c0 + q < CH && (c0 + q) * chunk_px < npx) s += v[q];
+                for (int q = 0; q < 4; ++q) {
+                    const bool ex = c0 + q < CH && (c0 + q) * chunk_px < npx;
+                    const double *const ptr = r0 + (size_t)(ex ? c0 + q : c0) * ACC_N;
+                    v[q] = COH_ACC ? ldc<true>(ptr) : *ptr;
                 }
-            } else {
-                for (int ch = 0; ch < CH; ++ch)
-                    if (ch * chunk_px < npx) s += r0[(size_t)ch * ACC_N];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (c0 + q < CH && (c0 + q) * chunk_px < npx) s += v[q];
             }
             s_rec[i][e] = s;
         }
@@ -2781,15 +2781,33 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
             else o_h[k] = v;   // upper triangle, by columns: (p1, p2) at p2 (p2 + 1) / 2 + p1
         }
     } else if (want_hess && o_h) {
-        // (o_h in HBM: consecutive threads store consecutive entries)
-        for (int k = tid; k < CEL_P * CEL_P; k += nthr) {
-            const int c2 = k / CEL_P, c1 = k - c2 * CEL_P;
-            const int p1 = c1 < c2 ? c1 : c2, p2 = c1 < c2 ? c2 : c1;
+        // (o_h in HBM) Every entry (p1 <= p2) of the upper triangle is formed ONCE, in the order that groups the entries by the
+        // branch of kl_hess they take (c_lift.adesc: a wavefront's lanes run the same branch), and parked in LDS -- the
+        // per-image records and Jacobians are dead by now, 990 doubles fit over them; then consecutive threads store
+        // consecutive entries of the full, exactly symmetric matrix.  (Round 4 formed all 1936 entries in storage order: twice
+        // the KL evaluations, lanes of one wavefront in different branches -- a third of the kernel's time.)  Same values.
+        static_assert(sizeof(L.s_rec) + sizeof(L.s_jz) >= CELESTE_HP * sizeof(double), "the packed triangle lies over s_rec and s_jz");
+        static_assert(offsetof(LiftShared, s_jz) == offsetof(LiftShared, s_rec) + sizeof(L.s_rec), "s_rec and s_jz are adjacent");
+        double *const packed = &L.s_rec[0][0];
+        unsigned ad_next = c_lift.adesc[tid < CELESTE_HP ? tid : 0];
+        for (int kk = tid; kk < CELESTE_HP; kk += nthr) {
+            const unsigned ad = ad_next;
+            if (kk + nthr < CELESTE_HP) ad_next = c_lift.adesc[kk + nthr];
+            const int k = ad & 0x3ff, p1 = (ad >> 10) & 0x3f, p2 = (ad >> 16) & 0x3f;
             double v = (p2 < LIFT_NP) ? sh_h[p1 + LIFT_NP * p2] : 0.0;
-            if (want_kl && c_lift.akl[p2 * (p2 + 1) / 2 + p1]) v += kl_hess(K, prior, vs, p1, p2);
+            if (want_kl && (ad >> 22)) v += kl_hess(K, prior, vs, p1, p2);
             if (!isfinite(v)) bad = 1;
-            if (!(flags & CELESTE_FLAG_PACKED_HESS)) o_h[k] = v;
-            else if (c1 <= c2) o_h[c2 * (c2 + 1) / 2 + c1] = v;   // upper triangle, by columns
+            packed[k] = v;     // upper triangle, by columns: (p1, p2) at p2 (p2 + 1) / 2 + p1
+        }
+        __syncthreads();
+        if (flags & CELESTE_FLAG_PACKED_HESS) {
+            for (int k = tid; k < CELESTE_HP; k += nthr) o_h[k] = packed[k];
+        } else {
+            for (int k = tid; k < CEL_P * CEL_P; k += nthr) {
+                const int c2 = k / CEL_P, c1 = k - c2 * CEL_P;
+                const int p1 = c1 < c2 ? c1 : c2, p2 = c1 < c2 ? c2 : c1;
+                o_h[k] = packed[p2 * (p2 + 1) / 2 + p1];
+            }
         }
     }
     if (bad) atomicOr(&sh_bad, 1);
