@@ -161,7 +161,14 @@ __device__ __forceinline__ void brightness_moments_wave(int lane, const double *
 __device__ __forceinline__ void prep_visit(int c, int s, int n, int sn, const double *__restrict__ vp,
                                            const DevImage *__restrict__ images, const DevPatch *__restrict__ patches, int K,
                                            SrcImg *__restrict__ srcimg, Comp *__restrict__ comps) {
-    prep_visit_values(c, vp + (size_t)s * CEL_P, patches[sn], images[n].band - 1, K, srcimg + sn, comps + (size_t)sn * (14 * K));
+    // (called by whole wavefronts: the components on lanes < 14 K, the brightness moments by brightness_moments_wave -- twenty
+    // lanes evaluate the twenty exponentials side by side instead of lane 63 one after the other, same bits; the serial version
+    // was the wavefront's critical path: prep_kernel 0.18 ms for the 178 636 visits of config 5)
+    const double *vs = vp + (size_t)s * CEL_P;
+    const DevPatch &p = patches[sn];
+    const int b = images[n].band - 1;
+    prep_visit_values<false>(c, vs, p, b, K, srcimg + sn, comps + (size_t)sn * (14 * K));
+    brightness_moments_wave(c, vs, p, b, srcimg + sn);
 }
 
 __global__ void __launch_bounds__(64)
