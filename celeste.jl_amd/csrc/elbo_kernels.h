@@ -2562,42 +2562,65 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
         }
     }
 
-    // KL per (type, component) terms: 16 threads of the last wave, concurrent with the first lift pass
-    if (want_kl && tid >= 240 && tid < 256) {
-        const int q = tid - 240, i = q >> 3, d = q & 7;
+    // KL pieces: the fourth wavefront, concurrent with the first lift pass.  Every logarithm and every division the pieces need
+    // is evaluated in ONE uniform call with a lane-specific argument (round 4: sixteen threads ran six logarithms and four
+    // divisions each, one after the other, then two more threads three logarithms -- 3.7 k cycles of the pass the other
+    // wavefronts waited for at its barrier); the pieces are then assembled from lane exchanges with the same expressions in
+    // the same order: same bits.
+    //   lane  0..15  log k[q]            16..31  log prior.k[q]        32..39  log lam[j], 1 / lam[j]   (j = 4 i + c)
+    //        40..41  log a[i], (var1 + (mu1 - mu2)^2) / var2           42..43  log prior.is_star[i], (mu1 - mu2) / var2
+    //        44..45  log var2[i], -1 / var1                            46..47  log var1[i], 1 / var2
+    //        48      (x - mu)^2 / s2                                   49      log s2
+    if (want_kl && tid >= 192 && tid < 256) {
+        const int L = tid - 192;
         const celeste_prior_t &pr = prior->p;
-        const double k = vs[28 + 8 * i + d];
-        K.t[q] = log(k) - log(pr.k[i][d]);
-        double diff[4], tr = 0, sl = 0, quad = 0;
-        for (int c = 0; c < 4; ++c) diff[c] = pr.color_mean[i][d][c] - vs[10 + 4 * i + c];
-        for (int c = 0; c < 4; ++c) {
-            const double lam = vs[18 + 4 * i + c];
-            tr += prior->inv_cov[i][d][c + 4 * c] * lam; sl += log(lam);
+        const int i2 = L & 1;
+        const double mu1 = vs[6 + i2], var1 = vs[8 + i2], mu2 = pr.flux_mean[i2], var2 = pr.flux_var[i2];
+        const double rx = vs[5], rmu = pr.gal_radius_px_mean, rs2 = pr.gal_radius_px_var;
+        double lx = 1.0, num = 1.0, den = 1.0;
+        if (L < 16) lx = vs[28 + L];
+        else if (L < 32) lx = (&pr.k[0][0])[L - 16];
+        else if (L < 40) { lx = vs[18 + (L - 32)]; den = lx; }
+        else if (L < 42) { lx = vs[26 + i2]; num = var1 + (mu1 - mu2) * (mu1 - mu2); den = var2; }
+        else if (L < 44) { lx = pr.is_star[i2]; num = mu1 - mu2; den = var2; }
+        else if (L < 46) { lx = var2; num = -1.0; den = var1; }
+        else if (L < 48) { lx = var1; den = var2; }
+        else if (L == 48) { num = (rx - rmu) * (rx - rmu); den = rs2; }
+        else if (L == 49) lx = rs2;
+        const double lg = log(lx), dv = num / den;
+        const int q = L & 15, qi = q >> 3;
+        const double lgpk = __shfl(lg, 16 + q, 64);
+        double l4[4], r4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { l4[c] = __shfl(lg, 32 + 4 * qi + c, 64); r4[c] = __shfl(dv, 32 + 4 * qi + c, 64); }
+        const double lg_pa = __shfl(lg, 42 + i2, 64), lg_v2 = __shfl(lg, 44 + i2, 64), lg_v1 = __shfl(lg, 46 + i2, 64);
+        const double dv_r = __shfl(dv, 42 + i2, 64), dv_m = __shfl(dv, 44 + i2, 64), dv_p = __shfl(dv, 46 + i2, 64);
+        const double lg_s2 = __shfl(lg, 49, 64);
+        if (L < 16) {
+            const int i = qi, d = q & 7;
+            K.t[q] = lg - lgpk;
+            double diff[4], tr = 0, sl = 0, quad = 0;
+            for (int c = 0; c < 4; ++c) diff[c] = pr.color_mean[i][d][c] - vs[10 + 4 * i + c];
+            for (int c = 0; c < 4; ++c) {
+                const double lam = vs[18 + 4 * i + c];
+                tr += prior->inv_cov[i][d][c + 4 * c] * lam; sl += l4[c];
+            }
+            for (int r = 0; r < 4; ++r) {
+                double Ld = 0;
+                for (int c = 0; c < 4; ++c) Ld += prior->inv_cov[i][d][r + 4 * c] * diff[c];
+                K.Ld[q][r] = Ld; quad += diff[r] * Ld;
+                K.ml[q][r] = 0.5 * (prior->inv_cov[i][d][r + 4 * r] - r4[r]);
+            }
+            K.m[q] = 0.5 * ((tr - 4.0) + quad + (prior->logdet[i][d] - sl));
+        } else if (L == 40 || L == 41) {
+            K.ta[i2] = lg - lg_pa;
+            K.g[i2] = .5 * (lg_v2 - lg_v1 + dv - 1.0);
+            K.g_r[i2] = dv_r;
+            K.g_v[i2] = .5 * (dv_m + dv_p);
+        } else if (L == 48) {
+            // log p(radius) (elbo_kl.jl:130-137)
+            K.rad = -0.5 * (log(2.0 * M_PI) + lg_s2 + dv);
         }
-        for (int r = 0; r < 4; ++r) {
-            double Ld = 0;
-            for (int c = 0; c < 4; ++c) Ld += prior->inv_cov[i][d][r + 4 * c] * diff[c];
-            K.Ld[q][r] = Ld; quad += diff[r] * Ld;
-            K.ml[q][r] = 0.5 * (prior->inv_cov[i][d][r + 4 * r] - 1.0 / vs[18 + 4 * i + r]);
-        }
-        K.m[q] = 0.5 * ((tr - 4.0) + quad + (prior->logdet[i][d] - sl));
-    }
-    if (want_kl && tid >= 238 && tid < 240) {
-        const int i = tid - 238;
-        const celeste_prior_t &pr = prior->p;
-        const double a = vs[26 + i];
-        K.ta[i] = log(a) - log(pr.is_star[i]);
-        const double mu1 = vs[6 + i], var1 = vs[8 + i], mu2 = pr.flux_mean[i], var2 = pr.flux_var[i];
-        K.g[i] = .5 * (log(var2) - log(var1) + (var1 + (mu1 - mu2) * (mu1 - mu2)) / var2 - 1.0);
-        K.g_r[i] = (mu1 - mu2) / var2;
-        K.g_v[i] = .5 * (-1.0 / var1 + 1.0 / var2);
-    }
-    // (the radius prior here, not in kl_value: that lambda runs inside the image loop, and the constants of its library
-    // logarithms -- hoisted out of the loop -- were what lift_kernel spilled: 88 B of scratch per thread, stored by EVERY
-    // thread, 45 MB of HBM writes per 2000-target sweep next to 31 MB of Hessians)
-    if (want_kl && tid == 237) {
-        const double x = vs[5], mu = prior->p.gal_radius_px_mean, s2 = prior->p.gal_radius_px_var;
-        K.rad = -0.5 * (log(2.0 * M_PI) + log(s2) + (x - mu) * (x - mu) / s2);
     }
     // ---- KL value (elbo_kl.jl:140-154): by the same wavefront, while the others are in the second pass ----
     auto kl_value = [&]() {

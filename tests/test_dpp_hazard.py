@@ -94,7 +94,7 @@ def test_register_and_scratch_budgets_of_the_hot_kernels():
     # the lift: 8 workgroups of 256 threads per CU (64 VGPRs); its spill is stored by every thread, i.e. it is HBM traffic
     # (88 B per thread = 45 MB per 2000-target sweep before round 5 moved the radius prior's logarithms out of the image loop)
     v, s, l = one("_Z11lift_kernel")
-    assert s <= 40 and v <= 64 and 8 * l <= 160 * 1024
+    assert s <= 48 and v <= 64 and 8 * l <= 160 * 1024
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")

@@ -11,3 +11,4 @@ done
 done
 unset CELESTE_MI355X_LIB
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3
+timeout 300 python bench.py --height 300 --width 260 --sources 60 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('layer us', d['optimizer']['cyclades_layer']['us_per_newton_iteration_of_the_slowest_target'])"
