@@ -262,14 +262,64 @@ def bad_sky_flags(entries, images, device=None, force_torch: bool = False) -> Li
     return [bool(x) for x in out]
 
 
+def group_single_infer(group, catalog, target_sources: Sequence[int], cfg: Optional[ElboConfig] = None,
+                       failed: Optional[set] = None) -> np.ndarray:
+    """one_node_single_infer (ParallelRun.jl:546-607) over the devices of a `group.FieldGroup`: the N workers of the
+    reference's loop are the group's members (celeste_group_maximize_batch)."""
+    vp_nbr = init_source_table(catalog)
+    vp = init_source_table(catalog, target_sources)
+    new, _, _, _, st = group.maximize_batch(vp, list(target_sources), cfg or default_infer_config(), vp_neighbors=vp_nbr,
+                                            raise_on_error=False)
+    _report_failures(target_sources, st, "one_node_single_infer", failed)
+    return new[list(target_sources)]
+
+
+def group_joint_infer(group, catalog, target_sources: Sequence[int], neighbors: List[List[int]],
+                      cfg: Optional[ElboConfig] = None, batch_size: int = 400, n_iters: int = NUM_JOINT_VI_ITERS,
+                      rng: Optional[np.random.Generator] = None, failed: Optional[set] = None) -> np.ndarray:
+    """one_node_joint_infer (ParallelRun.jl:135-196) over the devices of a `group.FieldGroup`: the connected components of
+    every Cyclades batch are sharded over the members, the rows a batch updated are exchanged once per batch
+    (celeste_group_joint_infer).  Same table as one_node_joint_infer on one device, bit for bit."""
+    from .group import cyclades_schedule
+    targets = list(target_sources)
+    vp = init_source_table(catalog, targets)
+    b_off, c_off, flat = cyclades_schedule(targets, neighbors, batch_size=batch_size, rng=rng)
+    pos = vp[flat, 0:2].copy()                                   # boxes stay at the initial positions
+    vp, _, _, _, st, _ = group.joint_infer(vp, b_off, c_off, flat, n_iters, cfg or default_infer_config(), pos_centers=pos)
+    for sweep in st:
+        _report_failures([int(t) for t in flat], sweep, "one_node_joint_infer", failed)
+    return vp[targets]
+
+
 def infer_box(images, box: BoundingBox, catalog, method: str = "joint_vi", cfg: Optional[ElboConfig] = None,
-              n_iters: int = NUM_JOINT_VI_ITERS, device: int = 0, schedule: str = "cyclades") -> List[OptimizedSource]:
+              n_iters: int = NUM_JOINT_VI_ITERS, device: int = 0, schedule: str = "cyclades",
+              devices: Optional[Sequence[int]] = None) -> List[OptimizedSource]:
     """infer_box / _infer_box (ParallelRun.jl:610-672) for a given catalog: patches for every catalog entry, targets
     = entries strictly inside the box, neighbours may lie outside it, then joint or single variational inference
-    on the device.  (Source detection and MCMC are out of scope: `catalog` is required, method in {joint_vi, single_vi}.)"""
+    on the device.  (Source detection and MCMC are out of scope: `catalog` is required, method in {joint_vi, single_vi}.)
+    devices: HIP ordinals of a device group (celeste_group_*: one process, the reference's N workers = N devices, RCCL
+    inside the library); None = the one `device`."""
     targets = [i for i, ce in enumerate(catalog) if box.contains(ce.pos)]
     if not targets:
         return []
+    if devices is not None:
+        from .group import FieldGroup
+        if schedule != "cyclades":
+            raise ValueError("a device group runs the reference's Cyclades schedule")
+        group = FieldGroup.from_catalog(images, catalog, devices=list(devices), sparse=len(images) > 5)
+        failed = set()
+        try:
+            if method == "joint_vi":
+                vs = group_joint_infer(group, catalog, targets, group.problem.neighbors, cfg, n_iters=n_iters, failed=failed)
+            elif method == "single_vi":
+                vs = group_single_infer(group, catalog, targets, cfg, failed=failed)
+            else:
+                raise ValueError("unknown method: %s" % method)
+        finally:
+            group.close()
+        flags = bad_sky_flags([catalog[t] for t in targets], images, devices[0])
+        return [OptimizedSource(float(catalog[t].pos[0]), float(catalog[t].pos[1]), vs[k].copy(), flags[k], t in failed)
+                for k, t in enumerate(targets)]
     # patches and neighbour lists as arrays (model.patch_table: the geometry of get_sky_patches / find_neighbors
     # without a Python object per patch); several fields: sources see a few images each -> sparse patch list
     ctx = FieldContext.from_catalog(images, catalog, device=device, sparse=len(images) > 5)

@@ -240,6 +240,22 @@ def test_group_on_overlapping_fields_with_the_sparse_patch_list():
     ctx.close()
 
 
+def test_infer_box_over_a_device_group_equals_the_one_device_run():
+    """ParallelRun.infer_box with `devices=`: the node-level loops through celeste_group_* (two members on the one device)
+    leave the optimised sources the one-device run leaves, joint and single"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(300, 340, 40, seed=77)
+    box = cel.BoundingBox(0, 300, 0, 340)
+    for method in ("joint_vi", "single_vi"):
+        ref = cel.infer_box(f.images, box, f.catalog, method=method)
+        got = cel.infer_box(f.images, box, f.catalog, method=method, devices=[0, 0])
+        assert len(ref) == len(got) > 30
+        for a, b in zip(ref, got):
+            assert a.init_ra == b.init_ra and a.is_sky_bad == b.is_sky_bad and a.failed == b.failed
+            assert np.array_equal(a.vs, b.vs), (method, np.abs(a.vs - b.vs).max())
+
+
 def test_bench_group_driver_prints_the_line_and_the_single_rank_catalog(tmp_path):
     """`bench.py --driver group`: ONE process, the members behind the C ABI -- one member (RCCL, one rank: `ranks_seen` is
     ncclCommCount) and two members on the one device; both leave the catalog the torch driver's single rank leaves"""
