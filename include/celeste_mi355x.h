@@ -22,6 +22,14 @@
  *       src/ParallelRun.jl:45-47
  *   images shared by the per-source ElboArgs of a box        celeste_images_create + celeste_ctx_create_on
  *       src/ParallelRun.jl:468-488 (process_source)
+ *   ElboMaximize.maximize!(ea, vp, cfg)                      celeste_maximize_batch[_device]
+ *       src/deterministic_vi/ElboMaximize.jl:228-242
+ *   one_node_joint_infer's inner loop                         celeste_joint_infer
+ *       src/ParallelRun.jl:135-196, 302-397
+ *   the N workers of one process draining a source list      celeste_group_create + celeste_group_elbo_eval_batch /
+ *       src/ParallelRun.jl:546-607 (one_node_single_infer),      celeste_group_maximize_batch / celeste_group_joint_infer
+ *       :302-369 (process_sources_dynamic!), :45-56               (one process, N HIP devices, RCCL inside the library)
+ *       (estimate_time, load balancing)
  *
  * Conventions (all taken from the reference):
  *   - matrices are column-major with the first index (h, image row) fastest;
