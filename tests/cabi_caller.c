@@ -174,7 +174,7 @@ static void print_row(const char *tag, int s, const double *x, int n) {
 }
 
 int main(int argc, char **argv) {
-    int N, S, n, s, k, device = 0, members = 1;
+    int N, S, n, s, k, device = 0, members = 1, distinct = 0;
     celeste_image_t *images;
     celeste_patch_t *patches;
     double *stamps;
@@ -184,9 +184,10 @@ int main(int argc, char **argv) {
     celeste_problem_t prob;
     celeste_ctx_t *ctx = NULL;
 
-    if (argc < 2) die("usage: cabi_caller <fixture stem, e.g. tests/golden/raw/sample_two_body> [device [group members]]");
+    if (argc < 2) die("usage: cabi_caller <fixture stem, e.g. tests/golden/raw/sample_two_body> [device [group members [distinct]]]");
     if (argc > 2) device = atoi(argv[2]);
     if (argc > 3) members = atoi(argv[3]);
+    if (argc > 4) distinct = atoi(argv[4]);      /* 1: member q on device + q (RCCL between real devices); 0: all on `device` */
     if (members < 1 || members > 16) die("group members: 1 .. 16");
     if (celeste_version() / 100 != CELESTE_ABI_VERSION / 100) die("library / header ABI version mismatch");
     load_fixture(argv[1]);
@@ -306,7 +307,7 @@ int main(int argc, char **argv) {
         int64_t *cnt[2], *off = (int64_t *)malloc((size_t)(2 * S + 1) * sizeof(int64_t)), n_exch = -1;
         int32_t *st[2], *it[2], *ev[2], *tg = (int32_t *)malloc((size_t)2 * S * sizeof(int32_t));
         int q, eq_eval, eq_max, eq_joint;
-        for (q = 0; q < members; ++q) devs[q] = device;
+        for (q = 0; q < members; ++q) devs[q] = distinct ? device + q : device;
         for (q = 0; q < 2; ++q) {
             v[q] = (double *)calloc(nv, sizeof(double)); d[q] = (double *)calloc(nd, sizeof(double)); h[q] = (double *)calloc(nh, sizeof(double));
             vp[q] = (double *)malloc(nd * sizeof(double)); el[q] = (double *)calloc(2 * nv, sizeof(double));

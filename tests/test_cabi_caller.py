@@ -132,3 +132,23 @@ def test_c_caller_drives_two_group_members_on_one_device(exe):
     assert r.returncode == 0, r.stderr[-2000:]
     got = _parse(r.stdout)
     assert got["group"] == [2, cabi.EXCHANGE_PEER_COPY, 0] and got["group_equal"] == [1, 1, 1, 4]
+
+
+def _n_devices():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_devices() < 2, reason="needs >= 2 HIP devices (RCCL between real ranks, from a C caller)")
+def test_c_caller_drives_a_group_over_real_devices(exe):
+    """arms itself on a node with several devices: the compiled C caller, one member per device, RCCL between them"""
+    from celeste_jl_amd import cabi
+    n = min(_n_devices(), 8)
+    r = subprocess.run([exe, os.path.join(RAW, "sample_two_body"), "0", str(n), "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = _parse(r.stdout)
+    assert got["group"] == [n, cabi.EXCHANGE_RCCL, n] and got["group_equal"] == [1, 1, 1, 4]
