@@ -2495,7 +2495,7 @@ struct LiftShared {
     double s_kap[LIFT_NT][10], s_lam[LIFT_NT][10], s_El[LIFT_NT][2], s_Ell[LIFT_NT][2];
     KLShared K;
     double sh_v, sh_cnt[2];
-    int sh_bad, own_finite;
+    int sh_bad, own_finite, nbr_finite;
 };
 
 // The lift of ONE target by the calling workgroup (>= 256 threads): chunk records -> value, 44-gradient, 44 x 44 Hessian
@@ -2548,6 +2548,16 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
+    // The finiteness flags of the target and its neighbours (elbo_objective.jl:487) are three dependent global loads -- offsets,
+    // neighbour ids, flags.  Thread 0 used to walk them at the very end of the lift, alone, with the whole workgroup (and, in the
+    // optimiser, the target's next Newton step) waiting behind: a spare thread of the third wavefront fetches them now, under
+    // the first pass.
+    if (tid == 190) {
+        int fin = 1;
+        if constexpr (!COH) fin = geo[t].finite;
+        for (int64_t q = nbr_off[t]; q < nbr_off[t + 1]; ++q) fin &= ldc<COH>(&geo[nbr_idx[q]].finite);
+        L.nbr_finite = fin;
+    }
     if constexpr (COH) {
         // the target moved since the batch's tables were made: its shape derivatives from its current parameters
         // (source_geo_values, the function setup_thread fills the table with)
@@ -2844,8 +2854,7 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
     __syncthreads();
     if (tid == 0) {
         int st = sh_bad ? CELESTE_ERR_NONFINITE_RESULT : CELESTE_OK;
-        int fin = COH ? L.own_finite : geo[t].finite;
-        for (int64_t q = nbr_off[t]; q < nbr_off[t + 1]; ++q) fin &= ldc<COH>(&geo[nbr_idx[q]].finite);
+        const int fin = (COH ? L.own_finite : 1) & L.nbr_finite;
         if (!fin) st = CELESTE_ERR_NONFINITE_INPUT;
         *o_status = st;
         *o_v = sh_v;
