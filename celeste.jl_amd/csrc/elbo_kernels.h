@@ -1180,12 +1180,6 @@ __device__ __forceinline__ void accum_entries(const TT &T, double *__restrict__ 
 // and row r of the wavefront adds its entry E + r: 17 conflict-free adds instead of 65 four-way ones.  The sum of a slot's
 // four lanes is formed in fp32 in a fixed order, (l + l16) + (l32 + l48): reproducible, inside the mode's 1e-4 by orders
 // of magnitude.  Entries a mode does not produce, and the identically zero ones, enter as 0.
-template <int MODE, int E, class TT>
-__device__ __forceinline__ float entry_or_zero(const TT &T) {
-    constexpr bool hess_only = E > ZV && E < ACC_CNT;
-    if constexpr (E >= ACC_N || (MODE == 1 && hess_only) || entry_is_zero<E < ACC_N ? E : 0>()) return 0.0f;
-    else return (float)record_entry<E>(T);
-}
 template <int MODE, int E>
 constexpr bool group_is_empty() {    // none of E .. E + 3 is produced
     bool any = false;
@@ -1202,17 +1196,7 @@ __device__ __forceinline__ float fold_rows_pair16(float a, float b) {   // rows 
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-template <int MODE, int E, class TT>
-__device__ __forceinline__ void accum_entries_rows(const TT &T, double *__restrict__ slot_row) {
-    if constexpr (!group_is_empty<MODE, E>()) {
-        const float s01 = fold_rows_pair16(entry_or_zero<MODE, E>(T), entry_or_zero<MODE, E + 1>(T));
-        const float s23 = fold_rows_pair16(entry_or_zero<MODE, E + 2>(T), entry_or_zero<MODE, E + 3>(T));
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
-        const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // row r: entry E + r, slot lane & 15
-        __hip_atomic_fetch_add(slot_row + ACC_SLOTS * E, (double)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    if constexpr (E + 4 < ACC_N) accum_entries_rows<MODE, E + 4>(T, slot_row);
-}
+// (the adds themselves: accum_entries_rows2, two pixels per lane -- the only user since round 5)
 
 // the same in two steps: the values (pinned in registers by an empty asm, so that they are formed where this is called),
 // then the adds
@@ -1471,7 +1455,10 @@ __device__ __forceinline__ typename TT::scalar galaxy_sums_pk(const CompR<float>
     // the records are staged pair-interleaved (pixel_kernel's prologue): field i of components c, c + 1 sits in the two
     // halves of one 8-byte slot, so the packed operands come out of the LDS reads as they are (13 v_mov per trip saved)
     const f2v *tp = reinterpret_cast<const f2v *>(tc);
-    if constexpr (MODE == 2) {
+    // (Hessian sums only: the split variant, pixel_kernel<3, float>, is the one user left -- the fused single-precision modes
+    // run galaxy_sums_px2, two pixels per lane)
+    static_assert(MODE == 2, "split variant only");
+    {
         // as in galaxy_sums: the six sums that exist f-weighted and d-weighted are accumulated once, d-weighted, per profile
         // type (U0: de Vaucouleurs, U1: exponential, carrying wd's minus sign); pairs never straddle the types (8 psf_K and
         // 6 psf_K are even).  18 packed accumulations per pair instead of 24, and the Hermite polynomials take their
@@ -1511,25 +1498,8 @@ __device__ __forceinline__ typename TT::scalar galaxy_sums_pk(const CompR<float>
         T.S3a = PKH(S3a); T.S3b = PKH(S3b); T.S3c = PKH(S3c); T.S3d = PKH(S3d);
         T.S4a = PKH(S4a); T.S4b = PKH(S4b); T.S4c = PKH(S4c); T.S4d = PKH(S4d); T.S4e = PKH(S4e);
         return th0 * u0[0] - th1 * u1[0];
-    } else {
-        f2v S0 = z, S0d = z, S1x = z, S1y = z, S2an = z, S2bn = z, S2cn = z;
-        for (int c = 0; c < nc; c += 2) {
-            const f2v *k = tp + (PKSLOTS / 2) * c;
-            const f2v p11 = k[0], p12 = k[1], p22 = k[2], w0 = k[3], wd = k[4], nu = k[5], xi1 = k[6], xi2 = k[7];
-            const f2v d1 = dxx - xi1, d2 = dyy - xi2;
-            const f2v u = p11 * d1 + p12 * d2, v = p12 * d1 + p22 * d2;
-            const f2v q = -0.5f * (d1 * u + d2 * v);
-            const f2v e = {__expf(q.x), __expf(q.y)};
-            const f2v f = w0 * e, fd = wd * e, fn = f * nu;
-            const f2v ha = u * u - p11, hb = u * v - p12, hc = v * v - p22;
-            S0 += f; S0d += fd;
-            S1x += u * f; S1y += v * f;
-            S2an += ha * fn; S2bn += hb * fn; S2cn += hc * fn;
-        }
-        T.S0d = PKH(S0d); T.S1x = PKH(S1x); T.S1y = PKH(S1y); T.S2an = PKH(S2an); T.S2bn = PKH(S2bn); T.S2cn = PKH(S2cn);
-        return PKH(S0);
-#undef PKH
     }
+#undef PKH
 }
 
 
@@ -1791,10 +1761,7 @@ __device__ __forceinline__ void pixel_iter(const PixWork<R> &W, int base, int p1
             add_entries<MODE, 0>(ent, slot_s);
         } else {
             gate();
-            if constexpr (sizeof(S) == 4) {
-                static_assert(ACC_N % 4 == 0, "entries are added four at a time");
-                accum_entries_rows<MODE, 0>(T, slot_s + ACC_SLOTS * (lane >> 4));
-            } else
+            static_assert(sizeof(S) == 8, "the single-precision derivative modes run pixel_iter_px2");
             accum_entries<MODE, 0>(T, slot_s);
         }
     }
@@ -1907,6 +1874,7 @@ __device__ __forceinline__ float entry2_or_zero(const TT &T) {
 }
 template <int MODE, int E, class TT>
 __device__ __forceinline__ void accum_entries_rows2(const TT &T, double *__restrict__ slot_row) {
+    static_assert(ACC_N % 4 == 0, "entries are added four at a time");
     if constexpr (!group_is_empty<MODE, E>()) {
         const float s01 = fold_rows_pair16(entry2_or_zero<MODE, E>(T), entry2_or_zero<MODE, E + 1>(T));
         const float s23 = fold_rows_pair16(entry2_or_zero<MODE, E + 2>(T), entry2_or_zero<MODE, E + 3>(T));
