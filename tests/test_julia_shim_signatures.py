@@ -107,3 +107,11 @@ def test_the_context_table_of_the_shim_is_only_touched_under_its_lock():
         locks = [m.start() for m in re.finditer(r"(?<!un)lock\(MI355X_CONTEXTS_LOCK\)", before)]
         assert locks and locks[-1] > before.rfind("unlock(MI355X_CONTEXTS_LOCK)"), code[pos - 80:pos + 40]
         assert code.find("unlock(MI355X_CONTEXTS_LOCK)", pos) > 0
+
+
+def test_integration_md_shows_the_shim_as_shipped():
+    """INTEGRATION.md section 1 prints the reference-side binding a maintainer would add: it must be the file under shim/, not an
+    older copy of it"""
+    shim = open(os.path.join(ROOT, "shim", "CelesteMI355X.jl")).read().rstrip()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert shim in doc
