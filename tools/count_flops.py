@@ -2,8 +2,9 @@
 counted in the compiled ISA (no GPU needed).
 
 usage: python tools/count_flops.py [--write]
-Prints the static counts and the per-visit figures bench.py uses: (pixel loop body - one copy of each component loop) +
-trips x (component loop); FMA = 2 flops, multiply / add = 1, packed fp32 instructions count both halves.  --write stores
+Prints the static counts and the per-visit figures bench.py uses: every basic block LLVM's loop annotations place inside the
+pixel loop, component-loop blocks times their trip counts; FMA = 2 flops, multiply / add = 1, packed fp32 instructions count
+both halves.  --write stores
 them in profiles/hbm_traffic.json (flops_per_pixel_visit, flops_per_pixel_visit_f32, instruction_mix, instruction_mix_f32)."""
 import json
 import os
@@ -44,14 +45,33 @@ def stats(lines):
     return s
 
 
-def loops_of(lines):
-    labels = {ln.strip().split(":")[0]: k for k, ln in enumerate(lines) if ln.strip().startswith(".LBB") and ":" in ln}
-    out = []   # (first line, last line) of every backward branch
-    for k, ln in enumerate(lines):
-        t = ln.strip().split()
-        if t and t[0].startswith(("s_cbranch", "s_branch")) and t[-1] in labels and labels[t[-1]] < k:
-            out.append((labels[t[-1]], k))
-    return out
+def blocks_of(lines):
+    """The function's basic blocks with LLVM's loop annotations: [(label or None, first line, last line, loop)], where loop is
+    the header label of the innermost loop the block belongs to (None outside loops), and parent[header] = the header of the
+    enclosing loop.  Membership comes from the assembler comments ("in Loop: Header=BBx_y", "Parent Loop BBx_y", "Loop
+    Header"), not from address ranges: block placement moves rarely-skipped blocks (the star spline) behind a loop's first
+    back edge, where a range-based count loses them."""
+    import re
+    starts = [k for k, ln in enumerate(lines) if re.match(r"\.LBB\d+_\d+:", ln) or ln.startswith("; %bb.")]
+    blocks, parent = [], {}
+    for n, k in enumerate(starts):
+        end = (starts[n + 1] if n + 1 < len(starts) else len(lines)) - 1
+        m = re.match(r"\.(LBB\d+_\d+):", lines[k])
+        label = m.group(1)[1:] if m else None
+        note = [lines[k]]
+        j = k + 1
+        while j <= end and lines[j].strip().startswith(";") and not lines[j].startswith("; %bb."):
+            note.append(lines[j]); j += 1
+        note = "\n".join(note)
+        if "Loop Header" in note:
+            loop = label
+            ps = re.findall(r"Parent Loop (BB\d+_\d+)", note)
+            parent[label] = ps[-1] if ps else None
+        else:
+            m = re.search(r"in Loop: Header=(BB\d+_\d+)", note)
+            loop = m.group(1) if m else None
+        blocks.append((label, k, end, loop))
+    return blocks, parent
 
 
 def analyse(txt, symbol, psf_k=2, pixels_per_lane=1):
@@ -60,28 +80,48 @@ def analyse(txt, symbol, psf_k=2, pixels_per_lane=1):
     i = txt.index(symbol)
     i = txt.index(":\n", i)
     lines = txt[i:txt.index("s_endpgm", i)].split("\n")
-    loops = loops_of(lines)
-    # the component loops: innermost loops that read component records (ds_read_b128): fp64 -- one per profile type
-    # (8 psf_K de Vaucouleurs, 6 psf_K exponential components, two per trip); fp32 -- one loop, two components per trip
-    comp = sorted((a, b) for a, b in loops if any("ds_read_b128" in l for l in lines[a:b])
-                  and not any(a < a2 and b2 < b for a2, b2 in loops))
-    outer = min((l for l in loops if all(l[0] < a and b < l[1] for a, b in comp)), key=lambda l: l[1] - l[0])
-    body = stats(lines[outer[0]:outer[1]])
-    n_comp = [8 * psf_k, 6 * psf_k] if len(comp) == 2 else [14 * psf_k]
-    per_visit = dict(body)
-    report = []
-    for (a, b), n in zip(comp, n_comp):
-        c = stats(lines[a:b + 1])
-        # components per trip: the fp64 loop requests every record with six explicit ds_read_b128 (a run of 8 / 6
-        # prototypes is unrolled: 8 / 6 per trip); the packed fp32 loop handles one pair per trip
-        reads = sum("ds_read_b128" in l for l in lines[a:b + 1])
+    blocks, parent = blocks_of(lines)
+
+    def inside(loop, anc):     # is `loop` the loop `anc` or nested in it
+        while loop is not None:
+            if loop == anc:
+                return True
+            loop = parent.get(loop)
+        return False
+
+    def own_lines(loop):       # the blocks whose INNERMOST loop is `loop`
+        return [ln for _, a, b, lp in blocks if lp == loop for ln in lines[a:b + 1]]
+
+    # the component loops: innermost loops that read component records (ds_read_b128): fp64 -- one per profile type, a run of
+    # 8 / 6 prototypes unrolled per trip; fp32 -- one per profile type inside a loop over the runs, two components per trip
+    inner = [h for h in parent if h not in parent.values()]
+    comp = sorted((h for h in inner if sum("ds_read_b128" in l for l in own_lines(h)) >= 4),
+                  key=lambda h: next(a for lb, a, _, _ in blocks if lb == h))
+    assert len(comp) == 2, comp
+    nested = parent[comp[0]] != parent[comp[1]]          # fp32: each sits in its own loop over the runs
+    pixel = parent[parent[comp[0]]] if nested else parent[comp[0]]
+    assert pixel is not None and inside(comp[1], pixel)
+    # multiplicity of every loop inside the pixel loop (other loops -- the neighbour gather -- count once)
+    mult, report = {}, []
+    for h, per_run in zip(comp, (8, 6)):
+        reads = sum("ds_read_b128" in l for l in own_lines(h))
         per_trip = reads // 6 if reads >= 30 else 2
-        trips = n // per_trip
+        c = stats(own_lines(h))
+        if nested:
+            mult[parent[h]] = psf_k
+            mult[h] = psf_k * (per_run // per_trip)
+        else:
+            mult[h] = psf_k * per_run // per_trip
         report.append("component loop (%d trips of %d components): %d fp64 + %d fp32 flops, %d VALU (%d FMA-class) per trip"
-                      % (trips, per_trip, c["f64"], c["f32"], c["valu"], c["fma"]))
+                      % (mult[h], per_trip, c["f64"], c["f32"], c["valu"], c["fma"]))
+    per_visit = {"f64": 0, "f32": 0, "valu": 0, "fma": 0, "fp_instr": 0}
+    loops_in = sorted({lp for _, _, _, lp in blocks if inside(lp, pixel)}, key=str)
+    for lp in loops_in:
+        c = stats(own_lines(lp))
         for k in per_visit:
-            per_visit[k] += (trips - 1) * c[k]
-    report.append("pixel loop body (one copy of each component loop inside): %d fp64 + %d fp32 flops, %d VALU" %
+            per_visit[k] += mult.get(lp, 1) * c[k]
+    body = stats(own_lines(pixel))
+    report.append("pixel loop, the blocks outside the component loops: %d fp64 + %d fp32 flops, %d VALU" %
                   (body["f64"], body["f32"], body["valu"]))
     if pixels_per_lane > 1:
         report.append("a trip of the pixel loop handles %d pixels per lane: per-visit figures = per-trip / %d" % (pixels_per_lane, pixels_per_lane))
