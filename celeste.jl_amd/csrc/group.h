@@ -99,8 +99,9 @@ struct celeste_group {
     std::mutex call_mu;                        // one call per group at a time
 };
 
-// All members meet here (PEER mode only: RCCL's collectives are the meeting point otherwise).  A member that leaves a call
-// with an error never arrives: group_fail wakes the ones that wait, and they leave with an error too instead of hanging.
+// All members meet here (host side; in front of every row exchange, and in PEER mode behind it as well -- RCCL's collective
+// is the second meeting point otherwise).  A member that leaves a call with an error never arrives: group_fail wakes the ones
+// that wait, and they leave with an error too instead of hanging.
 static bool group_barrier(celeste_group *g) {
     if (g->n <= 1) return true;
     std::unique_lock<std::mutex> lk(g->bmu);
@@ -447,12 +448,13 @@ static int group_sweep_member(celeste_group *g, GroupMember *m, int k) {
     double *blk = m->d_block[k];
     HIP_TRY(hipStreamWaitEvent(st, m->buf_free[k], 0));      // the gather that last read this block is through
     if (g->timing) HIP_TRY(hipEventRecord(m->t0, st));
-    if (!m->tg.empty()) {
-        int rc = launch_eval(m->ctx, m->d_vp, (int32_t)m->tg.size(), m->d_targets, g->plan_flags, blk, blk + W, m->d_h,
+    int own_rc = CELESTE_OK;
+    if (!m->tg.empty())
+        own_rc = launch_eval(m->ctx, m->d_vp, (int32_t)m->tg.size(), m->d_targets, g->plan_flags, blk, blk + W, m->d_h,
                              reinterpret_cast<int64_t *>(blk + (size_t)W * (1 + CEL_P)),
                              reinterpret_cast<int32_t *>(blk + (size_t)W * (1 + CEL_P + 2)), st, true, nullptr, m->n_chunks);
-        if (rc != CELESTE_OK) return rc;
-    }
+    // (a member whose launch failed still takes part in the gather -- the collective needs every rank, and the others' sweeps
+    // are sound; the call reports this member's error)
     if (g->timing) HIP_TRY(hipEventRecord(m->t1, st));
     HIP_TRY(hipEventRecord(m->done[k], st));
     HIP_TRY(hipStreamWaitEvent(m->comm_stream, m->done[k], 0));
@@ -460,7 +462,7 @@ static int group_sweep_member(celeste_group *g, GroupMember *m, int k) {
     if (rc != CELESTE_OK) return rc;
     HIP_TRY(hipEventRecord(m->buf_free[k], m->comm_stream));
     if (g->timing) HIP_TRY(hipEventRecord(m->t2, m->comm_stream));
-    return CELESTE_OK;
+    return own_rc;
 }
 
 extern "C" int celeste_group_sweep(celeste_group_t *g) {
@@ -599,8 +601,11 @@ static int group_exchange_rows(celeste_group *g, GroupMember *m, double *d_table
     }
     int s1 = group_grow(&m->d_gathered, &m->gathered_cap, blk * g->n, st);
     if (s1 != CELESTE_OK) return s1;
-    // PEER mode: the other members copy into d_gathered; it must exist on every member before anyone copies
-    if (g->exchange == GROUP_EXCHANGE_PEER && !group_barrier(g)) return CELESTE_ERR_HIP;
+    // Every member arrives here before anyone enqueues the exchange.  PEER mode needs it (the others copy into d_gathered: it
+    // must exist on every member first); with RCCL it is what keeps a member that failed above -- an allocation, its launch's
+    // set-up -- from leaving the others inside a collective that will never complete: the failing member's return wakes the
+    // barrier (group_fail), and every member leaves the call with an error instead.
+    if (!group_barrier(g)) return CELESTE_ERR_HIP;
     HIP_TRY(hipMemsetAsync(m->d_block[0], 0, blk * sizeof(double), st));
     if (n_own > 0)
         hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)n_own), dim3(64), 0, st, d_table, d_own_targets, n_own, d_it, d_ev, d_el, d_st,
