@@ -95,6 +95,41 @@ def test_group_eval_equals_the_one_device_entry_bit_for_bit(crowded, devices):
     g.close()
 
 
+def test_one_member_on_its_worker_thread_runs_rccl_off_the_calling_thread(crowded, monkeypatch):
+    """CELESTE_GROUP_THREADS=1: a group of ONE member still gets its worker thread, so its launches AND its RCCL collectives
+    (communicator from ncclCommInitAll on the calling thread, ncclAllGather with one rank enqueued by the worker) run the way
+    every member of a multi-device group runs them -- the closest a one-GPU box comes to the real thing.  Sweep, maximize!
+    and joint inference equal the one-device entry points bit for bit."""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import cabi
+    from celeste_jl_amd.group import cyclades_schedule, schedule_layers
+    f, ctx = crowded
+    S = len(f.catalog)
+    monkeypatch.setenv("CELESTE_GROUP_THREADS", "1")
+    g = _group(f, [0])
+    monkeypatch.delenv("CELESTE_GROUP_THREADS")
+    info = g.info()
+    assert info["exchange"] == "rccl" and info["rccl_ranks"] == 1 and info["n_members"] == 1
+    flags = cabi.FLAG_GRAD | cabi.FLAG_HESS | cabi.FLAG_KL
+    tg = list(range(S))
+    _same(ctx.eval_batch(f.vp, tg, flags), g.eval_batch(f.vp, tg, flags), "sweep on the worker thread")
+    g.plan(f.vp, tg, flags)
+    for _ in range(5):
+        g.sweep()                                        # (dispatched back to back: the worker overlaps gather k with sweep k + 1)
+    g.wait()
+    _same(ctx.eval_batch(f.vp, tg, flags), g.results(), "resident sweeps on the worker thread")
+    cfg = cel.ElboConfig(max_iters=5)
+    _same(ctx.maximize_batch(f.vp, tg, cfg), g.maximize_batch(f.vp, tg, cfg), "maximize! on the worker thread")
+    b_off, c_off, flat = cyclades_schedule(tg, f.neighbors, batch_size=12, rng=np.random.default_rng(3))
+    layers, entries = schedule_layers(b_off, c_off, flat, 1)
+    ref = ctx.joint_infer(f.vp, layers, cfg)
+    new, its, evals, el, st, nx = g.joint_infer(f.vp, b_off, c_off, flat, 1, cfg)
+    assert nx == len(b_off) - 1 and np.array_equal(new, ref[0])
+    flat_entry = np.concatenate([np.asarray(e) for e in entries])
+    assert np.array_equal(its.reshape(-1)[flat_entry], ref[1]) and np.array_equal(el.reshape(-1)[flat_entry], ref[3])
+    g.close()
+
+
 def test_group_resident_sweeps_track_the_table_and_overlap_their_gathers(crowded):
     """plan once, sweep many times (the gather of sweep k runs while sweep k + 1 computes; two blocks alternate): the last
     sweep's results are the one-device results; a new plan with another table and other targets replaces the first"""
