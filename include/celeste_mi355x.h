@@ -384,7 +384,11 @@ int celeste_render_expected(celeste_ctx_t *ctx, const double *vp, int32_t image,
  * one included (the collective then runs with one rank).  A device that appears more than once makes the group exchange
  * by plain device-to-device copies instead (RCCL refuses duplicate devices in a communicator): two members on one GPU
  * exercise the shard / gather bookkeeping on a one-GPU box; it is a test configuration, not a fast one.
- * At most 16 members.  One call per group at a time (the entry points serialise themselves). */
+ * At most 16 members.  One call per group at a time (the entry points serialise themselves).
+ * Errors: per-source failures are statuses, as in the one-device entry points.  A member whose launch fails still takes
+ * part in the exchange (the collective needs every rank) and the call returns its error; a member that fails before an
+ * exchange of rows never reaches the host barrier in front of it, which wakes the others: every member leaves the call
+ * with an error and nobody waits inside a collective. */
 typedef struct celeste_group celeste_group_t;
 enum { CELESTE_EXCHANGE_RCCL = 1, CELESTE_EXCHANGE_PEER_COPY = 2 };
 typedef struct celeste_group_info_t {
