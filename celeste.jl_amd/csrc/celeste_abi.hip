@@ -173,6 +173,10 @@ struct celeste_ctx {
     int ev_valid = 0;
 };
 
+// No C++ exception crosses the C ABI (the callers are C, Julia's ccall, ctypes): every entry point that can allocate through
+// the standard library is a function-try-block ending in this handler.
+#define ABI_CATCH catch (const std::bad_alloc &) { return CELESTE_ERR_ALLOC; } catch (...) { return CELESTE_ERR_HIP; }
+
 extern "C" int celeste_version(void) { return CELESTE_ABI_VERSION; }
 
 extern "C" const char *celeste_strerror(int status) {
@@ -233,7 +237,7 @@ static void prefilter_line(int n, const double *d, int dstride, double *c, int c
     for (int q = 0; q < n + 2; ++q) c[(size_t)q * cstride] = x[q];
 }
 
-extern "C" int celeste_spline_prefilter(const double *stamp51, double *coef53) {
+extern "C" int celeste_spline_prefilter(const double *stamp51, double *coef53) try {
     if (!stamp51 || !coef53) return CELESTE_ERR_INVALID_ARG;
     const int n = CEL_STAMP, m = CEL_COEF;
     std::vector<double> g((size_t)n * n), tmp((size_t)m * n);
@@ -246,7 +250,7 @@ extern "C" int celeste_spline_prefilter(const double *stamp51, double *coef53) {
     for (int w = 0; w < n; ++w) prefilter_line(n, g.data() + (size_t)n * w, 1, tmp.data() + (size_t)m * w, 1);
     for (int h = 0; h < m; ++h) prefilter_line(n, tmp.data() + h, m, coef53 + h, m);
     return CELESTE_OK;
-}
+} ABI_CATCH
 
 static void inv4_logdet(const double *S, double *Inv, double *logdet) {
     double a[4][8];
@@ -283,7 +287,7 @@ static int select_device(int device) {
 }
 
 extern "C" int celeste_images_create(int32_t n_images, const celeste_image_t *images, int device,
-                                     celeste_images_t **out) {
+                                     celeste_images_t **out) try {
     if (!images || !out || n_images <= 0) return CELESTE_ERR_INVALID_ARG;
     *out = nullptr;
     int st = select_device(device);
@@ -315,11 +319,11 @@ extern "C" int celeste_images_create(int32_t n_images, const celeste_image_t *im
     if (hipDeviceSynchronize() != hipSuccess) { images_release(c); return CELESTE_ERR_HIP; }
     *out = c;
     return CELESTE_OK;
-}
+} ABI_CATCH
 
 extern "C" void celeste_images_destroy(celeste_images_t *images) { images_release(images); }
 
-extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celeste_ctx_t **out) {
+extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celeste_ctx_t **out) try {
     if (!pr || !out) return CELESTE_ERR_INVALID_ARG;
     *out = nullptr;
     if (pr->n_images <= 0 || !pr->images) return CELESTE_ERR_INVALID_ARG;
@@ -329,9 +333,9 @@ extern "C" int celeste_ctx_create(const celeste_problem_t *pr, int device, celes
     st = celeste_ctx_create_on(im, pr, out);
     images_release(im);   // the context holds its own reference
     return st;
-}
+} ABI_CATCH
 
-extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_problem_t *pr, celeste_ctx_t **out) {
+extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_problem_t *pr, celeste_ctx_t **out) try {
     if (!imgs || !pr || !out) return CELESTE_ERR_INVALID_ARG;
     *out = nullptr;
     if (pr->n_images != imgs->N || pr->n_sources <= 0 || pr->psf_K <= 0 || pr->psf_K > CEL_MAXK ||
@@ -599,7 +603,7 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
 #undef CTX_TRY
     *out = c;
     return CELESTE_OK;
-}
+} ABI_CATCH
 
 extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     if (!c) return;
@@ -663,9 +667,9 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
 
 extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_vp, int32_t n_targets,
                                               const int32_t *d_targets, uint32_t flags, double *d_v, double *d_d,
-                                              double *d_h, int64_t *d_counters, int32_t *d_status, void *stream_) {
+                                              double *d_h, int64_t *d_counters, int32_t *d_status, void *stream_) try {
     return launch_eval(c, d_vp, n_targets, d_targets, flags, d_v, d_d, d_h, d_counters, d_status, stream_, true);
-}
+} ABI_CATCH
 
 // the context's tables, as the fused kernels take them
 static void fused_args_tables(celeste_ctx_t *c, FusedArgs &A) {
@@ -963,16 +967,16 @@ extern "C" void *celeste_host_alloc(size_t bytes) {
     return p;
 }
 extern "C" void celeste_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
-extern "C" int celeste_host_register(void *ptr, size_t bytes) {
+extern "C" int celeste_host_register(void *ptr, size_t bytes) try {
     if (!ptr || bytes == 0) return CELESTE_ERR_INVALID_ARG;
     if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return CELESTE_ERR_HIP; }
     return CELESTE_OK;
-}
-extern "C" int celeste_host_unregister(void *ptr) {
+} ABI_CATCH
+extern "C" int celeste_host_unregister(void *ptr) try {
     if (!ptr) return CELESTE_ERR_INVALID_ARG;
     if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return CELESTE_ERR_HIP; }
     return CELESTE_OK;
-}
+} ABI_CATCH
 // is [ptr, ptr + bytes) page-locked memory the DMA engines can write directly?
 static bool is_pinned(const void *ptr, size_t bytes) {
     if (!ptr || bytes == 0) return false;
@@ -1046,7 +1050,7 @@ static int eval_small(celeste_ctx_t *c, const double *vp, int32_t n_targets, con
 // context's own streams are waited for.
 extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32_t n_targets, const int32_t *targets,
                                        uint32_t flags, double *v, double *d, double *h, int64_t *counters,
-                                       int32_t *status) {
+                                       int32_t *status) try {
     if (!c || !vp || !targets || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
     if (n_targets == 0) return CELESTE_OK;
     for (int t = 0; t < n_targets; ++t) if (targets[t] < 0 || targets[t] >= c->S) return CELESTE_ERR_INVALID_ARG;
@@ -1153,10 +1157,10 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
         if (s1 != CELESTE_OK && worst == CELESTE_OK) worst = s1;
     }
     return worst;
-}
+} ABI_CATCH
 
 extern "C" int celeste_elbo_eval(celeste_ctx_t *c, const double *vp, int32_t target, uint32_t flags, double *v,
-                                 double *d, double *h, int64_t *n_active_px, int64_t *n_inactive_px) {
+                                 double *d, double *h, int64_t *n_active_px, int64_t *n_inactive_px) try {
     int64_t cnt[2] = {0, 0};
     int32_t st1 = 0;
     double vv = 0;
@@ -1165,12 +1169,12 @@ extern "C" int celeste_elbo_eval(celeste_ctx_t *c, const double *vp, int32_t tar
     if (n_active_px) *n_active_px = cnt[0];
     if (n_inactive_px) *n_inactive_px = cnt[1];
     return st;
-}
+} ABI_CATCH
 
 // ---- elbo() with several active sources (ElboArgs.active_sources, elbo_args.jl:165-211) -------------------
 extern "C" int celeste_elbo_eval_multi(celeste_ctx_t *c, const double *vp, int32_t n_active, const int32_t *active,
                                        uint32_t flags, double *v, double *d, double *h, int64_t *n_active_px,
-                                       int64_t *n_inactive_px) {
+                                       int64_t *n_inactive_px) try {
     if (!c || !vp || !active || n_active < 1 || (flags & (CELESTE_FLAG_SPLIT | CELESTE_FLAG_PACKED_HESS))) return CELESTE_ERR_INVALID_ARG;
     const int Sa = n_active;
     for (int a = 0; a < Sa; ++a) {
@@ -1265,32 +1269,32 @@ done:
 #undef MU_TRY
     (void)hipStreamSynchronize(c->stream);   // nothing of this call is in flight when it returns
     return rc;
-}
+} ABI_CATCH
 
-extern "C" int celeste_ctx_enable_timing(celeste_ctx_t *c, int enable) {
+extern "C" int celeste_ctx_enable_timing(celeste_ctx_t *c, int enable) try {
     if (!c) return CELESTE_ERR_INVALID_ARG;
     c->timing = enable ? 1 : 0;
     c->ev_valid = 0;
     return CELESTE_OK;
-}
+} ABI_CATCH
 
-extern "C" int celeste_ctx_last_kernel_ms(celeste_ctx_t *c, float ms[3]) {
+extern "C" int celeste_ctx_last_kernel_ms(celeste_ctx_t *c, float ms[3]) try {
     if (!c || !ms || !c->ev_valid) return CELESTE_ERR_INVALID_ARG;
     HIP_TRY(hipEventSynchronize(c->ev[3]));
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
     if (c->ev_split) HIP_TRY(hipEventElapsedTime(&ms[2], c->ev[4], c->ev[3]));  // lift alone
     return CELESTE_OK;
-}
+} ABI_CATCH
 
-extern "C" int celeste_ctx_last_record_sum_ms(celeste_ctx_t *c, float *ms) {
+extern "C" int celeste_ctx_last_record_sum_ms(celeste_ctx_t *c, float *ms) try {
     if (!c || !ms || !c->ev_valid || !c->ev_split) return CELESTE_ERR_INVALID_ARG;
     HIP_TRY(hipEventSynchronize(c->ev[3]));
     HIP_TRY(hipEventElapsedTime(ms, c->ev[2], c->ev[4]));
     return CELESTE_OK;
-}
+} ABI_CATCH
 
 extern "C" int celeste_ctx_work_stats(celeste_ctx_t *c, int32_t n_targets, const int32_t *targets,
-                                      celeste_work_stats_t *out) {
+                                      celeste_work_stats_t *out) try {
     if (!c || !out || (n_targets > 0 && !targets)) return CELESTE_ERR_INVALID_ARG;
     memset(out, 0, sizeof *out);
     out->n_targets = n_targets;
@@ -1321,10 +1325,10 @@ extern "C" int celeste_ctx_work_stats(celeste_ctx_t *c, int32_t n_targets, const
         out->algorithmic_bytes += 9 * A + 4 * R + 352 * (1 + Kn) + 200 * PC + 8288;
     }
     return CELESTE_OK;
-}
+} ABI_CATCH
 
 extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, const double *rows, int32_t n_rows,
-                                  const double *cols, int32_t n_cols, double *out) {
+                                  const double *cols, int32_t n_cols, double *out) try {
     if (!psf || K <= 0 || !rows || !cols || n_rows <= 0 || n_cols <= 0 || !out) return CELESTE_ERR_INVALID_ARG;
     int st = select_device(device);
     if (st != CELESTE_OK) return st;
@@ -1341,7 +1345,7 @@ extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, cons
     }
     (void)hipFree(d_psf); (void)hipFree(d_rows); (void)hipFree(d_cols); (void)hipFree(d_out);
     return st;
-}
+} ABI_CATCH
 
 
 // ---- maximize! for a batch of targets (ElboMaximize.jl:228-242; neighbours frozen at the input vp) ----------
@@ -1586,7 +1590,7 @@ static int fused_abort_status(celeste_ctx_t *c) {
 extern "C" int celeste_maximize_batch_device(celeste_ctx_t *c, double *d_vp, const double *d_vp_neighbors,
                                              const double *d_pos_centers, int32_t n_targets, const int32_t *d_targets,
                                              const celeste_optim_config_t *cfg_in, int32_t *d_iterations, int32_t *d_f_evals,
-                                             double *d_elbo, int32_t *d_status, void *stream_) {
+                                             double *d_elbo, int32_t *d_status, void *stream_) try {
     if (!c || !d_vp || !d_targets || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
     if (n_targets == 0) return CELESTE_OK;
     OptParams op;
@@ -1601,7 +1605,7 @@ extern "C" int celeste_maximize_batch_device(celeste_ctx_t *c, double *d_vp, con
     if (st != CELESTE_OK) return st;
     return optim_run(c, d_vp, d_pos_centers, n_targets, d_targets, -1, op, flags, d_iterations, d_f_evals, d_elbo, d_status,
                      stream, nullptr);
-}
+} ABI_CATCH
 
 static int check_distinct_targets(celeste_ctx_t *c, int32_t n, const int32_t *targets, std::vector<uint8_t> &seen) {
     seen.assign((size_t)c->S, 0);   // two optimisations of one source would share its row of vp
@@ -1615,7 +1619,7 @@ static int check_distinct_targets(celeste_ctx_t *c, int32_t n, const int32_t *ta
 extern "C" int celeste_maximize_batch(celeste_ctx_t *c, double *vp, const double *vp_neighbors,
                                       const double *pos_centers, int32_t n_targets, const int32_t *targets,
                                       const celeste_optim_config_t *cfg_in, int32_t *iterations, int32_t *f_evals,
-                                      double *elbo, int32_t *status) {
+                                      double *elbo, int32_t *status) try {
     if (!c || !vp || !targets || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
     if (n_targets == 0) return CELESTE_OK;
     std::vector<uint8_t> seen;
@@ -1673,7 +1677,7 @@ cleanup:
 #undef MX_TRY
     if (rc == CELESTE_ERR_HIP) (void)hipStreamSynchronize(stream);
     return rc;
-}
+} ABI_CATCH
 
 
 // ---- joint inference as ONE launch: the schedule's entries as a dataflow (fused_kernels.h, joint mode) ----------------
@@ -1880,7 +1884,7 @@ done:
 extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layers, const int64_t *layer_offsets,
                                    const int32_t *layer_targets, const double *pos_centers,
                                    const celeste_optim_config_t *cfg_in, int32_t *iterations, int32_t *f_evals,
-                                   double *elbo, int32_t *status) {
+                                   double *elbo, int32_t *status) try {
     if (!c || !vp || n_layers < 0 || (n_layers > 0 && (!layer_offsets || !layer_targets))) return CELESTE_ERR_INVALID_ARG;
     if (n_layers == 0) return CELESTE_OK;
     if (layer_offsets[0] != 0) return CELESTE_ERR_INVALID_ARG;
@@ -1903,9 +1907,9 @@ extern "C" int celeste_joint_infer(celeste_ctx_t *c, double *vp, int32_t n_layer
         memcpy(vp, h_out, vp_bytes);
     }
     return rc;
-}
+} ABI_CATCH
 
-extern "C" int celeste_optim_stats(int reset, uint64_t out[5]) {
+extern "C" int celeste_optim_stats(int reset, uint64_t out[5]) try {
     unsigned long long h[5] = {0, 0, 0, 0, 0};
     if (out) {
         HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_optim_stats), sizeof h));
@@ -1913,11 +1917,11 @@ extern "C" int celeste_optim_stats(int reset, uint64_t out[5]) {
     }
     if (reset) { unsigned long long z[5] = {0, 0, 0, 0, 0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_optim_stats), z, sizeof z)); }
     return CELESTE_OK;
-}
+} ABI_CATCH
 
 extern "C" int celeste_tr_solve_batch(int device, int32_t n, const double *H, const double *g, const double *delta,
                                       int32_t solver, int32_t secular_iters, double *p, double *m, int32_t *interior,
-                                      int32_t *fell_back) {
+                                      int32_t *fell_back) try {
     if (n < 0 || !H || !g || !delta || !p || solver < 0 || solver > 2 || secular_iters < 0) return CELESTE_ERR_INVALID_ARG;
     if (n == 0) return CELESTE_OK;
     int st = select_device(device);
@@ -1949,7 +1953,7 @@ extern "C" int celeste_tr_solve_batch(int device, int32_t n, const double *H, co
     (void)hipFree(d_H); (void)hipFree(d_g); (void)hipFree(d_delta); (void)hipFree(d_p); (void)hipFree(d_m);
     (void)hipFree(d_i); (void)hipFree(d_f);
     return st;
-}
+} ABI_CATCH
 
 #ifdef OPTIM_DEBUG_T
 extern "C" int celeste_debug_T(int32_t n, double *out) {   // n = 0: allocate for 4096 problems; n > 0: fetch n records
@@ -1997,7 +2001,7 @@ extern "C" int celeste_optim_clocks(int reset, uint64_t out[16]) {   // debug bu
 #endif
 
 // ---- expected-image renderer (bin/write_celeste_expectation.jl:112-156, fsm_util.jl:349-400) ------------
-extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32_t image, double *out_plane) {
+extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32_t image, double *out_plane) try {
     if (!c || !vp || !out_plane || image < 0 || image >= c->N) return CELESTE_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
     const DevImage &im = c->imgs->h_images[image];
@@ -2020,7 +2024,7 @@ extern "C" int celeste_render_expected(celeste_ctx_t *c, const double *vp, int32
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = CELESTE_ERR_HIP;
     return rc;
-}
+} ABI_CATCH
 
 // ---- one process, N devices (celeste_group_*) ----------------------------------------------------------------------
 #include "group.h"

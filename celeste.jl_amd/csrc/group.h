@@ -130,7 +130,8 @@ static void group_worker(GroupMember *m) {
         std::function<int()> fn = std::move(m->task);
         m->has_task = false;
         lk.unlock();
-        const int r = fn();
+        int r;
+        try { r = fn(); } catch (const std::bad_alloc &) { r = CELESTE_ERR_ALLOC; } catch (...) { r = CELESTE_ERR_HIP; }   // (nothing escapes a worker)
         lk.lock();
         if (m->result == CELESTE_OK) m->result = r;      // (sticky until the next join: sweeps are dispatched back to back)
         m->busy = false;
@@ -146,7 +147,8 @@ static void group_dispatch(celeste_group *g, const std::function<int(GroupMember
         std::unique_lock<std::mutex> lk(m->mu);
         m->cv.wait(lk, [&] { return !m->busy; });
         m->task = [fn, m, gg] {
-            const int r = fn(m);
+            int r;
+            try { r = fn(m); } catch (const std::bad_alloc &) { r = CELESTE_ERR_ALLOC; } catch (...) { r = CELESTE_ERR_HIP; }
             // (per-source failures are statuses, not errors of the call: the other members go on)
             if (r != CELESTE_OK && r != CELESTE_ERR_NONFINITE_INPUT && r != CELESTE_ERR_NONFINITE_RESULT) group_fail(gg);
             return r;
@@ -234,7 +236,7 @@ extern "C" void celeste_group_destroy(celeste_group_t *g) {
     delete g;
 }
 
-extern "C" int celeste_group_create(const celeste_problem_t *pr, int32_t n_members, const int32_t *devices, celeste_group_t **out) {
+extern "C" int celeste_group_create(const celeste_problem_t *pr, int32_t n_members, const int32_t *devices, celeste_group_t **out) try {
     if (!pr || !out || n_members < 1 || n_members > GROUP_MAX_MEMBERS) return CELESTE_ERR_INVALID_ARG;
     *out = nullptr;
     int count = 0;
@@ -320,15 +322,15 @@ extern "C" int celeste_group_create(const celeste_problem_t *pr, int32_t n_membe
 #undef GR_HIP
     *out = g;
     return CELESTE_OK;
-}
+} ABI_CATCH
 
-extern "C" int celeste_group_info(celeste_group_t *g, celeste_group_info_t *out) {
+extern "C" int celeste_group_info(celeste_group_t *g, celeste_group_info_t *out) try {
     if (!g || !out) return CELESTE_ERR_INVALID_ARG;
     memset(out, 0, sizeof *out);
     out->n_members = g->n; out->n_devices = g->n_devices; out->exchange = g->exchange; out->rccl_ranks = g->rccl_ranks;
     for (int r = 0; r < g->n; ++r) out->devices[r] = g->mem[r]->device;
     return CELESTE_OK;
-}
+} ABI_CATCH
 
 // ---- sharding: longest processing time first onto the least loaded member (partition.shard_targets) ----------------
 // weight[i] of unit i; returns for every member the ascending list of unit indices
@@ -400,7 +402,7 @@ static int group_quiesce(celeste_group *g) {
 }
 
 extern "C" int celeste_group_sweep_plan(celeste_group_t *g, const double *vp, int32_t n_targets, const int32_t *targets,
-                                        uint32_t flags) {
+                                        uint32_t flags) try {
     if (!g || !vp || n_targets < 1 || (flags & (CELESTE_FLAG_SPLIT))) return CELESTE_ERR_INVALID_ARG;
     if (group_check_targets(g, n_targets, targets) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(g->call_mu);
@@ -439,7 +441,7 @@ extern "C" int celeste_group_sweep_plan(celeste_group_t *g, const double *vp, in
     });
     g->planned = rc == CELESTE_OK;
     return rc;
-}
+} ABI_CATCH
 
 static int group_sweep_member(celeste_group *g, GroupMember *m, int k) {
     HIP_TRY(hipSetDevice(m->device));
@@ -465,23 +467,23 @@ static int group_sweep_member(celeste_group *g, GroupMember *m, int k) {
     return own_rc;
 }
 
-extern "C" int celeste_group_sweep(celeste_group_t *g) {
+extern "C" int celeste_group_sweep(celeste_group_t *g) try {
     if (!g || !g->planned) return CELESTE_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(g->call_mu);
     const int k = (int)(g->sweep_k++ & 1);
     group_dispatch(g, [g, k](GroupMember *m) -> int { return group_sweep_member(g, m, k); });
     if (!g->threads) return group_join(g);
     return CELESTE_OK;     // (errors of the workers surface in celeste_group_sweep_wait)
-}
+} ABI_CATCH
 
-extern "C" int celeste_group_sweep_wait(celeste_group_t *g) {
+extern "C" int celeste_group_sweep_wait(celeste_group_t *g) try {
     if (!g) return CELESTE_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(g->call_mu);
     // every member's kernels and copies: in PEER mode a member's gathered buffer is written by the OTHER members' streams
     return group_quiesce(g);
-}
+} ABI_CATCH
 
-extern "C" int celeste_group_sweep_results(celeste_group_t *g, double *v, double *d, double *h, int64_t *counters, int32_t *status) {
+extern "C" int celeste_group_sweep_results(celeste_group_t *g, double *v, double *d, double *h, int64_t *counters, int32_t *status) try {
     if (!g || !g->planned || g->sweep_k == 0) return CELESTE_ERR_INVALID_ARG;
     int rc = celeste_group_sweep_wait(g);
     if (rc != CELESTE_OK) return rc;
@@ -529,27 +531,27 @@ extern "C" int celeste_group_sweep_results(celeste_group_t *g, double *v, double
         return CELESTE_OK;
     });
     return rc != CELESTE_OK ? rc : worst[0];
-}
+} ABI_CATCH
 
-extern "C" int celeste_group_enable_timing(celeste_group_t *g, int enable) {
+extern "C" int celeste_group_enable_timing(celeste_group_t *g, int enable) try {
     if (!g) return CELESTE_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(g->call_mu);
     (void)group_quiesce(g);
     g->timing = enable != 0;
     for (GroupMember *m : g->mem) (void)celeste_ctx_enable_timing(m->ctx, enable);
     return CELESTE_OK;
-}
+} ABI_CATCH
 
 // celeste_ctx_last_kernel_ms of one member's last launch chain (prep / pixel / lift)
-extern "C" int celeste_group_last_kernel_ms(celeste_group_t *g, int32_t member, float ms[3]) {
+extern "C" int celeste_group_last_kernel_ms(celeste_group_t *g, int32_t member, float ms[3]) try {
     if (!g || member < 0 || member >= g->n || !ms) return CELESTE_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(g->mem[member]->device));
     return celeste_ctx_last_kernel_ms(g->mem[member]->ctx, ms);
-}
+} ABI_CATCH
 
 // HIP-event durations of the last sweep, per member: eval_ms[r] = the member's launch chain (its shard), gather_ms[r] = from
 // the end of its chain to the end of its catalog gather.  After celeste_group_sweep_wait.
-extern "C" int celeste_group_last_sweep_ms(celeste_group_t *g, float *eval_ms, float *gather_ms) {
+extern "C" int celeste_group_last_sweep_ms(celeste_group_t *g, float *eval_ms, float *gather_ms) try {
     if (!g || !g->timing || g->sweep_k == 0) return CELESTE_ERR_INVALID_ARG;
     for (int r = 0; r < g->n; ++r) {
         GroupMember *m = g->mem[r];
@@ -562,20 +564,20 @@ extern "C" int celeste_group_last_sweep_ms(celeste_group_t *g, float *eval_ms, f
         if (gather_ms) gather_ms[r] = b;
     }
     return CELESTE_OK;
-}
+} ABI_CATCH
 
-extern "C" int celeste_group_shard_sizes(celeste_group_t *g, int32_t *sizes, int64_t *costs) {
+extern "C" int celeste_group_shard_sizes(celeste_group_t *g, int32_t *sizes, int64_t *costs) try {
     if (!g || !g->planned) return CELESTE_ERR_INVALID_ARG;
     for (int r = 0; r < g->n; ++r) {
         if (sizes) sizes[r] = (int32_t)g->mem[r]->idx.size();
         if (costs) { costs[r] = 0; for (int32_t t : g->mem[r]->tg) costs[r] += g->cost[t]; }
     }
     return CELESTE_OK;
-}
+} ABI_CATCH
 
 // elbo() for a batch of targets over all members (the drop-in call): plan + one sweep + results
 extern "C" int celeste_group_elbo_eval_batch(celeste_group_t *g, const double *vp, int32_t n_targets, const int32_t *targets,
-                                             uint32_t flags, double *v, double *d, double *h, int64_t *counters, int32_t *status) {
+                                             uint32_t flags, double *v, double *d, double *h, int64_t *counters, int32_t *status) try {
     if (!g || !vp || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
     if (n_targets == 0) return CELESTE_OK;
     int rc = celeste_group_sweep_plan(g, vp, n_targets, targets, flags);
@@ -583,7 +585,7 @@ extern "C" int celeste_group_elbo_eval_batch(celeste_group_t *g, const double *v
     if (rc == CELESTE_OK) rc = celeste_group_sweep_results(g, v, d, h, counters, status);
     else (void)celeste_group_sweep_wait(g);
     return rc;
-}
+} ABI_CATCH
 
 // ---- maximize! over the members (one_node_single_infer, ParallelRun.jl:546-607) ------------------------------------
 // after the members' optimisations: pack the updated rows, exchange them, bring every member's table up to date
@@ -625,7 +627,7 @@ static int group_exchange_rows(celeste_group *g, GroupMember *m, double *d_table
 
 extern "C" int celeste_group_maximize_batch(celeste_group_t *g, double *vp, const double *vp_neighbors, const double *pos_centers,
                                             int32_t n_targets, const int32_t *targets, const celeste_optim_config_t *cfg,
-                                            int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status) {
+                                            int32_t *iterations, int32_t *f_evals, double *elbo, int32_t *status) try {
     if (!g || !vp || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
     if (n_targets == 0) return CELESTE_OK;
     if (group_check_targets(g, n_targets, targets) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
@@ -698,7 +700,7 @@ extern "C" int celeste_group_maximize_batch(celeste_group_t *g, double *vp, cons
         }
     }
     return worst;
-}
+} ABI_CATCH
 
 // ---- joint inference over the members (one_node_joint_infer, ParallelRun.jl:135-196, 302-397) -----------------------
 // The connected components of a Cyclades batch never conflict (partition.jl:173-236): they are sharded over the members by
@@ -707,7 +709,7 @@ extern "C" int celeste_group_maximize_batch(celeste_group_t *g, double *vp, cons
 extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t n_sweeps, int32_t n_batches, const int64_t *batch_offsets,
                                          const int64_t *comp_offsets, const int32_t *comp_targets, const double *pos_centers,
                                          const celeste_optim_config_t *cfg, int32_t *iterations, int32_t *f_evals, double *elbo,
-                                         int32_t *status, int64_t *n_exchanges) {
+                                         int32_t *status, int64_t *n_exchanges) try {
     if (!g || !vp || n_sweeps < 0 || n_batches < 0 || (n_batches > 0 && (!batch_offsets || !comp_offsets || !comp_targets)))
         return CELESTE_ERR_INVALID_ARG;
     if (n_exchanges) *n_exchanges = 0;
@@ -829,4 +831,4 @@ extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t
     if (n_exchanges) *n_exchanges = exchanges.load();
     if (rc == CELESTE_OK || rc == CELESTE_ERR_NONFINITE_INPUT || rc == CELESTE_ERR_NONFINITE_RESULT) memcpy(vp, g->p_vp_nbr, tb);
     return rc;
-}
+} ABI_CATCH

@@ -56,7 +56,8 @@ extern "C" {
 #define CELESTE_COEF 53         /* padded B-spline coefficient edge */
 #define CELESTE_NUM_COLOR_COMPONENTS 8
 
-/* status codes (replace the reference's @assert / AssertionError) */
+/* status codes (replace the reference's @assert / AssertionError).  No C++ exception crosses this ABI: a host allocation
+ * that fails inside the library returns CELESTE_ERR_ALLOC, any other host-side failure CELESTE_ERR_HIP. */
 enum {
     CELESTE_OK = 0,
     CELESTE_ERR_INVALID_ARG = 1,
