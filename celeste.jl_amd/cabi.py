@@ -13,7 +13,7 @@ P = 44
 STAMP = 51
 COEF = 53
 
-OK, ERR_INVALID_ARG, ERR_NONFINITE_INPUT, ERR_NONFINITE_RESULT, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = range(7)
+OK, ERR_INVALID_ARG, ERR_NONFINITE_INPUT, ERR_NONFINITE_RESULT, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC, ERR_ABORTED = range(8)
 FLAG_GRAD, FLAG_HESS, FLAG_KL, FLAG_FP32, FLAG_SPLIT, FLAG_PACKED_HESS = 1, 2, 4, 8, 16, 32
 HP = 990   # doubles of a packed Hessian (upper triangle by columns)
 
@@ -94,9 +94,9 @@ EXPORTED_SYMBOLS = [
     "celeste_group_create", "celeste_group_destroy", "celeste_group_info", "celeste_group_elbo_eval_batch",
     "celeste_group_sweep_plan", "celeste_group_sweep", "celeste_group_sweep_wait", "celeste_group_sweep_results",
     "celeste_group_shard_sizes", "celeste_group_enable_timing", "celeste_group_last_sweep_ms", "celeste_group_last_kernel_ms",
-    "celeste_group_maximize_batch", "celeste_group_joint_infer",
+    "celeste_group_maximize_batch", "celeste_group_joint_infer", "celeste_group_collectives",
 ]
-ABI_VERSION = 210   # CELESTE_ABI_VERSION of include/celeste_mi355x.h these structs were written against
+ABI_VERSION = 220   # CELESTE_ABI_VERSION of include/celeste_mi355x.h these structs were written against
 
 _lib = None
 
@@ -172,6 +172,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.celeste_group_destroy.argtypes = [vp]
     lib.celeste_group_destroy.restype = None
     lib.celeste_group_info.argtypes = [vp, C.POINTER(GroupInfoT)]
+    lib.celeste_group_collectives.argtypes = [vp, c_int64_p, c_int32_p]
     lib.celeste_group_elbo_eval_batch.argtypes = [vp, c_double_p, C.c_int32, c_int32_p, C.c_uint32, c_double_p, c_double_p,
                                                   c_double_p, c_int64_p, c_int32_p]
     lib.celeste_group_sweep_plan.argtypes = [vp, c_double_p, C.c_int32, c_int32_p, C.c_uint32]

@@ -188,6 +188,7 @@ extern "C" const char *celeste_strerror(int status) {
         case CELESTE_ERR_HIP: return "HIP runtime error";
         case CELESTE_ERR_NO_DEVICE: return "no HIP device (the engine has no CPU fallback)";
         case CELESTE_ERR_ALLOC: return "allocation failed";
+        case CELESTE_ERR_ABORTED: return "device group aborted: a member failed in front of a collective (destroy the group and create it again)";
         default: return "unknown status";
     }
 }
@@ -879,7 +880,9 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         hipLaunchKernelGGL((value_kernel<R, WAVES>), dim3((unsigned)c->n_value_items), dim3(64 * WAVES), 0, stream,       \
                            c->d_patches, c->d_coefs, c->d_srcimg, c->d_comps, c->d_needed, c->stamp, c->d_val_off,          \
                            c->d_value_items, c->NC, c->chunk_px, c->d_val, c->d_coefs_f)
-        if (flags & CELESTE_FLAG_FP32) { if (wide_items) LAUNCH_VALUE(float, 4); else LAUNCH_VALUE(float, 1); }
+        // (single precision: value_pixels_f2 for every batch size -- two wavefronts x 128 pixels when wide -- so that a
+        // target's fp32 result does not depend on the size of the batch it is in)
+        if (flags & CELESTE_FLAG_FP32) { if (wide_items) LAUNCH_VALUE(float, 2); else LAUNCH_VALUE(float, 1); }
         else { if (wide_items) LAUNCH_VALUE(double, 4); else LAUNCH_VALUE(double, 1); }
 #undef LAUNCH_VALUE
     }

@@ -954,8 +954,9 @@ __device__ __forceinline__ void value_pixels_f2(int lane, const DevPatch &P, con
 #ifdef VALUE_TIMING   // debug builds (tools/variants): shader clocks per section of the value kernel
 __device__ unsigned long long g_value_clk[8];
 #endif
-// WAVES = 4 (small, latency-bound batches): the item's up to four 64-pixel iterations on four wavefronts of one workgroup
-// instead of one after the other -- same values (every pixel is computed on its own), a quarter of the item's latency.
+// WAVES = 4 (small, latency-bound batches; 2 in single precision, two pixels per lane): the item's up to four 64-pixel
+// iterations on four wavefronts of one workgroup instead of one after the other -- same values (every pixel is computed on
+// its own, by the same instructions whatever WAVES is), a quarter of the item's latency.
 template <typename R, int WAVES = 1>
 __global__ void __launch_bounds__(64 * WAVES)
 value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ coefs,
@@ -1006,10 +1007,14 @@ value_kernel(const DevPatch *__restrict__ patches, const double *__restrict__ co
         __syncthreads();
     }
     VT(1);
-    if constexpr (WAVES == 1 && sizeof(R) == 4)
-        value_pixels_f2(threadIdx.x, P, si, NC, coefs_f + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF), h_lo, w_lo, RH,
-                        p0, p1, val + val_off[sn], tcf);
-    else if constexpr (WAVES == 1)
+    if constexpr (sizeof(R) == 4) {
+        // single precision: ONE per-pixel arithmetic (value_pixels_f2: packed, exp2 with the pre-scaled exponent) whatever the
+        // batch size -- a target's result must not depend on what else is in its launch.  WAVES wavefronts take 128 pixels each.
+        const int q0 = p0 + 128 * (int)(threadIdx.x >> 6);
+        if (WAVES == 1 || q0 < p1)
+            value_pixels_f2(threadIdx.x & 63, P, si, NC, coefs_f + (size_t)(CELESTE_MUTANT == 3 ? 0 : P.stamp) * (CEL_COEF * CEL_COEF), h_lo, w_lo, RH,
+                            WAVES == 1 ? p0 : q0, WAVES == 1 ? p1 : min(p1, q0 + 128), val + val_off[sn], tcf);
+    } else if constexpr (WAVES == 1)
         value_pixels<false, R>(threadIdx.x, P, si, tc, NC, coefs, etab, h_lo, w_lo, RH, p0, p1, val + val_off[sn], tcf);
     else {
         const int q0 = p0 + 64 * (int)(threadIdx.x >> 6);

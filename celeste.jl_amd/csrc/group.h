@@ -10,9 +10,24 @@
 // Exchange modes: RCCL when the members sit on distinct devices (also a group of one: the collective then runs with one
 // rank); PEER -- plain hipMemcpyAsync between the members' buffers -- when a device appears twice (RCCL refuses duplicate
 // devices in one communicator).  PEER exists so that the shard / gather bookkeeping can be exercised on a one-GPU box; both
-// modes fill the same buffers with the same bytes.
+// modes fill the same buffers with the same bytes.  CELESTE_GROUP_EXCHANGE=rccl forces the RCCL branch whatever the devices: real
+// RCCL then refuses a repeated device at ncclCommInitAll; tests/fake_rccl.c (preloaded, strict host rendezvous) accepts it, which
+// is how the RCCL branch's multi-rank ordering is executed on a one-GPU box (tests/test_gpu_group_rccl_branch.py).
+//
+// Failure protocol (who waits where is in INTEGRATION.md section 3):
+//   * per-source failures are statuses, never errors of a member;
+//   * a member whose LAUNCH fails still enqueues every collective of the call (the others' results are sound) and the call
+//     returns its error;
+//   * a member that leaves a call WITHOUT a collective the others enqueue (a HIP call failed in front of it) would leave their
+//     streams inside an all-gather that never completes.  Every member counts the collectives it has enqueued; the dispatcher
+//     knows how many the dispatched work holds; a member that returns an error short of that count raises `need_abort`, and
+//     whoever joins the workers (every entry point does) aborts ALL communicators (ncclCommAbort), which releases the streams.
+//     The group is then `broken`: every later call returns CELESTE_ERR_ABORTED until it is destroyed and created again;
+//   * a stream that holds a collective is waited for by polling, with ncclCommGetAsyncError consulted between naps and a
+//     time limit (CELESTE_GROUP_TIMEOUT_MS, default 300 000, 0 = none): an asynchronous RCCL error or the limit aborts as above.
 #pragma once
 #include <rccl/rccl.h>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -48,6 +63,7 @@ __global__ void group_scatter_kernel(double *__restrict__ vp, const double *__re
     if (j == self || j >= n_members || i >= cnt.n[j] || k >= CEL_P) return;
     const double *in = gathered + ((size_t)j * width + i) * row;
     const int t = (int)in[0];
+    if (t < 0) return;          // (an unused row: the member packed fewer rows than its shard holds -- its launch failed)
     vp[(size_t)t * CEL_P + k] = in[row - CEL_P + k];
 }
 
@@ -78,8 +94,12 @@ struct GroupMember {
     std::mutex mu;
     std::condition_variable cv;
     std::function<int()> task;
-    bool has_task = false, busy = false, quit = false;
+    bool has_task = false, quit = false;
+    std::atomic<bool> busy{false};              // (written under mu; read without it by the abort check)
     int result = CELESTE_OK;
+    // collectives: enqueued so far on this member's communicator; inside the enqueue call right now
+    std::atomic<uint64_t> enq{0};
+    std::atomic<int> in_coll{0}, in_wait{0};    // ... waiting for a stream that holds one
 };
 
 struct celeste_group {
@@ -97,7 +117,24 @@ struct celeste_group {
     bool timing = false;
     std::atomic<int> abort_rc{0};              // joint inference: a member's launch failed -- every member leaves after the exchange
     std::mutex call_mu;                        // one call per group at a time
+    // failure protocol (see the head of this file)
+    uint64_t enq_expected = 0;                 // collectives every member will have enqueued when the dispatched work is through
+    std::atomic<bool> need_abort{false}, force_abort{false}, broken{false};
+    int64_t timeout_ms = 300000;
+    // fault injection, tests only: CELESTE_GROUP_FAULT="member,site[,nth[,delay_ms]]" -- the member's nth (1-based, default 1)
+    // arrival at `site` fails, after delay_ms (so that the others are certainly past the point the test is about): "sweep" = a HIP call in front of a sweep's collective, "rows" = between the host barrier and a row
+    // exchange's collective, "barrier" = in front of that barrier, "launch" = the member's own launch (it still takes part)
+    int fault_member = -1, fault_site = 0, fault_delay_ms = 0;
+    std::atomic<int> fault_nth{0};
 };
+enum { GROUP_FAULT_SWEEP = 1, GROUP_FAULT_ROWS = 2, GROUP_FAULT_BARRIER = 3, GROUP_FAULT_LAUNCH = 4 };
+static bool group_fault(celeste_group *g, const GroupMember *m, int site) {
+    if (g->fault_member != m->index || g->fault_site != site) return false;
+    if (g->fault_nth.fetch_sub(1) != 1) return false;
+    fprintf(stderr, "celeste_mi355x: injected fault (CELESTE_GROUP_FAULT): member %d, site %d\n", m->index, site);
+    if (g->fault_delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(g->fault_delay_ms));   // (the others get ahead)
+    return true;
+}
 
 // All members meet here (host side; in front of every row exchange, and in PEER mode behind it as well -- RCCL's collective
 // is the second meeting point otherwise).  A member that leaves a call with an error never arrives: group_fail wakes the ones
@@ -107,9 +144,11 @@ static bool group_barrier(celeste_group *g) {
     std::unique_lock<std::mutex> lk(g->bmu);
     if (g->b_abort) return false;
     const uint64_t gen = g->b_gen;
-    if (++g->b_count == g->n) { g->b_count = 0; ++g->b_gen; g->bcv.notify_all(); }
-    else g->bcv.wait(lk, [&] { return g->b_gen != gen || g->b_abort; });
-    return !g->b_abort;
+    if (++g->b_count == g->n) { g->b_count = 0; ++g->b_gen; g->bcv.notify_all(); return true; }
+    g->bcv.wait(lk, [&] { return g->b_gen != gen || g->b_abort; });
+    // (a barrier that completed has completed, whatever was flagged afterwards: a member that fails BEHIND it must find the
+    // others inside the collective -- the abort protocol's case -- not half of them turned back here)
+    return g->b_gen != gen;
 }
 static void group_fail(celeste_group *g) {
     std::lock_guard<std::mutex> lk(g->bmu);
@@ -139,18 +178,95 @@ static void group_worker(GroupMember *m) {
     }
 }
 
-// fn(member) on every member, concurrently; dispatch returns at once, join returns the first non-OK status
-static void group_dispatch(celeste_group *g, const std::function<int(GroupMember *)> &fn) {
+// ---- abort: a member left without a collective the others enqueue (or RCCL reported an asynchronous error, or a wait timed out)
+// Called by the thread that holds call_mu (the one that dispatches and joins).  `broken` goes up first, so a member that has
+// not reached its enqueue yet skips it (group_exchange); a member that is inside the enqueue gets a moment to leave it (real RCCL
+// returns in microseconds; the strict test fake blocks until aborted); then every communicator is aborted, which ends the
+// collectives the other members' streams sit in.
+static void group_abort_comms(celeste_group *g, const char *why) {
+    if (g->broken.exchange(true)) return;
+    {   // (the host barriers of the row exchanges too)
+        std::lock_guard<std::mutex> lk(g->bmu);
+        g->b_abort = true;
+        g->bcv.notify_all();
+    }
+    fprintf(stderr, "celeste_mi355x: device group aborted (%s): communicators torn down, the group must be recreated\n", why);
     for (GroupMember *m : g->mem) {
-        if (!g->threads) { (void)hipSetDevice(m->device); const int r = fn(m); if (m->result == CELESTE_OK) m->result = r; continue; }
+        if (!m->comm) continue;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (m->in_coll.load() && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200))
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        (void)ncclCommAbort(m->comm);
+        m->comm = nullptr;
+    }
+}
+// Does the group have to be aborted?  force_abort: yes (an asynchronous RCCL error, a wait that timed out).  need_abort: a
+// member returned an error short of the collectives its work holds (from then on it enqueues nothing: group_exchange).  While
+// other members still run, that is fatal as soon as one of them is blocked -- inside the enqueue, or waiting for a stream -- on
+// a collective BEHIND the last one the returned members enqueued: nobody will ever complete it.  (A member blocked on a
+// collective everybody did enqueue is merely waiting; a member that is still computing will reach the host barrier or its own
+// collective by itself.)  Once all have returned, it is fatal exactly when their counts differ: equal counts mean everybody
+// left in front of the same collective (the host barrier's case, or a member whose launch failed and who told the others),
+// and the group stays usable.
+static void group_check_abort(celeste_group *g, bool all_idle) {
+    if (g->broken.load()) return;
+    if (g->force_abort.load()) { group_abort_comms(g, "asynchronous RCCL error or time limit while waiting for a collective"); return; }
+    if (!g->need_abort.load()) return;
+    if (all_idle) {
+        const uint64_t e0 = g->mem[0]->enq.load();
+        bool same = true;
+        for (GroupMember *m : g->mem) same = same && m->enq.load() == e0;
+        if (same) { g->need_abort.store(false); g->enq_expected = e0; return; }
+        group_abort_comms(g, "a member left a call without a collective the others enqueued");
+        return;
+    }
+    uint64_t low = ~(uint64_t)0;
+    for (GroupMember *m : g->mem) if (!m->busy.load()) low = std::min(low, m->enq.load());
+    if (low == ~(uint64_t)0) return;
+    for (GroupMember *m : g->mem) {
+        if (!m->busy.load()) continue;
+        const uint64_t e = m->enq.load();                    // (read before the flags: an enqueue that completes in between
+        const bool in_c = m->in_coll.load() != 0, in_w = m->in_wait.load() != 0;   // makes this member look less stuck, never more)
+        if ((in_c && e + 1 > low) || (in_w && e > low)) {
+            group_abort_comms(g, "a member left a call without its collective; another waits inside that collective");
+            return;
+        }
+    }
+}
+// the member's worker is idle (its last task has returned); while waiting, serve an abort request -- the task may be one that
+// waits for a collective a failed member never enqueued
+static void group_wait_idle(celeste_group *g, GroupMember *m, std::unique_lock<std::mutex> &lk) {
+    while (m->busy.load()) {
+        if ((g->need_abort.load() || g->force_abort.load()) && !g->broken.load()) { lk.unlock(); group_check_abort(g, false); lk.lock(); }
+        if (m->busy.load()) m->cv.wait_for(lk, std::chrono::milliseconds(2));
+    }
+}
+
+// fn(member) on every member, concurrently; dispatch returns at once, join returns the first non-OK status.
+// n_collectives: the collectives fn enqueues on the member's communicator when nothing fails.
+static void group_dispatch(celeste_group *g, const std::function<int(GroupMember *)> &fn, uint64_t n_collectives = 0) {
+    g->enq_expected += n_collectives;
+    const uint64_t expected = g->enq_expected;
+    for (GroupMember *m : g->mem) {
+        if (!g->threads) {
+            (void)hipSetDevice(m->device);
+            int r;
+            try { r = fn(m); } catch (const std::bad_alloc &) { r = CELESTE_ERR_ALLOC; } catch (...) { r = CELESTE_ERR_HIP; }
+            if (m->result == CELESTE_OK) m->result = r;
+            continue;
+        }
         celeste_group *const gg = g;
         std::unique_lock<std::mutex> lk(m->mu);
-        m->cv.wait(lk, [&] { return !m->busy; });
-        m->task = [fn, m, gg] {
+        group_wait_idle(g, m, lk);
+        m->task = [fn, m, gg, expected] {
             int r;
             try { r = fn(m); } catch (const std::bad_alloc &) { r = CELESTE_ERR_ALLOC; } catch (...) { r = CELESTE_ERR_HIP; }
             // (per-source failures are statuses, not errors of the call: the other members go on)
-            if (r != CELESTE_OK && r != CELESTE_ERR_NONFINITE_INPUT && r != CELESTE_ERR_NONFINITE_RESULT) group_fail(gg);
+            if (r != CELESTE_OK && r != CELESTE_ERR_NONFINITE_INPUT && r != CELESTE_ERR_NONFINITE_RESULT) {
+                group_fail(gg);
+                // short of the collectives this work holds: the others' streams will wait for this member for ever
+                if (gg->exchange == GROUP_EXCHANGE_RCCL && gg->n > 1 && m->enq.load() < expected) gg->need_abort.store(true);
+            }
             return r;
         };
         m->has_task = true; m->busy = true;
@@ -160,13 +276,54 @@ static void group_dispatch(celeste_group *g, const std::function<int(GroupMember
 static int group_join(celeste_group *g) {
     int rc = CELESTE_OK;
     for (GroupMember *m : g->mem) {
-        if (g->threads) { std::unique_lock<std::mutex> lk(m->mu); m->cv.wait(lk, [&] { return !m->busy; }); }
+        if (g->threads) { std::unique_lock<std::mutex> lk(m->mu); group_wait_idle(g, m, lk); }
         if (m->result != CELESTE_OK && rc == CELESTE_OK) rc = m->result;
         m->result = CELESTE_OK;
     }
+    group_check_abort(g, true);      // (every task has returned; streams may still sit in a collective the failed member skipped)
+    if (g->broken.load()) rc = CELESTE_ERR_ABORTED;
     return rc;
 }
-static int group_run(celeste_group *g, const std::function<int(GroupMember *)> &fn) { group_dispatch(g, fn); return group_join(g); }
+static int group_run(celeste_group *g, const std::function<int(GroupMember *)> &fn, uint64_t n_collectives = 0) {
+    group_dispatch(g, fn, n_collectives);
+    return group_join(g);
+}
+
+// Wait for a stream that may hold a collective.  Plain synchronisation where no other rank can be missing; otherwise poll, look
+// at the communicator between naps, and give up at the time limit -- both abort the group (which releases the stream).
+// joiner = the thread that holds call_mu waits itself (group_quiesce): it is also the one that has to tear the communicators down
+static int group_stream_wait(celeste_group *g, GroupMember *m, hipStream_t s, bool joiner = false) {
+    if (g->exchange != GROUP_EXCHANGE_RCCL || g->n <= 1 || g->broken.load() || !m->comm) {
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return CELESTE_ERR_HIP; }
+        return g->broken.load() ? CELESTE_ERR_ABORTED : CELESTE_OK;
+    }
+    struct Waiting { std::atomic<int> &f; Waiting(std::atomic<int> &x) : f(x) { f.store(1); } ~Waiting() { f.store(0); } } waiting(m->in_wait);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool reported = false;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return g->broken.load() ? CELESTE_ERR_ABORTED : CELESTE_OK;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); return CELESTE_ERR_HIP; }
+        if (g->broken.load()) { (void)hipStreamSynchronize(s); (void)hipGetLastError(); return CELESTE_ERR_ABORTED; }   // (aborted: the stream is released)
+        const auto el = std::chrono::steady_clock::now() - t0;
+        if (el < std::chrono::milliseconds(2)) continue;          // (a sweep is through long before)
+        if (!reported) {
+            ncclResult_t ae = ncclSuccess;
+            ncclComm_t comm = m->comm;
+            if (comm && (ncclCommGetAsyncError(comm, &ae) != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress))) {
+                fprintf(stderr, "celeste_mi355x: member %d: asynchronous RCCL error: %s\n", m->index, ncclGetErrorString(ae));
+                g->force_abort.store(true); reported = true;
+            } else if (g->timeout_ms > 0 && el > std::chrono::milliseconds(g->timeout_ms)) {
+                fprintf(stderr, "celeste_mi355x: member %d: a stream holding a collective did not complete within %lld ms\n", m->index,
+                        (long long)g->timeout_ms);
+                g->force_abort.store(true); reported = true;
+            }
+        }
+        // (a worker keeps waiting until whoever joins the workers has torn the communicators down; the joiner does it itself)
+        if (joiner && g->force_abort.load()) group_check_abort(g, true);
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
 
 #define NCCL_TRY(expr)                                                                                                   \
     do {                                                                                                                 \
@@ -199,11 +356,25 @@ static int group_grow_pinned(T **p, size_t *cap, size_t n) {
 // the member's block (count doubles at `send`) to slot `index` of every member's gathered buffer, on `stream`
 static int group_exchange(celeste_group *g, GroupMember *m, const double *send, size_t count, hipStream_t stream) {
     if (g->exchange == GROUP_EXCHANGE_RCCL) {
-        NCCL_TRY(ncclAllGather(send, m->d_gathered, count, ncclDouble, m->comm, stream));
+        ncclComm_t comm = m->comm;
+        m->in_coll.store(1);
+        // (need_abort: some member has left short of a collective -- pairing further ones up with the others' would hand them the
+        // wrong blocks; whoever joins the workers decides whether the group survives)
+        if (g->broken.load() || !comm) { m->in_coll.store(0); return CELESTE_ERR_ABORTED; }
+        if (g->need_abort.load()) { m->in_coll.store(0); return CELESTE_ERR_HIP; }
+        const ncclResult_t r = ncclAllGather(send, m->d_gathered, count, ncclDouble, comm, stream);
+        m->in_coll.store(0);
+        if (r != ncclSuccess) {
+            if (g->broken.load()) return CELESTE_ERR_ABORTED;
+            fprintf(stderr, "celeste_mi355x: member %d: ncclAllGather failed: %s\n", m->index, ncclGetErrorString(r));
+            return CELESTE_ERR_HIP;
+        }
+        m->enq.fetch_add(1);
         return CELESTE_OK;
     }
     for (GroupMember *o : g->mem)
         HIP_TRY(hipMemcpyAsync(o->d_gathered + (size_t)m->index * count, send, count * sizeof(double), hipMemcpyDefault, stream));
+    m->enq.fetch_add(1);
     return CELESTE_OK;
 }
 
@@ -212,7 +383,7 @@ extern "C" void celeste_group_destroy(celeste_group_t *g) {
     for (GroupMember *m : g->mem) {
         if (!m) continue;
         if (m->th.joinable()) {
-            { std::unique_lock<std::mutex> lk(m->mu); m->cv.wait(lk, [&] { return !m->busy; }); m->quit = true; m->cv.notify_all(); }
+            { std::unique_lock<std::mutex> lk(m->mu); group_wait_idle(g, m, lk); m->quit = true; m->cv.notify_all(); }
             m->th.join();
         }
         (void)hipSetDevice(m->device);
@@ -253,8 +424,18 @@ extern "C" int celeste_group_create(const celeste_problem_t *pr, int32_t n_membe
     for (int d : dev) if (std::find(distinct.begin(), distinct.end(), d) == distinct.end()) distinct.push_back(d);
     g->n_devices = (int)distinct.size();
     g->exchange = g->n_devices == g->n ? GROUP_EXCHANGE_RCCL : GROUP_EXCHANGE_PEER;
-    if (const char *e = getenv("CELESTE_GROUP_EXCHANGE")) {   // "peer": hipMemcpyAsync between the members instead of RCCL (A/B, debugging)
-        if (strcmp(e, "peer") == 0) g->exchange = GROUP_EXCHANGE_PEER;
+    if (const char *e = getenv("CELESTE_GROUP_EXCHANGE")) {   // "peer": hipMemcpyAsync between the members instead of RCCL (A/B, debugging);
+        if (strcmp(e, "peer") == 0) g->exchange = GROUP_EXCHANGE_PEER;      // "rccl": the RCCL branch whatever the devices (real RCCL
+        else if (strcmp(e, "rccl") == 0) g->exchange = GROUP_EXCHANGE_RCCL; // refuses repeated devices; the tests' stand-in does not)
+    }
+    if (const char *e = getenv("CELESTE_GROUP_TIMEOUT_MS")) g->timeout_ms = atoll(e);
+    if (const char *e = getenv("CELESTE_GROUP_FAULT")) {      // tests only (see celeste_group)
+        int mem = -1, nth = 1, delay = 0; char site[16] = {0};
+        if (sscanf(e, "%d,%15[a-z],%d,%d", &mem, site, &nth, &delay) >= 2) {
+            g->fault_member = mem; g->fault_nth.store(nth); g->fault_delay_ms = delay;
+            g->fault_site = !strcmp(site, "sweep") ? GROUP_FAULT_SWEEP : !strcmp(site, "rows") ? GROUP_FAULT_ROWS
+                          : !strcmp(site, "barrier") ? GROUP_FAULT_BARRIER : !strcmp(site, "launch") ? GROUP_FAULT_LAUNCH : 0;
+        }
     }
     g->threads = g->n > 1 || (getenv("CELESTE_GROUP_THREADS") && atoi(getenv("CELESTE_GROUP_THREADS")) == 1);
 #define GR_TRY(expr) do { int s__ = (expr); if (s__ != CELESTE_OK) { celeste_group_destroy(g); return s__; } } while (0)
@@ -332,10 +513,26 @@ extern "C" int celeste_group_info(celeste_group_t *g, celeste_group_info_t *out)
     return CELESTE_OK;
 } ABI_CATCH
 
+// enqueued[n_members] (may be NULL): the collectives (catalog gathers, row exchanges) each member has enqueued since the group
+// was created -- equal on every member whenever no call is in flight; *aborted (may be NULL): 1 = the communicators were torn
+// down (CELESTE_ERR_ABORTED from every entry point)
+extern "C" int celeste_group_collectives(celeste_group_t *g, int64_t *enqueued, int32_t *aborted) try {
+    if (!g) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    if (enqueued) for (int r = 0; r < g->n; ++r) enqueued[r] = (int64_t)g->mem[r]->enq.load();
+    if (aborted) *aborted = g->broken.load() ? 1 : 0;
+    return CELESTE_OK;
+} ABI_CATCH
+
 // ---- sharding: longest processing time first onto the least loaded member (partition.shard_targets) ----------------
 // weight[i] of unit i; returns for every member the ascending list of unit indices
 static void group_lpt(int n_members, const std::vector<int64_t> &weight, std::vector<std::vector<int32_t>> &shards) {
     const size_t n = weight.size();
+    if (n_members == 1) {      // (nothing to balance)
+        shards.assign(1, std::vector<int32_t>(n));
+        for (size_t i = 0; i < n; ++i) shards[0][i] = (int32_t)i;
+        return;
+    }
     std::vector<int32_t> order(n);
     for (size_t i = 0; i < n; ++i) order[i] = (int32_t)i;
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return weight[a] > weight[b]; });
@@ -395,19 +592,24 @@ static int group_quiesce(celeste_group *g) {
     int rc = group_join(g);
     for (GroupMember *m : g->mem) {
         if (!m->ctx) continue;
-        if (hipSetDevice(m->device) != hipSuccess || hipStreamSynchronize(m->ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(m->comm_stream) != hipSuccess) { (void)hipGetLastError(); if (rc == CELESTE_OK) rc = CELESTE_ERR_HIP; }
+        int s1 = CELESTE_OK;
+        if (hipSetDevice(m->device) != hipSuccess) { (void)hipGetLastError(); s1 = CELESTE_ERR_HIP; }
+        if (s1 == CELESTE_OK) s1 = group_stream_wait(g, m, m->comm_stream, true);
+        if (s1 == CELESTE_OK || s1 == CELESTE_ERR_ABORTED) { const int s2 = group_stream_wait(g, m, m->ctx->stream, true); if (s1 == CELESTE_OK) s1 = s2; }
+        if (m->ctx->copy_stream && hipStreamSynchronize(m->ctx->copy_stream) != hipSuccess) { (void)hipGetLastError(); if (s1 == CELESTE_OK) s1 = CELESTE_ERR_HIP; }
+        if (s1 != CELESTE_OK && rc == CELESTE_OK) rc = s1;
     }
+    if (g->broken.load()) rc = CELESTE_ERR_ABORTED;
     return rc;
 }
 
-extern "C" int celeste_group_sweep_plan(celeste_group_t *g, const double *vp, int32_t n_targets, const int32_t *targets,
-                                        uint32_t flags) try {
-    if (!g || !vp || n_targets < 1 || (flags & (CELESTE_FLAG_SPLIT))) return CELESTE_ERR_INVALID_ARG;
-    if (group_check_targets(g, n_targets, targets) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(g->call_mu);
+// (call_mu held)
+// sync = false: the uploads stay in flight on the members' streams (the caller enqueues its work behind them and waits then)
+static int group_plan_locked(celeste_group *g, const double *vp, int32_t n_targets, const int32_t *targets, uint32_t flags, bool sync = true) {
     g->planned = false;
     (void)group_quiesce(g);     // (sweeps of an earlier plan may still be in flight: their buffers are about to move)
+    if (g->broken.load()) return CELESTE_ERR_ABORTED;
+    group_barrier_reset(g);
     group_shard(g, n_targets, targets);
     int W = 1;
     for (GroupMember *m : g->mem) W = std::max(W, (int)m->idx.size());
@@ -436,13 +638,23 @@ extern "C" int celeste_group_sweep_plan(celeste_group_t *g, const double *vp, in
         if (!m->tg.empty())
             HIP_TRY(hipMemcpyAsync(m->d_targets, m->tg.data(), m->tg.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         for (int k = 0; k < 2; ++k) HIP_TRY(hipEventRecord(m->buf_free[k], st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (sync) HIP_TRY(hipStreamSynchronize(st));
         return CELESTE_OK;
     });
     g->planned = rc == CELESTE_OK;
     return rc;
+}
+
+extern "C" int celeste_group_sweep_plan(celeste_group_t *g, const double *vp, int32_t n_targets, const int32_t *targets,
+                                        uint32_t flags) try {
+    if (!g || !vp || n_targets < 1 || (flags & (CELESTE_FLAG_SPLIT))) return CELESTE_ERR_INVALID_ARG;
+    if (group_check_targets(g, n_targets, targets) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    return group_plan_locked(g, vp, n_targets, targets, flags);
 } ABI_CATCH
 
+// One sweep of the member's shard into block k, then the catalog gather on the second stream.  Whatever fails in front of the
+// collective, the collective is still attempted: a member that cannot enqueue it is what the abort protocol is for.
 static int group_sweep_member(celeste_group *g, GroupMember *m, int k) {
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = m->ctx->stream;
@@ -451,13 +663,15 @@ static int group_sweep_member(celeste_group *g, GroupMember *m, int k) {
     HIP_TRY(hipStreamWaitEvent(st, m->buf_free[k], 0));      // the gather that last read this block is through
     if (g->timing) HIP_TRY(hipEventRecord(m->t0, st));
     int own_rc = CELESTE_OK;
-    if (!m->tg.empty())
+    if (group_fault(g, m, GROUP_FAULT_LAUNCH)) own_rc = CELESTE_ERR_HIP;
+    else if (!m->tg.empty())
         own_rc = launch_eval(m->ctx, m->d_vp, (int32_t)m->tg.size(), m->d_targets, g->plan_flags, blk, blk + W, m->d_h,
                              reinterpret_cast<int64_t *>(blk + (size_t)W * (1 + CEL_P)),
                              reinterpret_cast<int32_t *>(blk + (size_t)W * (1 + CEL_P + 2)), st, true, nullptr, m->n_chunks);
     // (a member whose launch failed still takes part in the gather -- the collective needs every rank, and the others' sweeps
     // are sound; the call reports this member's error)
     if (g->timing) HIP_TRY(hipEventRecord(m->t1, st));
+    if (group_fault(g, m, GROUP_FAULT_SWEEP)) return CELESTE_ERR_HIP;
     HIP_TRY(hipEventRecord(m->done[k], st));
     HIP_TRY(hipStreamWaitEvent(m->comm_stream, m->done[k], 0));
     int rc = group_exchange(g, m, blk, g->plan_blk, m->comm_stream);
@@ -468,12 +682,14 @@ static int group_sweep_member(celeste_group *g, GroupMember *m, int k) {
 }
 
 extern "C" int celeste_group_sweep(celeste_group_t *g) try {
-    if (!g || !g->planned) return CELESTE_ERR_INVALID_ARG;
+    if (!g) return CELESTE_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(g->call_mu);
+    if (g->broken.load()) return CELESTE_ERR_ABORTED;
+    if (!g->planned) return CELESTE_ERR_INVALID_ARG;
     const int k = (int)(g->sweep_k++ & 1);
-    group_dispatch(g, [g, k](GroupMember *m) -> int { return group_sweep_member(g, m, k); });
+    group_dispatch(g, [g, k](GroupMember *m) -> int { return group_sweep_member(g, m, k); }, 1);
     if (!g->threads) return group_join(g);
-    return CELESTE_OK;     // (errors of the workers surface in celeste_group_sweep_wait)
+    return g->broken.load() ? CELESTE_ERR_ABORTED : CELESTE_OK;     // (errors of the workers surface in celeste_group_sweep_wait)
 } ABI_CATCH
 
 extern "C" int celeste_group_sweep_wait(celeste_group_t *g) try {
@@ -483,54 +699,95 @@ extern "C" int celeste_group_sweep_wait(celeste_group_t *g) try {
     return group_quiesce(g);
 } ABI_CATCH
 
-extern "C" int celeste_group_sweep_results(celeste_group_t *g, double *v, double *d, double *h, int64_t *counters, int32_t *status) try {
-    if (!g || !g->planned || g->sweep_k == 0) return CELESTE_ERR_INVALID_ARG;
-    int rc = celeste_group_sweep_wait(g);
-    if (rc != CELESTE_OK) return rc;
-    std::lock_guard<std::mutex> lock(g->call_mu);
+// the catalog block member 0 brought down -> the caller's arrays, in the caller's order; returns the first non-OK status
+static int group_catalog_to_host(celeste_group *g, const double *p_gathered, uint32_t flags, double *v, double *d, int64_t *counters,
+                                 int32_t *status) {
     const int W = g->plan_width;
     const size_t blk = g->plan_blk;
+    const bool want_d = d && (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS));
+    int worst = CELESTE_OK;
+    for (int r = 0; r < g->n; ++r) {
+        const GroupMember *o = g->mem[r];
+        const double *b = p_gathered + (size_t)r * blk;
+        const int64_t *bc = reinterpret_cast<const int64_t *>(b + (size_t)W * (1 + CEL_P));
+        const int32_t *bs = reinterpret_cast<const int32_t *>(b + (size_t)W * (1 + CEL_P + 2));
+        for (size_t i = 0; i < o->idx.size(); ++i) {
+            const size_t q = (size_t)o->idx[i];
+            if (v) v[q] = b[i];
+            if (want_d) memcpy(d + q * CEL_P, b + W + i * CEL_P, CEL_P * sizeof(double));
+            if (counters) { counters[2 * q] = bc[2 * i]; counters[2 * q + 1] = bc[2 * i + 1]; }
+            if (status) status[q] = bs[i];
+            if (bs[i] != CELESTE_OK && worst == CELESTE_OK) worst = bs[i];
+        }
+    }
+    return worst;
+}
+
+// a shard's Hessians, rows [lo, hi) of the member's d_h, down on `stream`: straight into the caller's array when that is
+// page-locked and the shard is a run of consecutive positions (always, for a group of one), else into page-locked staging
+static inline bool shard_contiguous(const GroupMember *m) { return !m->idx.empty() && (size_t)(m->idx.back() - m->idx.front()) + 1 == m->idx.size(); }
+static int group_hessians_down(GroupMember *m, double *h, bool direct, size_t HS, size_t lo, size_t hi, hipStream_t stream) {
+    if (hi <= lo) return CELESTE_OK;
+    double *dst = direct ? h + ((size_t)m->idx[0] + lo) * HS : m->p_h + lo * HS;
+    HIP_TRY(hipMemcpyAsync(dst, m->d_h + lo * HS, (hi - lo) * HS * sizeof(double), hipMemcpyDeviceToHost, stream));
+    return CELESTE_OK;
+}
+static inline void group_hessians_scatter(const GroupMember *m, double *h, size_t HS, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) memcpy(h + (size_t)m->idx[i] * HS, m->p_h + i * HS, HS * sizeof(double));
+}
+
+// (call_mu held; every sweep and gather is through)
+static int group_results_locked(celeste_group *g, double *v, double *d, double *h, int64_t *counters, int32_t *status) {
+    const size_t blk = g->plan_blk;
     const uint32_t flags = g->plan_flags;
-    const bool want_h = h && (flags & CELESTE_FLAG_HESS), want_d = d && (flags & (CELESTE_FLAG_GRAD | CELESTE_FLAG_HESS));
+    const bool want_h = h && (flags & CELESTE_FLAG_HESS);
     const size_t HS = (flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;
-    std::vector<int> worst((size_t)g->n, CELESTE_OK);
-    rc = group_run(g, [&](GroupMember *m) -> int {
+    const bool pin_h = want_h && is_pinned(h, (size_t)g->plan_n * HS * sizeof(double));
+    int worst = CELESTE_OK;
+    int rc = group_run(g, [&](GroupMember *m) -> int {
         HIP_TRY(hipSetDevice(m->device));
         hipStream_t st = m->ctx->stream;
         // the catalog (values, gradients, counters, status of ALL targets) is on every member: member 0 hands it to the host;
-        // Hessians stay with the member that owns the target and come down from there, all members at once
+        // Hessians stay with the member that owns the target and come down from there, all members at once, in parts whose
+        // host-side scatter overlaps the copies of the parts behind them
         if (m->index == 0) {
             int s1 = group_grow_pinned(&m->p_gathered, &m->p_gathered_cap, blk * g->n);
             if (s1 != CELESTE_OK) return s1;
             HIP_TRY(hipMemcpyAsync(m->p_gathered, m->d_gathered, blk * g->n * sizeof(double), hipMemcpyDeviceToHost, st));
         }
         const size_t nr = m->tg.size();
+        const bool direct = pin_h && shard_contiguous(m);
+        int n_parts = 0;
+        size_t part_lo[celeste_ctx::MAX_PARTS + 1] = {0};
         if (want_h && nr > 0) {
-            int s1 = group_grow_pinned(&m->p_h, &m->p_h_cap, nr * HS);
-            if (s1 != CELESTE_OK) return s1;
-            HIP_TRY(hipMemcpyAsync(m->p_h, m->d_h, nr * HS * sizeof(double), hipMemcpyDeviceToHost, st));
-        }
-        HIP_TRY(hipStreamSynchronize(st));
-        if (want_h) for (size_t i = 0; i < nr; ++i) memcpy(h + (size_t)m->idx[i] * HS, m->p_h + i * HS, HS * sizeof(double));
-        if (m->index == 0) {
-            for (int r = 0; r < g->n; ++r) {
-                const GroupMember *o = g->mem[r];
-                const double *b = m->p_gathered + (size_t)r * blk;
-                const int64_t *bc = reinterpret_cast<const int64_t *>(b + (size_t)W * (1 + CEL_P));
-                const int32_t *bs = reinterpret_cast<const int32_t *>(b + (size_t)W * (1 + CEL_P + 2));
-                for (size_t i = 0; i < o->idx.size(); ++i) {
-                    const size_t q = (size_t)o->idx[i];
-                    if (v) v[q] = b[i];
-                    if (want_d) memcpy(d + q * CEL_P, b + W + i * CEL_P, CEL_P * sizeof(double));
-                    if (counters) { counters[2 * q] = bc[2 * i]; counters[2 * q + 1] = bc[2 * i + 1]; }
-                    if (status) status[q] = bs[i];
-                    if (bs[i] != CELESTE_OK && worst[0] == CELESTE_OK) worst[0] = bs[i];
-                }
+            if (!direct) { int s1 = group_grow_pinned(&m->p_h, &m->p_h_cap, nr * HS); if (s1 != CELESTE_OK) return s1; }
+            n_parts = direct ? 1 : (int)std::min<size_t>(celeste_ctx::MAX_PARTS, std::max<size_t>(1, nr / 192));
+            for (int k = 0; k <= n_parts; ++k) part_lo[k] = nr * (size_t)k / (size_t)n_parts;
+            for (int k = 0; k < n_parts; ++k) {
+                int s1 = group_hessians_down(m, h, direct, HS, part_lo[k], part_lo[k + 1], st);
+                if (s1 != CELESTE_OK) { (void)hipStreamSynchronize(st); return s1; }
+                if (hipEventRecord(m->ctx->part_copied[k], st) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(st); return CELESTE_ERR_HIP; }
             }
         }
+        for (int k = 0; k < n_parts && !direct; ++k) {
+            if (hipEventSynchronize(m->ctx->part_copied[k]) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(st); return CELESTE_ERR_HIP; }
+            group_hessians_scatter(m, h, HS, part_lo[k], part_lo[k + 1]);
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        if (m->index == 0) worst = group_catalog_to_host(g, m->p_gathered, flags, v, d, counters, status);
         return CELESTE_OK;
     });
-    return rc != CELESTE_OK ? rc : worst[0];
+    return rc != CELESTE_OK ? rc : worst;
+}
+
+extern "C" int celeste_group_sweep_results(celeste_group_t *g, double *v, double *d, double *h, int64_t *counters, int32_t *status) try {
+    if (!g) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    if (g->broken.load()) return CELESTE_ERR_ABORTED;
+    if (!g->planned || g->sweep_k == 0) return CELESTE_ERR_INVALID_ARG;
+    int rc = group_quiesce(g);
+    if (rc != CELESTE_OK) return rc;
+    return group_results_locked(g, v, d, h, counters, status);
 } ABI_CATCH
 
 extern "C" int celeste_group_enable_timing(celeste_group_t *g, int enable) try {
@@ -545,6 +802,7 @@ extern "C" int celeste_group_enable_timing(celeste_group_t *g, int enable) try {
 // celeste_ctx_last_kernel_ms of one member's last launch chain (prep / pixel / lift)
 extern "C" int celeste_group_last_kernel_ms(celeste_group_t *g, int32_t member, float ms[3]) try {
     if (!g || member < 0 || member >= g->n || !ms) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
     HIP_TRY(hipSetDevice(g->mem[member]->device));
     return celeste_ctx_last_kernel_ms(g->mem[member]->ctx, ms);
 } ABI_CATCH
@@ -552,7 +810,10 @@ extern "C" int celeste_group_last_kernel_ms(celeste_group_t *g, int32_t member, 
 // HIP-event durations of the last sweep, per member: eval_ms[r] = the member's launch chain (its shard), gather_ms[r] = from
 // the end of its chain to the end of its catalog gather.  After celeste_group_sweep_wait.
 extern "C" int celeste_group_last_sweep_ms(celeste_group_t *g, float *eval_ms, float *gather_ms) try {
-    if (!g || !g->timing || g->sweep_k == 0) return CELESTE_ERR_INVALID_ARG;
+    if (!g) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    if (g->broken.load()) return CELESTE_ERR_ABORTED;
+    if (!g->timing || g->sweep_k == 0) return CELESTE_ERR_INVALID_ARG;
     for (int r = 0; r < g->n; ++r) {
         GroupMember *m = g->mem[r];
         HIP_TRY(hipSetDevice(m->device));
@@ -567,7 +828,9 @@ extern "C" int celeste_group_last_sweep_ms(celeste_group_t *g, float *eval_ms, f
 } ABI_CATCH
 
 extern "C" int celeste_group_shard_sizes(celeste_group_t *g, int32_t *sizes, int64_t *costs) try {
-    if (!g || !g->planned) return CELESTE_ERR_INVALID_ARG;
+    if (!g) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    if (!g->planned) return CELESTE_ERR_INVALID_ARG;
     for (int r = 0; r < g->n; ++r) {
         if (sizes) sizes[r] = (int32_t)g->mem[r]->idx.size();
         if (costs) { costs[r] = 0; for (int32_t t : g->mem[r]->tg) costs[r] += g->cost[t]; }
@@ -575,19 +838,119 @@ extern "C" int celeste_group_shard_sizes(celeste_group_t *g, int32_t *sizes, int
     return CELESTE_OK;
 } ABI_CATCH
 
-// elbo() for a batch of targets over all members (the drop-in call): plan + one sweep + results
+// elbo() for a batch of targets over all members (the drop-in call, host pointers).  As celeste_elbo_eval_batch does on one
+// device, every member cuts its shard into parts that are evaluated back to back on its stream while the Hessians of the
+// finished parts come down on its copy stream -- straight into the caller's array when that is page-locked and the shard is a
+// run of consecutive positions (a group of one), else through page-locked staging and a host scatter that overlaps the later
+// parts; the catalog gather (v, d, counters, status of all targets) follows the last part on the gather stream.
 extern "C" int celeste_group_elbo_eval_batch(celeste_group_t *g, const double *vp, int32_t n_targets, const int32_t *targets,
                                              uint32_t flags, double *v, double *d, double *h, int64_t *counters, int32_t *status) try {
-    if (!g || !vp || n_targets < 0) return CELESTE_ERR_INVALID_ARG;
+    if (!g || !vp || n_targets < 0 || (flags & CELESTE_FLAG_SPLIT)) return CELESTE_ERR_INVALID_ARG;
     if (n_targets == 0) return CELESTE_OK;
-    int rc = celeste_group_sweep_plan(g, vp, n_targets, targets, flags);
-    if (rc == CELESTE_OK) rc = celeste_group_sweep(g);
-    if (rc == CELESTE_OK) rc = celeste_group_sweep_results(g, v, d, h, counters, status);
-    else (void)celeste_group_sweep_wait(g);
-    return rc;
+    if (group_check_targets(g, n_targets, targets) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    if (g->broken.load()) return CELESTE_ERR_ABORTED;
+    const bool trace = getenv("CELESTE_GROUP_TRACE") != nullptr;    // host-side phase times of member 0 to stderr
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr_us = [&] { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tr0).count() * 1e-3; };
+    double tr[8] = {0};
+    int rc = group_plan_locked(g, vp, n_targets, targets, flags, /*sync=*/false);
+    if (rc != CELESTE_OK) return rc;
+    tr[0] = tr_us();
+    const int W = g->plan_width;
+    const size_t blk = g->plan_blk;
+    const bool want_h = h && (flags & CELESTE_FLAG_HESS);
+    const size_t HS = (flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;
+    const bool pin_h = want_h && is_pinned(h, (size_t)n_targets * HS * sizeof(double));
+    int worst = CELESTE_OK;
+    g->sweep_k = 1;            // (celeste_group_sweep_results afterwards hands out this sweep: block 0)
+    rc = group_run(g, [&](GroupMember *m) -> int {
+        HIP_TRY(hipSetDevice(m->device));
+        celeste_ctx *c = m->ctx;
+        hipStream_t st = c->stream, cs = c->copy_stream;
+        double *b = m->d_block[0];
+        const size_t nr = m->tg.size();
+        const bool direct = pin_h && shard_contiguous(m);
+        if (want_h && nr > 0 && !direct) { int s1 = group_grow_pinned(&m->p_h, &m->p_h_cap, nr * HS); if (s1 != CELESTE_OK) return s1; }
+        if (m->index == 0) { int s1 = group_grow_pinned(&m->p_gathered, &m->p_gathered_cap, blk * g->n); if (s1 != CELESTE_OK) return s1; }
+        // parts: at least 192 targets each so that a part still fills the chip; one part when nothing large comes back
+        int n_parts = 1;
+        if (want_h && !g->timing) n_parts = (int)std::min<size_t>(celeste_ctx::MAX_PARTS, std::max<size_t>(1, nr / 192));
+        size_t part_lo[celeste_ctx::MAX_PARTS + 1];
+        for (int k = 0; k <= n_parts; ++k) part_lo[k] = nr * (size_t)k / (size_t)n_parts;
+        int own_rc = CELESTE_OK, copies = 0;
+        if (g->timing) HIP_TRY(hipEventRecord(m->t0, st));
+        if (group_fault(g, m, GROUP_FAULT_LAUNCH)) own_rc = CELESTE_ERR_HIP;
+        for (int k = 0; k < n_parts && own_rc == CELESTE_OK && nr > 0; ++k) {
+            const size_t lo = part_lo[k], cnt = part_lo[k + 1] - lo;
+            int64_t n_chunks = 0;
+            for (size_t i = lo; i < lo + cnt; ++i) n_chunks += c->h_src_chunks[m->tg[i]];
+            own_rc = launch_eval(c, m->d_vp, (int32_t)cnt, m->d_targets + lo, flags, b + lo, b + W + lo * CEL_P, m->d_h ? m->d_h + lo * HS : nullptr,
+                                 reinterpret_cast<int64_t *>(b + (size_t)W * (1 + CEL_P)) + 2 * lo,
+                                 reinterpret_cast<int32_t *>(b + (size_t)W * (1 + CEL_P + 2)) + lo, st, true, nullptr, n_chunks, k > 0,
+                                 nullptr, n_parts > 1);
+            if (own_rc != CELESTE_OK || !want_h) continue;
+            if (hipEventRecord(c->part_done[k], st) != hipSuccess || hipStreamWaitEvent(cs, c->part_done[k], 0) != hipSuccess ||
+                group_hessians_down(m, h, direct, HS, lo, lo + cnt, cs) != CELESTE_OK ||
+                hipEventRecord(c->part_copied[k], cs) != hipSuccess) { (void)hipGetLastError(); own_rc = CELESTE_ERR_HIP; break; }
+            copies = k + 1;
+        }
+        // (a member whose launch failed still takes part in the gather: the collective needs every rank)
+        int rc2 = CELESTE_OK;
+        if (m->index == 0) tr[1] = tr_us();
+        if (g->timing && hipEventRecord(m->t1, st) != hipSuccess) rc2 = CELESTE_ERR_HIP;
+        const bool skip = group_fault(g, m, GROUP_FAULT_SWEEP);
+        if (!skip && rc2 == CELESTE_OK) {
+            if (hipEventRecord(m->done[0], st) != hipSuccess || hipStreamWaitEvent(m->comm_stream, m->done[0], 0) != hipSuccess) { (void)hipGetLastError(); rc2 = CELESTE_ERR_HIP; }
+            if (rc2 == CELESTE_OK) rc2 = group_exchange(g, m, b, blk, m->comm_stream);
+            if (rc2 == CELESTE_OK && g->timing && hipEventRecord(m->t2, m->comm_stream) != hipSuccess) rc2 = CELESTE_ERR_HIP;
+            if (rc2 == CELESTE_OK && m->index == 0 && (g->exchange == GROUP_EXCHANGE_RCCL || g->n == 1) &&
+                hipMemcpyAsync(m->p_gathered, m->d_gathered, blk * g->n * sizeof(double), hipMemcpyDeviceToHost, m->comm_stream) != hipSuccess) {
+                (void)hipGetLastError(); rc2 = CELESTE_ERR_HIP;
+            }
+        } else if (skip) rc2 = CELESTE_ERR_HIP;
+        if (m->index == 0) tr[2] = tr_us();
+        // staged Hessians: host scatter of part k while the later parts are still in flight
+        for (int k = 0; k < copies; ++k) {
+            if (hipEventSynchronize(c->part_copied[k]) != hipSuccess) { (void)hipGetLastError(); if (own_rc == CELESTE_OK) own_rc = CELESTE_ERR_HIP; break; }
+            if (!direct) group_hessians_scatter(m, h, HS, part_lo[k], part_lo[k + 1]);
+        }
+        if (m->index == 0) tr[3] = tr_us();
+        // nothing of this call stays in flight into the caller's memory, whatever happened above
+        if (hipStreamSynchronize(cs) != hipSuccess) { (void)hipGetLastError(); if (own_rc == CELESTE_OK) own_rc = CELESTE_ERR_HIP; }
+        if (m->index == 0) tr[4] = tr_us();
+        if (rc2 == CELESTE_OK) rc2 = group_stream_wait(g, m, m->comm_stream);
+        if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); if (own_rc == CELESTE_OK) own_rc = CELESTE_ERR_HIP; }
+        if (m->index == 0) tr[5] = tr_us();
+        if (rc2 != CELESTE_OK) return rc2;
+        if (own_rc != CELESTE_OK) return own_rc;
+        if (m->index == 0 && (g->exchange == GROUP_EXCHANGE_RCCL || g->n == 1)) worst = group_catalog_to_host(g, m->p_gathered, flags, v, d, counters, status);
+        if (m->index == 0) tr[6] = tr_us();
+        return CELESTE_OK;
+    }, 1);
+    if (trace) fprintf(stderr, "celeste_group_elbo_eval_batch: plan %.0f us | parts launched %.0f | gather enqueued %.0f | part copies waited %.0f | copy stream %.0f | "
+                               "gather + eval streams %.0f | catalog on host %.0f | joined %.0f\n", tr[0], tr[1], tr[2], tr[3], tr[4], tr[5], tr[6], tr_us());
+    if (rc != CELESTE_OK) { (void)group_quiesce(g); return g->broken.load() ? CELESTE_ERR_ABORTED : rc; }
+    // PEER mode: member 0's gathered block is written by the OTHER members' streams; every member has waited for its own gather
+    // stream by now, so the block is complete after the join -- it comes down here
+    if (g->exchange == GROUP_EXCHANGE_PEER && g->n > 1) {
+        GroupMember *m0 = g->mem[0];
+        HIP_TRY(hipSetDevice(m0->device));
+        HIP_TRY(hipMemcpyAsync(m0->p_gathered, m0->d_gathered, blk * g->n * sizeof(double), hipMemcpyDeviceToHost, m0->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(m0->ctx->stream));
+        worst = group_catalog_to_host(g, m0->p_gathered, flags, v, d, counters, status);
+    }
+    return worst;
 } ABI_CATCH
 
 // ---- maximize! over the members (one_node_single_infer, ParallelRun.jl:546-607) ------------------------------------
+// rows of the member's own targets -> its exchange block; the rows behind them are marked unused (target -1): a member whose
+// launch failed packs nothing, and the others' scatter must not take its zeroed block for rows of source 0
+__global__ void group_mark_unused_kernel(double *__restrict__ block, int n_used, int width, int row) {
+    const int i = n_used + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < width) block[(size_t)i * row] = -1.0;
+}
+
 // after the members' optimisations: pack the updated rows, exchange them, bring every member's table up to date
 static int group_exchange_rows(celeste_group *g, GroupMember *m, double *d_table, int n_own, const int32_t *d_own_targets,
                                const int32_t *d_it, const int32_t *d_ev, const double *d_el, const int32_t *d_st, int width, int row,
@@ -603,15 +966,20 @@ static int group_exchange_rows(celeste_group *g, GroupMember *m, double *d_table
     }
     int s1 = group_grow(&m->d_gathered, &m->gathered_cap, blk * g->n, st);
     if (s1 != CELESTE_OK) return s1;
+    if (group_fault(g, m, GROUP_FAULT_BARRIER)) return CELESTE_ERR_HIP;
     // Every member arrives here before anyone enqueues the exchange.  PEER mode needs it (the others copy into d_gathered: it
     // must exist on every member first); with RCCL it is what keeps a member that failed above -- an allocation, its launch's
     // set-up -- from leaving the others inside a collective that will never complete: the failing member's return wakes the
     // barrier (group_fail), and every member leaves the call with an error instead.
-    if (!group_barrier(g)) return CELESTE_ERR_HIP;
+    if (!group_barrier(g)) return g->broken.load() ? CELESTE_ERR_ABORTED : CELESTE_ERR_HIP;
+    // (a failure from here to the collective leaves the others inside theirs: the abort protocol's case)
+    if (group_fault(g, m, GROUP_FAULT_ROWS)) return CELESTE_ERR_HIP;
     HIP_TRY(hipMemsetAsync(m->d_block[0], 0, blk * sizeof(double), st));
     if (n_own > 0)
         hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)n_own), dim3(64), 0, st, d_table, d_own_targets, n_own, d_it, d_ev, d_el, d_st,
                            m->d_block[0], row);
+    if (n_own < width)
+        hipLaunchKernelGGL(group_mark_unused_kernel, dim3((unsigned)((width - n_own + 255) / 256)), dim3(256), 0, st, m->d_block[0], n_own, width, row);
     s1 = group_exchange(g, m, m->d_block[0], blk, st);
     if (s1 != CELESTE_OK) return s1;
     if (g->exchange == GROUP_EXCHANGE_PEER) {    // every member's copies have landed before anyone reads its gathered buffer
@@ -638,8 +1006,10 @@ extern "C" int celeste_group_maximize_batch(celeste_group_t *g, double *vp, cons
         if (optim_config(cfg, &op, &fl) != CELESTE_OK) return CELESTE_ERR_INVALID_ARG;
     }
     std::lock_guard<std::mutex> lock(g->call_mu);
+    if (g->broken.load()) return CELESTE_ERR_ABORTED;
     g->planned = false;
     (void)group_quiesce(g);
+    if (g->broken.load()) return CELESTE_ERR_ABORTED;
     group_barrier_reset(g);
     group_shard(g, n_targets, targets);
     int W = 1;
@@ -666,10 +1036,12 @@ extern "C" int celeste_group_maximize_batch(celeste_group_t *g, double *vp, cons
                 HIP_TRY(hipMemcpyAsync(m->d_pos, pc.data(), nr * 2 * sizeof(double), hipMemcpyHostToDevice, st));
                 HIP_TRY(hipStreamSynchronize(st));   // (pc is a local)
             }
-            own_rc = celeste_maximize_batch_device(m->ctx, m->d_vp, vp_neighbors ? m->d_vp_nbr : nullptr, pos_centers ? m->d_pos : nullptr,
-                                                   (int32_t)nr, m->d_targets, cfg, m->d_it, m->d_ev, m->d_el, m->d_st, st);
+            if (group_fault(g, m, GROUP_FAULT_LAUNCH)) own_rc = CELESTE_ERR_HIP;
+            else own_rc = celeste_maximize_batch_device(m->ctx, m->d_vp, vp_neighbors ? m->d_vp_nbr : nullptr, pos_centers ? m->d_pos : nullptr,
+                                                        (int32_t)nr, m->d_targets, cfg, m->d_it, m->d_ev, m->d_el, m->d_st, st);
         }
-        // (a member whose launch failed still takes part in the exchange: the collective needs every rank)
+        // (a member whose launch failed still takes part in the exchange: the collective needs every rank; its rows are
+        // marked unused)
         s1 = group_exchange_rows(g, m, m->d_vp, own_rc == CELESTE_OK ? (int)nr : 0, m->d_targets, m->d_it, m->d_ev, m->d_el, m->d_st, W,
                                  GROUP_ROW, cnt);
         if (s1 != CELESTE_OK) return s1;
@@ -678,10 +1050,11 @@ extern "C" int celeste_group_maximize_batch(celeste_group_t *g, double *vp, cons
             if (s1 != CELESTE_OK) return s1;
             HIP_TRY(hipMemcpyAsync(m->p_gathered, m->d_gathered, blk * g->n * sizeof(double), hipMemcpyDeviceToHost, st));
         }
-        HIP_TRY(hipStreamSynchronize(st));
+        s1 = group_stream_wait(g, m, st);
+        if (s1 != CELESTE_OK) return s1;
         return own_rc;      // (a fused launch that gave up shows as CELESTE_ERR_HIP in its targets' status: optim_finalize_kernel)
-    });
-    if (rc != CELESTE_OK) return rc;
+    }, 1);
+    if (rc != CELESTE_OK) { (void)group_quiesce(g); return g->broken.load() ? CELESTE_ERR_ABORTED : rc; }
     int worst = CELESTE_OK;
     const double *gp = g->mem[0]->p_gathered;
     for (int r = 0; r < g->n; ++r) {
@@ -704,8 +1077,14 @@ extern "C" int celeste_group_maximize_batch(celeste_group_t *g, double *vp, cons
 
 // ---- joint inference over the members (one_node_joint_infer, ParallelRun.jl:135-196, 302-397) -----------------------
 // The connected components of a Cyclades batch never conflict (partition.jl:173-236): they are sharded over the members by
-// cost, every member runs its components' sources one after another against ITS table (celeste_joint_infer's schedule: layer
-// j = the j-th sources of its components), and the rows the batch updated are exchanged ONCE per batch -- not per layer.
+// cost, and every member runs its components' sources one after another against ITS table (celeste_joint_infer's schedule:
+// layer j = the j-th sources of its components).  A member's table must be brought up to date only when the member is about
+// to READ a row -- a target's own, a neighbour's -- that ANOTHER member has written since the last exchange; the host knows
+// both (the shards and the neighbour graph), so the steps (sweep, batch) are cut into SEGMENTS: maximal runs in front of
+// which no such read exists.  A segment is ONE launch chain per member (celeste_joint_infer's dataflow launch over the
+// member's layers of all its batches) followed by ONE exchange of the rows the segment wrote.  A group of one has nobody to
+// wait for: its whole schedule is one segment -- celeste_joint_infer's single launch -- and one (one-rank) exchange.  In a crowded
+// field on several members every batch reads what the batch before wrote on another member: one exchange per batch.
 extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t n_sweeps, int32_t n_batches, const int64_t *batch_offsets,
                                          const int64_t *comp_offsets, const int32_t *comp_targets, const double *pos_centers,
                                          const celeste_optim_config_t *cfg, int32_t *iterations, int32_t *f_evals, double *elbo,
@@ -715,6 +1094,8 @@ extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t
     if (n_exchanges) *n_exchanges = 0;
     if (n_batches == 0 || n_sweeps == 0) return CELESTE_OK;
     if (batch_offsets[0] != 0 || comp_offsets[0] != 0) return CELESTE_ERR_INVALID_ARG;
+    // the schedule's shape first: nothing below indexes comp_offsets / comp_targets before these hold
+    for (int b = 0; b < n_batches; ++b) if (batch_offsets[b + 1] < batch_offsets[b]) return CELESTE_ERR_INVALID_ARG;
     const int64_t n_comps = batch_offsets[n_batches];
     if (n_comps < 0) return CELESTE_ERR_INVALID_ARG;
     for (int64_t k = 0; k < n_comps; ++k) if (comp_offsets[k + 1] < comp_offsets[k]) return CELESTE_ERR_INVALID_ARG;
@@ -725,7 +1106,6 @@ extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t
     {
         std::vector<int32_t> comp_of((size_t)g->S);
         for (int b = 0; b < n_batches; ++b) {
-            if (batch_offsets[b + 1] < batch_offsets[b]) return CELESTE_ERR_INVALID_ARG;
             std::fill(comp_of.begin(), comp_of.end(), -1);
             for (int64_t k = batch_offsets[b]; k < batch_offsets[b + 1]; ++k)
                 for (int64_t e = comp_offsets[k]; e < comp_offsets[k + 1]; ++e) {
@@ -743,16 +1123,17 @@ extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t
         }
     }
     std::lock_guard<std::mutex> lock(g->call_mu);
+    if (g->broken.load()) return CELESTE_ERR_ABORTED;
     g->planned = false;
     (void)group_quiesce(g);
+    if (g->broken.load()) return CELESTE_ERR_ABORTED;
     group_barrier_reset(g);
     g->abort_rc.store(0);
     const size_t tb = (size_t)g->S * CEL_P * sizeof(double);
     memcpy(g->p_vp, vp, tb);
     // per batch and member: its components (cost = the chunks of their sources), flattened into layers
-    struct Part { std::vector<int64_t> off; std::vector<int32_t> tg; std::vector<int64_t> entry; std::vector<double> pos; std::vector<int32_t> rows; };
+    struct Part { std::vector<int64_t> off; std::vector<int32_t> tg; std::vector<int64_t> entry; std::vector<double> pos; };
     std::vector<std::vector<Part>> parts((size_t)n_batches, std::vector<Part>((size_t)g->n));
-    std::vector<int> widths((size_t)n_batches, 1);
     for (int b = 0; b < n_batches; ++b) {
         const int64_t k0 = batch_offsets[b], nk = batch_offsets[b + 1] - k0;
         std::vector<int64_t> w((size_t)nk, 0);
@@ -775,9 +1156,55 @@ extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t
                 }
                 p.off.push_back((int64_t)p.tg.size());
             }
-            p.rows = p.tg;     // every source of a batch appears once: the rows this member updates
-            widths[b] = std::max(widths[b], (int)p.rows.size());
         }
+    }
+    // segments of steps (step u = sweep u / n_batches, batch u % n_batches): a new segment starts where a member reads a row
+    // another member has written since the last exchange
+    const int64_t U = (int64_t)n_sweeps * n_batches;
+    std::vector<int64_t> seg_lo;
+    {
+        std::vector<int32_t> writer((size_t)g->S, -1);
+        seg_lo.push_back(0);
+        for (int64_t u = 0; u < U; ++u) {
+            const int b = (int)(u % n_batches);
+            bool stale = false;
+            for (int r = 0; r < g->n && !stale; ++r)
+                for (int32_t t : parts[b][r].tg) {
+                    if (writer[t] >= 0 && writer[t] != r) { stale = true; break; }
+                    for (int64_t q = c0->h_nbr_off[t]; q < c0->h_nbr_off[t + 1] && !stale; ++q) {
+                        const int32_t w = writer[c0->h_nbr_idx[q]];
+                        if (w >= 0 && w != r) stale = true;
+                    }
+                    if (stale) break;
+                }
+            if (stale && u > seg_lo.back()) { seg_lo.push_back(u); std::fill(writer.begin(), writer.end(), -1); }
+            for (int r = 0; r < g->n; ++r) for (int32_t t : parts[b][r].tg) writer[t] = r;
+        }
+        seg_lo.push_back(U);
+    }
+    const size_t n_seg = seg_lo.size() - 1;
+    // per segment and member: the concatenated layers, and the rows the segment writes (every source once)
+    struct Seg { std::vector<int64_t> off; std::vector<int32_t> tg, rows; std::vector<int64_t> out; std::vector<double> pos; };
+    std::vector<std::vector<Seg>> segs(n_seg, std::vector<Seg>((size_t)g->n));
+    std::vector<int> widths(n_seg, 1);
+    {
+        std::vector<uint8_t> in_rows((size_t)g->S);
+        for (size_t sg = 0; sg < n_seg; ++sg)
+            for (int r = 0; r < g->n; ++r) {
+                Seg &q = segs[sg][(size_t)r];
+                q.off.push_back(0);
+                std::fill(in_rows.begin(), in_rows.end(), 0);
+                for (int64_t u = seg_lo[sg]; u < seg_lo[sg + 1]; ++u) {
+                    const Part &p = parts[(size_t)(u % n_batches)][(size_t)r];
+                    const int64_t base = (int64_t)q.tg.size(), sw = u / n_batches;
+                    q.tg.insert(q.tg.end(), p.tg.begin(), p.tg.end());
+                    q.pos.insert(q.pos.end(), p.pos.begin(), p.pos.end());
+                    for (int64_t e : p.entry) q.out.push_back(sw * E + e);
+                    for (size_t l = 1; l < p.off.size(); ++l) q.off.push_back(base + p.off[l]);
+                    for (int32_t t : p.tg) if (!in_rows[t]) { in_rows[t] = 1; q.rows.push_back(t); }
+                }
+                widths[sg] = std::max(widths[sg], (int)q.rows.size());
+            }
     }
     std::atomic<int64_t> exchanges{0};
     int rc = group_run(g, [&](GroupMember *m) -> int {
@@ -785,50 +1212,53 @@ extern "C" int celeste_group_joint_infer(celeste_group_t *g, double *vp, int32_t
         hipStream_t st = m->ctx->stream;
         HIP_TRY(hipMemcpyAsync(m->d_vp, g->p_vp, tb, hipMemcpyHostToDevice, st));
         int worst = CELESTE_OK;
-        for (int sw = 0; sw < n_sweeps; ++sw)
-            for (int b = 0; b < n_batches; ++b) {
-                const Part &p = parts[b][(size_t)m->index];
-                const size_t ne = p.tg.size();
-                int own_rc = CELESTE_OK;
-                if (ne > 0) {
-                    std::vector<int32_t> it(ne), ev(ne), stt(ne);
-                    std::vector<double> el(ne);
-                    // (the entry state of the table, should the dataflow launch hand the schedule to the layered driver)
-                    HIP_TRY(hipMemcpyAsync(m->d_entry, m->d_vp, tb, hipMemcpyDeviceToDevice, st));
-                    own_rc = joint_run(m->ctx, m->d_vp, m->d_entry, (int32_t)(p.off.size() - 1), p.off.data(), p.tg.data(),
-                                       pos_centers ? p.pos.data() : nullptr, cfg, it.data(), ev.data(), el.data(), stt.data(), false);
+        for (size_t sg = 0; sg < n_seg; ++sg) {
+            const Seg &p = segs[sg][(size_t)m->index];
+            const size_t ne = p.tg.size();
+            int own_rc = CELESTE_OK;
+            if (ne > 0) {
+                std::vector<int32_t> it(ne), ev(ne), stt(ne);
+                std::vector<double> el(ne);
+                // (the entry state of the table, should the dataflow launch hand the schedule to the layered driver)
+                HIP_TRY(hipMemcpyAsync(m->d_entry, m->d_vp, tb, hipMemcpyDeviceToDevice, st));
+                if (group_fault(g, m, GROUP_FAULT_LAUNCH)) own_rc = CELESTE_ERR_HIP;
+                else own_rc = joint_run(m->ctx, m->d_vp, m->d_entry, (int32_t)(p.off.size() - 1), p.off.data(), p.tg.data(),
+                                        pos_centers ? p.pos.data() : nullptr, cfg, it.data(), ev.data(), el.data(), stt.data(), false);
+                if (own_rc == CELESTE_OK || own_rc == CELESTE_ERR_NONFINITE_INPUT || own_rc == CELESTE_ERR_NONFINITE_RESULT)
                     for (size_t i = 0; i < ne; ++i) {
-                        const size_t q = (size_t)sw * (size_t)E + (size_t)p.entry[i];
+                        const size_t q = (size_t)p.out[i];
                         if (iterations) iterations[q] = it[i];
                         if (f_evals) f_evals[q] = ev[i];
                         if (elbo) elbo[q] = el[i];
                         if (status) status[q] = stt[i];
                     }
-                    if (own_rc == CELESTE_ERR_NONFINITE_INPUT || own_rc == CELESTE_ERR_NONFINITE_RESULT) { if (worst == CELESTE_OK) worst = own_rc; own_rc = CELESTE_OK; }
-                    // a launch that failed: the others would wait for this member at the next exchange -- tell them before this one
-                    if (own_rc != CELESTE_OK) { int z = 0; g->abort_rc.compare_exchange_strong(z, own_rc); }
-                }
-                int s1 = group_target_buffers(m, p.rows.size());
-                if (s1 != CELESTE_OK) return s1;
-                if (!p.rows.empty()) HIP_TRY(hipMemcpyAsync(m->d_targets, p.rows.data(), p.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-                GroupCounts cnt; memset(&cnt, 0, sizeof cnt);
-                for (int r = 0; r < g->n; ++r) cnt.n[r] = (int)parts[b][r].rows.size();
-                s1 = group_exchange_rows(g, m, m->d_vp, (int)p.rows.size(), m->d_targets, nullptr, nullptr, nullptr, nullptr, widths[b],
-                                         GROUP_JROW, cnt);
-                if (s1 != CELESTE_OK) return s1;
-                HIP_TRY(hipStreamSynchronize(st));
-                if (m->index == 0) exchanges.fetch_add(1);
-                // (the exchange needed every member's enqueue, and a failing member raised the flag before its own)
-                if (g->exchange == GROUP_EXCHANGE_PEER && !group_barrier(g)) return CELESTE_ERR_HIP;
-                if (const int a = g->abort_rc.load()) return a;
+                if (own_rc == CELESTE_ERR_NONFINITE_INPUT || own_rc == CELESTE_ERR_NONFINITE_RESULT) { if (worst == CELESTE_OK) worst = own_rc; own_rc = CELESTE_OK; }
+                // a launch that failed: the others would wait for this member at the next exchange -- tell them before this one
+                if (own_rc != CELESTE_OK) { int z = 0; g->abort_rc.compare_exchange_strong(z, own_rc); }
             }
+            int s1 = group_target_buffers(m, p.rows.size());
+            if (s1 != CELESTE_OK) return s1;
+            if (!p.rows.empty()) HIP_TRY(hipMemcpyAsync(m->d_targets, p.rows.data(), p.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            GroupCounts cnt; memset(&cnt, 0, sizeof cnt);
+            for (int r = 0; r < g->n; ++r) cnt.n[r] = (int)segs[sg][(size_t)r].rows.size();
+            s1 = group_exchange_rows(g, m, m->d_vp, own_rc == CELESTE_OK ? (int)p.rows.size() : 0, m->d_targets, nullptr, nullptr, nullptr, nullptr,
+                                     widths[sg], GROUP_JROW, cnt);
+            if (s1 != CELESTE_OK) return s1;
+            s1 = group_stream_wait(g, m, st);
+            if (s1 != CELESTE_OK) return s1;
+            if (m->index == 0) exchanges.fetch_add(1);
+            // (the exchange needed every member's enqueue, and a failing member raised the flag before its own)
+            if (g->exchange == GROUP_EXCHANGE_PEER && !group_barrier(g)) return CELESTE_ERR_HIP;
+            if (const int a = g->abort_rc.load()) return a;
+        }
         if (m->index == 0) {
             HIP_TRY(hipMemcpyAsync(g->p_vp_nbr, m->d_vp, tb, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
         return worst;
-    });
+    }, n_seg);
     if (n_exchanges) *n_exchanges = exchanges.load();
     if (rc == CELESTE_OK || rc == CELESTE_ERR_NONFINITE_INPUT || rc == CELESTE_ERR_NONFINITE_RESULT) memcpy(vp, g->p_vp_nbr, tb);
+    else { (void)group_quiesce(g); if (g->broken.load()) rc = CELESTE_ERR_ABORTED; }
     return rc;
 } ABI_CATCH

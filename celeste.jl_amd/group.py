@@ -105,13 +105,22 @@ class FieldGroup:
                 "exchange": {cabi.EXCHANGE_RCCL: "rccl", cabi.EXCHANGE_PEER_COPY: "peer_copy"}.get(gi.exchange, str(gi.exchange)),
                 "rccl_ranks": gi.rccl_ranks, "devices": [int(gi.devices[k]) for k in range(gi.n_members)]}
 
+    def collectives(self):
+        """celeste_group_collectives: ([collectives enqueued per member], aborted)"""
+        enq = np.zeros(self.n_members, dtype=np.int64)
+        ab = C.c_int32(0)
+        cabi.check(self.lib.celeste_group_collectives(self.handle, enq.ctypes.data_as(cabi.c_int64_p), C.byref(ab)), self.lib)
+        return enq.tolist(), bool(ab.value)
+
     # -- elbo() over the members ------------------------------------------------------------------------------------
-    def _outputs(self, n: int, flags: int):
+    def _outputs(self, n: int, flags: int, pinned: bool = True):
         v = np.zeros(n)
         d = np.zeros((n, P)) if flags & (FLAG_GRAD | FLAG_HESS) else None
         h = None
         if flags & FLAG_HESS:
-            h = np.zeros((n, cabi.HP) if flags & cabi.FLAG_PACKED_HESS else (n, P, P))
+            hshape = (n, cabi.HP) if flags & cabi.FLAG_PACKED_HESS else (n, P, P)
+            # (page-locked, as FieldContext.eval_batch allocates it: the members' DMA lands Hessians in it directly)
+            h = cabi.pinned_empty(hshape) if pinned and n >= 64 else np.zeros(hshape)
         return v, d, h, np.zeros((n, 2), dtype=np.int64), np.zeros(n, dtype=np.int32)
 
     def _finish(self, st, outs, raise_on_error):

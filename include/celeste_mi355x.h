@@ -65,7 +65,8 @@ enum {
     CELESTE_ERR_NONFINITE_RESULT = 3,  /* elbo_args.jl:145-149 */
     CELESTE_ERR_HIP = 4,
     CELESTE_ERR_NO_DEVICE = 5,
-    CELESTE_ERR_ALLOC = 6
+    CELESTE_ERR_ALLOC = 6,
+    CELESTE_ERR_ABORTED = 7            /* celeste_group_*: the group's communicators were torn down (see "Errors" there) */
 };
 
 /* evaluation flags: has_gradient / has_hessian of the result SensitiveFloat
@@ -177,8 +178,9 @@ typedef struct celeste_work_stats_t {
 /* ABI version: major * 100 + minor.  200: celeste_optim_config_t carries tr_secular_iters (round 2 grew the struct by 8
  * bytes without bumping the version); celeste_maximize_batch_device and celeste_joint_infer exist.  Bindings check it
  * (cabi.load_library, shim/CelesteMI355X.jl): a caller built against another major version must not pass structs.
- * 210: the celeste_group_* entry points (one process, N devices). */
-#define CELESTE_ABI_VERSION 210
+ * 210: the celeste_group_* entry points (one process, N devices).
+ * 220: CELESTE_ERR_ABORTED, celeste_group_collectives; celeste_group_joint_infer exchanges once per SEGMENT of batches. */
+#define CELESTE_ABI_VERSION 220
 int celeste_version(void);
 const char *celeste_strerror(int status);
 
@@ -385,11 +387,21 @@ int celeste_render_expected(celeste_ctx_t *ctx, const double *vp, int32_t image,
  * one included (the collective then runs with one rank).  A device that appears more than once makes the group exchange
  * by plain device-to-device copies instead (RCCL refuses duplicate devices in a communicator): two members on one GPU
  * exercise the shard / gather bookkeeping on a one-GPU box; it is a test configuration, not a fast one.
- * At most 16 members.  One call per group at a time (the entry points serialise themselves).
- * Errors: per-source failures are statuses, as in the one-device entry points.  A member whose launch fails still takes
- * part in the exchange (the collective needs every rank) and the call returns its error; a member that fails before an
- * exchange of rows never reaches the host barrier in front of it, which wakes the others: every member leaves the call
- * with an error and nobody waits inside a collective. */
+ * At most 16 members.  One call per group at a time: every entry point takes the group's lock for its whole duration (a
+ * second thread's call waits); celeste_group_sweep returns with its sweep in flight and the lock released.
+ * CELESTE_GROUP_EXCHANGE=rccl / peer forces an exchange mode (tests; real RCCL refuses repeated devices).
+ * Errors: per-source failures are statuses, as in the one-device entry points.  A member whose LAUNCH fails still enqueues
+ * every collective of the call (the others' results are sound) and the call returns its error.  A member that fails in front
+ * of a row exchange's host barrier wakes the barrier: every member leaves the call with an error, nobody enters the
+ * collective.  A member that leaves a call WITHOUT a collective the others enqueue (a HIP call failed between the barrier and
+ * the collective, or in front of a sweep's gather -- the sweep path has no host barrier, its gathers overlap the next sweep)
+ * is detected by count -- every member counts the collectives it has enqueued, the dispatcher knows how many the call
+ * holds -- and answered by ncclCommAbort on every communicator, which releases the streams that wait inside the collective:
+ * the call (celeste_group_sweep_wait for sweeps in flight) returns CELESTE_ERR_ABORTED, and so does every later call until
+ * the group is destroyed and created again.  The same happens when ncclCommGetAsyncError reports an error while a stream
+ * holding a collective is waited for, or when that wait exceeds CELESTE_GROUP_TIMEOUT_MS (default 300 000; 0 = no limit).
+ * (The reference logs a failing source and goes on, ParallelRun.jl:389-396: that is the per-source status; a device that
+ * drops out has no counterpart there.) */
 typedef struct celeste_group celeste_group_t;
 enum { CELESTE_EXCHANGE_RCCL = 1, CELESTE_EXCHANGE_PEER_COPY = 2 };
 typedef struct celeste_group_info_t {
@@ -402,6 +414,10 @@ typedef struct celeste_group_info_t {
 int celeste_group_create(const celeste_problem_t *problem, int32_t n_members, const int32_t *devices, celeste_group_t **out);
 void celeste_group_destroy(celeste_group_t *group);
 int celeste_group_info(celeste_group_t *group, celeste_group_info_t *out);
+/* enqueued[n_members] (may be NULL): the collectives -- catalog gathers, row exchanges -- each member has enqueued on its
+ * communicator since the group was created (equal on all members whenever no call is in flight); *aborted (may be NULL): 1 once
+ * the communicators have been torn down. */
+int celeste_group_collectives(celeste_group_t *group, int64_t *enqueued, int32_t *aborted);
 
 /* celeste_elbo_eval_batch over the members: same arguments, same outputs in the caller's order.  v / d / counters / status
  * of every target are all-gathered to every member (member 0 hands them to the host); Hessians come down from the member
@@ -438,11 +454,15 @@ int celeste_group_maximize_batch(celeste_group_t *group, double *vp, const doubl
  * component k = the sources comp_targets[comp_offsets[k] .. comp_offsets[k+1]) in the order they are optimised.  Components of
  * a batch never conflict (checked: CELESTE_ERR_INVALID_ARG if a source appears twice in a batch or has a neighbour in another
  * component of it), so they are sharded over the members by cost; a member optimises the sources of its components one
- * after another against its table (celeste_joint_infer's schedule), and the rows a batch updated are exchanged ONCE per
- * batch -- n_batches exchanges per sweep, not one per layer.  The batches are repeated n_sweeps times
- * (Config.num_joint_vi_iters).  pos_centers: 2 doubles per entry of comp_targets (may be NULL), the same in every sweep
- * (ParallelRun.jl:96-100).  Per-entry outputs (may be NULL): [sweep * n_entries + entry].  *n_exchanges (may be NULL)
- * receives the number of exchanges made.  Equals celeste_joint_infer on the flattened schedule bit for bit. */
+ * after another against its table (celeste_joint_infer's schedule).  A member's table needs the others' rows only when it is
+ * about to READ one -- a target's own row, a neighbour's -- that another member has written since the last exchange; the shards
+ * and the neighbour graph are known on the host, so the (sweep, batch) steps are cut into SEGMENTS, maximal runs in front of
+ * which no such read exists: one launch chain per member and ONE exchange per segment.  A group of one runs the whole call as
+ * celeste_joint_infer's single launch + one exchange; a crowded field on several members exchanges once per batch -- at most
+ * n_batches exchanges per sweep, never one per layer.  The batches are repeated n_sweeps times (Config.num_joint_vi_iters).
+ * pos_centers: 2 doubles per entry of comp_targets (may be NULL), the same in every sweep (ParallelRun.jl:96-100).  Per-entry
+ * outputs (may be NULL): [sweep * n_entries + entry].  *n_exchanges (may be NULL) receives the number of exchanges made.
+ * Equals celeste_joint_infer on the flattened schedule bit for bit. */
 int celeste_group_joint_infer(celeste_group_t *group, double *vp, int32_t n_sweeps, int32_t n_batches,
                               const int64_t *batch_offsets, const int64_t *comp_offsets, const int32_t *comp_targets,
                               const double *pos_centers, const celeste_optim_config_t *cfg, int32_t *iterations,

@@ -304,6 +304,18 @@ function group_info(g::MI355XGroup)
     gi[]
 end
 
+"""
+(collectives each member has enqueued, aborted?).  `aborted` = a member dropped out in front of a collective and the library
+tore the communicators down: every call on the group returns status 7 (CELESTE_ERR_ABORTED) from then on -- finalize the
+group and build a new one (the reference's try/catch around a source, ParallelRun.jl:389-396, is the per-source status; a
+device dropping out has no counterpart there).
+"""
+function group_collectives(g::MI355XGroup)
+    enq = zeros(Int64, g.n_members); ab = Ref{Int32}(0)
+    check(ccall((:celeste_group_collectives, libceleste), Cint, (Ptr{Void}, Ptr{Int64}, Ref{Int32}), g.handle, enq, ab))
+    enq, ab[] != 0
+end
+
 """elbo_batch! over every device of the group: same arguments, same outputs (in the order of `targets0`)."""
 function elbo_batch!(out::PinnedOutputs, g::MI355XGroup, vp_all::Matrix{Float64}, targets0::Vector{Int32};
                      flags::UInt32 = UInt32(7 | 32))
@@ -329,7 +341,8 @@ end
 """
 one_node_joint_infer over every device of the group.  `batches` is partition_cyclades_dynamic's result as the reference has
 it (partition.jl:173-236): batches[b][k] = the 0-based source ids of connected component k of batch b, in the order they are
-optimised.  The components of a batch are sharded over the devices; the rows a batch updated are exchanged once per batch.
+optimised.  The components of a batch are sharded over the devices; rows are exchanged only in front of a batch in which a
+device reads a row another device has written since the last exchange (at most once per batch; a group of one: once).
 box_centres: 2 x (number of entries), a column per entry of vcat(vcat(batches...)...).  Per-entry outputs: entry fastest, then
 sweep.
 """

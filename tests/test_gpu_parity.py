@@ -490,6 +490,18 @@ def test_single_precision_mode_counts_and_masks_like_the_fp64_path(seed):
     assert np.array_equal(cg, c64)
     assert float(np.max(np.abs(vg - v64) / np.abs(v64))) <= 1e-4
     assert max(np.abs(dg[k] - d64[k]).max() / np.abs(d64[k]).max() for k in range(len(tg))) <= 1e-4
+    # a target's fp32 result does not depend on the size of the batch it is in: beyond 768 targets the neighbours' light is
+    # rendered by one wavefront per item instead of two (celeste_abi.hip VALUE_WIDE_MAX) -- same per-pixel arithmetic
+    # (value_pixels_f2), so the SAME targets repeated into a batch of > 768 give the same bits, masks and counters included
+    reps = 800 // len(tg) + 1
+    big = tg * reps
+    assert len(big) > 768
+    vb, db, hb, cb, sb = ctx.eval_batch(f.vp, big, ALL | cabi.FLAG_FP32)
+    n = len(tg)
+    for r in (0, reps // 2, reps - 1):
+        sl = slice(r * n, (r + 1) * n)
+        assert np.array_equal(vb[sl], v32) and np.array_equal(db[sl], d32) and np.array_equal(hb[sl], h32)
+        assert np.array_equal(cb[sl], c32) and np.array_equal(sb[sl], s32)
     print("fp32 fuzz", seed, (H, W, S), "psf_K", psf_K, "errors", ev, ed, eh)
 
 

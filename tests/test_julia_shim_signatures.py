@@ -55,7 +55,7 @@ def _header_prototypes():
 
 def test_every_ccall_of_the_julia_shim_matches_the_header():
     protos = _header_prototypes()
-    assert len(protos) == 41
+    assert len(protos) == 42
     jl = open(os.path.join(ROOT, "shim", "CelesteMI355X.jl")).read()
     calls = re.findall(r"ccall\(\(:(celeste_[a-z_0-9]+),\s*libceleste\),\s*([A-Za-z{}0-9]+),\s*\(", jl)
     assert len(calls) >= 14
@@ -77,7 +77,7 @@ def test_every_ccall_of_the_julia_shim_matches_the_header():
     for need in ("celeste_images_create", "celeste_ctx_create_on", "celeste_elbo_eval", "celeste_elbo_eval_batch",
                  "celeste_maximize_batch", "celeste_joint_infer", "celeste_tr_solve_batch", "celeste_host_alloc", "celeste_version",
                  "celeste_group_create", "celeste_group_destroy", "celeste_group_info", "celeste_group_elbo_eval_batch",
-                 "celeste_group_maximize_batch", "celeste_group_joint_infer"):
+                 "celeste_group_maximize_batch", "celeste_group_joint_infer", "celeste_group_collectives"):
         assert need in seen, need
 
 
