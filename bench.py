@@ -70,6 +70,8 @@ def live_pmc(args, timeout_s=60, split=False):
     out = {}
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "split" if split else "fused", "--steps", "3", "--warmup", "1",
              "--height", str(args.height), "--width", str(args.width), "--sources", str(args.sources), "--seed", str(args.seed)]
+    if getattr(args, "variable_psf", False):
+        child.append("--variable-psf")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -129,11 +131,11 @@ def _cached(path, make, cache=True):
     return obj
 
 
-def build_field(H, W, n_sources, seed, cache=True):
+def build_field(H, W, n_sources, seed, cache=True, variable=False):
     from celeste_jl_amd import synthetic
-    return _cached("/tmp/celeste_field_%d_%d_%d_%d.pkl" % (H, W, n_sources, seed),
-                   lambda: synthetic.make_field(H, W, n_sources, seed=seed,
-                                                name="synthetic_%dx%dx5_%dsrc" % (H, W, n_sources)), cache)
+    return _cached("/tmp/celeste_field_%d_%d_%d_%d%s.pkl" % (H, W, n_sources, seed, "_var" if variable else ""),
+                   lambda: synthetic.make_field(H, W, n_sources, seed=seed, variable=variable,
+                                                name="synthetic_%dx%dx5_%dsrc%s" % (H, W, n_sources, "_variable" if variable else "")), cache)
 
 
 def build_multifield(grid, H, W, n_sources, seed, cache=True):
@@ -192,6 +194,32 @@ def cpu_baseline(problem, vp, targets, seconds_target=15.0):
                          len(os.sched_getaffinity(0)), dt, dt2)}
 
 
+def read_sclk_mhz(device_index=0):
+    """The shader clock (MHz) the driver reports for the HIP device right now: the starred level of pp_dpm_sclk of the card
+    whose PCI address is the device's (sysfs: one file read, no tool start-up -- rocm-smi takes long enough for the chip to
+    fall back to its idle state).  None when sysfs does not say."""
+    import glob
+    import re
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        bdf = None
+    best = None
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            if bdf and bdf not in os.path.realpath(os.path.dirname(f)):
+                continue
+            for ln in open(f).read().splitlines():
+                m = re.match(r"\s*\d+:\s*(\d+)\s*[Mm][Hh]z\s*\*", ln)
+                if m:
+                    best = int(m.group(1))
+        except Exception:
+            pass
+    return best
+
+
 def self_launch(n):
     """Re-run this command line as n ranks under torch.distributed.run on this node; returns the launcher's exit code.
     --standalone: the launcher itself binds a free port for the rendezvous (no bind-and-release race), on 127.0.0.1 (the
@@ -246,6 +274,13 @@ def main():
     ap.add_argument("--shard-projection", action="store_true",
                     help="one GPU: sweep rank 0's cost-balanced shard of this workload for N = 1, 2, 4, 8 ranks (fp32 and fp64) -- "
                          "a one-GPU bound on the strong-scaling efficiency (used for the config5 sub-record)")
+    ap.add_argument("--variable-psf", action="store_true",
+                    help="config 3 with the PSF the reference's production path uses: an SDSSPSFMap evaluated at every source "
+                         "(SDSSIO.jl:239-299) -- one 51x51 stamp, hence one set of spline coefficients, per (source, band) -- plus a "
+                         "varying sky plane and per-row calibration, instead of AccuracyBenchmark's ConstantPSFMap")
+    ap.add_argument("--no-variable-psf", action="store_true", help="config 3, one GPU: do not append the variable_psf sub-record")
+    ap.add_argument("--no-group-driver", action="store_true",
+                    help="N > 1: do not let rank 0 repeat the sweep through celeste_group_* (the in-library driver) after the ranks' run")
     ap.add_argument("--check-dir", default=None,
                     help="every rank writes its gathered (v, d) of the last sweep to <dir>/rank<r>.npz (tests)")
     args = ap.parse_args()
@@ -324,7 +359,7 @@ def main():
 
     def make():
         if args.config == 3:
-            return build_field(args.height, args.width, args.sources, seed)
+            return build_field(args.height, args.width, args.sources, seed, variable=args.variable_psf)
         grid = tuple(int(x) for x in args.grid.split(","))
         return build_multifield(grid, args.height, args.width, args.sources, seed)
     if use_dist and strong and args.config == 3:
@@ -357,14 +392,21 @@ def main():
     kms_in_pass = []
     if args.kernels_in_pass:      # (the config-5 sub-record: steps of several ms, one synchronisation per step costs nothing)
         ctx.enable_timing(True)
+    # per-step durations of the timed loop: one HIP event per step boundary on the stream the launch chain runs on (recorded,
+    # never waited for, inside the loop: ~2 us of host time per step; read after the clock has stopped)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        step_ev[i].record(sweep.compute_stream)
         sweep.step(d_vp.data_ptr())
         if args.kernels_in_pass:
             sweep.wait()
             kms_in_pass.append(ctx.last_kernel_ms())
+    step_ev[args.steps].record(sweep.compute_stream)
     sync()
     dt = time.perf_counter() - t0
+    sclk_after = read_sclk_mhz(dev.index)      # (once, after the clock has stopped: what the chip reports right behind the loop)
+    step_ms = np.array([step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)])
     if args.kernels_in_pass:
         ctx.enable_timing(False)
     if args.pmc_child == "split":   # the profiled child of live_pmc(split=True): a few sweeps of the split variant
@@ -417,6 +459,38 @@ def main():
     ctx.enable_timing(False)
     kms = np.array(kms_in_pass if kms_in_pass else kms).mean(axis=0)
     sync()
+    # the same loop once more when the timed one was short: what a step costs once the chip has left its idle power state
+    # (a secondary figure: `value` stays the K steps the caller asked for)
+    steady = None
+    if args.steps < 100 and args.config == 3 and not args.pmc_child:
+        for _ in range(20):
+            sweep.step(d_vp.data_ptr())
+        sync()
+        ts0 = time.perf_counter()
+        for _ in range(200):
+            sweep.step(d_vp.data_ptr())
+        sync()
+        steady = {"ms_per_step": (time.perf_counter() - ts0) / 200 * 1e3, "steps": 200, "warmup": 20,
+                  "sclk_mhz_after_loop": read_sclk_mhz(dev.index),
+                  "note": "the timed loop repeated with 200 steps behind everything else of this run (rank 0's clock)"}
+
+    # N > 1: the OTHER driver of the same sweep in the same run -- rank 0 alone, ONE process, the N devices behind the C ABI
+    # (celeste_group_*: worker threads, ncclCommInitAll + ncclAllGather inside the library) -- while the other ranks wait on the
+    # host (the rendezvous store, not a collective: their GPUs stay idle for the group's members)
+    group_rec = None
+    if use_dist and world > 1 and not args.no_group_driver and not args.pmc_child:
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            try:
+                if n_dev < world and args.backend == "nccl":
+                    raise RuntimeError("rank 0 sees %d device(s), the group needs %d" % (n_dev, world))
+                group_rec = group_measure(args, fld, [r % n_dev for r in range(world)], flags, check=False)
+            except Exception as e:      # (the ranks' line does not depend on it)
+                group_rec = {"error": repr(e)}
+            store.set("celeste_group_driver_done", "1")
+        else:
+            store.wait(["celeste_group_driver_done"])
+        sync()
 
     # N > 1: every rank's sweep of its own shard WITHOUT the catalog gather (same launches, wall clock between two
     # device synchronisations) -- what separates load imbalance / small-shard latency from the cost of the exchange
@@ -506,11 +580,11 @@ def main():
     # HBM bytes and VALU utilisation of the dominant kernel: measured now when rocprofv3 can run here, else the
     # committed figures (the flop count per pixel visit always comes from the ISA of the tree, tools/count_flops.py)
     pmc_live = pmc_split = None
-    if world == 1 and rank == 0 and args.config == 3 and args.dtype == "f64" and extras and not args.no_live_pmc:
+    if world == 1 and rank == 0 and args.config == 3 and args.dtype == "f64" and (extras or args.variable_psf) and not args.no_live_pmc:
         pmc_live = live_pmc(args)
         if pmc_live:
             facts = dict(facts, **pmc_live)
-        pmc_split = live_pmc(args, split=True)
+        pmc_split = live_pmc(args, split=True) if extras else None
         if pmc_split:
             facts = dict(facts, **pmc_split)
     if extras and args.config == 3:
@@ -553,17 +627,21 @@ def main():
         n_total = int(sum(p[0] for p in per_rank))           # sources evaluated per step by the whole job
         ms_per_step = dt / args.steps * 1e3
         value = n_total / (dt / args.steps)
-        alg_bytes = stats["algorithmic_bytes"]                # of rank 0's launch
+        # the star spline coefficients (53 x 53 f64 = 22 472 B per stamp) count once per band per sweep when
+        # the PSF map is constant, per patch otherwise: the context's distinct stamps are exactly that
+        spline_bytes = int(ctx.problem.c.n_stamps) * 53 * 53 * 8
+        alg_bytes = stats["algorithmic_bytes"] + spline_bytes   # of rank 0's launch
         achieved = alg_bytes / (kms[1] * 1e-3) / 1e9
         fpp = facts.get("flops_per_pixel_visit_f32" if args.dtype == "f32" else "flops_per_pixel_visit")
         peak_fl = FP32_VECTOR_PEAK_TFLOPS if args.dtype == "f32" else FP64_VECTOR_PEAK_TFLOPS
         kname = "pixel_kernel<2, %s>" % ("float" if args.dtype == "f32" else "double")
         if args.config == 3:
             workload = ("BASELINE.json configs[%d]: synthetic %dx%dx5 SDSS-size field, %d star+galaxy sources%s, fp64, "
-                        "Sa=1 with value-only neighbours, psf_K=2"
+                        "Sa=1 with value-only neighbours, psf_K=2%s"
                         % (2 if world == 1 else 3, args.height, args.width, S,
                            "" if world == 1 else (" sharded by source across %d GPUs" % world if strong
-                                                  else " per GPU (one field per rank)")))
+                                                  else " per GPU (one field per rank)"),
+                           ", SDSSPSFMap: one PSF stamp per (source, band), varying sky and calibration" if args.variable_psf else ""))
         else:
             workload = ("BASELINE.json configs[4]: %s grid of overlapping %dx%dx5 fields (%d images), %d sources in the "
                         "sparse patch list, %s component loop%s, tolerance 1e-4 vs fp64"
@@ -591,7 +669,8 @@ def main():
                                                                                      args.dtype == "f64") else None,
                          "traffic_source": facts.get("source"), "traffic_measured_in_this_run": bool(pmc_live),
                          "kernel": kname, "kernel_ms": float(kms[1]),
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_launch": alg_bytes, "spline_coefficient_bytes": spline_bytes,
+                         "psf_stamps": int(ctx.problem.c.n_stamps),
                          "valu_utilization": facts.get("pixel_kernel_valu_utilization") if args.dtype == "f64" else None},
             "timing_method": ("value / ms_per_step: wall clock around K sweeps (launch chain + catalog gather) between two device "
                               "synchronisations + barriers, max over ranks; kernels_ms / roofline.kernel_ms: HIP events recorded by "
@@ -599,6 +678,17 @@ def main():
                                                                      if args.kernels_in_pass else "in a pass of their own after the timed region")),
             "parity_pin": parity_pin_status(),
             "kernels_ms": {"prep": float(kms[0]), "pixel": float(kms[1]), "lift": float(kms[2])},
+            # where ms_per_step goes (rank 0): the steps of the timed loop one by one, the part of a step no kernel accounts
+            # for, and the shader clock the chip reported right behind the loop -- a short run (--steps 20 after --warmup 5 is
+            # 18 ms of work) measures a chip that is still leaving its idle power state; step_ms shows it
+            "step_ms": {"min": float(step_ms.min()), "p50": float(np.median(step_ms)), "max": float(step_ms.max()),
+                        "first": float(step_ms[0]), "last": float(step_ms[-1]),
+                        "first_quarter_mean": float(step_ms[:max(1, len(step_ms) // 4)].mean()),
+                        "last_quarter_mean": float(step_ms[-max(1, len(step_ms) // 4):].mean()),
+                        "sum": float(step_ms.sum()), "wall_ms": dt * 1e3,
+                        "source": "HIP events at the step boundaries of the timed loop, on the launch stream"},
+            "gaps_ms": float(ms_per_step - (kms[0] + kms[1] + kms[2])),
+            "sclk_mhz_after_loop": sclk_after,
             "pixel_visits_per_sec_rank0": pixel_visits_local / (kms[1] * 1e-3),
         }
         if fpp:
@@ -632,6 +722,10 @@ def main():
             out["roofline"]["valu"] = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "sustained_fma_peak",
                                                                        "frac_of_sustained", "flops_per_pixel_visit", "pixel_visits",
                                                                        "dtype", "instruction_mix")}   # (the rounds-1..4 location)
+        if steady is not None:
+            out["steady_state"] = steady
+        if group_rec is not None:
+            out["group_driver"] = group_rec
         if sweep_only_ms is not None:
             out["config"]["sweep_ms_without_gather_per_rank"] = sweep_only_ms
             out["config"]["gather_and_imbalance_ms"] = ms_per_step - max(sweep_only_ms)
@@ -640,6 +734,8 @@ def main():
             out["split_variant"] = split
         if extras:
             out.update(secondary_figures(ctx, fld, targets, args, costs))
+        if extras and args.config == 3 and not args.variable_psf and not args.no_variable_psf and args.height >= 2048:
+            out["variable_psf"] = variable_psf_record(args, out)
         if extras and args.config == 3 and not args.no_config5 and args.height >= 2048:
             out["config5"] = config5_record(args)
         if not args.no_cpu_baseline and world == 1:
@@ -671,7 +767,6 @@ def group_main(args):
         args.seed = 3 if args.config == 3 else 5
     import torch
     from celeste_jl_amd import cabi
-    from celeste_jl_amd.group import FieldGroup
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     cabi.load_library()
@@ -682,9 +777,22 @@ def group_main(args):
         raise SystemExit("--driver group over devices %s: only %d visible" % (devices, torch.cuda.device_count()))
     flags = FLAGS_ALL | (cabi.FLAG_FP32 if args.dtype == "f32" else 0)
     if args.config == 3:
-        fld = build_field(args.height, args.width, args.sources, args.seed)
+        fld = build_field(args.height, args.width, args.sources, args.seed, variable=args.variable_psf)
     else:
         fld = build_multifield(tuple(int(x) for x in args.grid.split(",")), args.height, args.width, args.sources, args.seed)
+    out = group_measure(args, fld, devices, flags)
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
+
+def group_measure(args, fld, devices, flags, check=True):
+    """The sweep of `fld` through a celeste_group_t over `devices`: W warm-up sweeps, K timed ones between two
+    celeste_group_sweep_wait, then a pass with HIP-event timing.  Returns the bench line of the group driver (also nested as
+    `group_driver` in the ranks' line at N > 1)."""
+    from celeste_jl_amd.group import FieldGroup
     S = len(fld.catalog)
     targets = np.arange(S, dtype=np.int32)
     g = FieldGroup(fld.images, fld.patches, fld.neighbors, devices=devices)
@@ -701,7 +809,7 @@ def group_main(args):
     dt = time.perf_counter() - t0
     v, d, _, cnt, st = g.results(hessians=False)
     assert (st == 0).all() and np.isfinite(v).all() and np.isfinite(d).all()
-    if args.check_dir:
+    if args.check_dir and check:
         os.makedirs(args.check_dir, exist_ok=True)
         np.savez(os.path.join(args.check_dir, "group.npz"), v=v, d=d)
     g.enable_timing(True)
@@ -722,6 +830,7 @@ def group_main(args):
     # member 0's share of the visits (its launch is the one timed), by shard cost
     visits0 = pixel_visits * costs[0] / max(1, sum(costs))
     n = len(devices)
+    enq, aborted = g.collectives()
     out = {"metric": "sources/sec (ELBO value+gradient+Hessian+KL per target source)",
            "value": S / (dt / args.steps), "unit": "sources/sec", "n_gpus": info["n_devices"], "ranks_seen": info["rccl_ranks"],
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -735,6 +844,7 @@ def group_main(args):
                                 "targets sharded by estimate_time, one all-gather of (v, d, counters, status) per sweep)",
                       "sources_per_step": S, "shard_sizes": sizes, "shard_costs": costs,
                       "gather_backend": info["exchange"], "members": n, "devices": devices,
+                      "collectives_enqueued_per_member": enq, "aborted": aborted,
                       "catalog_gather_bytes_per_step": n * (max(sizes) * 47 + (max(sizes) + 1) // 2) * 8,
                       "pixel_visits_per_sweep": pixel_visits,
                       "member_eval_ms": [float(x) for x in ev_ms], "member_gather_ms": [float(x) for x in ga_ms]},
@@ -745,14 +855,10 @@ def group_main(args):
                            "unit": "TFLOP/s", "frac": fl / peak_fl, "traffic": None, "kernel_ms": float(kms[1]),
                            "kernel": "pixel_kernel<2, %s>" % ("float" if args.dtype == "f32" else "double"),
                            "note": "member 0's launch; its share of the pixel visits by shard cost"}
-    if not args.no_cpu_baseline and n == 1 and args.config == 3:
+    if check and not args.no_cpu_baseline and n == 1 and args.config == 3:
         out["cpu_baseline"] = cpu_baseline(g.problem, fld.vp, targets)
     g.close()
-    sys.stdout.flush()
-    os.dup2(real_stdout, 1)
-    print(json.dumps(out))
-    sys.stdout.flush()
-    os.dup2(2, 1)
+    return out
 
 
 def conflict_free_layer(fld, S, n):
@@ -914,6 +1020,47 @@ def shard_projection(ctx, fld, targets, costs, d_vp, dev, modes, K=10):
     out["note"] = ("rank 0's shard of this workload for N ranks, swept on ONE GPU: the strong-scaling efficiency the kernels allow "
                    "if the catalog gather hides under the next sweep; not a multi-GPU measurement")
     return out
+
+
+def variable_psf_record(args, head):
+    """configs[2]'s field with the PSF the reference's production path really uses -- an SDSSPSFMap evaluated at every source
+    (SDSSIO.jl:239-299; one stamp per patch, imaged_sources.jl:97-107): ~8 800 stamps = ~200 MB of spline coefficients per sweep,
+    gathered 4 x 4 per pixel (fsm_util.jl:225-248) instead of one 22 KB table per band that never leaves L2 -- swept exactly like
+    the headline, as a child run of this script (`--variable-psf`), counters included."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--variable-psf", "--steps", "100", "--warmup", "5", "--no-cpu-baseline",
+           "--no-extras", "--no-config5", "--height", str(args.height), "--width", str(args.width), "--sources", str(args.sources),
+           "--seed", str(args.seed)] + (["--no-live-pmc"] if args.no_live_pmc else [])
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": "child run failed (rc %d): %s" % (r.returncode, r.stderr[-300:])}
+        d = json.loads(line[-1])
+    except Exception as e:   # (the headline does not depend on it)
+        return {"error": repr(e)}
+    keep = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "kernels_ms", "gaps_ms", "step_ms",
+                              "sclk_mhz_after_loop", "pixel_visits_per_sec_rank0") if k in d}
+    keep["workload"] = d["config"]["workload"]
+    keep["sources_per_step"] = d["config"]["sources_per_step"]
+    keep["pixel_visits_per_sweep"] = d["config"]["pixel_visits_per_sweep"]
+    rf = d["roofline"]
+    hbm = rf.get("hbm", rf)
+    keep["roofline_valu"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_of_sustained", "kernel", "kernel_ms",
+                                                "valu_utilization") if k in rf}
+    keep["roofline_hbm"] = {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_measured_in_this_run",
+                                                "algorithmic_bytes_per_launch", "spline_coefficient_bytes", "psf_stamps") if k in hbm}
+    if hbm.get("traffic") and hbm.get("algorithmic_bytes_per_launch"):
+        keep["traffic_over_algorithmic"] = hbm["traffic"] / hbm["algorithmic_bytes_per_launch"]
+    keep["slowdown_vs_constant_psf"] = {"step": d["ms_per_step"] / head["ms_per_step"],
+                                        "pixel_kernel": d["kernels_ms"]["pixel"] / head["kernels_ms"]["pixel"],
+                                        "prep_and_neighbour_light": d["kernels_ms"]["prep"] / head["kernels_ms"]["prep"]}
+    keep["wall_s_including_field_generation"] = time.time() - t0
+    return keep
 
 
 def config5_record(args):

@@ -354,6 +354,11 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
     c->N = pr->n_images; c->S = pr->n_sources; c->K = pr->psf_K; c->NC = 14 * pr->psf_K;
     c->n_stamps = pr->n_stamps;
 #define CTX_TRY(expr) do { int s__ = (expr); if (s__ != CELESTE_OK) { celeste_ctx_destroy(c); return s__; } } while (0)
+    // (The copy stream carries the device-to-host copies of finished parts while the next part computes on `stream`.  HIP maps
+    // streams onto a handful of hardware queues, and which queue a stream gets depends on how many streams the process has
+    // created before: one context in four or so sweeps 2000 sources through the host-pointer entry in 2.0 - 2.4 ms instead of
+    // 1.35 -- its copies do not overlap its kernels.  Creating the copy stream at high priority only moves the bad draw to other
+    // contexts: tools/gpu_group_stream_lottery.py, profiles/r06_stream_lottery.txt.)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
         celeste_ctx_destroy(c); return CELESTE_ERR_HIP;

@@ -47,6 +47,30 @@ def test_bench_json_line():
     v = r["valu"]
     assert v["pixel_visits"] == d["config"]["pixel_visits_per_sweep"] and 0 < v["frac"] < 1 and v["instruction_mix"]["fma_class"] > 0
     assert "config5" not in d          # (appended to full-size config-3 runs only: it generates 16 SDSS-size fields)
+    assert "variable_psf" not in d     # (likewise: a full-size field with one PSF stamp per patch)
+    # where the step goes: the timed loop's steps one by one (HIP events), what no kernel accounts for, the clock behind the loop
+    sm = d["step_ms"]
+    assert 0 < sm["min"] <= sm["p50"] <= sm["max"] and sm["sum"] <= sm["wall_ms"] * 1.05
+    assert abs(d["gaps_ms"] - (d["ms_per_step"] - sum(d["kernels_ms"].values()))) < 1e-9
+    assert "sclk_mhz_after_loop" in d and (d["sclk_mhz_after_loop"] is None or d["sclk_mhz_after_loop"] > 50)
+    assert d["steady_state"]["steps"] == 200 and d["steady_state"]["ms_per_step"] > 0      # (the timed loop was short)
+    # ConstantPSFMap: one stamp per band (two bands of the synthetic recipe share a PSF width, hence a stamp)
+    assert h["psf_stamps"] in (4, 5) and h["spline_coefficient_bytes"] == h["psf_stamps"] * 53 * 53 * 8
+
+
+@pytest.mark.gpu
+def test_bench_variable_psf_flag():
+    """--variable-psf: the same sweep on a field whose PSF is an SDSSPSFMap evaluated at every source -- one stamp per patch, its
+    spline coefficients counted per patch in the algorithmic bytes"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--height", "300", "--width", "260", "--sources", "60",
+                          "--steps", "3", "--warmup", "1", "--variable-psf", "--no-extras", "--no-cpu-baseline", "--no-live-pmc"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    h = d["roofline"]["hbm"]
+    assert "SDSSPSFMap" in d["config"]["workload"] and 200 <= h["psf_stamps"] <= 300
+    assert h["spline_coefficient_bytes"] == h["psf_stamps"] * 53 * 53 * 8 < h["algorithmic_bytes_per_launch"]
+    assert d["value"] > 0
 
 
 def test_bench_refuses_to_run_without_a_gpu():

@@ -77,6 +77,30 @@ def test_config3_size_independent_properties(field3, ctx3):
     assert np.all(dl[:, 28:] == 0) and np.all(hl[:, 28:, :] == 0)
 
 
+def test_config3_with_one_psf_stamp_per_patch_oracle_parity_on_a_sample(oracle):
+    """configs[2]'s field as production Celeste would see it (bench.py's `variable_psf` sub-record): an SDSSPSFMap evaluated at
+    every source (SDSSIO.jl:239-299) -- ~8 800 stamps, one spline per (source, band), imaged_sources.jl:97-107 -- a varying
+    sky plane and per-row calibration.  Every 8th source against the dense CPU restatement; all 2000: finite, exactly symmetric,
+    order-invariant; and the constant-PSF field's numbers are NOT reproduced (the stamps matter)."""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd import synthetic
+    f = synthetic.make_field(2048, 1489, 2000, seed=3, variable=True)
+    ctx = cel.FieldContext(f.images, f.patches, f.neighbors)
+    assert ctx.problem.c.n_stamps > 8000
+    tg = np.arange(2000)
+    v, d, h, cnt, st = ctx.eval_batch(f.vp, tg, ALL)
+    assert (st == 0).all() and np.isfinite(v).all() and np.isfinite(d).all() and np.isfinite(h).all()
+    assert np.array_equal(h, h.transpose(0, 2, 1))
+    sample = tg[::8]
+    r = oracle.elbo_batch(ctx.problem, f.vp, sample, ALL)
+    errs = assert_parity((v[sample], d[sample], h[sample], cnt[sample], st[sample]), r, "config3, one stamp per patch")
+    print("config3 with SDSSPSFMap, 250 of 2000 sources", errs)
+    perm = np.random.default_rng(1).permutation(2000)
+    v2, d2, h2, _, _ = ctx.eval_batch(f.vp, perm, ALL)
+    assert np.array_equal(v2, v[perm]) and np.array_equal(d2, d[perm]) and np.array_equal(h2, h[perm])
+    ctx.close()
+
+
 def field3_no_neighbors(f):
     return np.array([len(n) == 0 for n in f.neighbors])
 

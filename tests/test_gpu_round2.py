@@ -50,6 +50,12 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu_equals_single_rank(tmp_path):
     d = _launch_bench(tmp_path, 2, shape + ["--backend", "gloo", "--steps", "3", "--warmup", "1", "--no-extras",
                                             "--check-dir", str(tmp_path)])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gather_backend"] == "gloo"
+    # the same run carries the OTHER driver too: rank 0 alone, one process, two group members (here both on the one device,
+    # peer copies; on a node: one per device, RCCL inside the library) while rank 1 waits on the rendezvous store
+    gd = d["group_driver"]
+    assert "error" not in gd, gd
+    assert gd["config"]["members"] == 2 and gd["config"]["gather_backend"] == "peer_copy" and gd["value"] > 0
+    assert gd["config"]["shard_sizes"] == d["config"]["shard_sizes"] and not gd["config"]["aborted"]
     sizes = d["config"]["shard_sizes"]
     assert sum(sizes) == 180 == d["config"]["sources_per_step"] and len(sizes) == 2 and min(sizes) > 0
     assert d["config"]["catalog_gather_bytes_per_step"] == 2 * max(sizes) * 45 * 8
