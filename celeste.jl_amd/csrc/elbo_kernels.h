@@ -417,11 +417,12 @@ __device__ inline double galaxy_value(const Comp *tc, int NC, double dx, double 
     for (int c0 = 0; c0 < NC; c0 += (c0 < n_dev ? 8 : 6)) {
         const int len = c0 < n_dev ? 8 : 6;
         const double d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
-        const double hd1 = -0.5 * d1, hd2 = -0.5 * d2;
+        // value only: -d' P d / 2 = p11 (-d1^2 / 2) + p12 (-d1 d2) + p22 (-d2^2 / 2) -- the three products of the offset once per
+        // run, three instructions per component where P d and d' (P d) take six (the derivative loops need P d itself)
+        const double s11 = -0.5 * (d1 * d1), s12 = -(d1 * d2), s22 = -0.5 * (d2 * d2);
         for (int c = c0; c < c0 + len; ++c) {
             const Comp k = tc[c];
-            const double u = k.p11 * d1 + k.p12 * d2, vv = k.p12 * d1 + k.p22 * d2;
-            v = __builtin_fma(k.w0, exp_nonpos(__builtin_fma(hd1, u, hd2 * vv), etab), v);
+            v = __builtin_fma(k.w0, exp_nonpos(__builtin_fma(k.p11, s11, __builtin_fma(k.p12, s12, k.p22 * s22)), etab), v);
         }
     }
     return v;
@@ -896,19 +897,19 @@ __device__ __forceinline__ void value_pixels_f2(int lane, const DevPatch &P, con
             const int len = c0 < n_dev ? 8 : 6;
             const f2v *k0 = tp + 3 * c0;
             const f2v d1 = dx - k0[3].xx, d2 = dy - k0[4].xx;
-            const f2v hd1 = -0.72134752044448170368f * d1, hd2 = -0.72134752044448170368f * d2;
+            // (as galaxy_value: the exponent from the three products of the offset, here with log2(e) folded in)
+            const f2v s11 = -0.72134752044448170368f * (d1 * d1), s12 = -1.44269504088896340736f * (d1 * d2),
+                      s22 = -0.72134752044448170368f * (d2 * d2);
             for (int c = c0; c < c0 + len; c += 2) {
                 const f2v *k = tp + 3 * c;
                 {
                     const f2v p11 = k[0].xx, p12 = k[1].xx, p22 = k[2].xx, w = k[5].xx;
-                    const f2v u = p11 * d1 + p12 * d2, vv = p12 * d1 + p22 * d2;
-                    const f2v q2 = hd1 * u + hd2 * vv;
+                    const f2v q2 = p11 * s11 + (p12 * s12 + p22 * s22);
                     f1 += w * (f2v){__builtin_amdgcn_exp2f(q2.x), __builtin_amdgcn_exp2f(q2.y)};
                 }
                 {
                     const f2v p11 = k[0].yy, p12 = k[1].yy, p22 = k[2].yy, w = k[5].yy;
-                    const f2v u = p11 * d1 + p12 * d2, vv = p12 * d1 + p22 * d2;
-                    const f2v q2 = hd1 * u + hd2 * vv;
+                    const f2v q2 = p11 * s11 + (p12 * s12 + p22 * s22);
                     f1 += w * (f2v){__builtin_amdgcn_exp2f(q2.x), __builtin_amdgcn_exp2f(q2.y)};
                 }
             }
@@ -1826,10 +1827,23 @@ __device__ __forceinline__ f2v galaxy_sums_px2(const f2v *tp, int n_dev, int nc,
             }
         };
         const f2v th0 = (f2v)(dev), th1 = (f2v)(1.0f - dev);
+        // (do-while: psf_K >= 1, so each profile type has at least one run -- a `for` makes the compiler keep a zeroed copy of
+        // every sum for the path around the loop: 52 register moves per trip of the pixel loop; measured 0.9 % on config 5)
+#ifndef PX2_DOWHILE
+#define PX2_DOWHILE 1
+#endif
+#if PX2_DOWHILE
+        { int c0 = 0; do { run(c0, 8, std::true_type(), U0); c0 += 8; } while (c0 < n_dev); }
+#else
         for (int c0 = 0; c0 < n_dev; c0 += 8) run(c0, 8, std::true_type(), U0);
+#endif
         S2a *= th0; S2b *= th0; S2c *= th0; S3a *= th0; S3b *= th0; S3c *= th0; S3d *= th0;
         S4a *= th0; S4b *= th0; S4c *= th0; S4d *= th0; S4e *= th0;
+#if PX2_DOWHILE
+        { int c0 = n_dev; do { run(c0, 6, std::false_type(), U1); c0 += 6; } while (c0 < nc); }
+#else
         for (int c0 = n_dev; c0 < nc; c0 += 6) run(c0, 6, std::false_type(), U1);
+#endif
         T.S0d = U0[0] + U1[0]; T.S1xd = U0[1] + U1[1]; T.S1yd = U0[2] + U1[2];
         T.S2ad = U0[3] + U1[3]; T.S2bd = U0[4] + U1[4]; T.S2cd = U0[5] + U1[5];
         T.S1x = th0 * U0[1] - th1 * U1[1]; T.S1y = th0 * U0[2] - th1 * U1[2];
@@ -1862,8 +1876,8 @@ __device__ __forceinline__ f2v galaxy_sums_px2(const f2v *tp, int n_dev, int nc,
                 comp(std::false_type(), k, d1, d2, hd1, hd2); comp(std::true_type(), k, d1, d2, hd1, hd2);
             }
         };
-        for (int c0 = 0; c0 < n_dev; c0 += 8) run(c0, 8);
-        for (int c0 = n_dev; c0 < nc; c0 += 6) run(c0, 6);
+        { int c0 = 0; do { run(c0, 8); c0 += 8; } while (c0 < n_dev); }
+        { int c0 = n_dev; do { run(c0, 6); c0 += 6; } while (c0 < nc); }
         T.S0d = S0d; T.S1x = S1x; T.S1y = S1y; T.S2an = S2an; T.S2bn = S2bn; T.S2cn = S2cn;
         return S0;
     }
@@ -1891,6 +1905,12 @@ __device__ __forceinline__ void accum_entries_rows2(const TT &T, double *__restr
 }
 
 // one iteration of the single-precision pixel loop: 128 pixels, lanes = the pixels base + lane and base + 64 + lane
+// PX2_GUARD 0 drops the two exec-mask guards below (they almost never skip anything, and without them the compiler keeps one
+// zeroed copy of the sums fewer: 912 -> 856 VALU per trip): measured 1.7 % SLOWER on config 5 (5.07 against 4.95 ms) -- the
+// masked-off lanes of the guarded region are what the kernel gains, not the skipped trips (profiles/r06_fp32_loop_variants.txt)
+#ifndef PX2_GUARD
+#define PX2_GUARD 1
+#endif
 template <int MODE>
 __device__ __forceinline__ void pixel_iter_px2(const PixWork<float> &W, int base, int p1, int lane, double *__restrict__ slot) {
     static_assert(MODE == 1 || MODE == 2, "derivative modes only");
@@ -1923,7 +1943,7 @@ __device__ __forceinline__ void pixel_iter_px2(const PixWork<float> &W, int base
     T.S2a = z; T.S2b = z; T.S2c = z; T.S2an = z; T.S2bn = z; T.S2cn = z; T.S2ad = z; T.S2bd = z; T.S2cd = z;
     T.S3a = z; T.S3b = z; T.S3c = z; T.S3d = z; T.S4a = z; T.S4b = z; T.S4c = z; T.S4d = z; T.S4e = z;
     // the component loop runs before the pixels' inputs are fetched (it needs only their coordinates)
-    if (own_geo[0] || own_geo[1])
+    if (PX2_GUARD ? (own_geo[0] || own_geo[1]) : true)
         S0 = galaxy_sums_px2<MODE>(reinterpret_cast<const f2v *>(W.tcr), 8 * (NC / 14), NC, PK2(hh[0] - si.m1, hh[1] - si.m1),
                                    PK2(ww[0] - si.m2, ww[1] - si.m2), (float)si.dev, T);
     // (one gather loop over the neighbours for both pixels -- their dependent loads issued together -- measured no faster:
@@ -1942,7 +1962,7 @@ __device__ __forceinline__ void pixel_iter_px2(const PixWork<float> &W, int base
 
     // Star: natural bicubic spline value + derivatives with respect to the index, index = h - m + 26
     T.f0 = z; T.f0g0 = z; T.f0g1 = z; T.f0h0 = z; T.f0h1 = z; T.f0h2 = z;
-    if (own[0] || own[1]) {
+    if (PX2_GUARD ? (own[0] || own[1]) : true) {
         const float *cc[2];
         float fxs[2], fys[2];
 #pragma unroll
