@@ -63,6 +63,7 @@ struct celeste_ctx {
     celeste_images *imgs = nullptr;
     hipStream_t stream = nullptr;        // private non-blocking stream of the host-pointer entry points
     hipStream_t copy_stream = nullptr;   // device-to-host copies of finished parts of a batch
+    bool copy_stream_checked = false;    // pick_copy_stream has run (first batch that overlaps copies with kernels)
     int N = 0, S = 0, K = 0, NC = 0, n_stamps = 0;
     int chunk_px = 256, CH = 1;
     int max_npx = 0;
@@ -968,6 +969,57 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     return CELESTE_OK;
 }
 
+// ---- a copy stream whose copies really run beside the kernels -------------------------------------------------------
+// HIP maps streams onto a few hardware queues in the order of their first use, and what else a queue carries decides
+// whether a device-to-host copy on the copy stream overlaps a kernel on `stream` at all: one context in four or so drew a
+// stream whose copies waited for the kernels (2.0 - 2.4 ms per host-pointer sweep of 2000 sources instead of 1.35;
+// profiles/r06_stream_lottery.txt), and creating the stream at another priority only moved the draw.  So the first batch
+// that relies on the overlap MEASURES it: a 4 MB copy on the candidate stream against a 300 us spin on `stream`; a
+// candidate whose copy ends inside the spin is kept, otherwise up to three fresh streams are tried and the quickest wins.
+// About a millisecond, once per context (CELESTE_COPY_STREAM_CHECK=0 skips it).
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static int pick_copy_stream(celeste_ctx_t *c) {
+    if (c->copy_stream_checked) return CELESTE_OK;
+    c->copy_stream_checked = true;
+    if (const char *e = getenv("CELESTE_COPY_STREAM_CHECK")) if (atoi(e) == 0) return CELESTE_OK;
+    const size_t bytes = 4u << 20;
+    void *d_buf = nullptr, *h_buf = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMalloc(&d_buf, bytes) != hipSuccess || hipHostMalloc(&h_buf, bytes, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_buf) (void)hipFree(d_buf);
+        if (h_buf) (void)hipHostFree(h_buf);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        return CELESTE_OK;       // (no measurement: the stream stays as it is)
+    }
+    const float spin_ms = 0.3f;
+    auto measure = [&](hipStream_t s, float *ms) -> bool {   // copy end relative to the spin's start
+        if (hipEventRecord(e0, c->stream) != hipSuccess) return false;
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, c->stream, (long long)(spin_ms * 1e5));   // wall_clock64: 100 MHz
+        if (hipStreamWaitEvent(s, e0, 0) != hipSuccess || hipMemcpyAsync(h_buf, d_buf, bytes, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipEventRecord(e1, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+            return false;
+        return hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+    };
+    float best = 0;
+    bool ok = measure(c->copy_stream, &best) && measure(c->copy_stream, &best);     // (the first use of a stream creates its queue)
+    for (int k = 0; ok && best > spin_ms && k < 3; ++k) {
+        hipStream_t s = nullptr;
+        float ms = 0;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        if (measure(s, &ms) && measure(s, &ms) && ms < best) { std::swap(s, c->copy_stream); best = ms; }
+        (void)hipStreamDestroy(s);
+    }
+    (void)hipGetLastError();
+    (void)hipFree(d_buf); (void)hipHostFree(h_buf); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return CELESTE_OK;
+}
+
 // ---- page-locked host memory ---------------------------------------------------------------------------------
 extern "C" void *celeste_host_alloc(size_t bytes) {
     void *p = nullptr;
@@ -1110,6 +1162,7 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
     int n_parts = 1;
     if (want_h) n_parts = (int)std::min<size_t>(celeste_ctx::MAX_PARTS, std::max<size_t>(1, n / 192));
     if (c->timing) n_parts = 1;   // the kernel timers describe one launch
+    if (n_parts > 1) (void)pick_copy_stream(c);
     double *const o_v = pin_v ? v : c->p_v;
     double *const o_d = want_d ? (pin_d ? d : c->p_d) : nullptr;
     double *const o_h = want_h ? (pin_h ? h : c->p_h) : nullptr;

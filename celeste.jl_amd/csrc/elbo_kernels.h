@@ -1385,7 +1385,19 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
                 });
             };
 #define IC(n) std::integral_constant<int, n>()
-            for (int c0 = 0; c0 < n_dev; c0 += 8) {
+            // (do-while, here and below: psf_K >= 1, so each profile type has at least one run; with a `for` the compiler keeps a
+            // zeroed copy of every sum for the path around the loop -- PX_DOWHILE 0 restores it for the A/B)
+#ifndef PX_DOWHILE
+#define PX_DOWHILE 1
+#endif
+#if PX_DOWHILE
+#define RUN_LOOP(init, cond, step) { init; do {
+#define RUN_LOOP_END(cond, step) step; } while (cond); }
+#else
+#define RUN_LOOP(init, cond, step) for (init; cond; step) {
+#define RUN_LOOP_END(cond, step) }
+#endif
+            RUN_LOOP(int c0 = 0, c0 < n_dev, c0 += 8)
                 const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
                 hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
                 const unsigned vb = base + 64u * (unsigned)c0, vbx = basex + (unsigned)(COMPX * 8) * (unsigned)c0;
@@ -1394,9 +1406,9 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
                 half_imm(ra, rb, IC(3), vb, vbx, U0, d1, d2, GWT); half_imm(rb, ra, IC(4), vb, vbx, U0, d1, d2, GWT);
                 half_imm(ra, rb, IC(5), vb, vbx, U0, d1, d2, GWT); half_imm(rb, ra, IC(6), vb, vbx, U0, d1, d2, GWT);
                 half_imm(ra, rb, IC(7), vb, vbx, U0, d1, d2, GWT); half_imm(rb, ra, IC(8), vb, vbx, U0, d1, d2, GWT);
-            }
+            RUN_LOOP_END(c0 < n_dev, c0 += 8)
             scale_dev(dev);
-            for (int c0 = n_dev; c0 < nc; c0 += 6) {
+            RUN_LOOP(int c0 = n_dev, c0 < nc, c0 += 6)
                 const R d1 = dx - tc[c0].xi1, d2 = dy - tc[c0].xi2;
                 hd1 = (R)-0.5 * d1; hd2 = (R)-0.5 * d2;
                 const unsigned vb = base + 64u * (unsigned)c0, vbx = basex + (unsigned)(COMPX * 8) * (unsigned)c0;
@@ -1404,7 +1416,9 @@ __device__ __forceinline__ double galaxy_sums(const CompR<R> *tc, int n_dev, int
                 half_imm(ra, rb, IC(1), vb, vbx, U1, d1, d2, GWF); half_imm(rb, ra, IC(2), vb, vbx, U1, d1, d2, GWF);
                 half_imm(ra, rb, IC(3), vb, vbx, U1, d1, d2, GWF); half_imm(rb, ra, IC(4), vb, vbx, U1, d1, d2, GWF);
                 half_imm(ra, rb, IC(5), vb, vbx, U1, d1, d2, GWF); half_imm(rb, ra, IC(6), vb, vbx, U1, d1, d2, GWF);
-            }
+            RUN_LOOP_END(c0 < nc, c0 += 6)
+#undef RUN_LOOP
+#undef RUN_LOOP_END
 #undef IC
             lds_wait_comp(ra);   // the last (unused) request must land before its registers are reused
         } else

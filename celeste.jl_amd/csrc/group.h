@@ -867,6 +867,7 @@ extern "C" int celeste_group_elbo_eval_batch(celeste_group_t *g, const double *v
     rc = group_run(g, [&](GroupMember *m) -> int {
         HIP_TRY(hipSetDevice(m->device));
         celeste_ctx *c = m->ctx;
+        if (want_h && !g->timing && m->tg.size() >= 2 * 192) (void)pick_copy_stream(c);    // (parts will overlap copies with kernels)
         hipStream_t st = c->stream, cs = c->copy_stream;
         double *b = m->d_block[0];
         const size_t nr = m->tg.size();
