@@ -710,9 +710,9 @@ def main():
                                "flops_per_pixel_visit": fpp, "pixel_visits": pixel_visits_local, "dtype": args.dtype,
                                "flops_source": "tools/count_flops.py on the compiled ISA (profiles/hbm_traffic.json; "
                                                "tests/test_dpp_hazard.py holds the file to the tree); every basic block LLVM's loop "
-                                               "annotations place in the pixel loop -- through profiles/r05e the count stopped at "
-                                               "the loop's first back edge and missed the star-spline blocks (2990 / 2793.5 per "
-                                               "visit then, 3217 / 3017.5 now, same kernels)",
+                                               "annotations place in the pixel loop, guarded blocks (star spline, own-geometry region) "
+                                               "included once per visit: a static count, an upper bound of the executed one by the "
+                                               "rare trips that skip them",
                                "instruction_mix": facts.get("instruction_mix_f32" if args.dtype == "f32" else "instruction_mix"),
                                "valu_utilization": hbm["valu_utilization"],
                                "hbm": hbm,

@@ -1102,12 +1102,12 @@ static int eval_small(celeste_ctx_t *c, const double *vp, int32_t n_targets, con
     return worst;
 }
 
-// The host-pointer sweep (what the Julia shim calls).  vp and the target list go up through page-locked staging;
-// the batch is cut into up to MAX_PARTS parts that are evaluated back to back on the context's stream, and each
-// part's results are copied down on the copy stream while the next part computes -- straight into the caller's
-// buffers when those are page-locked (celeste_host_alloc / celeste_host_register), else into page-locked staging
-// followed by a host copy of that part (which again overlaps the device work of the following parts).  Only the
-// context's own streams are waited for.
+// The host-pointer sweep (what the Julia shim calls).  vp and the target list go up through page-locked staging.  A page-locked
+// Hessian array (celeste_host_alloc / celeste_host_register) is written by the lift kernel itself through its device address:
+// one launch chain, nothing to copy.  Otherwise the batch is cut into up to MAX_PARTS parts that are evaluated back to back on
+// the context's stream while each finished part's results are copied down on the copy stream into page-locked staging,
+// followed by a host copy of that part (which overlaps the device work of the following parts).  Only the context's own
+// streams are waited for.
 extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32_t n_targets, const int32_t *targets,
                                        uint32_t flags, double *v, double *d, double *h, int64_t *counters,
                                        int32_t *status) try {
@@ -1162,6 +1162,13 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
     int n_parts = 1;
     if (want_h) n_parts = (int)std::min<size_t>(celeste_ctx::MAX_PARTS, std::max<size_t>(1, n / 192));
     if (c->timing) n_parts = 1;   // the kernel timers describe one launch
+    // Page-locked Hessians: the lift kernel writes them STRAIGHT into the caller's array (the device address of the mapped host
+    // block) -- no copy engine, no second stream, no cross-stream dependency per part, whose latency is what made one context in
+    // four slow (pick_copy_stream); the PCIe writes are the lift's own (CELESTE_HOST_ZERO_COPY=0: the copied parts).
+    static const bool zero_copy_h = !(getenv("CELESTE_HOST_ZERO_COPY") && atoi(getenv("CELESTE_HOST_ZERO_COPY")) == 0);
+    double *h_mapped = nullptr;
+    if (want_h && pin_h && zero_copy_h && !c->timing && hipHostGetDevicePointer((void **)&h_mapped, h, 0) == hipSuccess && h_mapped) n_parts = 1;
+    else { h_mapped = nullptr; (void)hipGetLastError(); }
     if (n_parts > 1) (void)pick_copy_stream(c);
     double *const o_v = pin_v ? v : c->p_v;
     double *const o_d = want_d ? (pin_d ? d : c->p_d) : nullptr;
@@ -1185,13 +1192,13 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
         int64_t n_chunks = 0;   // the targets are known here: exact size of the pixel kernel's work list
         for (int t = lo; t < lo + cnt; ++t) n_chunks += c->h_src_chunks[targets[t]];
         int st = launch_eval(c, c->d_vp, cnt, c->d_targets + lo, flags, c->d_v + lo, c->d_d + (size_t)lo * CEL_P,
-                             c->d_h + (size_t)lo * HS, c->d_cnt + 2 * (size_t)lo, c->d_status + lo, c->stream, true,
-                             nullptr, n_chunks, k > 0, nullptr, n_parts > 1);
+                             h_mapped ? h_mapped + (size_t)lo * HS : c->d_h + (size_t)lo * HS, c->d_cnt + 2 * (size_t)lo,
+                             c->d_status + lo, c->stream, true, nullptr, n_chunks, k > 0, nullptr, n_parts > 1);
         if (st != CELESTE_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy_stream); return st; }
         EB_TRY(hipEventRecord(c->part_done[k], c->stream));
         EB_TRY(hipStreamWaitEvent(c->copy_stream, c->part_done[k], 0));
-        if (o_h) EB_TRY(hipMemcpyAsync(o_h + (size_t)lo * HS, c->d_h + (size_t)lo * HS, (size_t)cnt * HS * sizeof(double),
-                                        hipMemcpyDeviceToHost, c->copy_stream));
+        if (o_h && !h_mapped) EB_TRY(hipMemcpyAsync(o_h + (size_t)lo * HS, c->d_h + (size_t)lo * HS, (size_t)cnt * HS * sizeof(double),
+                                                     hipMemcpyDeviceToHost, c->copy_stream));
         if (o_d) EB_TRY(hipMemcpyAsync(o_d + (size_t)lo * CEL_P, c->d_d + (size_t)lo * CEL_P,
                                         (size_t)cnt * CEL_P * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
         EB_TRY(hipMemcpyAsync(o_v + lo, c->d_v + lo, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));

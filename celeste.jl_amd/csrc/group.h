@@ -863,20 +863,27 @@ extern "C" int celeste_group_elbo_eval_batch(celeste_group_t *g, const double *v
     const size_t HS = (flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;
     const bool pin_h = want_h && is_pinned(h, (size_t)n_targets * HS * sizeof(double));
     int worst = CELESTE_OK;
-    g->sweep_k = 1;            // (celeste_group_sweep_results afterwards hands out this sweep: block 0)
+    g->sweep_k = 0;            // (the Hessians of this call went straight to the caller: nothing is left for celeste_group_sweep_results)
     rc = group_run(g, [&](GroupMember *m) -> int {
         HIP_TRY(hipSetDevice(m->device));
         celeste_ctx *c = m->ctx;
-        if (want_h && !g->timing && m->tg.size() >= 2 * 192) (void)pick_copy_stream(c);    // (parts will overlap copies with kernels)
         hipStream_t st = c->stream, cs = c->copy_stream;
         double *b = m->d_block[0];
         const size_t nr = m->tg.size();
         const bool direct = pin_h && shard_contiguous(m);
         if (want_h && nr > 0 && !direct) { int s1 = group_grow_pinned(&m->p_h, &m->p_h_cap, nr * HS); if (s1 != CELESTE_OK) return s1; }
         if (m->index == 0) { int s1 = group_grow_pinned(&m->p_gathered, &m->p_gathered_cap, blk * g->n); if (s1 != CELESTE_OK) return s1; }
-        // parts: at least 192 targets each so that a part still fills the chip; one part when nothing large comes back
+        // Hessians: the lift kernel writes them into page-locked host memory itself (its device address) -- the caller's array
+        // when the shard is a run of consecutive positions there (always, for a group of one), else this member's staging block,
+        // scattered on the host part by part while the next part computes.  No copy engine, no second stream.
+        double *h_dev = nullptr;
+        if (want_h && nr > 0) {
+            void *host = direct ? (void *)(h + (size_t)m->idx[0] * HS) : (void *)m->p_h;
+            if (hipHostGetDevicePointer((void **)&h_dev, host, 0) != hipSuccess || !h_dev) { (void)hipGetLastError(); h_dev = nullptr; }
+        }
+        // parts (staged Hessians only): at least 192 targets each so that a part still fills the chip
         int n_parts = 1;
-        if (want_h && !g->timing) n_parts = (int)std::min<size_t>(celeste_ctx::MAX_PARTS, std::max<size_t>(1, nr / 192));
+        if (want_h && !direct && h_dev && !g->timing) n_parts = (int)std::min<size_t>(celeste_ctx::MAX_PARTS, std::max<size_t>(1, nr / 192));
         size_t part_lo[celeste_ctx::MAX_PARTS + 1];
         for (int k = 0; k <= n_parts; ++k) part_lo[k] = nr * (size_t)k / (size_t)n_parts;
         int own_rc = CELESTE_OK, copies = 0;
@@ -886,14 +893,17 @@ extern "C" int celeste_group_elbo_eval_batch(celeste_group_t *g, const double *v
             const size_t lo = part_lo[k], cnt = part_lo[k + 1] - lo;
             int64_t n_chunks = 0;
             for (size_t i = lo; i < lo + cnt; ++i) n_chunks += c->h_src_chunks[m->tg[i]];
-            own_rc = launch_eval(c, m->d_vp, (int32_t)cnt, m->d_targets + lo, flags, b + lo, b + W + lo * CEL_P, m->d_h ? m->d_h + lo * HS : nullptr,
+            double *hk = h_dev ? h_dev + lo * HS : (m->d_h ? m->d_h + lo * HS : nullptr);
+            own_rc = launch_eval(c, m->d_vp, (int32_t)cnt, m->d_targets + lo, flags, b + lo, b + W + lo * CEL_P, hk,
                                  reinterpret_cast<int64_t *>(b + (size_t)W * (1 + CEL_P)) + 2 * lo,
                                  reinterpret_cast<int32_t *>(b + (size_t)W * (1 + CEL_P + 2)) + lo, st, true, nullptr, n_chunks, k > 0,
                                  nullptr, n_parts > 1);
             if (own_rc != CELESTE_OK || !want_h) continue;
-            if (hipEventRecord(c->part_done[k], st) != hipSuccess || hipStreamWaitEvent(cs, c->part_done[k], 0) != hipSuccess ||
-                group_hessians_down(m, h, direct, HS, lo, lo + cnt, cs) != CELESTE_OK ||
-                hipEventRecord(c->part_copied[k], cs) != hipSuccess) { (void)hipGetLastError(); own_rc = CELESTE_ERR_HIP; break; }
+            if (!h_dev) {    // (the block could not be mapped: copy on the copy stream, as the one-device entry does for pageable arrays)
+                if (hipEventRecord(c->part_done[k], st) != hipSuccess || hipStreamWaitEvent(cs, c->part_done[k], 0) != hipSuccess ||
+                    group_hessians_down(m, h, direct, HS, lo, lo + cnt, cs) != CELESTE_OK ||
+                    hipEventRecord(c->part_copied[k], cs) != hipSuccess) { (void)hipGetLastError(); own_rc = CELESTE_ERR_HIP; break; }
+            } else if (hipEventRecord(c->part_copied[k], st) != hipSuccess) { (void)hipGetLastError(); own_rc = CELESTE_ERR_HIP; break; }
             copies = k + 1;
         }
         // (a member whose launch failed still takes part in the gather: the collective needs every rank)

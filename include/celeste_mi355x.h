@@ -209,10 +209,11 @@ int celeste_ctx_create_on(celeste_images_t *images, const celeste_problem_t *pro
  * contexts never synchronise each other: the host-pointer entry points run on a private non-blocking stream of the
  * context and wait for that stream only. */
 
-/* Page-locked host memory for the host-pointer entry points.  Outputs (and vp) that live in memory obtained from
- * celeste_host_alloc, or registered with celeste_host_register, are copied straight from / to HBM by DMA,
- * overlapped with the kernels of the next part of the batch; pageable buffers work too but go through a staging
- * copy on the host.  (hipHostMalloc / hipHostRegister; no reference counterpart.) */
+/* Page-locked host memory for the host-pointer entry points.  A Hessian array that lives in memory obtained from
+ * celeste_host_alloc, or registered with celeste_host_register, is written by the kernels themselves (its device address,
+ * hipHostGetDevicePointer): one launch chain, no copy; other outputs of such memory are copied by DMA.  Pageable buffers
+ * work too: large batches are then cut into parts whose copies (through page-locked staging) overlap the kernels of the next
+ * part.  (hipHostMalloc / hipHostRegister; no reference counterpart.) */
 void *celeste_host_alloc(size_t bytes);
 void celeste_host_free(void *ptr);
 int celeste_host_register(void *ptr, size_t bytes);
@@ -228,8 +229,8 @@ int celeste_elbo_eval(celeste_ctx_t *ctx, const double *vp, int32_t target, uint
 /* One launch for a whole batch of targets that may be evaluated together
  * (a Cyclades batch, or every source of the field for an evaluate-only sweep).
  * Host pointers; v[n], d[n*44], h[n*44*44] (n*990 with CELESTE_FLAG_PACKED_HESS), counters[n*2], status[n].
- * Large batches are cut into parts whose device-to-host copies overlap the kernels of the next part (results do not
- * depend on the cut).  Targets may repeat.  Returns the first non-OK per-target status, if any; the outputs of
+ * Page-locked Hessian arrays are filled by the kernels directly; with pageable ones large batches are cut into parts whose
+ * device-to-host copies overlap the kernels of the next part (results do not depend on the cut).  Targets may repeat.  Returns the first non-OK per-target status, if any; the outputs of
  * the other targets are valid. */
 int celeste_elbo_eval_batch(celeste_ctx_t *ctx, const double *vp, int32_t n_targets,
                             const int32_t *targets, uint32_t flags,

@@ -4,7 +4,9 @@ counted in the compiled ISA (no GPU needed).
 usage: python tools/count_flops.py [--write]
 Prints the static counts and the per-visit figures bench.py uses: every basic block LLVM's loop annotations place inside the
 pixel loop, component-loop blocks times their trip counts; FMA = 2 flops, multiply / add = 1, packed fp32 instructions count
-both halves.  --write stores
+both halves.  The count is STATIC: a block behind an exec-mask guard (the star spline, the own-geometry region) is counted once
+per visit although a trip in which no lane has a covered pixel skips it -- an upper bound of the executed count by that margin
+(the hardware's SQ_INSTS_VALU per visit, prologues and partial waves included, sits ABOVE the static figure).  --write stores
 them in profiles/hbm_traffic.json (flops_per_pixel_visit, flops_per_pixel_visit_f32, instruction_mix, instruction_mix_f32)."""
 import json
 import os
