@@ -947,6 +947,10 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     // every gradient / Hessian entry is owned by one thread whatever the block size: 512 threads halve the latency of
     // a batch that leaves the chip mostly idle anyway; 256 keep 8 workgroups per CU for a 2000-target sweep
     const int lift_nt = n_targets <= 1024 ? 512 : 256;
+    // (beyond one round of 8 workgroups per CU the spill-free instantiation: see lift_kernel; CELESTE_LIFT_WAVES=8 / 7 forces one)
+    bool lift7 = n_targets > 4096;
+    if (const char *e = getenv("CELESTE_LIFT_WAVES")) lift7 = atoi(e) == 7;
+#define LAUNCH_LIFT(...) do { if (lift7) hipLaunchKernelGGL(lift_kernel<7>, __VA_ARGS__); else hipLaunchKernelGGL(lift_kernel<8>, __VA_ARGS__); } while (0)
     if (split) {
         // per-patch sums of the records, then the lift reads one record per (target, image): CH = 1
         // its own (part, patch) grid, part index slowest: streaming order matters more to this kernel than the idle
@@ -955,15 +959,16 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                            stream, c->d_patches, d_targets, c->d_tile_off, reinterpret_cast<const double2 *>(c->d_rec),
                            c->d_items, c->N, c->M, c->RCH, c->sum_tiles, c->d_acc_split, nullptr, c->d_work_total);
         if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], stream)); c->ev_split = 1; }
-        hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
+        LAUNCH_LIFT(dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                            c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M,
                            c->RCH, c->sum_tiles * 64, flags,
                            d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum, nullptr);
     } else
-    hipLaunchKernelGGL(lift_kernel, dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
+    LAUNCH_LIFT(dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                        c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M, CH,
                        chunk_px, flags,
                        d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum, c->d_rec_off);
+#undef LAUNCH_LIFT
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[3], stream)); c->ev_valid = 1; }
     HIP_TRY(hipGetLastError());
     return CELESTE_OK;

@@ -2873,9 +2873,12 @@ __device__ __forceinline__ void lift_target(LiftShared &L, const int tid, int ti
 #endif
 }
 
-// 8 waves per SIMD (64 VGPRs, a 52-byte spill) and 17.7 KB of LDS: 8 workgroups per CU, so that a 2000-target batch is
-// resident in one round (with 5 per CU it ran in two: 76 -> 65 us)
-__global__ void __launch_bounds__(512, 8)
+// WAVES = 8 per SIMD (64 VGPRs, a 36-byte spill) and 20 KB of LDS: 8 workgroups per CU, so that a 2000-target batch is resident
+// in one round (with 5 per CU it ran in two: 76 -> 65 us).  WAVES = 7 (72 VGPRs, an 8-byte spill) for batches that take many rounds
+// anyway: the spill is stored by every thread -- 36 B x 256 threads x 30 000 targets = 276 MB of the 724 MB the lift of config 5
+// wrote for 476 MB of results (launch_eval picks by batch size).  Same code, same results.
+template <int WAVES>
+__global__ void __launch_bounds__(512, WAVES)
 lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const DevPatch *__restrict__ patches, const SrcGeo *__restrict__ geo,
             const int64_t *__restrict__ nbr_off, const int32_t *__restrict__ nbr_idx,

@@ -81,3 +81,25 @@ def test_product_does_not_reference_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", ".inc")):
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "oracle" not in txt.lower(), os.path.join(dirpath, fn)
+
+
+def test_the_fake_rccl_of_the_tests_exports_every_rccl_symbol_the_library_imports(lib):
+    """tests/fake_rccl.c (the strict stand-in preloaded under tests/test_gpu_group_rccl_branch.py) must cover exactly what
+    libceleste_mi355x.so asks librccl for -- a collective the product starts calling and the stand-in lacks would silently bind to
+    the real library inside the child process"""
+    import subprocess
+    import __graft_entry__ as g
+    fake = os.path.join(g.ROOT, "tests", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        g.build()
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", g.LIB], capture_output=True, text=True, check=True).stdout
+    wanted = {ln.split()[-1] for ln in undefined.splitlines() if ln.split()[-1].startswith("nccl")}
+    defined = subprocess.run(["nm", "-D", "--defined-only", fake], capture_output=True, text=True, check=True).stdout
+    have = {ln.split()[-1] for ln in defined.splitlines()}
+    assert wanted and wanted <= have, wanted - have
+    assert {"ncclAllGather", "ncclCommInitAll", "ncclCommAbort", "ncclCommGetAsyncError"} <= wanted
+    # and the product itself never mentions the stand-in
+    for root, _, files in os.walk(os.path.join(g.ROOT, "celeste.jl_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                assert "fake_rccl" not in open(os.path.join(root, f)).read().replace("tests/fake_rccl.c", ""), f
