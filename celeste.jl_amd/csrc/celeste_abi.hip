@@ -670,7 +670,7 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
                        void *stream_, bool render_neighbors, const int32_t *d_active_rank = nullptr,
                        int64_t n_chunks = -1, bool tables_current = false, const int32_t *d_live = nullptr,
-                       bool prep_all = false, bool render_only = false);
+                       bool prep_all = false, bool render_only = false, const int32_t *d_h_pos = nullptr);
 
 extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_vp, int32_t n_targets,
                                               const int32_t *d_targets, uint32_t flags, double *d_v, double *d_d,
@@ -721,7 +721,9 @@ static int fused_buffers(celeste_ctx_t *c, size_t n, size_t rec, hipStream_t str
 static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, const int32_t *d_targets,
                        uint32_t flags, double *d_v, double *d_d, double *d_h, int64_t *d_counters, int32_t *d_status,
                        void *stream_, bool render_neighbors, const int32_t *d_active_rank, int64_t n_chunks,
-                       bool tables_current, const int32_t *d_live, bool prep_all, bool render_only) {
+                       bool tables_current, const int32_t *d_live, bool prep_all, bool render_only, const int32_t *d_h_pos) {
+    // d_h_pos (device, optional): target i's Hessian goes to slot d_h_pos[i] of d_h instead of slot i (celeste_group_*: a
+    // member's shard written to its places in the caller's array)
     // render_only: the batch's bookkeeping (SrcGeo, visit items, record offsets, marks), the per-image tables of the
     // targets and their neighbours and the neighbours' pre-rendered light -- everything the optimiser needs before its
     // first evaluation -- and no evaluation
@@ -789,11 +791,11 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     if (const char *e = getenv("CELESTE_CHUNK_GROUP")) if (atoi(e) >= 1 && atoi(e) <= 16) G = atoi(e);
     // small Hessian-mode fp64 batches: eval_fused_kernel instead of pixel_kernel + lift_kernel (below)
     bool eval_fused = !render_only && (flags & CELESTE_FLAG_HESS) && !(flags & (CELESTE_FLAG_FP32 | CELESTE_FLAG_SPLIT)) &&
-                      !d_active_rank && !d_live && d_d && d_h && n_targets <= EVAL_FUSED_MAX;
+                      !d_active_rank && !d_live && !d_h_pos && d_d && d_h && n_targets <= EVAL_FUSED_MAX;
     if (const char *e = getenv("CELESTE_EVAL_FUSED")) {
         if (atoi(e) == 0) eval_fused = false;
         else if (atoi(e) == 1) eval_fused = !render_only && (flags & CELESTE_FLAG_HESS) && !(flags & (CELESTE_FLAG_FP32 | CELESTE_FLAG_SPLIT)) &&
-                                          !d_active_rank && !d_live && d_d && d_h;
+                                          !d_active_rank && !d_live && !d_h_pos && d_d && d_h;
     }
     if (eval_fused) G = 1;        // one record per work item: the work-list total is the batch's number of records
     const int n_classes = WORK_CLASSES;   // work-list classes: full groups, then the patches' last groups by length
@@ -962,12 +964,12 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         LAUNCH_LIFT(dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                            c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc_split, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M,
                            c->RCH, c->sum_tiles * 64, flags,
-                           d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum, nullptr);
+                           d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum, nullptr, d_h_pos);
     } else
     LAUNCH_LIFT(dim3(n_targets), dim3(lift_nt), 0, stream, d_vp, c->d_images, c->d_patches, c->d_geo,
                        c->d_nbr_off, c->d_nbr_idx, d_targets, c->d_acc, c->d_prior, c->d_vis_off, c->d_vis_img, c->N, c->M, CH,
                        chunk_px, flags,
-                       d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum, c->d_rec_off);
+                       d_v, d_d, d_h, d_counters, d_status, d_live, d_active_rank ? nullptr : c->d_lg_sum, c->d_rec_off, d_h_pos);
 #undef LAUNCH_LIFT
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[3], stream)); c->ev_valid = 1; }
     HIP_TRY(hipGetLastError());

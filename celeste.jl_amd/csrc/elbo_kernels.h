@@ -2887,14 +2887,17 @@ lift_kernel(const double *__restrict__ vp, const DevImage *__restrict__ images,
             const int32_t *__restrict__ vis_img, int N, int M, int CH, int chunk_px, uint32_t flags,
             double *__restrict__ out_v, double *__restrict__ out_d, double *__restrict__ out_h,
             int64_t *__restrict__ out_cnt, int32_t *__restrict__ out_status, const int32_t *__restrict__ live,
-            const double *__restrict__ lg_sum, const int32_t *__restrict__ rec_off) {
+            const double *__restrict__ lg_sum, const int32_t *__restrict__ rec_off, const int32_t *__restrict__ h_pos) {
     if (live && (int)blockIdx.x >= *live) return;
     __shared__ LiftShared L;
     const int ti = blockIdx.x;
     const size_t HS = (flags & CELESTE_FLAG_PACKED_HESS) ? CELESTE_HP : (size_t)CEL_P * CEL_P;
+    // h_pos (optional): the Hessian of target ti goes to slot h_pos[ti] of out_h -- a device group's member writes its shard's
+    // Hessians to their places in the CALLER's (mapped, page-locked) array
+    const size_t hslot = h_pos ? (size_t)h_pos[ti] : (size_t)ti;
     lift_target<false>(L, threadIdx.x, ti, targets[ti], vp, images, patches, geo, nbr_off, nbr_idx, acc, prior, vis_off, vis_img, N, M, CH,
                        chunk_px, flags, out_v + ti, out_d ? out_d + (size_t)ti * CEL_P : nullptr,
-                       out_h ? out_h + (size_t)ti * HS : nullptr, out_cnt ? out_cnt + 2 * (size_t)ti : nullptr, out_status + ti,
+                       out_h ? out_h + hslot * HS : nullptr, out_cnt ? out_cnt + 2 * (size_t)ti : nullptr, out_status + ti,
                        lg_sum, rec_off);
 }
 

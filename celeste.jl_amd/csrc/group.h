@@ -75,7 +75,7 @@ struct GroupMember {
     hipEvent_t done[2] = {}, buf_free[2] = {}, t0 = nullptr, t1 = nullptr, t2 = nullptr;
     // device
     double *d_vp = nullptr, *d_vp_nbr = nullptr, *d_entry = nullptr;   // S x 44 tables
-    int32_t *d_targets = nullptr;
+    int32_t *d_targets = nullptr, *d_idx = nullptr;     // the shard's targets; their positions in the caller's list
     double *d_pos = nullptr;
     int32_t *d_it = nullptr, *d_ev = nullptr, *d_st = nullptr;
     double *d_el = nullptr;
@@ -390,8 +390,8 @@ extern "C" void celeste_group_destroy(celeste_group_t *g) {
         if (m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
         if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
         if (m->comm) (void)ncclCommDestroy(m->comm);
-        void *dp[] = {m->d_vp, m->d_vp_nbr, m->d_entry, m->d_targets, m->d_pos, m->d_it, m->d_ev, m->d_st, m->d_el, m->d_block[0], m->d_block[1],
-                      m->d_gathered, m->d_h};
+        void *dp[] = {m->d_vp, m->d_vp_nbr, m->d_entry, m->d_targets, m->d_idx, m->d_pos, m->d_it, m->d_ev, m->d_st, m->d_el, m->d_block[0],
+                      m->d_block[1], m->d_gathered, m->d_h};
         for (void *p : dp) if (p) (void)hipFree(p);
         if (m->p_gathered) (void)hipHostFree(m->p_gathered);
         if (m->p_h) (void)hipHostFree(m->p_h);
@@ -572,10 +572,11 @@ static int group_target_buffers(GroupMember *m, size_t n) {
     if (n <= m->tgt_cap && m->d_targets) return CELESTE_OK;
     HIP_TRY(hipStreamSynchronize(m->ctx->stream));
     HIP_TRY(hipStreamSynchronize(m->comm_stream));
-    void **ps[] = {(void **)&m->d_targets, (void **)&m->d_pos, (void **)&m->d_it, (void **)&m->d_ev, (void **)&m->d_st, (void **)&m->d_el};
-    const size_t by[] = {sizeof(int32_t), 2 * sizeof(double), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t), sizeof(double)};
+    void **ps[] = {(void **)&m->d_targets, (void **)&m->d_pos, (void **)&m->d_it, (void **)&m->d_ev, (void **)&m->d_st, (void **)&m->d_el,
+                   (void **)&m->d_idx};
+    const size_t by[] = {sizeof(int32_t), 2 * sizeof(double), sizeof(int32_t), sizeof(int32_t), sizeof(int32_t), sizeof(double), sizeof(int32_t)};
     m->tgt_cap = 0;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 7; ++k) {
         if (*ps[k]) { (void)hipFree(*ps[k]); *ps[k] = nullptr; }
         HIP_TRY(hipMalloc(ps[k], std::max<size_t>(n, 1) * by[k]));
     }
@@ -635,8 +636,10 @@ static int group_plan_locked(celeste_group *g, const double *vp, int32_t n_targe
         if (s1 == CELESTE_OK && want_h) s1 = group_grow(&m->d_h, &m->h_cap, std::max<size_t>(m->tg.size(), 1) * HS, st);
         if (s1 != CELESTE_OK) return s1;
         HIP_TRY(hipMemcpyAsync(m->d_vp, g->p_vp, (size_t)g->S * CEL_P * sizeof(double), hipMemcpyHostToDevice, st));
-        if (!m->tg.empty())
+        if (!m->tg.empty()) {
             HIP_TRY(hipMemcpyAsync(m->d_targets, m->tg.data(), m->tg.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(m->d_idx, m->idx.data(), m->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        }
         for (int k = 0; k < 2; ++k) HIP_TRY(hipEventRecord(m->buf_free[k], st));
         if (sync) HIP_TRY(hipStreamSynchronize(st));
         return CELESTE_OK;
@@ -870,17 +873,19 @@ extern "C" int celeste_group_elbo_eval_batch(celeste_group_t *g, const double *v
         hipStream_t st = c->stream, cs = c->copy_stream;
         double *b = m->d_block[0];
         const size_t nr = m->tg.size();
-        const bool direct = pin_h && shard_contiguous(m);
-        if (want_h && nr > 0 && !direct) { int s1 = group_grow_pinned(&m->p_h, &m->p_h_cap, nr * HS); if (s1 != CELESTE_OK) return s1; }
-        if (m->index == 0) { int s1 = group_grow_pinned(&m->p_gathered, &m->p_gathered_cap, blk * g->n); if (s1 != CELESTE_OK) return s1; }
-        // Hessians: the lift kernel writes them into page-locked host memory itself (its device address) -- the caller's array
-        // when the shard is a run of consecutive positions there (always, for a group of one), else this member's staging block,
-        // scattered on the host part by part while the next part computes.  No copy engine, no second stream.
+        // Hessians: the lift kernel writes them into page-locked host memory itself (its device address).  A page-locked array of
+        // the caller's takes every member's shard directly, each Hessian at its target's position in the caller's order (the
+        // lift's position map: d_idx) -- no staging, no host scatter, whatever the number of members.  A pageable array goes
+        // through this member's page-locked staging block, scattered on the host part by part while the next part computes.
+        // No copy engine, no second stream.
+        bool direct = pin_h;
         double *h_dev = nullptr;
-        if (want_h && nr > 0) {
-            void *host = direct ? (void *)(h + (size_t)m->idx[0] * HS) : (void *)m->p_h;
-            if (hipHostGetDevicePointer((void **)&h_dev, host, 0) != hipSuccess || !h_dev) { (void)hipGetLastError(); h_dev = nullptr; }
+        if (want_h && nr > 0 && direct && (hipHostGetDevicePointer((void **)&h_dev, h, 0) != hipSuccess || !h_dev)) { (void)hipGetLastError(); h_dev = nullptr; direct = false; }
+        if (want_h && nr > 0 && !direct) {
+            int s1 = group_grow_pinned(&m->p_h, &m->p_h_cap, nr * HS); if (s1 != CELESTE_OK) return s1;
+            if (hipHostGetDevicePointer((void **)&h_dev, m->p_h, 0) != hipSuccess || !h_dev) { (void)hipGetLastError(); h_dev = nullptr; }
         }
+        if (m->index == 0) { int s1 = group_grow_pinned(&m->p_gathered, &m->p_gathered_cap, blk * g->n); if (s1 != CELESTE_OK) return s1; }
         // parts (staged Hessians only): at least 192 targets each so that a part still fills the chip
         int n_parts = 1;
         if (want_h && !direct && h_dev && !g->timing) n_parts = (int)std::min<size_t>(celeste_ctx::MAX_PARTS, std::max<size_t>(1, nr / 192));
@@ -893,15 +898,16 @@ extern "C" int celeste_group_elbo_eval_batch(celeste_group_t *g, const double *v
             const size_t lo = part_lo[k], cnt = part_lo[k + 1] - lo;
             int64_t n_chunks = 0;
             for (size_t i = lo; i < lo + cnt; ++i) n_chunks += c->h_src_chunks[m->tg[i]];
-            double *hk = h_dev ? h_dev + lo * HS : (m->d_h ? m->d_h + lo * HS : nullptr);
+            // (direct: the base of the caller's array + the position map; staged / device: slot i of this member's block)
+            double *hk = direct ? h_dev : (h_dev ? h_dev + lo * HS : (m->d_h ? m->d_h + lo * HS : nullptr));
             own_rc = launch_eval(c, m->d_vp, (int32_t)cnt, m->d_targets + lo, flags, b + lo, b + W + lo * CEL_P, hk,
                                  reinterpret_cast<int64_t *>(b + (size_t)W * (1 + CEL_P)) + 2 * lo,
                                  reinterpret_cast<int32_t *>(b + (size_t)W * (1 + CEL_P + 2)) + lo, st, true, nullptr, n_chunks, k > 0,
-                                 nullptr, n_parts > 1);
+                                 nullptr, n_parts > 1, false, direct ? m->d_idx + lo : nullptr);
             if (own_rc != CELESTE_OK || !want_h) continue;
             if (!h_dev) {    // (the block could not be mapped: copy on the copy stream, as the one-device entry does for pageable arrays)
                 if (hipEventRecord(c->part_done[k], st) != hipSuccess || hipStreamWaitEvent(cs, c->part_done[k], 0) != hipSuccess ||
-                    group_hessians_down(m, h, direct, HS, lo, lo + cnt, cs) != CELESTE_OK ||
+                    group_hessians_down(m, h, false, HS, lo, lo + cnt, cs) != CELESTE_OK ||
                     hipEventRecord(c->part_copied[k], cs) != hipSuccess) { (void)hipGetLastError(); own_rc = CELESTE_ERR_HIP; break; }
             } else if (hipEventRecord(c->part_copied[k], st) != hipSuccess) { (void)hipGetLastError(); own_rc = CELESTE_ERR_HIP; break; }
             copies = k + 1;
