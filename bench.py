@@ -1088,7 +1088,23 @@ def config5_record(args):
     keep["sources_per_step"] = d["config"]["sources_per_step"]
     keep["pixel_visits_per_sweep"] = d["config"]["pixel_visits_per_sweep"]
     keep["roofline_valu"] = d["roofline"].get("valu")
-    keep["roofline_hbm_frac"] = d["roofline"].get("hbm", d["roofline"])["frac"]
+    hbm = d["roofline"].get("hbm", d["roofline"])
+    keep["roofline_hbm_frac"] = hbm["frac"]
+    # counter traffic of the fp32 pixel kernel at this size: three rocprofv3 passes over 30 000 sources take minutes, so the figure
+    # is the committed one (tools/pmc_config5.sh -> profiles/<tag>_config5_pmc.json), not measured in this run
+    try:
+        import glob
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_config5_pmc.json")))[-1]
+        pk = json.load(open(prof))["pixel_kernel<2, float, false>"]
+        traffic = (pk["fetch_kib"] + pk["write_kib"]) * 1024.0
+        keep["roofline_hbm"] = {"achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"], "frac": hbm["frac"],
+                                "algorithmic_bytes_per_launch": hbm.get("algorithmic_bytes_per_launch"), "traffic": traffic,
+                                "traffic_measured_in_this_run": False,
+                                "traffic_over_algorithmic": traffic / hbm["algorithmic_bytes_per_launch"] if hbm.get("algorithmic_bytes_per_launch") else None,
+                                "traffic_source": os.path.relpath(prof, ROOT) + " (FETCH_SIZE + WRITE_SIZE, KiB x 1024, uncorrected; the "
+                                                  "writes include the kernel's 56 B per lane of scratch, stored once per work item)"}
+    except Exception:
+        pass
     if "shard_projection" in d:
         keep["shard_projection"] = d["shard_projection"]
     keep["wall_s_including_field_generation"] = time.time() - t0

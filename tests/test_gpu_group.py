@@ -272,6 +272,39 @@ def test_group_joint_inference_without_cross_member_reads_is_one_segment():
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_group_joint_inference_segments_fuzz(crowded, seed):
+    """random Cyclades schedules (batch size, sweeps, target subset) over two or three members: wherever the host cuts the
+    segments, table and per-entry outputs are celeste_joint_infer's on the flattened schedule, bit for bit, and every member has
+    enqueued the same number of exchanges"""
+    import celeste_jl_amd as cel
+    from celeste_jl_amd.group import cyclades_schedule, schedule_layers
+    f, ctx = crowded
+    S = len(f.catalog)
+    rng = np.random.default_rng(900 + seed)
+    targets = sorted(rng.choice(S, int(rng.integers(8, S + 1)), replace=False).tolist())
+    n_sweeps = int(rng.integers(1, 4))
+    batch = int(rng.choice([3, 5, 9, 14, 40]))
+    devices = [0] * int(rng.integers(2, 4))
+    b_off, c_off, flat = cyclades_schedule(targets, f.neighbors, batch_size=batch, rng=np.random.default_rng(seed))
+    layers, entries = schedule_layers(b_off, c_off, flat, n_sweeps)
+    cfg = cel.ElboConfig(max_iters=4)
+    pos = f.vp[flat, 0:2] + 0.01 * rng.standard_normal((len(flat), 2))
+    ref = ctx.joint_infer(f.vp, layers, cfg, pos_centers=[pos[e] for e in entries])
+    n_layers_per_sweep = len(layers) // n_sweeps
+    flat_entry = np.concatenate([np.asarray(e) + (k // n_layers_per_sweep) * len(flat) for k, e in enumerate(entries)])
+    g = _group(f, devices)
+    new, its, evals, el, st, nx = g.joint_infer(f.vp, b_off, c_off, flat, n_sweeps, cfg, pos_centers=pos)
+    assert 1 <= nx <= n_sweeps * (len(b_off) - 1)
+    assert np.array_equal(new, ref[0]), (seed, devices, batch, n_sweeps, np.abs(new - ref[0]).max())
+    for got, want in ((its, ref[1]), (evals, ref[2]), (el, ref[3]), (st, ref[4])):
+        assert np.array_equal(got.reshape(-1)[flat_entry], want)
+    enq, aborted = g.collectives()
+    assert not aborted and len(set(enq)) == 1 and enq[0] == nx
+    print("segments fuzz", seed, "members", len(devices), "batch", batch, "sweeps", n_sweeps, "batches", len(b_off) - 1, "exchanges", nx)
+    g.close()
+
+
 def test_group_on_the_bench_field_two_members_one_device():
     """config 3 at full size: 2000 targets, two members -- the sweep and one batch of joint inference"""
     import celeste_jl_amd as cel
