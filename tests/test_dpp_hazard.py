@@ -114,3 +114,34 @@ def test_the_flop_counts_bench_reports_are_those_of_this_tree():
         flops, mix, _ = cf.analyse(txt, sym, pixels_per_lane=cf.PIXELS_PER_LANE[key])
         assert flops == committed["flops_per_pixel_visit" + key], (key, flops, committed["flops_per_pixel_visit" + key])
         assert mix == committed["instruction_mix" + key], (key, mix, committed["instruction_mix" + key])
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_the_fp32_pixel_kernels_scratch_stays_out_of_its_loops():
+    """pixel_kernel<2, float> keeps 56 B per lane in scratch at three waves per SIMD (measured faster than two waves and none).
+    Where the spill code sits, from LLVM's loop annotations in the listing: STORES only in the kernel's prologue and once per
+    work item (depth <= 1: the work-list loop) -- never per chunk or per trip --; inside the pixel loop (depth 3) at most two
+    8-byte reloads per 128-pixel trip; nothing at all inside the component loops (depth >= 4).  The fp64 kernel has no scratch."""
+    import count_flops as cf
+    txt = "\n".join(compiled_listing())
+
+    def scratch_by_depth(sym):
+        i = txt.index(sym); i = txt.index(":\n", i)
+        lines = txt[i:txt.index("s_endpgm", i)].split("\n")
+        blocks, parent = cf.blocks_of(lines)
+
+        def depth(lp):
+            return 0 if lp is None else 1 + depth(parent.get(lp))
+        out = []
+        for _, a, b, lp in blocks:
+            for ln in lines[a:b + 1]:
+                t = ln.strip().split()
+                if t and t[0].startswith("scratch_"):
+                    out.append((depth(lp), t[0]))
+        return out
+    f32 = scratch_by_depth("_Z12pixel_kernelILi2EfLb0EEv")
+    assert f32, "the kernel no longer spills: tighten tests/test_dpp_hazard.py and DESIGN.md"
+    assert all(d <= 1 for d, op in f32 if op.startswith("scratch_store")), f32
+    assert sum(1 for d, op in f32 if d == 3) <= 2 and all(op.startswith("scratch_load") for d, op in f32 if d >= 2), f32
+    assert not [x for x in f32 if x[0] >= 4], f32
+    assert scratch_by_depth("_Z12pixel_kernelILi2EdLb0EEv") == []
