@@ -278,11 +278,11 @@ def group_joint_infer(group, catalog, target_sources: Sequence[int], neighbors: 
                       cfg: Optional[ElboConfig] = None, batch_size: int = 400, n_iters: int = NUM_JOINT_VI_ITERS,
                       rng: Optional[np.random.Generator] = None, failed: Optional[set] = None) -> np.ndarray:
     """one_node_joint_infer (ParallelRun.jl:135-196) over the devices of a `group.FieldGroup`: the connected components of
-    every Cyclades batch are sharded over the members, the rows a batch updated are exchanged once per batch
+    every Cyclades batch are sharded over the members, and rows are exchanged in front of every batch in which a member reads a
+    row another member wrote since the last exchange -- at most once per batch, once in all for a group of one
     (celeste_group_joint_infer).  Same table as one_node_joint_infer on one device, bit for bit.
-    batch_size is the reference's (Config: 400 sources per Cyclades batch, sized for CPU threads); a device wants batches of
-    thousands -- every batch is a launch that ends on its slowest component, and an exchange (30 000
-    sources, 0.75 s per sweep with batches of 400, 0.56 s with 4000)."""
+    batch_size is the reference's (Config: 400 sources per Cyclades batch, sized for CPU threads); several devices want batches
+    of thousands -- between two exchanges a member's launch ends on its slowest component."""
     from .group import cyclades_schedule
     targets = list(target_sources)
     vp = init_source_table(catalog, targets)
