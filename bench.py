@@ -484,7 +484,7 @@ def main():
             try:
                 if n_dev < world and args.backend == "nccl":
                     raise RuntimeError("rank 0 sees %d device(s), the group needs %d" % (n_dev, world))
-                group_rec = group_measure(args, fld, [r % n_dev for r in range(world)], flags, check=False)
+                group_rec = group_driver_child(args, [r % n_dev for r in range(world)])
             except Exception as e:      # (the ranks' line does not depend on it)
                 group_rec = {"error": repr(e)}
             store.set("celeste_group_driver_done", "1")
@@ -786,6 +786,34 @@ def group_main(args):
     print(json.dumps(out))
     sys.stdout.flush()
     os.dup2(2, 1)
+
+
+GROUP_CHILD_TIMEOUT_S = 300
+
+
+def group_driver_child(args, devices):
+    """The group driver's line for the ranks' run at N > 1, from a CHILD process of rank 0 (`bench.py --driver group` over the
+    same devices, outside the launcher's environment) under a time limit: the in-library driver has never met more than one
+    real device, and whatever it does on its first node -- a communicator that does not come up, a
+    crash -- must cost the ranks' line a `group_driver.error`, not the line itself."""
+    import subprocess
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE",
+            "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--driver", "group", "--gpus", str(len(devices)),
+           "--group-devices", ",".join(str(d) for d in devices), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--config", str(args.config), "--dtype", args.dtype, "--height", str(args.height), "--width", str(args.width),
+           "--sources", str(args.sources), "--seed", str(args.seed), "--grid", args.grid, "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=GROUP_CHILD_TIMEOUT_S)
+    except subprocess.TimeoutExpired:
+        return {"error": "the group driver's process did not finish within %d s (killed)" % GROUP_CHILD_TIMEOUT_S}
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "the group driver's process ended with code %d" % r.returncode, "stderr_tail": r.stderr[-600:]}
+    rec = json.loads(lines[-1])
+    rec["process"] = "child of rank 0 (time limit %d s)" % GROUP_CHILD_TIMEOUT_S
+    return rec
 
 
 def group_measure(args, fld, devices, flags, check=True):
