@@ -441,12 +441,17 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
 
     // conditioned + prefiltered star splines
     {
-        std::vector<double> coefs((size_t)c->n_stamps * CEL_COEF * CEL_COEF);
-        for (int k = 0; k < c->n_stamps; ++k)
-            celeste_spline_prefilter(pr->stamps + (size_t)k * CEL_STAMP * CEL_STAMP, coefs.data() + (size_t)k * CEL_COEF * CEL_COEF);
-        CTX_TRY(dev_upload(&c->d_coefs, coefs.data(), coefs.size()));
-        std::vector<float> coefs_f(coefs.begin(), coefs.end());
-        CTX_TRY(dev_upload(&c->d_coefs_f, coefs_f.data(), coefs_f.size()));
+        // (on the device: spline_prefilter_kernel -- the raw stamps go up, the coefficient tables never exist on the host)
+        double *d_stamps = nullptr;
+        CTX_TRY(dev_upload(&d_stamps, pr->stamps, (size_t)c->n_stamps * CEL_STAMP * CEL_STAMP));
+        int st_c = dev_upload<double>(&c->d_coefs, nullptr, (size_t)c->n_stamps * CEL_COEF * CEL_COEF);
+        if (st_c == CELESTE_OK) st_c = dev_upload<float>(&c->d_coefs_f, nullptr, (size_t)c->n_stamps * CEL_COEF * CEL_COEF);
+        if (st_c == CELESTE_OK) {
+            hipLaunchKernelGGL(spline_prefilter_kernel, dim3((unsigned)c->n_stamps), dim3(64), 0, nullptr, d_stamps, c->d_coefs, c->d_coefs_f);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) st_c = CELESTE_ERR_HIP;
+        }
+        (void)hipFree(d_stamps);
+        CTX_TRY(st_c);
     }
 
     // neighbour CSR

@@ -279,6 +279,80 @@ patch_lgamma_kernel(const DevImage *__restrict__ images, const DevPatch *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// spline_prefilter_kernel: the ImagePatch constructor's arithmetic for every PSF stamp of a context
+// (imaged_sources.jl:97-107: max(., 0), + 1e-6, normalise, softpluslike, then the prefilter of
+// interpolate(., BSpline(Cubic(Line())), OnGrid()): a (1, 4, 1) / 6 tridiagonal solve along each axis on a padded 53 x 53
+// grid) -- what celeste_spline_prefilter does for one stamp on the host.  Production Celeste has one stamp per (source,
+// image) patch (SDSSPSFMap evaluated at every source): 8765 on the bench field, 55 us each on a host core = 0.48 s of
+// celeste_ctx_create against a 0.06 s joint inference of the whole field.  One 64-thread workgroup per stamp; the same
+// operations in the same order as the host function (no contraction; the sum of the stamp in index order), so the
+// coefficients are the host's wherever the device's log agrees with libm's to the last bit, and within an ulp elsewhere.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void prefilter_line_dev(const double *__restrict__ d, int dstride, double *__restrict__ c, int cstride,
+                                                   const double *__restrict__ cp) {
+#pragma clang fp contract(off)
+    constexpr int n = CEL_STAMP, m = CEL_STAMP - 2;
+    const double x1 = d[0], xn = d[(n - 1) * dstride];
+    // forward sweep: dp[q] is kept in its final place c[2 + q]
+    double prev = 0.0;
+    for (int q = 0; q < m; ++q) {
+        double rhs = 6.0 * d[(q + 1) * dstride];
+        if (q == 0) rhs -= x1;
+        if (q == m - 1) rhs -= xn;
+        const double lower = (q == 0) ? 0.0 : 1.0;
+        const double denom = 4.0 - lower * (q ? cp[q - 1] : 0.0);
+        prev = (rhs - lower * prev) / denom;
+        c[(2 + q) * cstride] = prev;
+    }
+    double nxt = prev;                                    // x[2 + m - 1] = dp[m - 1]
+    for (int q = m - 2; q >= 0; --q) {
+        nxt = c[(2 + q) * cstride] - cp[q] * nxt;
+        c[(2 + q) * cstride] = nxt;
+    }
+    c[1 * cstride] = x1;
+    c[n * cstride] = xn;
+    c[0] = 2.0 * x1 - c[2 * cstride];
+    c[(n + 1) * cstride] = 2.0 * xn - c[(n - 1) * cstride];
+}
+__global__ void __launch_bounds__(64)
+spline_prefilter_kernel(const double *__restrict__ stamps, double *__restrict__ coefs, float *__restrict__ coefs_f) {
+#pragma clang fp contract(off)
+    constexpr int n = CEL_STAMP, m = CEL_COEF;
+    __shared__ double g[n * n];
+    __shared__ double tmp[m * n];
+    __shared__ double cp[n];
+    __shared__ double s_sum;
+    const int t = threadIdx.x;
+    const double *__restrict__ s = stamps + (size_t)blockIdx.x * (n * n);
+    double *__restrict__ out = coefs + (size_t)blockIdx.x * (m * m);
+    for (int k = t; k < n * n; k += 64) g[k] = fmax(s[k], 0.0) + 1e-6;
+    if (t == 1) {           // the Thomas factors of the (1, 4, 1) system: the same for every line
+        double prev = 0.0;
+        for (int q = 0; q < n - 2; ++q) { const double denom = 4.0 - (q ? 1.0 : 0.0) * prev; prev = 1.0 / denom; cp[q] = prev; }
+    }
+    __syncthreads();
+    if (t == 0) {           // the host's sum, in its order
+        double sum = 0.0;
+        for (int k = 0; k < n * n; ++k) sum += g[k];
+        s_sum = sum;
+    }
+    __syncthreads();
+    const double sum = s_sum;
+    for (int k = t; k < n * n; k += 64) {
+        const double x = g[k] / sum;
+        g[k] = (1000 * x > 1) ? 1000 * x - 1 : log(1000 * x);   // softpluslike (fsm_util.jl:221)
+    }
+    __syncthreads();
+    if (t < n) prefilter_line_dev(g + n * t, 1, tmp + m * t, 1, cp);
+    __syncthreads();
+    if (t < m) prefilter_line_dev(tmp + t, m, out + t, m, cp);
+    __syncthreads();
+    __threadfence_block();
+    float *__restrict__ outf = coefs_f + (size_t)blockIdx.x * (m * m);
+    for (int k = t; k < m * m; k += 64) outf[k] = (float)out[k];
+}
+
+// ---------------------------------------------------------------------------------------------
 // pixel_kernel
 // ---------------------------------------------------------------------------------------------
 template <typename S>
