@@ -86,7 +86,8 @@ class CelesteError(RuntimeError):
 EXPORTED_SYMBOLS = [
     "celeste_version", "celeste_strerror", "celeste_ctx_create", "celeste_ctx_destroy", "celeste_elbo_eval",
     "celeste_elbo_eval_batch", "celeste_elbo_eval_multi", "celeste_elbo_eval_batch_device", "celeste_ctx_enable_timing",
-    "celeste_ctx_last_kernel_ms", "celeste_ctx_last_record_sum_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter", "celeste_psf_raster",
+    "celeste_ctx_last_kernel_ms", "celeste_ctx_last_record_sum_ms", "celeste_ctx_work_stats", "celeste_spline_prefilter",
+    "celeste_ctx_spline_coefficients", "celeste_psf_raster",
     "celeste_maximize_batch", "celeste_render_expected", "celeste_optim_stats", "celeste_tr_solve_batch",
     "celeste_images_create", "celeste_images_destroy", "celeste_ctx_create_on",
     "celeste_host_alloc", "celeste_host_free", "celeste_host_register", "celeste_host_unregister",
@@ -146,6 +147,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.celeste_ctx_last_record_sum_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.celeste_ctx_work_stats.argtypes = [vp, C.c_int32, c_int32_p, C.POINTER(WorkStatsT)]
     lib.celeste_spline_prefilter.argtypes = [c_double_p, c_double_p]
+    lib.celeste_ctx_spline_coefficients.argtypes = [vp, C.c_int32, c_double_p]
     lib.celeste_psf_raster.argtypes = [C.c_int, c_double_p, C.c_int32, c_double_p, C.c_int32, c_double_p,
                                        C.c_int32, c_double_p]
     lib.celeste_maximize_batch.argtypes = [vp, c_double_p, c_double_p, c_double_p, C.c_int32, c_int32_p,

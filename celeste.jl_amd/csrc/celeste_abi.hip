@@ -1407,6 +1407,14 @@ extern "C" int celeste_ctx_work_stats(celeste_ctx_t *c, int32_t n_targets, const
     return CELESTE_OK;
 } ABI_CATCH
 
+extern "C" int celeste_ctx_spline_coefficients(celeste_ctx_t *c, int32_t stamp, double *coef53) try {
+    if (!c || !coef53 || stamp < 0 || stamp >= c->n_stamps) return CELESTE_ERR_INVALID_ARG;
+    int st = select_device(c->device);
+    if (st != CELESTE_OK) return st;
+    HIP_TRY(hipMemcpy(coef53, c->d_coefs + (size_t)stamp * CEL_COEF * CEL_COEF, sizeof(double) * CEL_COEF * CEL_COEF, hipMemcpyDeviceToHost));
+    return CELESTE_OK;
+} ABI_CATCH
+
 extern "C" int celeste_psf_raster(int device, const double *psf, int32_t K, const double *rows, int32_t n_rows,
                                   const double *cols, int32_t n_cols, double *out) try {
     if (!psf || K <= 0 || !rows || !cols || n_rows <= 0 || n_cols <= 0 || !out) return CELESTE_ERR_INVALID_ARG;

@@ -243,6 +243,13 @@ class FieldContext:
     def enable_timing(self, on: bool = True):
         cabi.check(self.lib.celeste_ctx_enable_timing(self.handle, 1 if on else 0), self.lib)
 
+    def spline_coefficients(self, stamp: int) -> np.ndarray:
+        """The 53 x 53 B-spline coefficients [h, w] the context holds for stamp `stamp` (conditioned + prefiltered on the
+        device at creation: spline_prefilter_kernel), as cabi.spline_prefilter returns them for one stamp on the host."""
+        out = np.empty(cabi.COEF * cabi.COEF)
+        cabi.check(self.lib.celeste_ctx_spline_coefficients(self.handle, int(stamp), out.ctypes.data_as(cabi.c_double_p)), self.lib)
+        return out.reshape(cabi.COEF, cabi.COEF).T.copy()
+
     def last_kernel_ms(self):
         ms = (C.c_float * 3)()
         cabi.check(self.lib.celeste_ctx_last_kernel_ms(self.handle, ms), self.lib)

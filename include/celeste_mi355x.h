@@ -268,8 +268,13 @@ int celeste_ctx_work_stats(celeste_ctx_t *ctx, int32_t n_targets, const int32_t 
                            celeste_work_stats_t *out);
 
 /* ImagePatch ctor arithmetic: max(.,0), +1e-6, normalise, softpluslike, then the
- * cubic B-spline prefilter with Line() boundaries on a padded 53x53 grid. */
+ * cubic B-spline prefilter with Line() boundaries on a padded 53x53 grid -- one stamp, on the host (a utility for
+ * callers and tests: celeste_ctx_create does the same for every stamp of the problem on the device, same
+ * operations in the same order, coefficients equal to these to the last bit or two of the logarithm). */
 int celeste_spline_prefilter(const double *stamp51, double *coef53);
+/* The coefficients the context holds for stamp `stamp` (53 x 53, as celeste_spline_prefilter lays them out), copied down
+ * from the device: a diagnostic / test accessor for the device-side constructor arithmetic. */
+int celeste_ctx_spline_coefficients(celeste_ctx_t *ctx, int32_t stamp, double *coef53);
 
 /* Gaussian-mixture PSF raster sum_k alphaBar_k N(x; xiBar_k, tauBar_k) on the
  * grid rows x cols (get_psf_at_point; render_psf uses rows = cols = -25:25).

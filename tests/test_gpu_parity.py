@@ -149,6 +149,36 @@ def test_affine_wcs_and_variable_psf(oracle):
     print("affine/variable psf", errs)
 
 
+def test_device_spline_prefilter_equals_the_host_function():
+    """spline_prefilter_kernel (celeste_ctx_create conditions and prefilters EVERY stamp of the problem on the device) against
+    celeste_spline_prefilter (one stamp, on the host -- the function test_host_logic pins to the oracle and to scipy): the 80
+    stamps of the variable-PSF field, some of them doctored (negative pixels, which the constructor clamps; a dead row; a
+    single hot pixel).  Same operations in the same order: equal to the last bit wherever the two logarithms agree."""
+    from celeste_jl_amd import cabi
+    f = _affine_variable_psf_field()
+    rng = np.random.default_rng(11)
+    for s in range(0, 16, 3):
+        st = f.patches[s][s % 5].stamp
+        st[rng.integers(0, 51, 40), rng.integers(0, 51, 40)] *= -1.0
+        st[7, :] = 0.0
+    f.patches[1][0].stamp[:] = 0.0
+    f.patches[1][0].stamp[25, 25] = 1.0
+    ctx = _ctx(f)
+    K = ctx.problem.c.n_stamps
+    assert K == 16 * 5
+    worst, equal = 0.0, 0
+    for k in range(K):
+        host = cabi.spline_prefilter(ctx.problem.stamps[k].reshape(51, 51).T)
+        dev = ctx.spline_coefficients(k)
+        assert np.isfinite(dev).all()
+        worst = max(worst, float(np.max(np.abs(dev - host)) / np.max(np.abs(host))))
+        equal += int(np.array_equal(dev, host))
+    print("device prefilter vs host: worst relative difference %.1e, %d of %d stamps bit-identical" % (worst, equal, K))
+    assert worst <= 1e-14
+    with pytest.raises(cabi.CelesteError):
+        ctx.spline_coefficients(K)
+
+
 def test_multifield_overlapping_images(oracle):
     """BASELINE config 5 in miniature: 2 x 2 overlapping fields (20 images); a source only has patches in the
     images it overlaps.  fp64 parity, then the fp32 component loop at the stated 1e-4 tolerance."""
