@@ -677,6 +677,9 @@ def main():
                               "the library on the launch stream, " + ("inside the timed steps (one synchronisation per step)"
                                                                      if args.kernels_in_pass else "in a pass of their own after the timed region")),
             "parity_pin": parity_pin_status(),
+            # celeste_ctx_create (the C call): image planes up, every PSF stamp conditioned + spline-prefiltered on the device
+            # (the ImagePatch constructor, imaged_sources.jl:97-107), patch / neighbour / work tables
+            "context_create_ms": float(getattr(ctx, "create_ms", float("nan"))),
             "kernels_ms": {"prep": float(kms[0]), "pixel": float(kms[1]), "lift": float(kms[2])},
             # where ms_per_step goes (rank 0): the steps of the timed loop one by one, the part of a step no kernel accounts
             # for, and the shader clock the chip reported right behind the loop -- a short run (--steps 20 after --warmup 5 is
@@ -1072,7 +1075,7 @@ def variable_psf_record(args, head):
     except Exception as e:   # (the headline does not depend on it)
         return {"error": repr(e)}
     keep = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "kernels_ms", "gaps_ms", "step_ms",
-                              "sclk_mhz_after_loop", "pixel_visits_per_sec_rank0") if k in d}
+                              "sclk_mhz_after_loop", "pixel_visits_per_sec_rank0", "context_create_ms") if k in d}
     keep["workload"] = d["config"]["workload"]
     keep["sources_per_step"] = d["config"]["sources_per_step"]
     keep["pixel_visits_per_sweep"] = d["config"]["pixel_visits_per_sweep"]

@@ -12,6 +12,7 @@ Same names, argument meaning and error behaviour: non-finite parameters or resul
 AssertionError like the reference's @assert (elbo_objective.jl:487, elbo_args.jl:145-149).
 Sa = 1 is the production configuration (batched, tuned); Sa > 1 goes through celeste_elbo_eval_multi.
 """
+import time
 import ctypes as C
 from dataclasses import dataclass
 from typing import Optional, Sequence
@@ -53,6 +54,7 @@ class FieldContext:
                                                                         marshal_images=image_set is None)
         self.S, self.N = self.problem.n_sources, self.problem.n_images
         h = C.c_void_p()
+        t0 = time.perf_counter()
         if image_set is None:
             self.device = device
             cabi.check(self.lib.celeste_ctx_create(C.byref(self.problem.c), device, C.byref(h)), self.lib)
@@ -60,6 +62,7 @@ class FieldContext:
             assert len(image_set.images) == self.N
             self.device = image_set.device
             cabi.check(self.lib.celeste_ctx_create_on(image_set.handle, C.byref(self.problem.c), C.byref(h)), self.lib)
+        self.create_ms = (time.perf_counter() - t0) * 1e3   # the C call alone: uploads, stamp conditioning + prefilter, tables
         self.handle = h
 
     @classmethod
