@@ -18,6 +18,8 @@ import pytest
 
 # (worker threads + barriers: a hang must end the process, not the GPU box's lease -- the thread method kills from outside the
 # blocked C call)
+# CELESTE_FUZZ_SEEDS=N: every seeded fuzz test with N seeds instead of its default handful (a long run on a GPU box)
+FUZZ_SEEDS = int(os.environ.get("CELESTE_FUZZ_SEEDS", "0"))
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900, method="thread")]
 
 
@@ -272,7 +274,7 @@ def test_group_joint_inference_without_cross_member_reads_is_one_segment():
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 6))
 def test_group_joint_inference_segments_fuzz(crowded, seed):
     """random Cyclades schedules (batch size, sweeps, target subset) over two or three members: wherever the host cuts the
     segments, table and per-entry outputs are celeste_joint_infer's on the flattened schedule, bit for bit, and every member has

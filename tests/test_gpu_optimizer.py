@@ -1,10 +1,14 @@
 """-m gpu: maximize! on the device (celeste_maximize_batch) against the CPU restatement of the same algorithm
 and against the reference's recovery tolerances (test/test_optimization.jl)."""
+import os
+
 import numpy as np
 import pytest
 
 from test_oracle_optimizer import _verify_sample_galaxy
 
+# CELESTE_FUZZ_SEEDS=N: every seeded fuzz test with N seeds instead of its default handful (a long run on a GPU box)
+FUZZ_SEEDS = int(os.environ.get("CELESTE_FUZZ_SEEDS", "0"))
 pytestmark = pytest.mark.gpu
 
 
@@ -111,7 +115,7 @@ def test_tridiagonal_solver_agrees_with_eigen_solver(monkeypatch):
             assert abs(el_t.sum() - el_e.sum()) <= 2e-3 * abs(el_e.sum())
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 6))
 def test_randomised_optimiser_against_cpu(oracle, seed):
     """fuzz: random crowded scenes, random targets, random iteration budget and box width; device vs CPU restatement"""
     import celeste_jl_amd as cel

@@ -1,9 +1,13 @@
 """-m gpu: the HIP path, called through the C ABI, against the CPU oracle on identical inputs."""
+import os
+
 import numpy as np
 import pytest
 
 from parity_util import assert_parity, rel_err
 
+# CELESTE_FUZZ_SEEDS=N: every seeded fuzz test with N seeds instead of its default handful (a long run on a GPU box)
+FUZZ_SEEDS = int(os.environ.get("CELESTE_FUZZ_SEEDS", "0"))
 pytestmark = pytest.mark.gpu
 
 ALL = 1 | 2 | 4
@@ -399,7 +403,7 @@ def test_edge_cases(oracle):
     assert_parity(ctx.eval_batch(vp, tg, ALL), oracle.elbo_batch(ctx.problem, vp, tg, ALL), "outside, multi-field")
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 16))
 def test_randomised_small_fields(oracle, seed):
     """fuzz: random image size, source count, NaN fraction, explicit bitmaps, target subset / order, flag set, and
     either evaluation path (fused / split / visit lists forced by giving one source no patch in one image)"""
@@ -457,7 +461,7 @@ def test_randomised_small_fields(oracle, seed):
     print("fuzz", seed, (H, W, S), "targets", len(tg), "flags", flags, "psf_K", psf_K, errs)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 10))
 def test_single_precision_mode_counts_and_masks_like_the_fp64_path(seed):
     """CELESTE_FLAG_FP32 runs its own pixel loop (two pixels per lane, pixel_iter_px2): on fields with NaN pixels, punched
     bitmaps, a missing patch, one-column patches, tiny patches (chunks with fewer than 64 / 128 pixels) and psf_K 1 / 3 the
@@ -535,7 +539,7 @@ def test_single_precision_mode_counts_and_masks_like_the_fp64_path(seed):
     print("fp32 fuzz", seed, (H, W, S), "psf_K", psf_K, "errors", ev, ed, eh)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 6))
 def test_randomised_multi_active(oracle, seed):
     """fuzz of celeste_elbo_eval_multi: random crowded scene with NaNs and punched bitmaps, random active subset and
     order (Sa = 2..4), every other source a value-only neighbour"""
