@@ -139,8 +139,11 @@ def test_randomised_optimiser_against_cpu(oracle, seed):
             assert np.abs(vp[t] - ovp[t]).max() <= 1e-6, (t, np.abs(vp[t] - ovp[t]).max())
         else:
             # long runs may part ways at a borderline accept / hard-case decision (rounding-level differences between
-            # the two eigen-solvers are amplified along flat directions) and meet again at the optimum
-            assert abs(int(its[k]) - oit) <= 3 and abs(elbo[k] - oelbo) <= 1e-7 * abs(oelbo), (t, its[k], oit, elbo[k], oelbo)
+            # the two eigen-solvers are amplified along flat directions) and meet again at the optimum -- as far as the
+            # stopping rule takes either of them: f_tol = 1e-6 relative (ElboMaximize.jl:228-242), and a run that ends on
+            # its iteration budget is not there yet.  (1e-7 held for the first handful of seeds; 4 of 2000 seeds end 6e-7
+            # apart: profiles/r07_extended_fuzz.txt)
+            assert abs(int(its[k]) - oit) <= 3 and abs(elbo[k] - oelbo) <= 2e-6 * abs(oelbo), (t, its[k], oit, elbo[k], oelbo)
     print("optimiser fuzz", seed, "S", S, "targets", tg, "iters", iters, "loc_width", lw, "ok")
 
 

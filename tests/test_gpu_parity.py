@@ -472,7 +472,8 @@ def test_single_precision_mode_counts_and_masks_like_the_fp64_path(seed):
     rng = np.random.default_rng(7000 + seed)
     H, W = int(rng.integers(50, 150)), int(rng.integers(50, 150))
     S = int(rng.integers(2, 12))
-    f = synthetic.make_field(H, W, S, seed=7100 + seed, nan_fraction=float(rng.choice([0.0, 0.02, 0.08])), margin=int(rng.integers(3, 27)))
+    f = synthetic.make_field(H, W, S, seed=7100 + seed, nan_fraction=float(rng.choice([0.0, 0.02, 0.08])),
+                             margin=min(int(rng.integers(3, 27)), min(H, W) // 2 - 1))   # (positions are drawn in [margin, size - margin])
     for s_ in range(S):
         if rng.random() < 0.4:
             p = f.patches[s_][int(rng.integers(5))]
