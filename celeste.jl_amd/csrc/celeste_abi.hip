@@ -36,6 +36,21 @@ struct celeste_group;
         }                                                                                \
     } while (0)
 
+// Every device allocation of the library goes through here.  CELESTE_POISON=1 (testing) fills fresh allocations with 0xFF
+// bytes -- NaN as a double or float, -1 as an integer -- so that a kernel that reads what no kernel or copy has written
+// shows it in every run instead of in the rare one where recycled memory happens to hold something harmful (the tables of a
+// batch are marked with batch stamps, not cleared: DESIGN.md section 3).
+static hipError_t celeste_device_malloc(void **p, size_t bytes) {
+    hipError_t e = (hipMalloc)(p, bytes);
+    static const bool poison = [] { const char *v = getenv("CELESTE_POISON"); return v && atoi(v) != 0; }();
+    if (e == hipSuccess && poison) {
+        e = hipMemset(*p, 0xFF, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    return e;
+}
+#define hipMalloc(p, bytes) celeste_device_malloc((void **)(p), (bytes))
+
 static const celeste_prior_t DEFAULT_PRIOR =
 #include "prior_tables.inc"
     ;

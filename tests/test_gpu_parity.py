@@ -407,12 +407,23 @@ def test_edge_cases(oracle):
 def test_randomised_small_fields(oracle, seed):
     """fuzz: random image size, source count, NaN fraction, explicit bitmaps, target subset / order, flag set, and
     either evaluation path (fused / split / visit lists forced by giving one source no patch in one image)"""
+    _randomised_field(oracle, seed, 1000, (60, 140), (1, 14))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS or 4))
+def test_randomised_medium_fields(oracle, seed):
+    """the same fuzz with 33 .. 90 sources: batches beyond the 32 targets of the one-launch path (eval_fused_kernel), i.e. the
+    work list + pixel_kernel + lift chain with groups of one chunk, on crowded scenes"""
+    _randomised_field(oracle, seed, 3000, (120, 240), (33, 91))
+
+
+def _randomised_field(oracle, seed, seed0, size_range, s_range):
     import celeste_jl_amd as cel
     from celeste_jl_amd import synthetic, cabi
-    rng = np.random.default_rng(1000 + seed)
-    H, W = int(rng.integers(60, 140)), int(rng.integers(60, 140))
-    S = int(rng.integers(1, 14))
-    f = synthetic.make_field(H, W, S, seed=2000 + seed, nan_fraction=float(rng.choice([0.0, 0.01, 0.05])), margin=int(rng.integers(3, 27)))
+    rng = np.random.default_rng(seed0 + seed)
+    H, W = int(rng.integers(*size_range)), int(rng.integers(*size_range))
+    S = int(rng.integers(*s_range))
+    f = synthetic.make_field(H, W, S, seed=seed0 + 1000 + seed, nan_fraction=float(rng.choice([0.0, 0.01, 0.05])), margin=int(rng.integers(3, 27)))
     for s_ in range(S):
         if rng.random() < 0.3:      # punch holes into some patches' bitmaps
             p = f.patches[s_][int(rng.integers(5))]
@@ -444,7 +455,7 @@ def test_randomised_small_fields(oracle, seed):
                 p.wcs_jacobian = Jm.copy()
                 p.world_center = world - Jinv @ (pix - p.pixel_center)
     ctx = cel.FieldContext(f.images, f.patches, f.neighbors, psf_K=psf_K)
-    tg = rng.permutation(S)[:int(rng.integers(1, S + 1))].tolist()
+    tg = rng.permutation(S)[:int(rng.integers(max(1, s_range[0] - 1), S + 1))].tolist()
     flags = int(rng.choice([0, 4, 1, 5, 3, 7, 7, 7]))
     if rng.random() < 0.25:
         flags_dev = flags | cabi.FLAG_FP32
