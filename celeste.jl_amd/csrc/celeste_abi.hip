@@ -51,6 +51,43 @@ static hipError_t celeste_device_malloc(void **p, size_t bytes) {
 }
 #define hipMalloc(p, bytes) celeste_device_malloc((void **)(p), (bytes))
 
+// ---- streams are recycled, never destroyed ------------------------------------------------------------------------------
+// The HIP runtime (ROCm 7.0.2's libamdhip64, the one PyTorch bundles) was caught writing into a stream object AFTER
+// hipStreamDestroy had freed it: with the host's cores oversubscribed (eight test processes, each with a 256-thread OpenMP
+// checker) one context in ~800 left a stale decrement and a stale 32-bit zero in whatever heap block took the 920 bytes of its
+// copy stream next -- a numpy array of the following test (found with tools/heapwho: the block's last owner allocated in
+// hipStreamCreateWithFlags under celeste_ctx_create_on and freed in hipStreamDestroy under celeste_ctx_destroy; the streams
+// were idle and synchronised, their events destroyed).  A library whose callers create a context per source
+// (ParallelRun.jl:468-488) cannot afford a destroy that corrupts the caller's heap, so a context's streams go back to a
+// per-device pool (idle, synchronised) and the next context takes them from there; the pool is never torn down.  It also
+// keeps the stream -> hardware-queue assignment of a process stable (pick_copy_stream).  CELESTE_STREAM_POOL_MAX (default
+// 256 per device) bounds what is kept; beyond it streams are destroyed as before.
+#include <mutex>
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> idle[16];
+};
+static StreamPool &stream_pool() { static StreamPool *p = new StreamPool(); return *p; }   // (leaked on purpose: no HIP call at exit)
+static hipError_t stream_acquire(int device, hipStream_t *out) {
+    *out = nullptr;
+    if (device >= 0 && device < 16) {
+        StreamPool &sp = stream_pool();
+        std::lock_guard<std::mutex> lk(sp.mu);
+        if (!sp.idle[device].empty()) { *out = sp.idle[device].back(); sp.idle[device].pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+static void stream_retire(int device, hipStream_t s) {
+    if (!s) return;
+    if (hipStreamSynchronize(s) == hipSuccess && device >= 0 && device < 16) {
+        static const size_t cap = [] { const char *e = getenv("CELESTE_STREAM_POOL_MAX"); return e ? (size_t)std::max(0, atoi(e)) : (size_t)256; }();
+        StreamPool &sp = stream_pool();
+        std::lock_guard<std::mutex> lk(sp.mu);
+        if (sp.idle[device].size() < cap) { sp.idle[device].push_back(s); return; }
+    } else (void)hipGetLastError();
+    (void)hipStreamDestroy(s);
+}
+
 static const celeste_prior_t DEFAULT_PRIOR =
 #include "prior_tables.inc"
     ;
@@ -375,8 +412,7 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
     // created before: one context in four or so sweeps 2000 sources through the host-pointer entry in 2.0 - 2.4 ms instead of
     // 1.35 -- its copies do not overlap its kernels.  Creating the copy stream at high priority only moves the bad draw to other
     // contexts: tools/gpu_group_stream_lottery.py, profiles/r06_stream_lottery.txt.)
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (stream_acquire(device, &c->stream) != hipSuccess || stream_acquire(device, &c->copy_stream) != hipSuccess) {
         celeste_ctx_destroy(c); return CELESTE_ERR_HIP;
     }
 
@@ -664,8 +700,8 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     if (c->d_small_in) (void)hipFree(c->d_small_in);
     if (c->d_small_out) (void)hipFree(c->d_small_out);
     for (void *q : pins) if (q) (void)hipHostFree(q);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    stream_retire(c->device, c->stream);
+    stream_retire(c->device, c->copy_stream);
     images_release(c->imgs);
     delete c;
 }
@@ -1034,14 +1070,16 @@ static int pick_copy_stream(celeste_ctx_t *c) {
         return hipEventElapsedTime(ms, e0, e1) == hipSuccess;
     };
     float best = 0;
+    hipStream_t retired[3]; int n_retired = 0;   // (back to the pool only at the end: a retired stream must not be drawn again here)
     bool ok = measure(c->copy_stream, &best) && measure(c->copy_stream, &best);     // (the first use of a stream creates its queue)
     for (int k = 0; ok && best > spin_ms && k < 3; ++k) {
         hipStream_t s = nullptr;
         float ms = 0;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        if (stream_acquire(c->device, &s) != hipSuccess) break;
         if (measure(s, &ms) && measure(s, &ms) && ms < best) { std::swap(s, c->copy_stream); best = ms; }
-        (void)hipStreamDestroy(s);
+        retired[n_retired++] = s;
     }
+    for (int k = 0; k < n_retired; ++k) stream_retire(c->device, retired[k]);
     (void)hipGetLastError();
     (void)hipFree(d_buf); (void)hipHostFree(h_buf); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return CELESTE_OK;

@@ -397,7 +397,7 @@ extern "C" void celeste_group_destroy(celeste_group_t *g) {
         if (m->p_h) (void)hipHostFree(m->p_h);
         hipEvent_t evs[] = {m->done[0], m->done[1], m->buf_free[0], m->buf_free[1], m->t0, m->t1, m->t2};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-        if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
+        stream_retire(m->device, m->comm_stream);   // (recycled, not destroyed: see stream_retire)
         if (m->ctx) celeste_ctx_destroy(m->ctx);
         delete m;
     }
@@ -460,7 +460,7 @@ extern "C" int celeste_group_create(const celeste_problem_t *pr, int32_t n_membe
             int st = celeste_ctx_create_on(g->images[k], pr, &m->ctx);
             if (st != CELESTE_OK) return st;
             HIP_TRY(hipSetDevice(m->device));
-            HIP_TRY(hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
+            HIP_TRY(stream_acquire(m->device, &m->comm_stream));
             for (int k2 = 0; k2 < 2; ++k2) {
                 HIP_TRY(hipEventCreateWithFlags(&m->done[k2], hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&m->buf_free[k2], hipEventDisableTiming));

@@ -102,7 +102,8 @@ def elbo_batch(problem: "cabi.Problem", vp, targets, flags=cabi.FLAG_GRAD | cabi
     v = np.zeros(n); d = np.zeros((n, P)); h = np.zeros((n, P, P))
     cnt = np.zeros((n, 2), dtype=np.int64); status = np.zeros(n, dtype=np.int32)
     if n_threads <= 0:
-        n_threads = os.cpu_count() or 1
+        n_threads = int(os.environ.get("CELESTE_ORACLE_THREADS", "0")) or os.cpu_count() or 1
+    n_threads = max(1, min(n_threads, n))     # (one target per thread at most: 256 threads for 40 targets only oversubscribe the host)
     L.celeste_oracle_elbo_batch(C.byref(problem.c), _dp(vp), n, tg.ctypes.data_as(cabi.c_int32_p), flags, _dp(v),
                                 _dp(d), _dp(h), cnt.ctypes.data_as(cabi.c_int64_p),
                                 status.ctypes.data_as(cabi.c_int32_p), n_threads)
@@ -120,7 +121,8 @@ def reduced_elbo_batch(problem: "cabi.Problem", vp, targets, flags=cabi.FLAG_GRA
     v = np.zeros(n); d = np.zeros((n, P)); h = np.zeros((n, P, P))
     cnt = np.zeros((n, 2), dtype=np.int64); status = np.zeros(n, dtype=np.int32)
     if n_threads <= 0:
-        n_threads = os.cpu_count() or 1
+        n_threads = int(os.environ.get("CELESTE_ORACLE_THREADS", "0")) or os.cpu_count() or 1
+    n_threads = max(1, min(n_threads, n))     # (one target per thread at most: 256 threads for 40 targets only oversubscribe the host)
     L.celeste_reduced_elbo_batch(C.byref(problem.c), _dp(vp), n, tg.ctypes.data_as(cabi.c_int32_p), flags, _dp(v),
                                  _dp(d), _dp(h), cnt.ctypes.data_as(cabi.c_int64_p),
                                  status.ctypes.data_as(cabi.c_int32_p), n_threads)

@@ -27,3 +27,49 @@ def oracle(lib):
     from oracle import oracle as o
     o.lib()
     return o
+
+
+# ---- CELESTE_CANARY=1: who writes into freed host memory? -------------------------------------------------------------------
+# After every test (garbage collected first) a set of small numpy arrays of every size class is filled with a pattern; the
+# arrays take the heap blocks the test just freed.  They are checked after the NEXT test: a changed byte is a write through a
+# stale pointer (or a late DMA) by something that test -- or the tail of the one before -- left behind.  Reports go to
+# gpurun_out/flaky/canary_<pid>.txt and fail the test that was running.
+_CANARY = {"sets": [], "log": []}
+
+
+@pytest.fixture(autouse=True)
+def _heap_canaries(request):
+    if not os.environ.get("CELESTE_CANARY"):
+        yield
+        return
+    import gc
+    import numpy as np
+    yield
+    gc.collect()
+    problems = []
+    for made_after, arrays in _CANARY["sets"]:
+        for a in arrays:
+            bad = np.flatnonzero(a != 0xA5)
+            if bad.size:
+                words = a.view(np.uint32) if a.size % 4 == 0 else None
+                problems.append("canary of %d bytes (made after %s) changed at byte offsets %s: bytes %s%s" % (
+                    a.size, made_after, bad[:16].tolist(), [hex(int(x)) for x in a[bad[:16]]],
+                    "" if words is None else "; words %s" % [(int(i), hex(int(words[i]))) for i in np.unique(bad // 4)[:8]]))
+                a[:] = 0xA5
+    _CANARY["sets"] = _CANARY["sets"][-2:]
+    arrays = []
+    for size in range(32, 4096 + 1, 16):
+        for _ in range(6 if size <= 1536 else 2):
+            a = np.empty(size, dtype=np.uint8)
+            a[:] = 0xA5
+            arrays.append(a)
+    _CANARY["sets"].append((request.node.name, arrays))
+    if problems:
+        msg = "heap canaries changed during %s:\n  " % request.node.name + "\n  ".join(problems)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out", "flaky"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "flaky", "canary_%d.txt" % os.getpid()), "a") as fh:
+                fh.write(msg + "\n")
+        except OSError:
+            pass
+        pytest.fail(msg)
