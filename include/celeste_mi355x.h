@@ -188,6 +188,11 @@ const char *celeste_strerror(int status);
  * neighbour graph to HBM of `device`.  Fails with CELESTE_ERR_NO_DEVICE when no
  * HIP device is present: there is no CPU fallback. */
 int celeste_ctx_create(const celeste_problem_t *problem, int device, celeste_ctx_t **out);
+/* Waits for the context's own work, releases its device and page-locked memory.  Its two HIP streams are NOT destroyed: they
+ * go to a per-device pool of idle streams (at most CELESTE_STREAM_POOL_MAX, default 32; an idle stream holds about 1 MB of
+ * device memory) from which the next context of the process takes them -- a caller that creates a context per source
+ * (ParallelRun.jl:468-488) neither pays for stream creation each time nor meets hipStreamDestroy, which the HIP runtime of
+ * ROCm 7.0 does not survive cleanly under host load (profiles/r08_stale_stream_write.md). */
 void celeste_ctx_destroy(celeste_ctx_t *ctx);
 
 /* Shared image handle.  The reference builds one ElboArgs per source over the SAME images
