@@ -73,3 +73,23 @@ def _heap_canaries(request):
         except OSError:
             pass
         pytest.fail(msg)
+
+
+# ---- tools/heapwho preloaded with HEAPWHO_QUARANTINE=<library>: after every test, look at the blocks that library has freed ----
+@pytest.fixture(autouse=True)
+def _heapwho_quarantine(request):
+    yield
+    if not os.environ.get("HEAPWHO_QUARANTINE"):
+        return
+    import ctypes as C
+    try:
+        hw = C.CDLL(None)
+        hw.heapwho_scan.argtypes = [C.c_char_p]
+    except (AttributeError, OSError):
+        return
+    out = os.path.join(ROOT, "gpurun_out", "flaky")
+    os.makedirs(out, exist_ok=True)
+    n = hw.heapwho_scan(os.path.join(out, "quarantine_%d.txt" % os.getpid()).encode())
+    if n:
+        with open(os.path.join(out, "quarantine_%d.txt" % os.getpid()), "a") as fh:
+            fh.write("    (after %s)\n" % request.node.name)
