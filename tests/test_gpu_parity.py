@@ -836,6 +836,8 @@ def test_psf_raster(oracle, lib):
 def test_contexts_release_their_memory():
     """create / use / destroy many contexts (evaluation, split variant, optimiser, renderer, multi-active): device
     memory returns to where it started"""
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("free device memory is a property of the whole GPU: other test processes allocate beside this one (run without -n)")
     import gc
     import torch
     import celeste_jl_amd as cel

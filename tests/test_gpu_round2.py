@@ -157,6 +157,8 @@ def test_device_sharded_sweep_single_process_matches_host_api():
 def test_hundred_contexts_on_one_image_handle(oracle):
     """the reference's per-source ElboArgs over shared images (process_source, ParallelRun.jl:468-488): every context
     holds only its patch table; the planes are uploaded once"""
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("free device memory is a property of the whole GPU: other test processes allocate beside this one (run without -n)")
     import celeste_jl_amd as cel
     from celeste_jl_amd import synthetic, cabi
     f = synthetic.make_field(1024, 900, 100, seed=31)
