@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "elbo_kernels.h"
@@ -64,7 +66,6 @@ static hipError_t celeste_device_malloc(void **p, size_t bytes) {
 // device memory (measured: 200 streams, 216 MB), so the pool keeps at most CELESTE_STREAM_POOL_MAX streams per device (default
 // 32: the streams of 16 contexts); beyond that a stream is destroyed as before -- only a process that closes more than
 // 16 contexts without opening one in between gets there.
-#include <mutex>
 struct StreamPool {
     std::mutex mu;
     std::vector<hipStream_t> idle[16];
@@ -88,6 +89,53 @@ static void stream_retire(int device, hipStream_t s) {
         if (sp.idle[device].size() < cap) { sp.idle[device].push_back(s); return; }
     } else (void)hipGetLastError();
     (void)hipStreamDestroy(s);
+}
+
+// ---- page-locked staging blocks are recycled too -------------------------------------------------------------------------
+// A context's staging (the block pair of the small host-pointer calls, the parts' blocks of a host-pointer sweep, the
+// optimiser's table and state copies) is page-locked memory, and the runtime takes 30 .. 115 us to lock a block and 210 .. 330 us
+// to release one: of the 1.1 ms that creating a per-source context, calling it once and destroying it took (process_source's
+// pattern, ParallelRun.jl:468-488; tools/gpu_per_source_ctx_time.py under rocprofv3 --hip-trace), two hipHostFree were 483 us and
+// two hipHostMalloc 102 -- against 76 us for an evaluation.  Blocks of up to 1 MB go back to a pool of power-of-two size classes
+// (CELESTE_PINNED_POOL_KB, default 16384 per process) instead; larger ones and everything beyond the cap are released as before.
+struct PinnedPool {
+    std::mutex mu;
+    std::unordered_map<void *, int> live;       // blocks handed out -> size class
+    std::vector<void *> idle[9];                // 4 KB << class, class 0 .. 8 (1 MB)
+    size_t idle_bytes = 0;
+};
+static PinnedPool &pinned_pool() { static PinnedPool *p = new PinnedPool(); return *p; }   // (leaked on purpose)
+static size_t pinned_pool_cap() {
+    static const size_t cap = [] { const char *v = getenv("CELESTE_PINNED_POOL_KB"); return (size_t)(v ? std::max(0, atoi(v)) : 16384) << 10; }();
+    return cap;
+}
+static hipError_t staging_alloc(void **p, size_t bytes) {
+    *p = nullptr;
+    int k = -1;
+    if (pinned_pool_cap() && bytes <= (1u << 20)) { k = 0; while (((size_t)4096 << k) < bytes) ++k; }
+    if (k < 0) return hipHostMalloc(p, std::max<size_t>(bytes, 1), hipHostMallocDefault);
+    PinnedPool &pp = pinned_pool();
+    {
+        std::lock_guard<std::mutex> lk(pp.mu);
+        if (!pp.idle[k].empty()) { *p = pp.idle[k].back(); pp.idle[k].pop_back(); pp.idle_bytes -= (size_t)4096 << k; pp.live[*p] = k; return hipSuccess; }
+    }
+    hipError_t e = hipHostMalloc(p, (size_t)4096 << k, hipHostMallocDefault);
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(pp.mu); pp.live[*p] = k; }
+    return e;
+}
+static void staging_free(void *p) {
+    if (!p) return;
+    {
+        PinnedPool &pp = pinned_pool();
+        std::lock_guard<std::mutex> lk(pp.mu);
+        auto it = pp.live.find(p);
+        if (it != pp.live.end()) {
+            const int k = it->second;
+            pp.live.erase(it);
+            if (pp.idle_bytes + ((size_t)4096 << k) <= pinned_pool_cap()) { pp.idle[k].push_back(p); pp.idle_bytes += (size_t)4096 << k; return; }
+        }
+    }
+    (void)hipHostFree(p);
 }
 
 static const celeste_prior_t DEFAULT_PRIOR =
@@ -527,14 +575,23 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         CTX_TRY(dev_upload(&c->d_prior, &pd, 1));
     }
     {
-        double eta[16], nu[16];
-        galaxy_prototypes(eta, nu);
-        if (hipMemcpyToSymbol(HIP_SYMBOL(c_eta), eta, sizeof eta) != hipSuccess ||
-            hipMemcpyToSymbol(HIP_SYMBOL(c_nu), nu, sizeof nu) != hipSuccess) {
-            celeste_ctx_destroy(c); return CELESTE_ERR_HIP;
+        // the galaxy prototypes and the exponential's table are constants of the library: written once per device and process
+        // (two synchronous symbol copies + a launch per context were 35 us of a per-source context's 320)
+        static std::mutex consts_mu;
+        static bool consts_ready[16] = {};
+        std::lock_guard<std::mutex> lk(consts_mu);
+        if (device < 0 || device >= 16 || !consts_ready[device]) {
+            double eta[16], nu[16];
+            galaxy_prototypes(eta, nu);
+            if (hipMemcpyToSymbol(HIP_SYMBOL(c_eta), eta, sizeof eta) != hipSuccess ||
+                hipMemcpyToSymbol(HIP_SYMBOL(c_nu), nu, sizeof nu) != hipSuccess) {
+                celeste_ctx_destroy(c); return CELESTE_ERR_HIP;
+            }
+            hipLaunchKernelGGL(exp_table_kernel, dim3(1), dim3(64), 0, nullptr);
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
+            if (device >= 0 && device < 16) consts_ready[device] = true;
         }
     }
-    hipLaunchKernelGGL(exp_table_kernel, dim3(1), dim3(64), 0, nullptr);
     CTX_TRY(dev_upload<SrcImg>(&c->d_srcimg, nullptr, (size_t)c->V));
     CTX_TRY(dev_upload<Comp>(&c->d_comps, nullptr, (size_t)c->V * c->NC));
     CTX_TRY(dev_upload<SrcGeo>(&c->d_geo, nullptr, (size_t)c->S));
@@ -656,13 +713,8 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
         if (const char *e = getenv("CELESTE_SUM_TILES")) if (atoi(e) > 0) c->sum_tiles = atoi(e);
         c->RCH = std::max(1, ((c->max_npx + 63) / 64 + c->sum_tiles - 1) / c->sum_tiles);
     }
-    for (int i = 0; i < 5; ++i)
-        if (hipEventCreate(&c->ev[i]) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
-    for (int i = 0; i < celeste_ctx::MAX_PARTS; ++i)
-        if (hipEventCreateWithFlags(&c->part_done[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->part_copied[i], hipEventDisableTiming) != hipSuccess) {
-            celeste_ctx_destroy(c); return CELESTE_ERR_HIP;
-        }
+    // (the timing events and the part events of the host-pointer sweep are created on first use: celeste_ctx_enable_timing,
+    // celeste_elbo_eval_batch -- a per-source context that serves a few one-target calls never needs them)
     // the constant tables above were written on the NULL stream; the context's own streams do not wait for it
     if (hipStreamSynchronize(nullptr) != hipSuccess) { celeste_ctx_destroy(c); return CELESTE_ERR_HIP; }
 #undef CTX_TRY
@@ -685,12 +737,12 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
                         o.d_count, o.d_st, o.d_state};
         for (void *q : optr) if (q) (void)hipFree(q);
         void *hptr[] = {o.h_vp, o.h_state, o.h_count};
-        for (void *q : hptr) if (q) (void)hipHostFree(q);
+        for (void *q : hptr) if (q) staging_free(q);
         for (int k = 0; k < celeste_ctx::OptBuffers::RING; ++k) if (o.ev[k]) (void)hipEventDestroy(o.ev[k]);
         auto &f = c->fused;
         void *fptr[] = {f.d_chunk_desc, f.d_tgt_rec, f.d_q_items, f.d_q_ctl, f.d_arrivals, f.d_saved};
         for (void *q : fptr) if (q) (void)hipFree(q);
-        if (f.h_ctl) (void)hipHostFree(f.h_ctl);
+        if (f.h_ctl) staging_free(f.h_ctl);
     }
     for (auto &sc : c->scratch) if (sc.p) (void)hipFree(sc.p);
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -701,7 +753,7 @@ extern "C" void celeste_ctx_destroy(celeste_ctx_t *c) {
     void *pins[] = {c->p_vp, c->p_targets, c->p_status, c->p_v, c->p_d, c->p_h, c->p_cnt, c->p_small_in, c->p_small_out};
     if (c->d_small_in) (void)hipFree(c->d_small_in);
     if (c->d_small_out) (void)hipFree(c->d_small_out);
-    for (void *q : pins) if (q) (void)hipHostFree(q);
+    for (void *q : pins) if (q) staging_free(q);
     stream_retire(c->device, c->stream);
     stream_retire(c->device, c->copy_stream);
     images_release(c->imgs);
@@ -735,6 +787,15 @@ extern "C" int celeste_elbo_eval_batch_device(celeste_ctx_t *c, const double *d_
                                               double *d_h, int64_t *d_counters, int32_t *d_status, void *stream_) try {
     return launch_eval(c, d_vp, n_targets, d_targets, flags, d_v, d_d, d_h, d_counters, d_status, stream_, true);
 } ABI_CATCH
+
+// the events of the first n parts of a host-pointer sweep (created on first use; the calling thread's device is the context's)
+static int ensure_part_events(celeste_ctx_t *c, int n) {
+    for (int k = 0; k < n && k < celeste_ctx::MAX_PARTS; ++k) {
+        if (!c->part_done[k]) HIP_TRY(hipEventCreateWithFlags(&c->part_done[k], hipEventDisableTiming));
+        if (!c->part_copied[k]) HIP_TRY(hipEventCreateWithFlags(&c->part_copied[k], hipEventDisableTiming));
+    }
+    return CELESTE_OK;
+}
 
 // the context's tables, as the fused kernels take them
 static void fused_args_tables(celeste_ctx_t *c, FusedArgs &A) {
@@ -1116,8 +1177,8 @@ static bool is_pinned(const void *ptr, size_t bytes) {
 
 template <class T>
 static int pinned_grow(T **p, size_t n) {
-    if (*p) { (void)hipHostFree(*p); *p = nullptr; }
-    HIP_TRY(hipHostMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault));
+    if (*p) { staging_free(*p); *p = nullptr; }
+    HIP_TRY(staging_alloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
     return CELESTE_OK;
 }
 
@@ -1131,9 +1192,9 @@ static int eval_small(celeste_ctx_t *c, const double *vp, int32_t n_targets, con
     const size_t in_n = vp_n + EVAL_SMALL_MAX / 2;                                     // doubles: table, then 32 int32
     const size_t per = 1 + CEL_P + (size_t)CEL_P * CEL_P + 2 + 1, out_n = EVAL_SMALL_MAX * per;
     if (!c->d_small_in) HIP_TRY(hipMalloc((void **)&c->d_small_in, in_n * sizeof(double)));
-    if (!c->p_small_in) HIP_TRY(hipHostMalloc((void **)&c->p_small_in, in_n * sizeof(double), hipHostMallocDefault));
+    if (!c->p_small_in) HIP_TRY(staging_alloc((void **)&c->p_small_in, in_n * sizeof(double)));
     if (!c->d_small_out) HIP_TRY(hipMalloc((void **)&c->d_small_out, out_n * sizeof(double)));
-    if (!c->p_small_out) HIP_TRY(hipHostMalloc((void **)&c->p_small_out, out_n * sizeof(double), hipHostMallocDefault));
+    if (!c->p_small_out) HIP_TRY(staging_alloc((void **)&c->p_small_out, out_n * sizeof(double)));
     memcpy(c->p_small_in, vp, vp_n * sizeof(double));
     memcpy(c->p_small_in + vp_n, targets, n * sizeof(int32_t));
     HIP_TRY(hipMemcpyAsync(c->d_small_in, c->p_small_in, (vp_n + (n + 1) / 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1254,6 +1315,7 @@ extern "C" int celeste_elbo_eval_batch(celeste_ctx_t *c, const double *vp, int32
     } while (0)
     int part_lo[celeste_ctx::MAX_PARTS + 1];
     for (int k = 0; k <= n_parts; ++k) part_lo[k] = (int)((int64_t)n_targets * k / n_parts);
+    { int st_e = ensure_part_events(c, n_parts); if (st_e != CELESTE_OK) return st_e; }
     for (int k = 0; k < n_parts; ++k) {
         const int lo = part_lo[k], cnt = part_lo[k + 1] - lo;
         int64_t n_chunks = 0;   // the targets are known here: exact size of the pixel kernel's work list
@@ -1408,6 +1470,13 @@ done:
 
 extern "C" int celeste_ctx_enable_timing(celeste_ctx_t *c, int enable) try {
     if (!c) return CELESTE_ERR_INVALID_ARG;
+    if (enable && !c->ev[4]) {      // (created on first use; the caller's current device is left as it was)
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        HIP_TRY(hipSetDevice(c->device));
+        for (int i = 0; i < 5; ++i) if (!c->ev[i]) HIP_TRY(hipEventCreate(&c->ev[i]));
+        if (prev >= 0 && prev != c->device) HIP_TRY(hipSetDevice(prev));
+    }
     c->timing = enable ? 1 : 0;
     c->ev_valid = 0;
     return CELESTE_OK;
@@ -1542,15 +1611,15 @@ static int optim_buffers(celeste_ctx_t *c, size_t n, hipStream_t stream) {
             if (*grow[k]) { (void)hipFree(*grow[k]); *grow[k] = nullptr; }
             HIP_TRY(hipMalloc(grow[k], n * bytes[k]));
         }
-        if (ob.h_state) { (void)hipHostFree(ob.h_state); ob.h_state = nullptr; }
-        HIP_TRY(hipHostMalloc(&ob.h_state, n * sizeof(OptState), hipHostMallocDefault));
+        if (ob.h_state) { staging_free(ob.h_state); ob.h_state = nullptr; }
+        HIP_TRY(staging_alloc(&ob.h_state, n * sizeof(OptState)));
         ob.cap = n;
     }
     if (!ob.d_vp) HIP_TRY(hipMalloc((void **)&ob.d_vp, vp_bytes));
     if (!ob.d_count) HIP_TRY(hipMalloc((void **)&ob.d_count, 3 * sizeof(int32_t)));   // two counters + blocks_done
-    if (!ob.h_vp) HIP_TRY(hipHostMalloc((void **)&ob.h_vp, 2 * vp_bytes, hipHostMallocDefault));
+    if (!ob.h_vp) HIP_TRY(staging_alloc((void **)&ob.h_vp, 2 * vp_bytes));
     if (!ob.h_count) {
-        HIP_TRY(hipHostMalloc((void **)&ob.h_count, celeste_ctx::OptBuffers::RING * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(staging_alloc((void **)&ob.h_count, celeste_ctx::OptBuffers::RING * sizeof(int32_t)));
         for (int k = 0; k < celeste_ctx::OptBuffers::RING; ++k) HIP_TRY(hipEventCreateWithFlags(&ob.ev[k], hipEventDisableTiming));
     }
     return CELESTE_OK;
@@ -1618,7 +1687,7 @@ static int optim_run_fused(celeste_ctx_t *c, double *d_vp, int32_t n_targets, co
         fb.cap_q = q_cap;
     }
     if (!fb.d_q_ctl) HIP_TRY(hipMalloc((void **)&fb.d_q_ctl, FQC_WORDS * sizeof(int32_t)));
-    if (!fb.h_ctl) HIP_TRY(hipHostMalloc((void **)&fb.h_ctl, FQC_WORDS * sizeof(int32_t), hipHostMallocDefault));
+    if (!fb.h_ctl) HIP_TRY(staging_alloc((void **)&fb.h_ctl, FQC_WORDS * sizeof(int32_t)));
     // every polled word is reset before every launch
     HIP_TRY(hipMemsetAsync(fb.d_q_items, 0xFF, q_cap * sizeof(int32_t), stream));
     HIP_TRY(hipMemsetAsync(fb.d_q_ctl, 0, FQC_WORDS * sizeof(int32_t), stream));

@@ -766,6 +766,7 @@ static int group_results_locked(celeste_group *g, double *v, double *d, double *
             if (!direct) { int s1 = group_grow_pinned(&m->p_h, &m->p_h_cap, nr * HS); if (s1 != CELESTE_OK) return s1; }
             n_parts = direct ? 1 : (int)std::min<size_t>(celeste_ctx::MAX_PARTS, std::max<size_t>(1, nr / 192));
             for (int k = 0; k <= n_parts; ++k) part_lo[k] = nr * (size_t)k / (size_t)n_parts;
+            { int s1 = ensure_part_events(m->ctx, n_parts); if (s1 != CELESTE_OK) return s1; }
             for (int k = 0; k < n_parts; ++k) {
                 int s1 = group_hessians_down(m, h, direct, HS, part_lo[k], part_lo[k + 1], st);
                 if (s1 != CELESTE_OK) { (void)hipStreamSynchronize(st); return s1; }
@@ -891,7 +892,7 @@ extern "C" int celeste_group_elbo_eval_batch(celeste_group_t *g, const double *v
         if (want_h && !direct && h_dev && !g->timing) n_parts = (int)std::min<size_t>(celeste_ctx::MAX_PARTS, std::max<size_t>(1, nr / 192));
         size_t part_lo[celeste_ctx::MAX_PARTS + 1];
         for (int k = 0; k <= n_parts; ++k) part_lo[k] = nr * (size_t)k / (size_t)n_parts;
-        int own_rc = CELESTE_OK, copies = 0;
+        int own_rc = ensure_part_events(c, n_parts), copies = 0;     // (a failure here is a failed launch: the collectives still follow)
         if (g->timing) HIP_TRY(hipEventRecord(m->t0, st));
         if (group_fault(g, m, GROUP_FAULT_LAUNCH)) own_rc = CELESTE_ERR_HIP;
         for (int k = 0; k < n_parts && own_rc == CELESTE_OK && nr > 0; ++k) {
