@@ -949,7 +949,7 @@ def secondary_figures(ctx, fld, targets, args, costs):
     # the literal drop-in (ElboMaximize.jl:166 inside process_source, ParallelRun.jl:468-488): one context per source over
     # ElboArgs(images, patches[[s; neighbors], :], [1]) on a shared image handle -- the table is the source and its neighbours
     iset = cel.cabi.ImageSet(fld.images)
-    lat = []
+    lat, t_create, t_first, t_close = [], [], [], []
     for k in range(24):
         t = int(targets[(k * 97) % S])
         loc = [t] + [int(x) for x in fld.neighbors[t]]
@@ -961,12 +961,21 @@ def secondary_figures(ctx, fld, targets, args, costs):
             pctx.eval_batch(vloc, [0], FLAGS_ALL, pinned=False)
             if rep >= 2:
                 lat.append(time.perf_counter() - t1)
+            elif rep == 0 and k >= 4:
+                t_first.append(time.perf_counter() - t1)
+        t1 = time.perf_counter()
         pctx.close()
+        if k >= 4:      # (the first contexts of a process fill the library's stream / staging pools)
+            t_close.append(time.perf_counter() - t1)
+            t_create.append(pctx.create_ms * 1e-3)
     iset.close()
     lat = np.sort(np.array(lat))
     out["single_call_latency_us"]["per_source_context"] = {
         "median": float(np.median(lat) * 1e6), "p90": float(lat[int(0.9 * len(lat))] * 1e6), "calls": int(len(lat)),
-        "what": "the same call on per-source contexts (the source and its neighbours) sharing one image handle"}
+        "what": "the same call on per-source contexts (the source and its neighbours) sharing one image handle",
+        "lifecycle_us": {"celeste_ctx_create_on": float(np.median(t_create) * 1e6), "first_call": float(np.median(t_first) * 1e6),
+                         "celeste_ctx_destroy": float(np.median(t_close) * 1e6),
+                         "what": "medians over 20 contexts; streams and page-locked staging come from the library's pools"}}
     # ElboMaximize.maximize! (Newton trust region, <= 50 iterations, KL on) for every source of the field,
     # neighbours frozen; wall time includes H2D/D2H
     ctx.maximize_batch(fld.vp, targets, cel.ElboConfig(max_iters=1))  # warm-up: the call's buffers at full size
