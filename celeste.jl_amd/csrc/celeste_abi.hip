@@ -373,11 +373,40 @@ static void inv4_logdet(const double *S, double *Inv, double *logdet) {
     *logdet = std::log(det);
 }
 
+// The small tables of a context go up through ONE page-locked arena with asynchronous copies on the NULL stream (a synchronous
+// hipMemcpy from pageable memory is 14 us, and a per-source context makes thirteen of them: 180 of its 300 us); celeste_ctx_create_on
+// opens the arena (ArenaScope), the copies complete at its final wait for the NULL stream.  A table that does not fit (a whole
+// field's patch list, 8765 PSF stamps) is copied synchronously as before.
+struct UploadArena { char *base = nullptr; size_t cap = 0, used = 0; };
+static thread_local UploadArena *tl_arena = nullptr;
+struct ArenaScope {
+    UploadArena a;
+    explicit ArenaScope(size_t cap) {
+        if (staging_alloc((void **)&a.base, cap) == hipSuccess) a.cap = cap;
+        else { (void)hipGetLastError(); a.base = nullptr; }
+        tl_arena = &a;
+    }
+    ~ArenaScope() {
+        tl_arena = nullptr;
+        if (a.base) { (void)hipStreamSynchronize(nullptr); staging_free(a.base); }   // (no copy out of the block is in flight when it goes back)
+    }
+    ArenaScope(const ArenaScope &) = delete;
+    ArenaScope &operator=(const ArenaScope &) = delete;
+};
+
 template <class T>
 static int dev_upload(T **dst, const T *src, size_t n) {
     *dst = nullptr;
     HIP_TRY(hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)));   // never a null table, even when empty
-    if (src && n > 0) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    if (src && n > 0) {
+        const size_t bytes = n * sizeof(T);
+        UploadArena *a = tl_arena;
+        if (a && a->base && a->used + bytes <= a->cap) {
+            memcpy(a->base + a->used, src, bytes);
+            HIP_TRY(hipMemcpyAsync(*dst, a->base + a->used, bytes, hipMemcpyHostToDevice, nullptr));
+            a->used += (bytes + 63) & ~(size_t)63;
+        } else HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    }
     return CELESTE_OK;
 }
 
@@ -451,6 +480,7 @@ extern "C" int celeste_ctx_create_on(celeste_images_t *imgs, const celeste_probl
 
     celeste_ctx *c = new (std::nothrow) celeste_ctx();
     if (!c) return CELESTE_ERR_ALLOC;
+    ArenaScope upload_arena(256u << 10);    // (declared after `c`: a failed creation destroys the context first, then the arena waits)
     c->device = device;
     c->imgs = imgs; imgs->refs.fetch_add(1);
     c->d_images = imgs->d_images;
