@@ -981,6 +981,8 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
     // the sources whose tables this launch fills are marked by the setup kernel (targets + neighbours)
     int32_t *const prep_mark = render_neighbors && !tables_current && !prep_all ? c->d_prep_mark : nullptr;
     bool prep_fused = false;
+    bool records_described = false;   // eval_fused: block 0 of the one-launch list has written chunk_desc / tgt_rec (no fused_setup_kernel)
+    if (eval_fused) { int stb = fused_buffers(c, (size_t)n_targets, rec_cap, stream); if (stb != CELESTE_OK) return stb; }
     if (n_visits <= WORK1_MAX_VISITS && !getenv("CELESTE_PARALLEL_WORKLIST")) {
         const unsigned setup_blocks = (unsigned)((setup_threads + WORK1_SETUP - 1) / WORK1_SETUP);
         // neighbours frozen: the targets' tables are filled by extra blocks of this launch (one launch less per iteration)
@@ -994,12 +996,16 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         const int prep_n = prep_all_here ? (int)c->V : n_visits;
         if (prep_all_here) prep_fused = true;
         const unsigned prep_blocks = prep_fused ? (unsigned)((prep_n + WORK1_NT / 64 - 1) / (WORK1_NT / 64)) : 0u;
+        const bool records_described_here = eval_fused && c->dense && !d_live && !getenv("CELESTE_NO_FUSED_DESCRIBE");
         hipLaunchKernelGGL(setup_worklist_kernel, dim3(1 + setup_blocks + prep_blocks), dim3(WORK1_NT),
                            0, stream, d_vp, geo_S, c->d_geo, d_targets, n_targets, c->d_vis_off, c->d_vis_img, c->M,
                            c->dense ? nullptr : c->d_items, render_neighbors ? c->d_needed : nullptr, c->stamp, c->d_patches,
                            c->N, CH, chunk_px, G, (int)c->dense, c->d_work, c->d_work_total, d_live, prep_mark,
                            c->d_nbr_off, c->d_nbr_idx, c->d_rec_off, (int)setup_blocks, c->d_images, c->K, c->d_srcimg,
-                           c->d_comps, prep_all_here ? (int)c->V : 0, c->d_vis_src);
+                           c->d_comps, prep_all_here ? (int)c->V : 0, c->d_vis_src,
+                           records_described_here ? c->fused.d_chunk_desc : nullptr, records_described_here ? c->fused.d_tgt_rec : nullptr,
+                           c->chunk_px);
+        records_described = records_described_here;
     } else {
         // (the work-list kernels depend on nothing setup / prep / value produce; built on a second stream beside them and
         // joined in front of the pixel kernel they measured no faster -- 0.6519 ms per sweep of the bench field either way --
@@ -1050,14 +1056,14 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         // small batch: one workgroup per chunk record (four wavefronts, one 64-pixel iteration each), the lift by the
         // workgroup that completes a target -- eval_fused_kernel; same records, same results as pixel_kernel + lift_kernel
         auto &fb = c->fused;
-        { int stb = fused_buffers(c, (size_t)n_targets, rec_cap, stream); if (stb != CELESTE_OK) return stb; }
         if (fb.arrivals_dirty) {
             HIP_TRY(hipMemsetAsync(fb.d_arrivals, 0, fb.cap_t * sizeof(int32_t), stream));
             fb.arrivals_dirty = false;
         }
-        hipLaunchKernelGGL(fused_setup_kernel, dim3((unsigned)((n_targets + 63) / 64)), dim3(64), 0, stream, d_targets, n_targets,
-                           c->d_patches, c->d_vis_off, c->dense ? nullptr : c->d_items, c->N, c->M, c->chunk_px, c->d_rec_off,
-                           fb.d_chunk_desc, fb.d_tgt_rec, (int32_t *)nullptr, (int32_t *)nullptr);
+        if (!records_described)
+            hipLaunchKernelGGL(fused_setup_kernel, dim3((unsigned)((n_targets + 63) / 64)), dim3(64), 0, stream, d_targets, n_targets,
+                               c->d_patches, c->d_vis_off, c->dense ? nullptr : c->d_items, c->N, c->M, c->chunk_px, c->d_rec_off,
+                               fb.d_chunk_desc, fb.d_tgt_rec, (int32_t *)nullptr, (int32_t *)nullptr);
         FusedArgs A;
         fused_args_tables(c, A);
         A.targets = d_targets; A.n_targets = n_targets; A.vp = const_cast<double *>(d_vp);

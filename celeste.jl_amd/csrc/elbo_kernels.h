@@ -797,6 +797,35 @@ work_fill_kernel(const int32_t *__restrict__ targets, int n_visits, const DevPat
     }
 }
 
+// The record range of target ti of a batch and the description of each of its chunk records (what a workgroup of the fused
+// kernels needs to start on a record, in one 32-byte read): fused_setup_kernel's per-target work; block 0 of
+// setup_worklist_kernel does it itself for small Hessian-mode batches on contexts whose sources are listed in every image
+// (one launch less in front of eval_fused_kernel: a one-target call is a chain of three kernels instead of four).
+// Returns the number of records; first = the first record (-1: none).
+__device__ __forceinline__ int describe_target_records(int ti, int t, const DevPatch *__restrict__ patches, const int2 *__restrict__ items,
+                                                       int N, int M, int chunk_px, const int32_t *rec_off, int4 *__restrict__ chunk_desc,
+                                                       int &first) {
+    int n_rec = 0;
+    first = -1;
+    for (int j = 0; j < M; ++j) {
+        const int tn = ti * M + j;
+        int v = t * N + j, n = j;                // items == nullptr: every source is listed in all M = N images
+        if (items) { v = items[tn].x; n = items[tn].y; }
+        if (v < 0) continue;
+        const DevPatch &P = patches[v];
+        const int npx = P.H2 * P.W2;
+        if (npx <= 0) continue;
+        const int nch = (npx + chunk_px - 1) / chunk_px, r0 = rec_off[tn];
+        if (first < 0) first = r0;
+        for (int ch = 0; ch < nch; ++ch) {
+            chunk_desc[2 * (r0 + ch)] = make_int4(ti, j, ch, t);
+            chunk_desc[2 * (r0 + ch) + 1] = make_int4(v, n, 0, 0);
+        }
+        n_rec += nch;
+    }
+    return n_rec;
+}
+
 // setup_kernel and the three work-list kernels in ONE launch, for batches of up to WORK1_MAX_VISITS candidate visits
 // (a rank's shard of a field, an optimiser iteration, a Cyclades layer): block 0 (1024 threads, every thread a
 // contiguous run of visits) counts, scans and fills the list; blocks 1.. are setup_kernel.  Four launches and their
@@ -815,9 +844,11 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
                       const DevPatch *__restrict__ patches, int N, int CH, int chunk_px, int G, int dense,
                       int32_t *__restrict__ work, int32_t *__restrict__ work_total, const int32_t *__restrict__ live,
                       int32_t *__restrict__ prep_mark, const int64_t *__restrict__ nbr_off,
-                      const int32_t *__restrict__ nbr_idx, int32_t *__restrict__ rec_off,
+                      const int32_t *__restrict__ nbr_idx, int32_t *rec_off,
                       int setup_blocks, const DevImage *__restrict__ images, int K, SrcImg *__restrict__ srcimg,
-                      Comp *__restrict__ comps, int prep_all_V, const int32_t *__restrict__ vis_src) {
+                      Comp *__restrict__ comps, int prep_all_V, const int32_t *__restrict__ vis_src,
+                      int4 *__restrict__ fz_chunk_desc = nullptr, int2 *__restrict__ fz_tgt_rec = nullptr, int fz_chunk_px = 0) {
+    // fz_*: (optional; dense contexts, no `live`) the record descriptions of eval_fused_kernel, by block 0 behind its list
     if ((int)blockIdx.x > setup_blocks) {
         const int k = ((int)blockIdx.x - setup_blocks - 1) * (WORK1_NT / 64) + (int)(threadIdx.x >> 6);
         if (prep_all_V > 0) {
@@ -900,6 +931,14 @@ setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__
         for (int c = 1; c < WORK_CLASSES; ++c) if (lc == c) work[off[c]++] = k * CH + n_full * G;
         rec_off[k] = off[WORK_CLASSES];      // (not offset by s_base: the chunk class starts at 0)
         off[WORK_CLASSES] += nch;
+    }
+    if (fz_tgt_rec) {
+        __syncthreads();      // rec_off is complete (written by the threads of this block)
+        for (int ti = threadIdx.x; ti < n_targets; ti += WORK1_NT) {
+            int first;
+            const int n_rec = describe_target_records(ti, targets[ti], patches, nullptr, N, M, fz_chunk_px, rec_off, fz_chunk_desc, first);
+            fz_tgt_rec[ti] = make_int2(first < 0 ? 0 : first, n_rec);
+        }
     }
 }
 

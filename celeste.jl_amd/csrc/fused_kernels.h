@@ -117,23 +117,8 @@ __global__ void fused_setup_kernel(const int32_t *__restrict__ targets, int n_ta
     const int ti = blockIdx.x * blockDim.x + threadIdx.x;
     if (ti >= n_targets) return;
     const int t = targets[ti];
-    int n_rec = 0, first = -1;
-    for (int j = 0; j < M; ++j) {
-        const int tn = ti * M + j;
-        int v = t * N + j, n = j;                // items == nullptr: every source is listed in all M = N images
-        if (items) { v = items[tn].x; n = items[tn].y; }
-        if (v < 0) continue;
-        const DevPatch &P = patches[v];
-        const int npx = P.H2 * P.W2;
-        if (npx <= 0) continue;
-        const int nch = (npx + chunk_px - 1) / chunk_px, r0 = rec_off[tn];
-        if (first < 0) first = r0;
-        for (int ch = 0; ch < nch; ++ch) {      // everything a workgroup needs to start on the record, in one 32-byte read
-            chunk_desc[2 * (r0 + ch)] = make_int4(ti, j, ch, t);
-            chunk_desc[2 * (r0 + ch) + 1] = make_int4(v, n, 0, 0);
-        }
-        n_rec += nch;
-    }
+    int first;
+    const int n_rec = describe_target_records(ti, t, patches, items, N, M, chunk_px, rec_off, chunk_desc, first);
     tgt_rec[ti] = make_int2(first < 0 ? 0 : first, n_rec);
     if (!q_items) return;
     if (j_dep) {     // joint mode: the entries without predecessors start
