@@ -991,8 +991,10 @@ static int launch_eval(celeste_ctx_t *c, const double *d_vp, int32_t n_targets, 
         // context: 10 000 visits, 15 us of work that hides under the list builder's block) -- a small batch's chain is one
         // launch shorter
         // (a handful of targets touch a handful of sources: there the marked tables of prep_kernel are the cheaper route)
+        // (... unless the context is tiny -- a per-source context, a source and its neighbours: ten visits -- where filling
+        // every table inside this launch beats a launch of its own whatever the batch: a one-target call 71 -> 67 us)
         const bool prep_all_here = render_neighbors && !tables_current && c->V > 0 && c->V <= WORK1_PREP_ALL_MAX &&
-                                   n_targets >= WORK1_PREP_ALL_MIN_TARGETS && !getenv("CELESTE_NO_FUSED_PREP");
+                                   (n_targets >= WORK1_PREP_ALL_MIN_TARGETS || c->V <= WORK1_PREP_ALL_TINY) && !getenv("CELESTE_NO_FUSED_PREP");
         const int prep_n = prep_all_here ? (int)c->V : n_visits;
         if (prep_all_here) prep_fused = true;
         const unsigned prep_blocks = prep_fused ? (unsigned)((prep_n + WORK1_NT / 64 - 1) / (WORK1_NT / 64)) : 0u;

@@ -837,6 +837,7 @@ __device__ __forceinline__ int describe_target_records(int ti, int t, const DevP
 #define WORK1_MAX_VISITS 4096
 #define WORK1_PREP_ALL_MAX 16384   // visits of a context whose tables the fused launch fills wholesale (neighbours rendered)
 #define WORK1_PREP_ALL_MIN_TARGETS 64
+#define WORK1_PREP_ALL_TINY 128     // contexts of up to this many visits: wholesale for every batch size
 __global__ void __launch_bounds__(WORK1_NT)
 setup_worklist_kernel(const double *__restrict__ vp, int S, SrcGeo *__restrict__ geo, const int32_t *__restrict__ targets,
                       int n_targets, const int32_t *__restrict__ vis_off, const int32_t *__restrict__ vis_img, int M,
