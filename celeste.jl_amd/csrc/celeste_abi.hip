@@ -795,7 +795,7 @@ template <class T>
 static hipError_t scratch_get(celeste_ctx_t *c, int k, size_t bytes, T **out) {
     auto &s = c->scratch[k];
     if (bytes > s.cap) {
-        hipError_t e = hipStreamSynchronize(c->stream);
+        hipError_t e = s.p ? hipStreamSynchronize(c->stream) : hipSuccess;     // (only a block in use has to be waited for)
         if (e != hipSuccess) return e;
         if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
         e = hipMalloc(&s.p, std::max<size_t>(bytes, 256));
@@ -845,7 +845,7 @@ static void fused_args_tables(celeste_ctx_t *c, FusedArgs &A) {
 static int fused_buffers(celeste_ctx_t *c, size_t n, size_t rec, hipStream_t stream) {
     auto &fb = c->fused;
     if (n > fb.cap_t) {
-        HIP_TRY(hipStreamSynchronize(stream));
+        if (fb.d_tgt_rec || fb.d_arrivals) HIP_TRY(hipStreamSynchronize(stream));   // (a buffer in use is about to be freed; nothing to wait for the first time)
         void **ps[] = {(void **)&fb.d_tgt_rec, (void **)&fb.d_arrivals};
         for (void **q : ps) if (*q) { (void)hipFree(*q); *q = nullptr; }
         fb.cap_t = 0;
@@ -855,8 +855,7 @@ static int fused_buffers(celeste_ctx_t *c, size_t n, size_t rec, hipStream_t str
         fb.arrivals_dirty = true;
     }
     if (rec > fb.cap_rec) {
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (fb.d_chunk_desc) { (void)hipFree(fb.d_chunk_desc); fb.d_chunk_desc = nullptr; }
+        if (fb.d_chunk_desc) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(fb.d_chunk_desc); fb.d_chunk_desc = nullptr; }
         fb.cap_rec = 0;
         HIP_TRY(hipMalloc((void **)&fb.d_chunk_desc, std::max<size_t>(rec, 1) * 2 * sizeof(int4)));
         fb.cap_rec = rec;

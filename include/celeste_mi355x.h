@@ -194,7 +194,7 @@ int celeste_ctx_create(const celeste_problem_t *problem, int device, celeste_ctx
  * (ParallelRun.jl:468-488) neither pays for stream creation each time nor meets hipStreamDestroy, which the HIP runtime of
  * ROCm 7.0 does not survive cleanly under host load (profiles/r08_stale_stream_write.md).  Its page-locked staging blocks of up
  * to 1 MB are kept for the next context as well (CELESTE_PINNED_POOL_KB, default 16 MB per process): creating a per-source
- * context on an image handle, one evaluation and destroying it take 0.17 + 0.11 + 0.02 ms (1.1 ms with every block locked
+ * context on an image handle, one evaluation and destroying it take 0.17 + 0.09 + 0.02 ms (1.1 ms with every block locked
  * and released each time and every table copied synchronously; tools/gpu_per_source_ctx_time.py). */
 void celeste_ctx_destroy(celeste_ctx_t *ctx);
 
