@@ -113,13 +113,14 @@ static hipError_t staging_alloc(void **p, size_t bytes) {
     *p = nullptr;
     int k = -1;
     if (pinned_pool_cap() && bytes <= (1u << 20)) { k = 0; while (((size_t)4096 << k) < bytes) ++k; }
-    if (k < 0) return hipHostMalloc(p, std::max<size_t>(bytes, 1), hipHostMallocDefault);
+    // (hipHostMallocPortable: a recycled block may serve a context on another device of the process)
+    if (k < 0) return hipHostMalloc(p, std::max<size_t>(bytes, 1), hipHostMallocPortable);
     PinnedPool &pp = pinned_pool();
     {
         std::lock_guard<std::mutex> lk(pp.mu);
         if (!pp.idle[k].empty()) { *p = pp.idle[k].back(); pp.idle[k].pop_back(); pp.idle_bytes -= (size_t)4096 << k; pp.live[*p] = k; return hipSuccess; }
     }
-    hipError_t e = hipHostMalloc(p, (size_t)4096 << k, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(p, (size_t)4096 << k, hipHostMallocPortable);
     if (e == hipSuccess) { std::lock_guard<std::mutex> lk(pp.mu); pp.live[*p] = k; }
     return e;
 }
